@@ -1,0 +1,235 @@
+#!/usr/bin/env python3
+"""bench.py — M k-mers mapped/sec on the fused reads -> node-counts hot path (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one pass of the hot path (kmm_map_reads_uniform: encode -> rolling 31-mer pack ->
+modulo -> bucket gather -> compare/filter -> atomic node counts) over one batch of synthetic reads
+that is already resident in HBM.  Workload at N=1: BASELINE configs[1] — 10 M synthetic 150 bp
+reads, k=31, 10 M-k-mer index.  With N ranks every rank maps its own 10 M-read batch per step
+(reads shard by chunk: weak scaling) against a replicated index and the per-rank uint32 count
+vectors are summed once with RCCL at the end of the job, inside the timed region.
+
+Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for every field).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# algorithmic bytes per k-mer of the fused path at alpha=0.5, p=0.18, d=1:
+# 150/120 read bytes + 8 bucket record + 8*(alpha + p*d) entry k-mers + 14*p*d (freq, node, count RMW)
+B_ALG_PER_KMER = 1.25 + 8.0 + 8.0 * (0.5 + 0.18) + 14.0 * 0.18      # = 17.21
+HBM_PEAK_GBPS = 8000.0                                               # MI355X_MICROARCH.md
+
+
+def log(*a):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(*a, file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--reads", type=int, default=10_000_000, help="reads per batch per GPU")
+    ap.add_argument("--index-kmers", type=int, default=10_000_000)
+    ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("-k", "--kmer-size", type=int, default=31)
+    ap.add_argument("--skewed", action="store_true", help="node = i mod 1000 (atomic contention)")
+    ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--general-path", action="store_true", help="use kmm_map_reads with an offsets array")
+    ap.add_argument("--cpu-sample-reads", type=int, default=2_000_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        log("note: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    dev_t = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev_t)
+
+    from kmer_mapper_amd import synthetic as syn
+    from kmer_mapper_amd.distributed import reduce_node_counts
+    from kmer_mapper_amd.engine import DeviceIndex
+
+    k, L, R = args.kmer_size, args.read_len, args.reads
+    t_setup = time.time()
+    index, genome = syn.make_index(args.index_kmers, k=k, seed=1, skewed=args.skewed)
+    mx = index.max_node_id()
+    log("index: %d entries, modulo %d, max_node_id %d (%.1fs)"
+        % (len(index._kmers), index._modulo, mx, time.time() - t_setup))
+    dev = DeviceIndex.from_index(index, mx, device=local_rank)
+    dev.set_variant(args.variant)
+    counts = torch.zeros(mx + 1, dtype=torch.int32, device=dev_t)    # uint32 bits; wrap-add == int32 add
+    dev.bind_counts(counts)
+
+    g_ascii = torch.from_numpy(syn.ACGT[genome]).to(dev_t)
+    batches = [syn.make_reads_torch(g_ascii, R, L, seed=1000 * (rank + 1) + b) for b in range(2)]
+    offs = None
+    if args.general_path:
+        offs = torch.arange(R + 1, dtype=torch.int64, device=dev_t) * L
+    del g_ascii
+    torch.cuda.synchronize()
+    kmers_per_step = R * max(L - k + 1, 0)
+    log("setup done in %.1fs; %d reads/batch/GPU, %d k-mers/step/GPU" % (time.time() - t_setup, R, kmers_per_step))
+
+    def step(i):
+        b = batches[i & 1]
+        if offs is not None:
+            dev.map_reads(b, offs, k)
+        else:
+            dev.map_reads_uniform(b, R, L, k)
+
+    def fence():
+        dev.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    if world > 1:                                   # warm the RCCL communicator too
+        reduce_node_counts(torch.zeros_like(counts), dst=0)
+    fence()
+    counts.zero_()
+    fence()
+
+    dev.set_timing(True)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    dev.synchronize()
+    t_map = time.perf_counter()
+    if world > 1:
+        reduce_node_counts(counts, dst=0)           # RCCL sum of the uint32 count vectors over xGMI
+    fence()
+    t1 = time.perf_counter()
+    dev.set_timing(False)
+    kernel_ms, launches = dev.get_timing()
+
+    elapsed = t1 - t0
+    reduce_s = t1 - t_map
+    if world > 1:
+        tt = torch.tensor([elapsed, reduce_s], dtype=torch.float64, device=dev_t)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed, reduce_s = tt[0].item(), tt[1].item()
+
+    total_kmers = kmers_per_step * args.steps * world
+    hits = int(counts.to(torch.int64).bitwise_and(0xFFFFFFFF).sum().item()) if rank == 0 else 0
+
+    result = None
+    if rank == 0:
+        value = total_kmers / elapsed / 1e6
+        avg_kernel_s = kernel_ms / 1e3 / max(launches, 1)
+        achieved = kmers_per_step * B_ALG_PER_KMER / avg_kernel_s / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                if tj.get("reads") == R and tj.get("index_kmers") == args.index_kmers and not args.skewed:
+                    traffic = tj.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        result = {
+            "metric": "M k-mers mapped/sec (whole node), k=%d %dbp reads" % (k, L),
+            "value": round(value, 1),
+            "unit": "M k-mers/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u64",
+            "data": "synthetic",
+            "config": {
+                "workload": "configs[1]: %d synthetic %d bp reads per batch per GPU, k=%d, %d-k-mer index "
+                            "(modulo %d, %d entries), reads resident in HBM, fused kmm_map_reads%s"
+                            % (R, L, k, args.index_kmers, index._modulo, len(index._kmers),
+                               "" if args.general_path else "_uniform"),
+                "kmers_per_step_per_gpu": kmers_per_step,
+                "hit_rate": round(hits / max(total_kmers, 1), 4),
+                "nodes": "skewed(mod 1000)" if args.skewed else "uniform",
+                "variant": args.variant,
+                "final_reduce_ms": round(reduce_s * 1e3, 3) if world > 1 else 0.0,
+                "parallelism": "reads sharded by batch over %d GPU(s), index replicated, one RCCL sum" % world,
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "k_map_reads",
+                "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                "traffic": traffic,
+                "algorithmic_bytes_per_kmer": round(B_ALG_PER_KMER, 2),
+                "avg_kernel_ms": round(avg_kernel_s * 1e3, 3),
+                "launches": launches,
+                "kernel_gkmers_per_s": round(kmers_per_step / avg_kernel_s / 1e9, 2),
+            },
+        }
+
+    # ---- CPU baseline + parity on a bounded sample (rank 0, N=1 only) ---------------------------
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle        # checker / reported baseline only
+        n_s = min(args.cpu_sample_reads, R)
+        sample = batches[0][: n_s * L].cpu().numpy()
+        s_offs = np.arange(n_s + 1, dtype=np.int64) * L
+        n_threads = min(16, os.cpu_count() or 1)          # reference CLI default -t 16
+        oracle.map_reads(index, mx, sample[: 20000 * L], s_offs[:20001], k, n_threads=n_threads)  # warm
+        tc0 = time.perf_counter()
+        expect, n_k = oracle.map_reads(index, mx, sample, s_offs, k, n_threads=n_threads)
+        tc = time.perf_counter() - tc0
+        counts.zero_()
+        torch.cuda.synchronize()
+        dev.map_reads_uniform(batches[0][: n_s * L], n_s, L, k)
+        dev.synchronize()
+        got = counts.cpu().numpy().view(np.uint32)
+        parity = bool(np.array_equal(got, expect))
+        result["cpu_baseline"] = {
+            "value": round(n_k / tc / 1e6, 2),
+            "unit": "M k-mers/s",
+            "cores": n_threads,
+            "kind": "port",
+            "sample": "first %d reads of batch 0 (%d k-mers, %.1f s wall); oracle/kmm_oracle.c "
+                      "oracle_map_reads, gcc -O3, %d pthreads, private count vectors summed"
+                      % (n_s, n_k, tc, n_threads),
+        }
+        result["parity_vs_oracle_on_sample"] = parity
+        if not parity:
+            log("PARITY FAILURE: GPU counts differ from the oracle on the CPU sample")
+    elif rank == 0:
+        result["cpu_baseline"] = None
+
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    dev.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0 and result.get("parity_vs_oracle_on_sample") is False:
+        sys.exit(1)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,140 @@
+/*
+ * kmm.h — C ABI of libkmm.so: the MI355X (gfx950) implementation of kmer_mapper's
+ * k-mer extraction + Kmer-Index lookup + per-node count accumulation hot path.
+ *
+ * This is the drop-in boundary.  Plain pointers and sizes only; nothing here knows about
+ * numpy, torch or Python.  Every entry point names the reference interface it replaces
+ * (paths relative to the ivargr/kmer_mapper tree).  INTEGRATION.md shows the ctypes binding a
+ * reference maintainer would add.
+ *
+ * Conventions
+ *   - All functions return KMM_OK (0) or a negative KMM_ERR_* code and never throw across the
+ *     ABI; kmm_last_error() returns a thread-local human-readable message for the last failure.
+ *   - Input pointers are BORROWED for the duration of the call.  Every data pointer may be a
+ *     host pointer or a device (HBM) pointer on the handle's device; the library detects which
+ *     (hipPointerGetAttributes).  Host inputs are staged to HBM by the call; device inputs are
+ *     used in place.
+ *   - One handle = one device + one HIP stream + one uint32 node-count vector in HBM.
+ *     map calls are asynchronous on the handle's stream and ACCUMULATE into the count vector
+ *     (the reference sums per-chunk vectors, command_line_interface.py:124-130);
+ *     kmm_get_node_counts / kmm_synchronize are the synchronisation points.  Calls on one
+ *     handle must be serialised by the caller; different handles are independent.
+ *   - Counts are uint32 and wrap modulo 2^32 exactly like the reference (mapper.pyx:37,68).
+ */
+#ifndef KMM_H
+#define KMM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KMM_OK 0
+#define KMM_ERR_INVALID_ARG (-1)   /* NULL pointer, k out of range, negative size ...            */
+#define KMM_ERR_HIP (-2)           /* a HIP runtime call failed (message has file:line)          */
+#define KMM_ERR_INDEX (-3)         /* index arrays inconsistent (bucket out of range, bad node)  */
+#define KMM_ERR_INVALID_BASE (-4)  /* a read byte is not a nucleotide under the lookup table     */
+#define KMM_ERR_NOMEM (-5)
+
+#define KMM_MAX_K 31               /* a k-mer is packed 2 bits/base into a uint64; bionumpy's
+                                      get_kmers (util.py:72) is used with k <= 31                */
+
+typedef struct kmm_index kmm_index_t;
+
+/* Library / device probes. */
+const char *kmm_version(void);
+const char *kmm_last_error(void);
+int kmm_device_count(int *n_devices);
+
+/*
+ * kmm_index_create — replaces the typed-memoryview binding of the five index arrays at
+ * mapper.pyx:22-29 and the cucounter table construction at gpu_counter.py:13-16.
+ * Arrays are the attributes of graph_kmer_index.KmerIndex after convert_to_int32()
+ * (util.py:60-62): hashes_to_index int32[modulo], n_kmers int32[modulo], kmers uint64[n_entries],
+ * nodes int32[n_entries], frequencies uint16[n_entries].  They are copied to HBM and repacked
+ * (interleaved {start,count} bucket records; 16-byte {kmer,node,freq} entries).  Unlike the
+ * reference (no bounds checks, mapper.pyx:17) the arrays are validated: every non-empty bucket
+ * must lie inside [0, n_entries) and every node inside [0, max_node_id], else KMM_ERR_INDEX.
+ */
+int kmm_index_create(const int32_t *hashes_to_index, const int32_t *n_kmers, uint64_t modulo,
+                     const uint64_t *kmers, const int32_t *nodes, const uint16_t *frequencies,
+                     int64_t n_entries, int64_t max_node_id, int device, kmm_index_t **out);
+void kmm_index_destroy(kmm_index_t *idx);
+
+/*
+ * Node-count vector management (mapper.pyx:37 allocates it per call; gpu_counter.py keeps it
+ * inside the counter).  kmm_bind_counts makes the handle accumulate into a caller-owned device
+ * buffer of max_node_id+1 uint32 (e.g. a torch tensor that is then reduced with RCCL); the
+ * buffer is NOT zeroed by the bind.  kmm_counts_device_ptr returns the current device buffer.
+ */
+int kmm_reset_counts(kmm_index_t *idx);
+int kmm_bind_counts(kmm_index_t *idx, uint32_t *device_counts);
+int kmm_counts_device_ptr(kmm_index_t *idx, uint32_t **out);
+/* Copies the max_node_id+1 counts to host memory `out` after draining the stream. */
+int kmm_get_node_counts(kmm_index_t *idx, uint32_t *out);
+int kmm_synchronize(kmm_index_t *idx);
+
+/*
+ * kmm_map_kmers — replaces map_kmers_to_graph_index (mapper.pyx:19-72, loop :53-69) and
+ * GpuCounter.count (gpu_counter.py:23-24): for each of the n packed k-mers q,
+ * h = q % modulo, scan bucket h, and for every entry with kmer == q and
+ * frequency <= max_index_lookup_frequency add 1 to counts[node].  If also_revcomp != 0 the
+ * reverse complement of q (k bases) is looked up as well (`-r`,
+ * command_line_interface.py:74,180-182).  k is only used for also_revcomp.
+ */
+int kmm_map_kmers(kmm_index_t *idx, const uint64_t *kmers, int64_t n,
+                  int max_index_lookup_frequency, int also_revcomp, int k);
+
+/*
+ * kmm_map_reads — the fused path: replaces map_cpu's three steps
+ * (command_line_interface.py:41 N->A, :42 get_kmer_hashes_from_chunk_sequence = util.py:71-75,
+ * :51 map_kmers_to_graph_index) without materialising the k-mer array.
+ * bases: the chunk's flat ASCII read bytes; read_offsets: int64[n_reads+1], read r is
+ * bases[read_offsets[r] : read_offsets[r+1]] (read_offsets[0] must be 0).  Every window of k
+ * bases inside one read is packed first-base-lowest, 2 bits/base through `lut`
+ * (uint8[256]: 0..3 = code, 0xFF = not a nucleotide; NULL = A,C,G,T->0,1,2,3 case-insensitive
+ * with N->A) and looked up as in kmm_map_kmers.  A byte with lut 0xFF makes the NEXT
+ * synchronising call fail with KMM_ERR_INVALID_BASE (the reference's encoder raises).
+ */
+int kmm_map_reads(kmm_index_t *idx, const uint8_t *bases, const int64_t *read_offsets,
+                  int64_t n_reads, int k, int max_index_lookup_frequency, int also_revcomp,
+                  const uint8_t *lut);
+/* Same for n_reads reads of identical length read_len stored back to back (no offsets array;
+ * the 150 bp short-read case of the reference's Readme.md:11-13). */
+int kmm_map_reads_uniform(kmm_index_t *idx, const uint8_t *bases, int64_t n_reads,
+                          int64_t read_len, int k, int max_index_lookup_frequency,
+                          int also_revcomp, const uint8_t *lut);
+
+/*
+ * kmm_extract_kmers — replaces get_kmer_hashes_from_chunk_sequence (util.py:71-75) as an
+ * operator: writes the packed k-mers of all reads, flattened in (read, offset) order, to `out`
+ * (host or device, n_out = sum(max(len_r-k+1,0)) uint64).  Not used by the fused path.
+ */
+int kmm_extract_kmers(int device, const uint8_t *bases, const int64_t *read_offsets,
+                      int64_t n_reads, int k, const uint8_t *lut, uint64_t *out, int64_t n_out);
+
+/*
+ * kmm_in_index — replaces in_graph_index / in_graph_index_no_memory_maps
+ * (mapper.pyx:81-130,137-190): out[i] = 1 iff some entry of bucket kmers[i] % modulo equals
+ * kmers[i] (no frequency filter).  out: uint8[n], host or device.
+ */
+int kmm_in_index(kmm_index_t *idx, const uint64_t *kmers, int64_t n, uint8_t *out);
+
+/*
+ * Measurement hooks (the reference only logs perf_counter deltas,
+ * command_line_interface.py:67-78).  With timing on, every launch of the dominant kernel
+ * (map_reads / map_kmers) is bracketed by HIP events on the handle's stream;
+ * kmm_get_timing drains the stream and returns the summed kernel milliseconds, the number of
+ * launches and the number of k-mer windows those launches covered, then clears the totals.
+ */
+int kmm_set_timing(kmm_index_t *idx, int enabled);
+int kmm_get_timing(kmm_index_t *idx, double *kernel_ms, int64_t *n_launches);
+
+/* Tuning knob, for experiments only: selects the kernel variant (0 = default). */
+int kmm_set_variant(kmm_index_t *idx, int variant);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KMM_H */

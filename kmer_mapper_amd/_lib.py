@@ -1,0 +1,106 @@
+"""ctypes binding of libkmm.so (the C ABI declared in include/kmm.h).
+
+The library is built in-tree by `build()` (hipcc --offload-arch=gfx950) and loaded from
+kmer_mapper_amd/libkmm.so.  No fallback exists: a missing library raises at first use.
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(_HERE)
+SO_PATH = os.path.join(_HERE, "libkmm.so")
+SRC = os.path.join(_HERE, "csrc", "kmm.hip")
+INCLUDE = os.path.join(ROOT, "include")
+
+KMM_OK = 0
+KMM_ERR_INVALID_ARG = -1
+KMM_ERR_HIP = -2
+KMM_ERR_INDEX = -3
+KMM_ERR_INVALID_BASE = -4
+KMM_ERR_NOMEM = -5
+
+_c = ctypes
+_P = ctypes.c_void_p
+
+# name -> (restype, argtypes); must list every symbol include/kmm.h declares
+SIGNATURES = {
+    "kmm_version": (_c.c_char_p, []),
+    "kmm_last_error": (_c.c_char_p, []),
+    "kmm_device_count": (_c.c_int, [_P]),
+    "kmm_index_create": (_c.c_int, [_P, _P, _c.c_uint64, _P, _P, _P, _c.c_int64, _c.c_int64,
+                                    _c.c_int, _P]),
+    "kmm_index_destroy": (None, [_P]),
+    "kmm_reset_counts": (_c.c_int, [_P]),
+    "kmm_bind_counts": (_c.c_int, [_P, _P]),
+    "kmm_counts_device_ptr": (_c.c_int, [_P, _P]),
+    "kmm_get_node_counts": (_c.c_int, [_P, _P]),
+    "kmm_synchronize": (_c.c_int, [_P]),
+    "kmm_map_kmers": (_c.c_int, [_P, _P, _c.c_int64, _c.c_int, _c.c_int, _c.c_int]),
+    "kmm_map_reads": (_c.c_int, [_P, _P, _P, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _P]),
+    "kmm_map_reads_uniform": (_c.c_int, [_P, _P, _c.c_int64, _c.c_int64, _c.c_int, _c.c_int,
+                                         _c.c_int, _P]),
+    "kmm_extract_kmers": (_c.c_int, [_c.c_int, _P, _P, _c.c_int64, _c.c_int, _P, _P, _c.c_int64]),
+    "kmm_in_index": (_c.c_int, [_P, _P, _c.c_int64, _P]),
+    "kmm_set_timing": (_c.c_int, [_P, _c.c_int]),
+    "kmm_get_timing": (_c.c_int, [_P, _P, _P]),
+    "kmm_set_variant": (_c.c_int, [_P, _c.c_int]),
+}
+
+
+def build(force=False, verbose=False):
+    """Compile csrc/kmm.hip for gfx950 into kmer_mapper_amd/libkmm.so (cross-compiles on CPU)."""
+    hdr = os.path.join(INCLUDE, "kmm.h")
+    if (not force and os.path.exists(SO_PATH)
+            and os.path.getmtime(SO_PATH) >= max(os.path.getmtime(SRC), os.path.getmtime(hdr))):
+        return SO_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+           "-I" + INCLUDE, "-o", SO_PATH, SRC]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return SO_PATH
+
+
+_lib = None
+
+
+def lib():
+    """The loaded library; raises RuntimeError if it has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise RuntimeError(
+                "kmer_mapper_amd: %s is missing — build it with "
+                "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc, gfx950). "
+                "There is no CPU fallback." % SO_PATH)
+        L = ctypes.CDLL(SO_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+class KmmError(RuntimeError):
+    pass
+
+
+def check(rc):
+    """Map a KMM_ERR_* code to the exception the reference raises in the same situation."""
+    if rc == KMM_OK:
+        return
+    msg = lib().kmm_last_error().decode("utf-8", "replace")
+    if rc in (KMM_ERR_INVALID_ARG, KMM_ERR_INDEX, KMM_ERR_INVALID_BASE):
+        raise ValueError(msg)       # Cython buffer / bionumpy encoding errors are ValueError-like
+    if rc == KMM_ERR_NOMEM:
+        raise MemoryError(msg)
+    raise KmmError(msg)
+
+
+def device_count():
+    n = _c.c_int(0)
+    check(lib().kmm_device_count(_c.byref(n)))
+    return n.value

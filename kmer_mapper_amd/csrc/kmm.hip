@@ -1,0 +1,1260 @@
+// kmm.hip — MI355X (gfx950 / CDNA4) kernels and C-ABI host code for kmer_mapper's hot path:
+// reads -> 2-bit codes -> rolling k-mer pack -> modulo hash -> bucket gather -> compare/filter ->
+// per-node atomic counts.  See include/kmm.h for the boundary and DESIGN.md for the layout.
+//
+// Reference semantics restated (never copied): kmer_mapper/mapper.pyx:53-69 (lookup),
+// kmer_mapper/util.py:71-75 (extraction), kmer_mapper/command_line_interface.py:41 (N->A).
+//
+// Integer / gather work: no MFMA.  The bound is random HBM accesses, so the kernels are built for
+// memory-level parallelism (U independent bucket gathers in flight per lane, then U independent
+// first-entry gathers) at high occupancy; reads are staged through LDS as packed 2-bit codes so
+// each byte is fetched from HBM exactly once with 16-byte coalesced loads.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "kmm.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------------
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                               \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(KMM_ERR_HIP, "%s:%d: %s -> %s", __FILE__, __LINE__, #expr,                 \
+                        hipGetErrorString(e_));                                                    \
+    } while (0)
+
+#define KMMCHK(expr)                                                                               \
+    do {                                                                                           \
+        int r_ = (expr);                                                                           \
+        if (r_ != KMM_OK)                                                                          \
+            return r_;                                                                             \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// device-side data layout (ours; the .npz surface is unchanged)
+//   bucket h : uint2 {start, count}           8 B  — one gather instead of the reference's two
+//   entry  l : uint4 {kmer_lo, kmer_hi, node, freq}  16 B — a hit touches one 16 B slot
+// ------------------------------------------------------------------------------------------------
+struct IndexView {
+    const uint2 *buckets;
+    const uint4 *entries;
+    uint32_t *counts;
+    uint64_t modulo;
+    uint64_t magic; // floor(2^64 / modulo) (all ones for modulo == 1)
+};
+
+struct ReadsView {
+    const uint8_t *bases;
+    int64_t total;             // number of base bytes
+    const int64_t *offsets;    // n_reads + 1 (general path)
+    int64_t n_reads;
+    const int64_t *tile_first; // per tile: first r with offsets[r] > tile start (general path)
+    uint64_t read_len;         // uniform path
+    uint64_t read_len_magic;   // floor(2^64 / read_len)
+    const uint8_t *lut;        // 256 bytes in HBM
+    unsigned long long *first_bad; // min position of a non-nucleotide byte (init ~0)
+};
+
+// Exact x % m for any m >= 1 with one 64x64->hi multiply: q = hi64(x * floor(2^64/m)) is either
+// floor(x/m) or one less (x * (2^64/m - magic) / 2^64 < 1), so a single conditional subtract
+// restores the remainder.  The reference computes kmers[i] % modulo with a hardware divide
+// (mapper.pyx:54); results are identical for every x.
+__device__ __forceinline__ uint64_t fastmod(uint64_t x, uint64_t m, uint64_t magic)
+{
+    uint64_t q = __umul64hi(x, magic);
+    uint64_t r = x - q * m;
+    return r >= m ? r - m : r;
+}
+
+__device__ __forceinline__ uint64_t fastdiv(uint64_t x, uint64_t m, uint64_t magic, uint64_t *rem)
+{
+    uint64_t q = __umul64hi(x, magic);
+    uint64_t r = x - q * m;
+    if (r >= m) {
+        r -= m;
+        q += 1;
+    }
+    *rem = r;
+    return q;
+}
+
+// Reverse complement under A,C,G,T = 0,1,2,3, first base in the lowest bits: complement every
+// 2-bit group (NOT), reverse the groups, realign (the `-r` operation).
+__device__ __forceinline__ uint64_t revcomp(uint64_t x, int k)
+{
+    x = ~x;
+    x = ((x >> 2) & 0x3333333333333333ull) | ((x & 0x3333333333333333ull) << 2);
+    x = ((x >> 4) & 0x0F0F0F0F0F0F0F0Full) | ((x & 0x0F0F0F0F0F0F0F0Full) << 4);
+    x = ((x >> 8) & 0x00FF00FF00FF00FFull) | ((x & 0x00FF00FF00FF00FFull) << 8);
+    x = ((x >> 16) & 0x0000FFFF0000FFFFull) | ((x & 0x0000FFFF0000FFFFull) << 16);
+    x = (x >> 32) | (x << 32);
+    return x >> (64 - 2 * k);
+}
+
+// mapper.pyx:60-68 for one entry.
+__device__ __forceinline__ void count_if_match(const IndexView &iv, uint4 e, uint64_t q,
+                                               int max_freq)
+{
+    uint64_t ek = (uint64_t)e.x | ((uint64_t)e.y << 32);
+    if (ek == q && (int)e.w <= max_freq)
+        atomicAdd(&iv.counts[e.z], 1u);
+}
+
+// The probe of mapper.pyx:53-69 for U k-mers per lane, arranged so that the U bucket gathers are
+// all in flight before any is consumed, then the U first-entry gathers likewise; only buckets
+// with more than one entry (hash collisions, duplicated k-mers) enter the serial tail.
+template <int U>
+__device__ __forceinline__ void probe_batch(const IndexView &iv, const uint64_t (&q)[U],
+                                            uint32_t valid, int max_freq)
+{
+    uint2 b[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        b[u] = make_uint2(0u, 0u);
+        if ((valid >> u) & 1u)
+            b[u] = iv.buckets[fastmod(q[u], iv.modulo, iv.magic)];
+    }
+    uint4 e[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        e[u] = make_uint4(0u, 0u, 0u, 0u);
+        if (b[u].y)
+            e[u] = iv.entries[b[u].x];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        if (b[u].y) {
+            count_if_match(iv, e[u], q[u], max_freq);
+            for (uint32_t j = 1; j < b[u].y; ++j)
+                count_if_match(iv, iv.entries[(uint64_t)b[u].x + j], q[u], max_freq);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2: operator-level lookup, uint64 k-mers already in HBM (drop-in for map_kmers_to_graph_index).
+// ------------------------------------------------------------------------------------------------
+template <int U>
+__global__ void __launch_bounds__(256) k_map_kmers(const uint64_t *__restrict__ kmers, int64_t n,
+                                                   IndexView iv, int max_freq, int also_rc, int k)
+{
+    const int64_t span = (int64_t)256 * U;
+    for (int64_t base = (int64_t)blockIdx.x * span; base < n; base += (int64_t)gridDim.x * span) {
+        uint64_t q[U];
+        uint32_t valid = 0;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            int64_t i = base + (int64_t)u * 256 + threadIdx.x;
+            q[u] = 0;
+            if (i < n) {
+                q[u] = kmers[i];
+                valid |= 1u << u;
+            }
+        }
+        probe_batch<U>(iv, q, valid, max_freq);
+        if (also_rc) {
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                q[u] = revcomp(q[u], k);
+            probe_batch<U>(iv, q, valid, max_freq);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1: fused reads -> counts.  One workgroup (4 wavefronts) owns tiles of T = 256*S consecutive
+// base positions of the chunk's flat byte stream:
+//   1. 16-byte coalesced loads of the T + 48 bytes the tile's windows can touch; each byte goes
+//      through the 256-entry LDS lookup table and 16 codes are packed into one 32-bit LDS word;
+//   2. read starts that fall inside the tile are marked in an LDS bitset (general path) so that
+//      no window spans two reads (bionumpy's ragged windowing, util.py:72);
+//   3. each lane takes S consecutive positions: three LDS words give it S+31 bases in a 128-bit
+//      register window, and successive k-mers are 2-bit funnel shifts of that window
+//      (first base in the lowest bits);
+//   4. probe_batch<S>.
+// ------------------------------------------------------------------------------------------------
+template <int S, bool UNIFORM>
+__global__ void __launch_bounds__(256) k_map_reads(ReadsView rv, IndexView iv, int k, int max_freq,
+                                                   int also_rc)
+{
+    constexpr int T = 256 * S;
+    constexpr int NV = T / 16 + 3; // 16-base words staged per tile (T + 48 positions)
+    constexpr int NB = T / 32 + 3; // 32-position words of the read-start bitset
+    __shared__ uint8_t s_lut[256];
+    __shared__ uint32_t s_codes[NV + 1];
+    __shared__ uint32_t s_bits[NB + 1];
+
+    const int tid = threadIdx.x;
+    s_lut[tid] = rv.lut[tid];
+
+    const uint64_t kmask = (1ull << (2 * k)) - 1ull; // k <= 31
+    const uint64_t bmask = (1ull << (k - 1)) - 1ull; // starts in (p, p+k-1] kill the window at p
+    const bool aligned = (((uintptr_t)rv.bases) & 15u) == 0;
+    const int64_t total = rv.total;
+    const int64_t n_tiles = (total + T - 1) / T;
+
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t t0 = tile * T;
+        if (!UNIFORM)
+            for (int i = tid; i < NB + 1; i += 256)
+                s_bits[i] = 0;
+        __syncthreads(); // LUT visible; bitset cleared; previous tile's LDS readers are done
+
+        // ---- stage 1: bytes -> 2-bit codes in LDS ------------------------------------------
+        for (int v = tid; v < NV; v += 256) {
+            const int64_t p = t0 + (int64_t)v * 16;
+            uint32_t w[4];
+            if (aligned && p + 16 <= total) {
+                uint4 x = *reinterpret_cast<const uint4 *>(rv.bases + p);
+                w[0] = x.x; w[1] = x.y; w[2] = x.z; w[3] = x.w;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    uint32_t acc = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        int64_t pp = p + i * 4 + j;
+                        uint32_t c = (pp < total) ? rv.bases[pp] : 0u;
+                        acc |= c << (8 * j);
+                    }
+                    w[i] = acc;
+                }
+            }
+            uint32_t code = 0;
+            int bad = -1;
+#pragma unroll
+            for (int i = 15; i >= 0; --i) {
+                uint32_t c = (w[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+                uint32_t l = s_lut[c];
+                if (l == 0xFFu && p + i < total)
+                    bad = i;
+                code |= (l & 3u) << (2 * i);
+            }
+            s_codes[v] = code;
+            if (bad >= 0)
+                atomicMin(rv.first_bad, (unsigned long long)(p + bad));
+        }
+        // ---- stage 2: read starts inside (t0, t0 + T + k - 2] ------------------------------
+        if (!UNIFORM) {
+            for (int64_t r = rv.tile_first[tile] + tid; r <= rv.n_reads; r += 256) {
+                int64_t o = rv.offsets[r] - t0;
+                if (o > (int64_t)T + k - 2)
+                    break;
+                if (o >= 1)
+                    atomicOr(&s_bits[o >> 5], 1u << (o & 31));
+            }
+        }
+        __syncthreads();
+
+        // ---- stage 3: S consecutive windows per lane ---------------------------------------
+        const int q0 = tid * S;
+        const int64_t p0 = t0 + q0;
+        uint64_t lo, hi;
+        {
+            const int w = q0 >> 4;
+            const uint32_t c0 = s_codes[w], c1 = s_codes[w + 1], c2 = s_codes[w + 2];
+            const int sh = (q0 & 15) * 2;
+            lo = ((uint64_t)c1 << 32) | c0;
+            hi = c2;
+            if (sh) {
+                lo = (lo >> sh) | (hi << (64 - sh));
+                hi >>= sh;
+            }
+        }
+        uint32_t valid = 0;
+        if (UNIFORM) {
+            uint64_t o;
+            (void)fastdiv((uint64_t)p0, rv.read_len, rv.read_len_magic, &o);
+#pragma unroll
+            for (int j = 0; j < S; ++j) {
+                uint64_t oj = o + j;
+                if (oj >= rv.read_len)
+                    oj -= rv.read_len;
+                if (oj + k <= rv.read_len && p0 + j < total)
+                    valid |= 1u << j;
+            }
+        } else {
+            const int sw = q0 >> 5, off = q0 & 31;
+            uint64_t B = ((uint64_t)s_bits[sw + 1] << 32) | s_bits[sw];
+            if (off)
+                B = (B >> off) | ((uint64_t)s_bits[sw + 2] << (64 - off));
+#pragma unroll
+            for (int j = 0; j < S; ++j)
+                if (((B >> (j + 1)) & bmask) == 0 && p0 + j + k <= total)
+                    valid |= 1u << j;
+        }
+        uint64_t q[S];
+#pragma unroll
+        for (int j = 0; j < S; ++j)
+            q[j] = (j == 0 ? lo : ((lo >> (2 * j)) | (hi << (64 - 2 * j)))) & kmask;
+
+        // ---- stage 4: gather + count -------------------------------------------------------
+        if (__builtin_amdgcn_ballot_w64(valid != 0)) {
+            probe_batch<S>(iv, q, valid, max_freq);
+            if (also_rc) {
+#pragma unroll
+                for (int j = 0; j < S; ++j)
+                    q[j] = revcomp(q[j], k);
+                probe_batch<S>(iv, q, valid, max_freq);
+            }
+        }
+    }
+}
+
+// General path helper: for every tile, the first read index r in [0, n_reads+1] whose start lies
+// strictly after the tile's first position (upper bound over the n_reads+1 offsets).
+__global__ void k_tile_first(const int64_t *__restrict__ offs, int64_t n_reads, int64_t n_tiles,
+                             int T, int64_t *__restrict__ out)
+{
+    int64_t tile = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tile >= n_tiles)
+        return;
+    const int64_t t0 = tile * T;
+    int64_t lo = 0, hi = n_reads + 1;
+    while (lo < hi) {
+        int64_t mid = (lo + hi) >> 1;
+        if (offs[mid] <= t0)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    out[tile] = lo;
+}
+
+__global__ void k_iota_offsets(int64_t *out, int64_t n_reads, int64_t read_len)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i <= n_reads)
+        out[i] = i * read_len;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Operator façade kernels (not on the fused path).
+// ------------------------------------------------------------------------------------------------
+// get_kmer_hashes_from_chunk_sequence (util.py:71-75): one lane per base position.
+__global__ void k_extract_kmers(const uint8_t *__restrict__ bases, const int64_t *__restrict__ offs,
+                                const int64_t *__restrict__ kmer_offs, int64_t n_reads, int k,
+                                const uint8_t *__restrict__ lut, uint64_t *__restrict__ out,
+                                unsigned long long *first_bad)
+{
+    const int64_t total = offs[n_reads];
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total;
+         p += (int64_t)gridDim.x * blockDim.x) {
+        if (lut[bases[p]] == 0xFFu)
+            atomicMin(first_bad, (unsigned long long)p);
+        // read containing p: last r with offs[r] <= p
+        int64_t lo = 0, hi = n_reads + 1;
+        while (lo < hi) {
+            int64_t mid = (lo + hi) >> 1;
+            if (offs[mid] <= p)
+                lo = mid + 1;
+            else
+                hi = mid;
+        }
+        const int64_t r = lo - 1;
+        if (p + k > offs[r + 1])
+            continue;
+        uint64_t w = 0;
+        for (int j = 0; j < k; ++j)
+            w |= (uint64_t)(lut[bases[p + j]] & 3u) << (2 * j);
+        out[kmer_offs[r] + (p - offs[r])] = w;
+    }
+}
+
+// in_graph_index (mapper.pyx:112-127): first match wins, no frequency filter.
+__global__ void k_in_index(const uint64_t *__restrict__ kmers, int64_t n, IndexView iv,
+                           uint8_t *__restrict__ out)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const uint64_t q = kmers[i];
+        const uint2 b = iv.buckets[fastmod(q, iv.modulo, iv.magic)];
+        uint8_t hit = 0;
+        for (uint32_t j = 0; j < b.y; ++j) {
+            uint4 e = iv.entries[(uint64_t)b.x + j];
+            if (((uint64_t)e.x | ((uint64_t)e.y << 32)) == q) {
+                hit = 1;
+                break;
+            }
+        }
+        out[i] = hit;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Index repack (on the GPU, at load).  Also the validation the reference does not do.
+// err bit 0: bucket outside [0, n_entries); bit 1: node outside [0, max_node_id].
+// ------------------------------------------------------------------------------------------------
+__global__ void k_pack_buckets(const int32_t *__restrict__ h2i, const int32_t *__restrict__ nk,
+                               uint64_t modulo, int64_t n_entries, uint2 *__restrict__ buckets,
+                               uint32_t *err)
+{
+    for (uint64_t h = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; h < modulo;
+         h += (uint64_t)gridDim.x * blockDim.x) {
+        int32_t c = nk[h], s = h2i[h];
+        if (c <= 0) { // `for j in range(n_local_hits)` runs zero times (mapper.pyx:58)
+            buckets[h] = make_uint2(0u, 0u);
+            continue;
+        }
+        if (s < 0 || (int64_t)s + c > n_entries) {
+            atomicOr(err, 1u);
+            buckets[h] = make_uint2(0u, 0u);
+            continue;
+        }
+        buckets[h] = make_uint2((uint32_t)s, (uint32_t)c);
+    }
+}
+
+__global__ void k_pack_entries(const uint64_t *__restrict__ kmers, const int32_t *__restrict__ nodes,
+                               const uint16_t *__restrict__ freqs, int64_t n, int64_t max_node_id,
+                               uint4 *__restrict__ entries, uint32_t *err)
+{
+    for (int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; l < n;
+         l += (int64_t)gridDim.x * blockDim.x) {
+        uint64_t km = kmers[l];
+        int32_t nd = nodes[l];
+        if (nd < 0 || (int64_t)nd > max_node_id) {
+            atomicOr(err, 2u);
+            nd = 0;
+        }
+        entries[l] = make_uint4((uint32_t)km, (uint32_t)(km >> 32), (uint32_t)nd, (uint32_t)freqs[l]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+int ensure(DevBuf &b, size_t bytes)
+{
+    if (bytes <= b.cap && b.p)
+        return KMM_OK;
+    if (b.p) {
+        HIPCHK(hipFree(b.p)); // blocks until the device is idle: safe w.r.t. in-flight kernels
+        b.p = nullptr;
+        b.cap = 0;
+    }
+    size_t want = bytes < 256 ? 256 : bytes;
+    hipError_t e = hipMalloc(&b.p, want);
+    if (e != hipSuccess) {
+        b.p = nullptr;
+        return fail(e == hipErrorOutOfMemory ? KMM_ERR_NOMEM : KMM_ERR_HIP,
+                    "hipMalloc(%zu bytes) -> %s", want, hipGetErrorString(e));
+    }
+    b.cap = want;
+    return KMM_OK;
+}
+
+void release(DevBuf &b)
+{
+    if (b.p)
+        (void)hipFree(b.p);
+    b.p = nullptr;
+    b.cap = 0;
+}
+
+bool is_device_ptr(const void *p)
+{
+    hipPointerAttribute_t a;
+    memset(&a, 0, sizeof a);
+    hipError_t e = hipPointerGetAttributes(&a, p);
+    if (e != hipSuccess) {
+        (void)hipGetLastError(); // unregistered host memory: clear the sticky error
+        return false;
+    }
+    return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
+}
+
+uint64_t magic_for(uint64_t m)
+{
+    if (m <= 1)
+        return ~0ull;
+    return (uint64_t)(((unsigned __int128)1 << 64) / m);
+}
+
+void default_lut(uint8_t lut[256])
+{
+    memset(lut, 0xFF, 256);
+    lut['A'] = lut['a'] = 0;
+    lut['C'] = lut['c'] = 1;
+    lut['G'] = lut['g'] = 2;
+    lut['T'] = lut['t'] = 3;
+    lut['N'] = lut['n'] = 0; // command_line_interface.py:41
+}
+
+struct Stage {
+    DevBuf bases, offsets, tile_first, kmers, lut;
+    hipEvent_t done = nullptr; // the last kernel that read this stage has finished
+    bool used = false;
+};
+
+constexpr unsigned long long NO_BAD = ~0ull;
+
+} // namespace
+
+struct kmm_index {
+    int device = 0;
+    hipStream_t stream = nullptr;      // kernels
+    hipStream_t copy_stream = nullptr; // host -> HBM staging, overlaps the previous kernel
+    hipEvent_t copied = nullptr;
+    uint2 *buckets = nullptr;
+    uint4 *entries = nullptr;
+    uint32_t *counts = nullptr;
+    bool own_counts = true;
+    uint32_t *own_counts_buf = nullptr;
+    uint8_t *lut_default = nullptr;
+    unsigned long long *first_bad = nullptr;
+    uint64_t modulo = 0, magic = 0;
+    int64_t n_entries = 0, max_node_id = 0;
+    Stage stage[2];
+    int cur = 0;
+    int variant = 0;
+    int n_cu = 256;
+    // timing
+    bool timing = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_used;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_free;
+    double ms_total = 0.0;
+    int64_t launches = 0;
+};
+
+namespace {
+
+IndexView view_of(const kmm_index *ix)
+{
+    IndexView v;
+    v.buckets = ix->buckets;
+    v.entries = ix->entries;
+    v.counts = ix->counts;
+    v.modulo = ix->modulo;
+    v.magic = ix->magic;
+    return v;
+}
+
+int timing_begin(kmm_index *ix, std::pair<hipEvent_t, hipEvent_t> &ev)
+{
+    if (!ix->timing)
+        return KMM_OK;
+    if (!ix->ev_free.empty()) {
+        ev = ix->ev_free.back();
+        ix->ev_free.pop_back();
+    } else {
+        HIPCHK(hipEventCreate(&ev.first));
+        HIPCHK(hipEventCreate(&ev.second));
+    }
+    HIPCHK(hipEventRecord(ev.first, ix->stream));
+    return KMM_OK;
+}
+
+int timing_end(kmm_index *ix, std::pair<hipEvent_t, hipEvent_t> &ev)
+{
+    if (!ix->timing)
+        return KMM_OK;
+    HIPCHK(hipEventRecord(ev.second, ix->stream));
+    ix->ev_used.push_back(ev);
+    return KMM_OK;
+}
+
+// Drain the stream and surface deferred device-side errors (invalid bases).
+int drain(kmm_index *ix)
+{
+    HIPCHK(hipStreamSynchronize(ix->copy_stream));
+    HIPCHK(hipStreamSynchronize(ix->stream));
+    unsigned long long bad = NO_BAD;
+    HIPCHK(hipMemcpy(&bad, ix->first_bad, sizeof bad, hipMemcpyDeviceToHost));
+    if (bad != NO_BAD) {
+        unsigned long long reset = NO_BAD;
+        HIPCHK(hipMemcpy(ix->first_bad, &reset, sizeof reset, hipMemcpyHostToDevice));
+        return fail(KMM_ERR_INVALID_BASE,
+                    "read byte at offset %llu of a mapped chunk is not a nucleotide under the "
+                    "lookup table (the reference's DNA encoder raises here)", bad);
+    }
+    return KMM_OK;
+}
+
+int grid_for(const kmm_index *ix, int64_t work_items, int per_cu)
+{
+    int64_t cap = (int64_t)ix->n_cu * per_cu;
+    int64_t g = work_items < cap ? work_items : cap;
+    return (int)(g < 1 ? 1 : g);
+}
+
+// Stage a host array into the given device buffer on the copy stream; device arrays pass through.
+template <typename TT>
+int stage_in(kmm_index *ix, DevBuf &buf, const TT *src, size_t count, const TT **dev, bool *staged)
+{
+    if (count == 0) {
+        KMMCHK(ensure(buf, 256));
+        *dev = static_cast<const TT *>(buf.p);
+        return KMM_OK;
+    }
+    if (is_device_ptr(src)) {
+        *dev = src;
+        return KMM_OK;
+    }
+    KMMCHK(ensure(buf, count * sizeof(TT)));
+    HIPCHK(hipMemcpyAsync(buf.p, src, count * sizeof(TT), hipMemcpyHostToDevice, ix->copy_stream));
+    *dev = static_cast<const TT *>(buf.p);
+    *staged = true;
+    return KMM_OK;
+}
+
+Stage &next_stage(kmm_index *ix)
+{
+    Stage &s = ix->stage[ix->cur];
+    ix->cur ^= 1;
+    return s;
+}
+
+// Common tail of every map call: kernels may start once the copies are in; the stage can be
+// overwritten once this call's kernels are done; host buffers are free once the copies are done.
+int stage_acquire(kmm_index *ix, Stage &s)
+{
+    if (s.used)
+        HIPCHK(hipStreamWaitEvent(ix->copy_stream, s.done, 0));
+    return KMM_OK;
+}
+
+int stage_copies_done(kmm_index *ix)
+{
+    HIPCHK(hipEventRecord(ix->copied, ix->copy_stream));
+    HIPCHK(hipStreamWaitEvent(ix->stream, ix->copied, 0));
+    return KMM_OK;
+}
+
+int stage_release(kmm_index *ix, Stage &s, bool staged)
+{
+    HIPCHK(hipEventRecord(s.done, ix->stream));
+    s.used = true;
+    if (staged)
+        HIPCHK(hipEventSynchronize(ix->copied)); // borrowed host pointers are free again
+    return KMM_OK;
+}
+
+int resolve_lut(kmm_index *ix, Stage &s, const uint8_t *lut, const uint8_t **dev, bool *staged)
+{
+    if (!lut) {
+        *dev = ix->lut_default;
+        return KMM_OK;
+    }
+    return stage_in<uint8_t>(ix, s.lut, lut, 256, dev, staged);
+}
+
+template <bool UNIFORM>
+int launch_map_reads(kmm_index *ix, const ReadsView &rv, int k, int max_freq, int also_rc)
+{
+    const IndexView iv = view_of(ix);
+    std::pair<hipEvent_t, hipEvent_t> ev{};
+    KMMCHK(timing_begin(ix, ev));
+    switch (ix->variant) {
+    case 1: {
+        constexpr int S = 4;
+        int64_t n_tiles = (rv.total + 256 * S - 1) / (256 * S);
+        hipLaunchKernelGGL((k_map_reads<S, UNIFORM>), dim3(grid_for(ix, n_tiles, 64)), dim3(256), 0,
+                           ix->stream, rv, iv, k, max_freq, also_rc);
+        break;
+    }
+    default: {
+        constexpr int S = 8;
+        int64_t n_tiles = (rv.total + 256 * S - 1) / (256 * S);
+        hipLaunchKernelGGL((k_map_reads<S, UNIFORM>), dim3(grid_for(ix, n_tiles, 64)), dim3(256), 0,
+                           ix->stream, rv, iv, k, max_freq, also_rc);
+        break;
+    }
+    }
+    HIPCHK(hipGetLastError());
+    KMMCHK(timing_end(ix, ev));
+    return KMM_OK;
+}
+
+int tile_size_for(const kmm_index *ix)
+{
+    return ix->variant == 1 ? 256 * 4 : 256 * 8;
+}
+
+int check_k(int k)
+{
+    if (k < 1 || k > KMM_MAX_K)
+        return fail(KMM_ERR_INVALID_ARG, "k=%d outside [1, %d]", k, KMM_MAX_K);
+    return KMM_OK;
+}
+
+} // namespace
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+extern "C" {
+
+const char *kmm_version(void) { return "kmm 0.1.0 (gfx950)"; }
+
+const char *kmm_last_error(void) { return g_err.c_str(); }
+
+int kmm_device_count(int *n_devices)
+{
+    if (!n_devices)
+        return fail(KMM_ERR_INVALID_ARG, "n_devices is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        n = 0;
+    }
+    *n_devices = n;
+    return KMM_OK;
+}
+
+void kmm_index_destroy(kmm_index_t *ix)
+{
+    if (!ix)
+        return;
+    (void)hipSetDevice(ix->device);
+    if (ix->stream)
+        (void)hipStreamSynchronize(ix->stream);
+    if (ix->copy_stream)
+        (void)hipStreamSynchronize(ix->copy_stream);
+    for (Stage &s : ix->stage) {
+        release(s.bases);
+        release(s.offsets);
+        release(s.tile_first);
+        release(s.kmers);
+        release(s.lut);
+        if (s.done)
+            (void)hipEventDestroy(s.done);
+    }
+    for (auto &ev : ix->ev_used) {
+        (void)hipEventDestroy(ev.first);
+        (void)hipEventDestroy(ev.second);
+    }
+    for (auto &ev : ix->ev_free) {
+        (void)hipEventDestroy(ev.first);
+        (void)hipEventDestroy(ev.second);
+    }
+    if (ix->copied)
+        (void)hipEventDestroy(ix->copied);
+    if (ix->buckets)
+        (void)hipFree(ix->buckets);
+    if (ix->entries)
+        (void)hipFree(ix->entries);
+    if (ix->own_counts_buf)
+        (void)hipFree(ix->own_counts_buf);
+    if (ix->lut_default)
+        (void)hipFree(ix->lut_default);
+    if (ix->first_bad)
+        (void)hipFree(ix->first_bad);
+    if (ix->copy_stream)
+        (void)hipStreamDestroy(ix->copy_stream);
+    if (ix->stream)
+        (void)hipStreamDestroy(ix->stream);
+    delete ix;
+}
+
+static int index_create_impl(kmm_index *ix, const int32_t *h2i, const int32_t *nk,
+                             const uint64_t *kmers, const int32_t *nodes, const uint16_t *freqs)
+{
+    const uint64_t M = ix->modulo;
+    const int64_t N = ix->n_entries;
+    HIPCHK(hipSetDevice(ix->device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, ix->device));
+    ix->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    HIPCHK(hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&ix->copy_stream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&ix->copied, hipEventDisableTiming));
+    for (Stage &s : ix->stage)
+        HIPCHK(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+
+    HIPCHK(hipMalloc(&ix->buckets, sizeof(uint2) * (size_t)M));
+    HIPCHK(hipMalloc(&ix->entries, sizeof(uint4) * (size_t)(N > 0 ? N : 1)));
+    HIPCHK(hipMalloc(&ix->own_counts_buf, sizeof(uint32_t) * (size_t)(ix->max_node_id + 1)));
+    ix->counts = ix->own_counts_buf;
+    HIPCHK(hipMemsetAsync(ix->counts, 0, sizeof(uint32_t) * (size_t)(ix->max_node_id + 1), ix->stream));
+    HIPCHK(hipMalloc(&ix->lut_default, 256));
+    HIPCHK(hipMalloc(&ix->first_bad, sizeof(unsigned long long)));
+    uint8_t lut[256];
+    default_lut(lut);
+    HIPCHK(hipMemcpy(ix->lut_default, lut, 256, hipMemcpyHostToDevice));
+    unsigned long long nb = NO_BAD;
+    HIPCHK(hipMemcpy(ix->first_bad, &nb, sizeof nb, hipMemcpyHostToDevice));
+
+    // raw arrays -> HBM (temporary), repack + validate on the GPU
+    DevBuf d_h2i, d_nk, d_km, d_nd, d_fr, d_err;
+    bool staged = false;
+    const int32_t *p_h2i, *p_nk, *p_nd;
+    const uint64_t *p_km;
+    const uint16_t *p_fr;
+    int rc = KMM_OK;
+    do {
+        if ((rc = stage_in<int32_t>(ix, d_h2i, h2i, (size_t)M, &p_h2i, &staged))) break;
+        if ((rc = stage_in<int32_t>(ix, d_nk, nk, (size_t)M, &p_nk, &staged))) break;
+        if ((rc = stage_in<uint64_t>(ix, d_km, kmers, (size_t)N, &p_km, &staged))) break;
+        if ((rc = stage_in<int32_t>(ix, d_nd, nodes, (size_t)N, &p_nd, &staged))) break;
+        if ((rc = stage_in<uint16_t>(ix, d_fr, freqs, (size_t)N, &p_fr, &staged))) break;
+        if ((rc = ensure(d_err, 4))) break;
+    } while (0);
+    if (rc == KMM_OK) {
+        hipError_t e = hipMemsetAsync(d_err.p, 0, 4, ix->copy_stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ix->copy_stream);
+        if (e != hipSuccess)
+            rc = fail(KMM_ERR_HIP, "index upload: %s", hipGetErrorString(e));
+    }
+    uint32_t err = 0;
+    if (rc == KMM_OK) {
+        hipLaunchKernelGGL(k_pack_buckets, dim3(grid_for(ix, (int64_t)((M + 255) / 256), 16)),
+                           dim3(256), 0, ix->stream, p_h2i, p_nk, M, N, ix->buckets,
+                           (uint32_t *)d_err.p);
+        if (N > 0)
+            hipLaunchKernelGGL(k_pack_entries, dim3(grid_for(ix, (N + 255) / 256, 16)), dim3(256),
+                               0, ix->stream, p_km, p_nd, p_fr, N, ix->max_node_id, ix->entries,
+                               (uint32_t *)d_err.p);
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(ix->stream);
+        if (e == hipSuccess) e = hipMemcpy(&err, d_err.p, 4, hipMemcpyDeviceToHost);
+        if (e != hipSuccess)
+            rc = fail(KMM_ERR_HIP, "index repack: %s", hipGetErrorString(e));
+    }
+    release(d_h2i); release(d_nk); release(d_km); release(d_nd); release(d_fr); release(d_err);
+    if (rc != KMM_OK)
+        return rc;
+    if (err & 1u)
+        return fail(KMM_ERR_INDEX, "index inconsistent: a non-empty bucket "
+                    "(hashes_to_index[h], n_kmers[h]) reaches outside [0, n_entries=%lld)",
+                    (long long)N);
+    if (err & 2u)
+        return fail(KMM_ERR_INDEX, "index inconsistent: a node id lies outside [0, max_node_id=%lld]",
+                    (long long)ix->max_node_id);
+    return KMM_OK;
+}
+
+int kmm_index_create(const int32_t *hashes_to_index, const int32_t *n_kmers, uint64_t modulo,
+                     const uint64_t *kmers, const int32_t *nodes, const uint16_t *frequencies,
+                     int64_t n_entries, int64_t max_node_id, int device, kmm_index_t **out)
+{
+    if (!out)
+        return fail(KMM_ERR_INVALID_ARG, "out is NULL");
+    *out = nullptr;
+    if (!hashes_to_index || !n_kmers)
+        return fail(KMM_ERR_INVALID_ARG, "hashes_to_index / n_kmers is NULL");
+    if (modulo < 1)
+        return fail(KMM_ERR_INVALID_ARG, "modulo must be >= 1");
+    if (n_entries < 0 || max_node_id < 0)
+        return fail(KMM_ERR_INVALID_ARG, "n_entries=%lld / max_node_id=%lld negative",
+                    (long long)n_entries, (long long)max_node_id);
+    if (n_entries > 0 && (!kmers || !nodes || !frequencies))
+        return fail(KMM_ERR_INVALID_ARG, "kmers / nodes / frequencies is NULL");
+    if (n_entries > 0xFFFFFFFFll)
+        return fail(KMM_ERR_INVALID_ARG, "n_entries exceeds the int32 bucket offsets of the index format");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev < 1) {
+        (void)hipGetLastError();
+        return fail(KMM_ERR_HIP, "no HIP device available (%s): libkmm has no CPU fallback",
+                    e != hipSuccess ? hipGetErrorString(e) : "0 devices");
+    }
+    if (device < 0 || device >= ndev)
+        return fail(KMM_ERR_INVALID_ARG, "device %d outside [0, %d)", device, ndev);
+    kmm_index *ix = new kmm_index();
+    ix->device = device;
+    ix->modulo = modulo;
+    ix->magic = magic_for(modulo);
+    ix->n_entries = n_entries;
+    ix->max_node_id = max_node_id;
+    int rc = index_create_impl(ix, hashes_to_index, n_kmers, kmers, nodes, frequencies);
+    if (rc != KMM_OK) {
+        std::string keep = g_err;
+        kmm_index_destroy(ix);
+        g_err = keep;
+        return rc;
+    }
+    *out = ix;
+    return KMM_OK;
+}
+
+int kmm_reset_counts(kmm_index_t *ix)
+{
+    if (!ix)
+        return fail(KMM_ERR_INVALID_ARG, "idx is NULL");
+    HIPCHK(hipSetDevice(ix->device));
+    HIPCHK(hipMemsetAsync(ix->counts, 0, sizeof(uint32_t) * (size_t)(ix->max_node_id + 1), ix->stream));
+    return KMM_OK;
+}
+
+int kmm_bind_counts(kmm_index_t *ix, uint32_t *device_counts)
+{
+    if (!ix)
+        return fail(KMM_ERR_INVALID_ARG, "idx is NULL");
+    HIPCHK(hipSetDevice(ix->device));
+    HIPCHK(hipStreamSynchronize(ix->stream));
+    if (!device_counts) {
+        ix->counts = ix->own_counts_buf;
+        return KMM_OK;
+    }
+    if (!is_device_ptr(device_counts))
+        return fail(KMM_ERR_INVALID_ARG, "kmm_bind_counts needs a device pointer");
+    ix->counts = device_counts;
+    return KMM_OK;
+}
+
+int kmm_counts_device_ptr(kmm_index_t *ix, uint32_t **out)
+{
+    if (!ix || !out)
+        return fail(KMM_ERR_INVALID_ARG, "NULL argument");
+    *out = ix->counts;
+    return KMM_OK;
+}
+
+int kmm_synchronize(kmm_index_t *ix)
+{
+    if (!ix)
+        return fail(KMM_ERR_INVALID_ARG, "idx is NULL");
+    HIPCHK(hipSetDevice(ix->device));
+    return drain(ix);
+}
+
+int kmm_get_node_counts(kmm_index_t *ix, uint32_t *out)
+{
+    if (!ix || !out)
+        return fail(KMM_ERR_INVALID_ARG, "NULL argument");
+    HIPCHK(hipSetDevice(ix->device));
+    KMMCHK(drain(ix));
+    HIPCHK(hipMemcpy(out, ix->counts, sizeof(uint32_t) * (size_t)(ix->max_node_id + 1),
+                     is_device_ptr(out) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost));
+    return KMM_OK;
+}
+
+int kmm_map_kmers(kmm_index_t *ix, const uint64_t *kmers, int64_t n, int max_freq, int also_revcomp,
+                  int k)
+{
+    if (!ix)
+        return fail(KMM_ERR_INVALID_ARG, "idx is NULL");
+    if (n < 0 || (n > 0 && !kmers))
+        return fail(KMM_ERR_INVALID_ARG, "kmers NULL or n negative");
+    if (also_revcomp)
+        KMMCHK(check_k(k));
+    if (n == 0)
+        return KMM_OK;
+    HIPCHK(hipSetDevice(ix->device));
+    Stage &s = next_stage(ix);
+    KMMCHK(stage_acquire(ix, s));
+    bool staged = false;
+    const uint64_t *d_kmers = nullptr;
+    KMMCHK(stage_in<uint64_t>(ix, s.kmers, kmers, (size_t)n, &d_kmers, &staged));
+    KMMCHK(stage_copies_done(ix));
+    constexpr int U = 8;
+    std::pair<hipEvent_t, hipEvent_t> ev{};
+    KMMCHK(timing_begin(ix, ev));
+    hipLaunchKernelGGL((k_map_kmers<U>), dim3(grid_for(ix, (n + 256 * U - 1) / (256 * U), 64)),
+                       dim3(256), 0, ix->stream, d_kmers, n, view_of(ix), max_freq,
+                       also_revcomp ? 1 : 0, k);
+    HIPCHK(hipGetLastError());
+    KMMCHK(timing_end(ix, ev));
+    return stage_release(ix, s, staged);
+}
+
+static int map_reads_common(kmm_index_t *ix, const uint8_t *bases, const int64_t *read_offsets,
+                            int64_t n_reads, int64_t read_len, int k, int max_freq,
+                            int also_revcomp, const uint8_t *lut)
+{
+    const bool uniform = (read_offsets == nullptr);
+    HIPCHK(hipSetDevice(ix->device));
+    int64_t total = 0;
+    const bool offs_on_device = !uniform && is_device_ptr(read_offsets);
+    if (uniform) {
+        total = n_reads * read_len;
+    } else {
+        int64_t ends[2] = {0, 0};
+        if (offs_on_device) {
+            HIPCHK(hipMemcpy(&ends[0], read_offsets, 8, hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(&ends[1], read_offsets + n_reads, 8, hipMemcpyDeviceToHost));
+        } else {
+            ends[0] = read_offsets[0];
+            ends[1] = read_offsets[n_reads];
+        }
+        if (ends[0] != 0)
+            return fail(KMM_ERR_INVALID_ARG, "read_offsets[0] must be 0 (got %lld)", (long long)ends[0]);
+        if (ends[1] < 0)
+            return fail(KMM_ERR_INVALID_ARG, "read_offsets[n_reads] negative");
+        if (!offs_on_device)
+            for (int64_t r = 0; r < n_reads; ++r)
+                if (read_offsets[r + 1] < read_offsets[r])
+                    return fail(KMM_ERR_INVALID_ARG, "read_offsets not non-decreasing at read %lld",
+                                (long long)r);
+        total = ends[1];
+    }
+    if (total == 0)
+        return KMM_OK;
+    if (!bases)
+        return fail(KMM_ERR_INVALID_ARG, "bases is NULL");
+
+    Stage &s = next_stage(ix);
+    KMMCHK(stage_acquire(ix, s));
+    bool staged = false;
+    ReadsView rv;
+    memset(&rv, 0, sizeof rv);
+    KMMCHK(stage_in<uint8_t>(ix, s.bases, bases, (size_t)total, &rv.bases, &staged));
+    KMMCHK(resolve_lut(ix, s, lut, &rv.lut, &staged));
+    rv.total = total;
+    rv.n_reads = n_reads;
+    rv.first_bad = ix->first_bad;
+    const int T = tile_size_for(ix);
+    const int64_t n_tiles = (total + T - 1) / T;
+    // the uniform kernel's wrap-around handles one read boundary per lane: needs read_len >= S
+    const bool uniform_kernel = uniform && read_len >= 16;
+    if (uniform_kernel) {
+        rv.read_len = (uint64_t)read_len;
+        rv.read_len_magic = magic_for((uint64_t)read_len);
+        KMMCHK(stage_copies_done(ix));
+        KMMCHK(launch_map_reads<true>(ix, rv, k, max_freq, also_revcomp ? 1 : 0));
+    } else {
+        if (uniform) {
+            KMMCHK(ensure(s.offsets, (size_t)(n_reads + 1) * 8));
+            hipLaunchKernelGGL(k_iota_offsets, dim3((unsigned)((n_reads + 1 + 255) / 256)), dim3(256),
+                               0, ix->copy_stream, (int64_t *)s.offsets.p, n_reads, read_len);
+            HIPCHK(hipGetLastError());
+            rv.offsets = (const int64_t *)s.offsets.p;
+        } else {
+            KMMCHK(stage_in<int64_t>(ix, s.offsets, read_offsets, (size_t)(n_reads + 1), &rv.offsets,
+                                     &staged));
+        }
+        KMMCHK(ensure(s.tile_first, (size_t)n_tiles * 8));
+        rv.tile_first = (const int64_t *)s.tile_first.p;
+        KMMCHK(stage_copies_done(ix));
+        hipLaunchKernelGGL(k_tile_first, dim3((unsigned)((n_tiles + 255) / 256)), dim3(256), 0,
+                           ix->stream, rv.offsets, n_reads, n_tiles, T, (int64_t *)s.tile_first.p);
+        HIPCHK(hipGetLastError());
+        KMMCHK(launch_map_reads<false>(ix, rv, k, max_freq, also_revcomp ? 1 : 0));
+    }
+    return stage_release(ix, s, staged);
+}
+
+int kmm_map_reads(kmm_index_t *ix, const uint8_t *bases, const int64_t *read_offsets, int64_t n_reads,
+                  int k, int max_freq, int also_revcomp, const uint8_t *lut)
+{
+    if (!ix)
+        return fail(KMM_ERR_INVALID_ARG, "idx is NULL");
+    KMMCHK(check_k(k));
+    if (n_reads < 0)
+        return fail(KMM_ERR_INVALID_ARG, "n_reads negative");
+    if (n_reads == 0)
+        return KMM_OK;
+    if (!read_offsets)
+        return fail(KMM_ERR_INVALID_ARG, "read_offsets is NULL");
+    return map_reads_common(ix, bases, read_offsets, n_reads, 0, k, max_freq, also_revcomp, lut);
+}
+
+int kmm_map_reads_uniform(kmm_index_t *ix, const uint8_t *bases, int64_t n_reads, int64_t read_len,
+                          int k, int max_freq, int also_revcomp, const uint8_t *lut)
+{
+    if (!ix)
+        return fail(KMM_ERR_INVALID_ARG, "idx is NULL");
+    KMMCHK(check_k(k));
+    if (n_reads < 0 || read_len < 0)
+        return fail(KMM_ERR_INVALID_ARG, "n_reads / read_len negative");
+    if (n_reads == 0 || read_len == 0)
+        return KMM_OK;
+    return map_reads_common(ix, bases, nullptr, n_reads, read_len, k, max_freq, also_revcomp, lut);
+}
+
+int kmm_in_index(kmm_index_t *ix, const uint64_t *kmers, int64_t n, uint8_t *out)
+{
+    if (!ix)
+        return fail(KMM_ERR_INVALID_ARG, "idx is NULL");
+    if (n < 0 || (n > 0 && (!kmers || !out)))
+        return fail(KMM_ERR_INVALID_ARG, "NULL argument or n negative");
+    if (n == 0)
+        return KMM_OK;
+    HIPCHK(hipSetDevice(ix->device));
+    Stage &s = next_stage(ix);
+    KMMCHK(stage_acquire(ix, s));
+    bool staged = false;
+    const uint64_t *d_kmers = nullptr;
+    KMMCHK(stage_in<uint64_t>(ix, s.kmers, kmers, (size_t)n, &d_kmers, &staged));
+    KMMCHK(stage_copies_done(ix));
+    const bool out_dev = is_device_ptr(out);
+    DevBuf tmp;
+    uint8_t *d_out = out;
+    if (!out_dev) {
+        KMMCHK(ensure(tmp, (size_t)n));
+        d_out = (uint8_t *)tmp.p;
+    }
+    hipLaunchKernelGGL(k_in_index, dim3(grid_for(ix, (n + 255) / 256, 32)), dim3(256), 0, ix->stream,
+                       d_kmers, n, view_of(ix), d_out);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess && !out_dev)
+        e = hipMemcpyAsync(out, d_out, (size_t)n, hipMemcpyDeviceToHost, ix->stream);
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(ix->stream);
+    release(tmp);
+    if (e != hipSuccess)
+        return fail(KMM_ERR_HIP, "kmm_in_index: %s", hipGetErrorString(e));
+    return stage_release(ix, s, staged);
+}
+
+int kmm_extract_kmers(int device, const uint8_t *bases, const int64_t *read_offsets, int64_t n_reads,
+                      int k, const uint8_t *lut, uint64_t *out, int64_t n_out)
+{
+    KMMCHK(check_k(k));
+    if (n_reads < 0 || n_out < 0)
+        return fail(KMM_ERR_INVALID_ARG, "negative size");
+    if (n_reads == 0)
+        return n_out == 0 ? KMM_OK : fail(KMM_ERR_INVALID_ARG, "n_out != 0 for zero reads");
+    if (!read_offsets)
+        return fail(KMM_ERR_INVALID_ARG, "read_offsets is NULL");
+    int ndev = 0;
+    hipError_t e0 = hipGetDeviceCount(&ndev);
+    if (e0 != hipSuccess || ndev < 1) {
+        (void)hipGetLastError();
+        return fail(KMM_ERR_HIP, "no HIP device available: libkmm has no CPU fallback");
+    }
+    HIPCHK(hipSetDevice(device));
+    // host copy of the offsets for the prefix sums of per-read k-mer counts
+    std::vector<int64_t> offs((size_t)n_reads + 1);
+    if (is_device_ptr(read_offsets))
+        HIPCHK(hipMemcpy(offs.data(), read_offsets, offs.size() * 8, hipMemcpyDeviceToHost));
+    else
+        memcpy(offs.data(), read_offsets, offs.size() * 8);
+    if (offs[0] != 0)
+        return fail(KMM_ERR_INVALID_ARG, "read_offsets[0] must be 0");
+    std::vector<int64_t> koffs((size_t)n_reads + 1);
+    koffs[0] = 0;
+    for (int64_t r = 0; r < n_reads; ++r) {
+        int64_t len = offs[r + 1] - offs[r];
+        if (len < 0)
+            return fail(KMM_ERR_INVALID_ARG, "read_offsets not non-decreasing at read %lld", (long long)r);
+        koffs[r + 1] = koffs[r] + (len >= k ? len - k + 1 : 0);
+    }
+    if (koffs[n_reads] != n_out)
+        return fail(KMM_ERR_INVALID_ARG, "n_out=%lld but the reads hold %lld k-mers", (long long)n_out,
+                    (long long)koffs[n_reads]);
+    const int64_t total = offs[n_reads];
+    if (total == 0 || n_out == 0)
+        return KMM_OK;
+    if (!bases || !out)
+        return fail(KMM_ERR_INVALID_ARG, "bases / out is NULL");
+
+    DevBuf d_bases, d_offs, d_koffs, d_lut, d_out, d_bad;
+    int rc = KMM_OK;
+    hipError_t e = hipSuccess;
+    const uint8_t *p_bases = bases;
+    uint64_t *p_out = out;
+    const bool bases_dev = is_device_ptr(bases), out_dev = is_device_ptr(out);
+    uint8_t lutbuf[256];
+    if (lut) {
+        if (is_device_ptr(lut))
+            e = hipMemcpy(lutbuf, lut, 256, hipMemcpyDeviceToHost);
+        else
+            memcpy(lutbuf, lut, 256);
+    } else {
+        default_lut(lutbuf);
+    }
+    unsigned long long bad = NO_BAD;
+    do {
+        if (e != hipSuccess) break;
+        if (!bases_dev) {
+            if ((rc = ensure(d_bases, (size_t)total))) break;
+            if ((e = hipMemcpy(d_bases.p, bases, (size_t)total, hipMemcpyHostToDevice))) break;
+            p_bases = (const uint8_t *)d_bases.p;
+        }
+        if (!out_dev) {
+            if ((rc = ensure(d_out, (size_t)n_out * 8))) break;
+            p_out = (uint64_t *)d_out.p;
+        }
+        if ((rc = ensure(d_offs, offs.size() * 8))) break;
+        if ((rc = ensure(d_koffs, koffs.size() * 8))) break;
+        if ((rc = ensure(d_lut, 256))) break;
+        if ((rc = ensure(d_bad, 8))) break;
+        if ((e = hipMemcpy(d_offs.p, offs.data(), offs.size() * 8, hipMemcpyHostToDevice))) break;
+        if ((e = hipMemcpy(d_koffs.p, koffs.data(), koffs.size() * 8, hipMemcpyHostToDevice))) break;
+        if ((e = hipMemcpy(d_lut.p, lutbuf, 256, hipMemcpyHostToDevice))) break;
+        if ((e = hipMemcpy(d_bad.p, &bad, 8, hipMemcpyHostToDevice))) break;
+        int64_t blocks = (total + 255) / 256;
+        if (blocks > 65536) blocks = 65536;
+        hipLaunchKernelGGL(k_extract_kmers, dim3((unsigned)blocks), dim3(256), 0, 0, p_bases,
+                           (const int64_t *)d_offs.p, (const int64_t *)d_koffs.p, n_reads, k,
+                           (const uint8_t *)d_lut.p, p_out, (unsigned long long *)d_bad.p);
+        if ((e = hipGetLastError())) break;
+        if ((e = hipDeviceSynchronize())) break;
+        if ((e = hipMemcpy(&bad, d_bad.p, 8, hipMemcpyDeviceToHost))) break;
+        if (!out_dev)
+            if ((e = hipMemcpy(out, d_out.p, (size_t)n_out * 8, hipMemcpyDeviceToHost))) break;
+    } while (0);
+    release(d_bases); release(d_offs); release(d_koffs); release(d_lut); release(d_out); release(d_bad);
+    if (rc != KMM_OK)
+        return rc;
+    if (e != hipSuccess)
+        return fail(KMM_ERR_HIP, "kmm_extract_kmers: %s", hipGetErrorString(e));
+    if (bad != NO_BAD)
+        return fail(KMM_ERR_INVALID_BASE, "read byte at offset %llu is not a nucleotide under the "
+                    "lookup table (the reference's DNA encoder raises here)", bad);
+    return KMM_OK;
+}
+
+int kmm_set_timing(kmm_index_t *ix, int enabled)
+{
+    if (!ix)
+        return fail(KMM_ERR_INVALID_ARG, "idx is NULL");
+    ix->timing = enabled != 0;
+    return KMM_OK;
+}
+
+int kmm_get_timing(kmm_index_t *ix, double *kernel_ms, int64_t *n_launches)
+{
+    if (!ix)
+        return fail(KMM_ERR_INVALID_ARG, "idx is NULL");
+    HIPCHK(hipSetDevice(ix->device));
+    HIPCHK(hipStreamSynchronize(ix->stream));
+    for (auto &ev : ix->ev_used) {
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, ev.first, ev.second));
+        ix->ms_total += ms;
+        ix->launches += 1;
+        ix->ev_free.push_back(ev);
+    }
+    ix->ev_used.clear();
+    if (kernel_ms)
+        *kernel_ms = ix->ms_total;
+    if (n_launches)
+        *n_launches = ix->launches;
+    ix->ms_total = 0.0;
+    ix->launches = 0;
+    return KMM_OK;
+}
+
+int kmm_set_variant(kmm_index_t *ix, int variant)
+{
+    if (!ix)
+        return fail(KMM_ERR_INVALID_ARG, "idx is NULL");
+    HIPCHK(hipSetDevice(ix->device));
+    HIPCHK(hipStreamSynchronize(ix->stream)); // tile size changes with the variant
+    ix->variant = variant;
+    return KMM_OK;
+}
+
+} // extern "C"

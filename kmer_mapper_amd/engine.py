@@ -1,0 +1,186 @@
+"""DeviceIndex — a Kmer Index resident in HBM plus its uint32 node-count vector.
+
+Thin object wrapper over the C ABI (include/kmm.h).  Everything the reference does per chunk in
+map_cpu (kmer_mapper/command_line_interface.py:32-56) happens inside `map_reads`; the
+operator-level `map_kmers` is the drop-in for mapper.pyx:19-72.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+
+_P = ctypes.c_void_p
+
+
+def _is_torch_tensor(x):
+    return type(x).__module__.startswith("torch") and hasattr(x, "data_ptr")
+
+
+class _Arg:
+    """A borrowed pointer for one C call: numpy array (host) or torch tensor (host or device)."""
+
+    def __init__(self, x, dtype, name):
+        self.keep = None
+        if x is None:
+            self.ptr, self.n = None, 0
+            return
+        if _is_torch_tensor(x):
+            import torch
+            want = {np.uint8: torch.uint8, np.int64: torch.int64, np.int32: torch.int32,
+                    np.uint64: getattr(torch, "uint64", None), np.uint16: getattr(torch, "uint16", None)}[dtype]
+            if x.dtype != want and not (dtype is np.uint64 and x.dtype == torch.int64):
+                raise ValueError("Buffer dtype mismatch for %s: expected %s got %s"
+                                 % (name, np.dtype(dtype), x.dtype))
+            if not x.is_contiguous():
+                raise ValueError("%s: ndarray is not C-contiguous" % name)
+            self.keep, self.ptr, self.n = x, _P(x.data_ptr()), x.numel()
+            return
+        a = np.asarray(x)
+        if a.dtype != np.dtype(dtype):
+            # the reference's typed memoryviews reject other dtypes (mapper.pyx:19,22-28)
+            raise ValueError("Buffer dtype mismatch for %s: expected '%s' but got '%s'"
+                             % (name, np.dtype(dtype), a.dtype))
+        if not a.flags.c_contiguous:
+            raise ValueError("%s: ndarray is not C-contiguous" % name)
+        self.keep, self.ptr, self.n = a, a.ctypes.data_as(_P), a.size
+
+
+class DeviceIndex:
+    """The five index arrays of graph_kmer_index.KmerIndex (mapper.pyx:22-29) repacked in HBM."""
+
+    def __init__(self, hashes_to_index, n_kmers, modulo, kmers, nodes, frequencies, max_node_id,
+                 device=0):
+        L = _lib.lib()
+        h2i = _Arg(hashes_to_index, np.int32, "hashes_to_index")
+        nk = _Arg(n_kmers, np.int32, "n_kmers")
+        km = _Arg(kmers, np.uint64, "kmers")
+        nd = _Arg(nodes, np.int32, "nodes")
+        fr = _Arg(frequencies, np.uint16, "frequencies")
+        modulo = int(modulo)
+        if h2i.n != modulo or nk.n != modulo:
+            raise ValueError("hashes_to_index / n_kmers must have `modulo`=%d entries (got %d, %d)"
+                             % (modulo, h2i.n, nk.n))
+        if not (km.n == nd.n == fr.n):
+            raise ValueError("kmers / nodes / frequencies differ in length")
+        self._h = _P()
+        self.max_node_id = int(max_node_id)
+        self.modulo = modulo
+        self.n_entries = km.n
+        self.device = int(device)
+        _lib.check(L.kmm_index_create(h2i.ptr, nk.ptr, modulo, km.ptr, nd.ptr, fr.ptr, km.n,
+                                      self.max_node_id, self.device, ctypes.byref(self._h)))
+        self._bound = None
+
+    @classmethod
+    def from_index(cls, index, max_node_id=None, device=0):
+        """From any object with the attributes mapper.pyx:22-29 reads (duck-typed, like the reference)."""
+        if max_node_id is None:
+            max_node_id = index.max_node_id()
+        return cls(index._hashes_to_index, index._n_kmers, index._modulo, index._kmers,
+                   index._nodes, index._frequencies, max_node_id, device=device)
+
+    # -- lifetime --------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            _lib.lib().kmm_index_destroy(self._h)
+            self._h = _P()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- counts ----------------------------------------------------------------------------------
+    def reset(self):
+        _lib.check(_lib.lib().kmm_reset_counts(self._h))
+
+    def bind_counts(self, tensor):
+        """Accumulate into a caller-owned device tensor of max_node_id+1 32-bit ints (for RCCL)."""
+        if tensor is None:
+            _lib.check(_lib.lib().kmm_bind_counts(self._h, None))
+            self._bound = None
+            return
+        if tensor.numel() != self.max_node_id + 1 or tensor.element_size() != 4:
+            raise ValueError("bind_counts needs %d 32-bit elements" % (self.max_node_id + 1))
+        _lib.check(_lib.lib().kmm_bind_counts(self._h, _P(tensor.data_ptr())))
+        self._bound = tensor
+
+    def synchronize(self):
+        _lib.check(_lib.lib().kmm_synchronize(self._h))
+
+    def get_node_counts(self, out=None):
+        if out is None:
+            out = np.empty(self.max_node_id + 1, dtype=np.uint32)
+        _lib.check(_lib.lib().kmm_get_node_counts(self._h, out.ctypes.data_as(_P)))
+        return out
+
+    # -- the hot path ----------------------------------------------------------------------------
+    def map_kmers(self, kmers, max_index_lookup_frequency=1000, also_revcomp=False, k=31):
+        a = _Arg(kmers, np.uint64, "kmers")
+        _lib.check(_lib.lib().kmm_map_kmers(self._h, a.ptr, a.n, int(max_index_lookup_frequency),
+                                            int(bool(also_revcomp)), int(k)))
+
+    def map_reads(self, bases, read_offsets, k=31, max_index_lookup_frequency=1000,
+                  also_revcomp=False, lut=None):
+        b = _Arg(bases, np.uint8, "bases")
+        o = _Arg(read_offsets, np.int64, "read_offsets")
+        t = _Arg(lut, np.uint8, "lut")
+        if lut is not None and t.n != 256:
+            raise ValueError("lut must have 256 entries")
+        if o.n < 1:
+            raise ValueError("read_offsets needs n_reads+1 entries")
+        _lib.check(_lib.lib().kmm_map_reads(self._h, b.ptr, o.ptr, o.n - 1, int(k),
+                                            int(max_index_lookup_frequency),
+                                            int(bool(also_revcomp)), t.ptr))
+
+    def map_reads_uniform(self, bases, n_reads, read_len, k=31, max_index_lookup_frequency=1000,
+                          also_revcomp=False, lut=None):
+        b = _Arg(bases, np.uint8, "bases")
+        t = _Arg(lut, np.uint8, "lut")
+        if b.n < int(n_reads) * int(read_len):
+            raise ValueError("bases holds %d bytes, need n_reads*read_len=%d"
+                             % (b.n, int(n_reads) * int(read_len)))
+        _lib.check(_lib.lib().kmm_map_reads_uniform(self._h, b.ptr, int(n_reads), int(read_len),
+                                                    int(k), int(max_index_lookup_frequency),
+                                                    int(bool(also_revcomp)), t.ptr))
+
+    def in_index(self, kmers):
+        a = _Arg(kmers, np.uint64, "kmers")
+        out = np.zeros(a.n, dtype=np.uint8)
+        _lib.check(_lib.lib().kmm_in_index(self._h, a.ptr, a.n, out.ctypes.data_as(_P)))
+        return out
+
+    # -- measurement -----------------------------------------------------------------------------
+    def set_timing(self, on=True):
+        _lib.check(_lib.lib().kmm_set_timing(self._h, int(bool(on))))
+
+    def get_timing(self):
+        ms = ctypes.c_double(0.0)
+        n = ctypes.c_int64(0)
+        _lib.check(_lib.lib().kmm_get_timing(self._h, ctypes.byref(ms), ctypes.byref(n)))
+        return ms.value, n.value
+
+    def set_variant(self, v):
+        _lib.check(_lib.lib().kmm_set_variant(self._h, int(v)))
+
+
+def extract_kmers(bases, read_offsets, k, lut=None, device=0):
+    """Operator form of util.py:71-75 on the GPU: flat uint64 k-mers in (read, offset) order."""
+    b = _Arg(bases, np.uint8, "bases")
+    offs = np.ascontiguousarray(np.asarray(read_offsets, dtype=np.int64))
+    t = _Arg(lut, np.uint8, "lut")
+    lens = np.diff(offs)
+    n_out = int(np.maximum(lens - int(k) + 1, 0).sum())
+    out = np.empty(n_out, dtype=np.uint64)
+    _lib.check(_lib.lib().kmm_extract_kmers(int(device), b.ptr, offs.ctypes.data_as(_P),
+                                            offs.size - 1, int(k), t.ptr,
+                                            out.ctypes.data_as(_P), n_out))
+    return out

@@ -1,0 +1,299 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle, the reference's known
+answers and the committed goldens.  Bit-exact: this is integer work."""
+import numpy as np
+import pytest
+
+from tests.helpers import batch, golden_small, index_from_vector, reference_vectors
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def kmm():
+    from kmer_mapper_amd import _lib
+    assert _lib.device_count() >= 1, "GPU tests need a HIP device"
+    import kmer_mapper_amd.engine as engine
+    return engine
+
+
+@pytest.fixture(scope="module")
+def syn():
+    from kmer_mapper_amd import synthetic
+    return synthetic
+
+
+# ---------------------------------------------------------------- reference known answers
+@pytest.mark.parametrize("v", reference_vectors()["lookup"], ids=lambda v: v["name"])
+def test_lookup_reference_vectors(kmm, v):
+    from kmer_mapper_amd.mapper import in_graph_index, map_kmers_to_graph_index
+    index = index_from_vector(v)
+    q = np.array(v["query"], dtype=np.uint64)
+    got = map_kmers_to_graph_index(index, v["max_node_id"], q, v["max_index_lookup_frequency"])
+    assert got.dtype == np.uint32 and got.shape == (v["max_node_id"] + 1,)
+    assert got.tolist() == v["expected_node_counts"]
+    if "expected_in_index" in v:
+        m = in_graph_index(index, q)
+        assert m.dtype == np.uint8 and m.tolist() == v["expected_in_index"]
+
+
+def test_gpu_counter_reference_known_answer(kmm):
+    """reference tests/test_gpucounter.py:41-48."""
+    from kmer_mapper_amd.gpu_counter import GpuCounter
+    kmers = np.array([1, 2, 3], dtype=np.uint64)
+    nodes = np.array([10, 11, 12])
+    counter = GpuCounter.from_kmers_and_nodes(kmers, nodes, 31)
+    counter.initialize_cuda(2003)
+    counter.count(np.array([1, 1, 1, 2, 3, 1, 3], dtype=np.uint64))
+    node_counts = counter.get_node_counts(15)
+    assert node_counts.dtype == np.float64 and len(node_counts) >= 15
+    assert np.all(node_counts[[10, 11, 12]] == [4, 1, 2])
+
+
+@pytest.mark.parametrize("v", reference_vectors()["extract"], ids=lambda v: v["name"])
+def test_extract_known_answers(kmm, v):
+    from kmer_mapper_amd.util import get_kmer_hashes_from_chunk_sequence
+    got = get_kmer_hashes_from_chunk_sequence(batch(v["reads"]), v["k"])
+    assert got.dtype == np.uint64 and got.tolist() == v["expected"]
+
+
+# ---------------------------------------------------------------- committed goldens
+@pytest.mark.parametrize("name", ["uniform", "ragged"])
+def test_goldens(kmm, name):
+    d, index, mx, k = golden_small()
+    bases, offs = d[name + "_bases"], d[name + "_offsets"]
+    km = kmm.extract_kmers(bases, offs, k)
+    assert np.array_equal(km, d[name + "_kmers"])
+    with kmm.DeviceIndex.from_index(index, mx) as dev:
+        dev.map_kmers(km)
+        assert np.array_equal(dev.get_node_counts(), d[name + "_counts"])
+        dev.reset(); dev.map_reads(bases, offs, k)
+        assert np.array_equal(dev.get_node_counts(), d[name + "_counts"])
+        dev.reset(); dev.map_reads(bases, offs, k, max_index_lookup_frequency=2)
+        assert np.array_equal(dev.get_node_counts(), d[name + "_counts_maxfreq2"])
+        dev.reset(); dev.map_reads(bases, offs, k, max_index_lookup_frequency=65535)
+        assert np.array_equal(dev.get_node_counts(), d[name + "_counts_nofilter"])
+        dev.reset(); dev.map_reads(bases, offs, k, also_revcomp=True)
+        assert np.array_equal(dev.get_node_counts(), d[name + "_counts_revcomp"])
+        dev.reset(); dev.map_kmers(km, also_revcomp=True, k=k)
+        assert np.array_equal(dev.get_node_counts(), d[name + "_counts_revcomp"])
+        assert np.array_equal(dev.in_index(km), d[name + "_in_index"])
+        if name == "uniform":
+            dev.reset(); dev.map_reads_uniform(bases, len(offs) - 1, 150, k)
+            assert np.array_equal(dev.get_node_counts(), d[name + "_counts"])
+
+
+# ---------------------------------------------------------------- seeded parity vs the oracle
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("k", [1, 2, 5, 16, 31])
+def test_fused_vs_oracle_ragged(kmm, syn, oracle, k, variant):
+    index, genome = syn.make_index(3000, k=k, seed=21 + k, plant=(k >= 16))
+    mx = index.max_node_id()
+    bases, offs = syn.make_ragged_reads(genome, 4000, 0, 220, seed=31 + k)
+    expect, n = oracle.map_reads(index, mx, bases, offs, k, n_threads=4)
+    with kmm.DeviceIndex.from_index(index, mx) as dev:
+        dev.set_variant(variant)
+        dev.map_reads(bases, offs, k)
+        got = dev.get_node_counts()
+    assert n > 0 and np.array_equal(got, expect)
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("read_len", [5, 16, 31, 32, 100, 150, 151, 4096, 5000])
+def test_fused_vs_oracle_uniform(kmm, syn, oracle, read_len, variant):
+    k = min(31, read_len)
+    index, genome = syn.make_index(5000, k=k, seed=41, plant=True)
+    mx = index.max_node_id()
+    n_reads = max(3, 300000 // read_len)
+    bases, offs = syn.make_reads(genome, n_reads, read_len, seed=43)
+    expect, n = oracle.map_reads(index, mx, bases, offs, k, n_threads=4)
+    with kmm.DeviceIndex.from_index(index, mx) as dev:
+        dev.set_variant(variant)
+        dev.map_reads_uniform(bases, n_reads, read_len, k)
+        got_u = dev.get_node_counts()
+        dev.reset()
+        dev.map_reads(bases, offs, k)
+        got_g = dev.get_node_counts()
+    assert np.array_equal(got_u, expect) and np.array_equal(got_g, expect)
+
+
+def test_operator_map_kmers_vs_oracle_and_accumulation(kmm, syn, oracle):
+    index, genome = syn.make_index(20000, seed=51)
+    mx = index.max_node_id()
+    bases, offs = syn.make_reads(genome, 3000, 150, seed=52)
+    km = oracle.extract(bases, offs, 31)
+    rng = np.random.default_rng(5)
+    km = np.concatenate([km, rng.integers(0, 2 ** 62, size=100000, dtype=np.uint64)])
+    expect = oracle.map_kmers(index, mx, km)
+    from kmer_mapper_amd.mapper import map_kmers_to_graph_index
+    assert np.array_equal(map_kmers_to_graph_index(index, mx, km), expect)
+    # second call starts from zero again (mapper.pyx:37), handle cache reused
+    assert np.array_equal(map_kmers_to_graph_index(index, mx, km), expect)
+    # handle-level calls accumulate across chunks (command_line_interface.py:124-130)
+    with kmm.DeviceIndex.from_index(index, mx) as dev:
+        for part in np.array_split(km, 7):
+            dev.map_kmers(np.ascontiguousarray(part))
+        assert np.array_equal(dev.get_node_counts(), expect)
+        assert np.array_equal(dev.in_index(km), oracle.in_index(index, km))
+
+
+def test_device_resident_inputs_and_bound_counts(kmm, syn, oracle):
+    import torch
+    index, genome = syn.make_index(10000, seed=61)
+    mx = index.max_node_id()
+    bases, offs = syn.make_reads(genome, 5000, 150, seed=62)
+    expect, _ = oracle.map_reads(index, mx, bases, offs, 31, n_threads=4)
+    d_bases = torch.from_numpy(bases).cuda()
+    d_offs = torch.from_numpy(offs).cuda()
+    counts = torch.zeros(mx + 1, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    with kmm.DeviceIndex.from_index(index, mx) as dev:
+        dev.bind_counts(counts)
+        dev.map_reads(d_bases, d_offs, 31)
+        dev.map_reads_uniform(d_bases, 5000, 150, 31)
+        dev.synchronize()
+        got = counts.cpu().numpy().view(np.uint32)
+        assert np.array_equal(got, expect * 2)
+        # unaligned device pointer: the kernel falls back to byte loads
+        d_shift = torch.empty(d_bases.numel() + 3, dtype=torch.uint8, device="cuda")
+        d_shift[3:] = d_bases
+        torch.cuda.synchronize()
+        counts.zero_(); torch.cuda.synchronize()
+        dev.map_reads(d_shift[3:], d_offs, 31)
+        dev.synchronize()
+        assert np.array_equal(counts.cpu().numpy().view(np.uint32), expect)
+
+
+def test_skewed_nodes_and_collisions(kmm, syn, oracle):
+    """Heavy atomic contention (1000 nodes) and a tiny modulo (long buckets, many collisions)."""
+    index, genome = syn.make_index(20000, seed=71, skewed=True, modulo=1009)
+    mx = index.max_node_id()
+    bases, offs = syn.make_reads(genome, 3000, 150, seed=72)
+    expect, _ = oracle.map_reads(index, mx, bases, offs, 31, n_threads=4)
+    with kmm.DeviceIndex.from_index(index, mx) as dev:
+        dev.map_reads(bases, offs, 31)
+        assert np.array_equal(dev.get_node_counts(), expect)
+
+
+def test_uint32_wraparound(kmm):
+    """counts wrap modulo 2^32 like the reference's uint32 vector (mapper.pyx:37,68)."""
+    import torch
+    v = reference_vectors()["lookup"][0]
+    index = index_from_vector(v)
+    counts = torch.full((16,), -3, dtype=torch.int32, device="cuda")   # 0xFFFFFFFD
+    torch.cuda.synchronize()
+    with kmm.DeviceIndex.from_index(index, 15) as dev:
+        dev.bind_counts(counts)
+        dev.map_kmers(np.array(v["query"], dtype=np.uint64))
+        dev.synchronize()
+    got = counts.cpu().numpy().view(np.uint32)
+    assert got[10] == 1 and got[11] == 0xFFFFFFFE and got[0] == 0xFFFFFFFD
+
+
+# ---------------------------------------------------------------- edge cases and errors
+def test_empty_and_degenerate_inputs(kmm, syn):
+    index, genome = syn.make_index(100, k=5, seed=81, plant=False)
+    with kmm.DeviceIndex.from_index(index) as dev:
+        dev.map_kmers(np.zeros(0, dtype=np.uint64))
+        dev.map_reads(np.zeros(0, dtype=np.uint8), np.zeros(1, dtype=np.int64), 5)
+        dev.map_reads(np.zeros(0, dtype=np.uint8), np.zeros(4, dtype=np.int64), 5)   # 3 empty reads
+        b = batch(["ACG", "T", ""])                                                   # all shorter than k
+        dev.map_reads(b.bases, b.offsets, 5)
+        assert dev.get_node_counts().sum() == 0
+        assert dev.in_index(np.zeros(0, dtype=np.uint64)).shape == (0,)
+    assert kmm.extract_kmers(np.zeros(0, np.uint8), np.zeros(1, np.int64), 5).shape == (0,)
+
+
+def test_invalid_base_raises(kmm, syn):
+    index, genome = syn.make_index(100, k=5, seed=82, plant=False)
+    b = batch(["ACGTACGT", "ACGTXCGT"])
+    with kmm.DeviceIndex.from_index(index) as dev:
+        dev.map_reads(b.bases, b.offsets, 5)
+        with pytest.raises(ValueError, match="offset 12"):
+            dev.get_node_counts()
+        dev.reset()
+        ok = batch(["ACGTACGT"])
+        dev.map_reads(ok.bases, ok.offsets, 5)
+        dev.get_node_counts()                      # error state was cleared
+    with pytest.raises(ValueError, match="offset 12"):
+        kmm.extract_kmers(b.bases, b.offsets, 5)
+
+
+def test_custom_lut(kmm, oracle, syn):
+    """Legacy A,C,T,G = 0,1,2,3 order (reference kmer_mapper/encodings.py:26-28) via the LUT knob."""
+    lut = np.full(256, 0xFF, dtype=np.uint8)
+    for i, c in enumerate("ACTG"):
+        lut[ord(c)] = lut[ord(c.lower())] = i
+    index, genome = syn.make_index(500, k=7, seed=83, plant=False)
+    bases, offs = syn.make_reads(genome, 200, 50, seed=84, n_rate=0.0)
+    expect, _ = oracle.map_reads(index, index.max_node_id(), bases, offs, 7, lut=lut)
+    with kmm.DeviceIndex.from_index(index) as dev:
+        dev.map_reads(bases, offs, 7, lut=lut)
+        assert np.array_equal(dev.get_node_counts(), expect)
+    assert np.array_equal(kmm.extract_kmers(bases, offs, 7, lut=lut), oracle.extract(bases, offs, 7, lut=lut))
+
+
+def test_argument_errors(kmm, syn):
+    from kmer_mapper_amd.mapper import map_kmers_to_graph_index
+    v = reference_vectors()["lookup"][1]
+    index = index_from_vector(v)
+    with pytest.raises(ValueError):                       # Cython: Buffer dtype mismatch
+        map_kmers_to_graph_index(index, 15, np.array(v["query"], dtype=np.int64))
+    with pytest.raises(ValueError):                       # node 14 > max_node_id 12
+        kmm.DeviceIndex.from_index(index, 12)
+    bad = index_from_vector(v)
+    bad._n_kmers = bad._n_kmers.copy(); bad._n_kmers[1] = 100      # bucket reaches past the entries
+    with pytest.raises(ValueError):
+        kmm.DeviceIndex.from_index(bad, 15)
+    with kmm.DeviceIndex.from_index(index, 15) as dev:
+        with pytest.raises(ValueError):
+            dev.map_reads(np.zeros(4, np.uint8), np.array([0, 4], np.int64), 32)
+        with pytest.raises(ValueError):
+            dev.map_reads(np.zeros(4, np.uint8), np.array([1, 4], np.int64), 3)
+
+
+# ---------------------------------------------------------------- full-size properties
+def test_config1_scale_and_linearity(kmm, syn, oracle):
+    """BASELINE config 1 (10 k reads of 150 bp, k=31) bit-exact; and counts are additive over any
+    split of the reads (the property the reference's additive reduce relies on)."""
+    index, genome = syn.make_index(1000, seed=1)
+    mx = index.max_node_id()
+    bases, offs = syn.make_reads(genome, 10000, 150, seed=2)
+    expect, n = oracle.map_reads(index, mx, bases, offs, 31, n_threads=4)
+    assert n == 1200000
+    with kmm.DeviceIndex.from_index(index, mx) as dev:
+        dev.map_reads_uniform(bases, 10000, 150, 31)
+        whole = dev.get_node_counts()
+        dev.reset()
+        for lo, hi in ((0, 1234), (1234, 7777), (7777, 10000)):
+            dev.map_reads_uniform(bases[lo * 150:hi * 150], hi - lo, 150, 31)
+        parts = dev.get_node_counts()
+    assert np.array_equal(whole, expect) and np.array_equal(parts, expect)
+
+
+def test_large_batch_properties(kmm, syn, oracle):
+    """2 M reads (240 M windows) resident in HBM: checksum of counts equals the number of hits a
+    sampled oracle run predicts exactly on the sample, and uniform == general path on the whole."""
+    import torch
+    index, genome = syn.make_index(200000, seed=91)
+    mx = index.max_node_id()
+    g_ascii = torch.from_numpy(syn.ACGT[genome]).cuda()
+    R = 2_000_000
+    d_bases = syn.make_reads_torch(g_ascii, R, 150, seed=92)
+    d_offs = torch.arange(R + 1, dtype=torch.int64, device="cuda") * 150
+    torch.cuda.synchronize()
+    with kmm.DeviceIndex.from_index(index, mx) as dev:
+        dev.map_reads_uniform(d_bases, R, 150, 31)
+        a = dev.get_node_counts()
+        dev.reset()
+        dev.map_reads(d_bases, d_offs, 31)
+        b = dev.get_node_counts()
+        assert np.array_equal(a, b)
+        # first 20 k reads against the oracle
+        sample = d_bases[:20000 * 150].cpu().numpy()
+        expect, _ = oracle.map_reads(index, mx, sample, np.arange(20001, dtype=np.int64) * 150, 31,
+                                     n_threads=4)
+        dev.reset()
+        dev.map_reads_uniform(d_bases[:20000 * 150], 20000, 150, 31)
+        assert np.array_equal(dev.get_node_counts(), expect)
+    rate = a.sum() / (R * 120)
+    assert 0.12 < rate < 0.25

@@ -1,0 +1,93 @@
+"""CPU tests: host logic, index builder, and that the C-ABI library loads and exports every
+symbol include/kmm.h declares (no compute calls — there is no GPU in this tier)."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from kmer_mapper_amd import _lib
+from kmer_mapper_amd import synthetic as syn
+from kmer_mapper_amd.kmer_index import KmerIndex
+from kmer_mapper_amd.util import ReadBatch, as_read_batch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "kmm.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(kmm_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    _lib.build()
+    L = _lib.lib()
+    syms = header_symbols()
+    assert len(syms) >= 15
+    for s in syms:
+        assert hasattr(L, s), "libkmm.so does not export %s" % s
+    assert set(syms) == set(_lib.SIGNATURES), "ctypes table and kmm.h disagree"
+    assert L.kmm_version().startswith(b"kmm ")
+
+
+def test_no_gpu_fails_loudly_not_silently():
+    if _lib.device_count() > 0:
+        pytest.skip("a GPU is present")
+    from kmer_mapper_amd.engine import DeviceIndex
+    ix, _ = syn.make_index(20, k=5, plant=False)
+    with pytest.raises(_lib.KmmError, match="no HIP device|no CPU fallback"):
+        DeviceIndex.from_index(ix)
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "kmer_mapper_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in text.replace("no CPU oracle", ""), (f, "mentions oracle")
+
+
+def test_kmer_index_invariants_and_roundtrip(tmp_path):
+    ix, genome = syn.make_index(300, k=31, seed=5)
+    M = ix._modulo
+    assert ix._hashes_to_index.dtype == np.int32 and ix._n_kmers.dtype == np.int32
+    assert ix._nodes.dtype == np.int32 and ix._kmers.dtype == np.uint64
+    assert ix._frequencies.dtype == np.uint16
+    assert len(ix._hashes_to_index) == M == len(ix._n_kmers)
+    assert int(ix._n_kmers.sum()) == len(ix._kmers)
+    h = (ix._kmers % np.uint64(M)).astype(np.int64)
+    assert np.all(np.diff(h) >= 0)                       # grouped by hash
+    for b in np.flatnonzero(ix._n_kmers)[:50]:
+        s, c = ix._hashes_to_index[b], ix._n_kmers[b]
+        assert np.all(h[s:s + c] == b)
+    uk, cnt = np.unique(ix._kmers, return_counts=True)
+    assert ix._frequencies.max() == min(cnt.max(), 65535) and cnt.max() >= 1501   # planted hot k-mer
+    p = str(tmp_path / "idx.npz")
+    ix.to_file(p)
+    back = KmerIndex.from_file(p)
+    back.convert_to_int32()
+    for a in ("_hashes_to_index", "_n_kmers", "_nodes", "_kmers", "_frequencies"):
+        assert np.array_equal(getattr(ix, a), getattr(back, a))
+    assert back._modulo == M and back.max_node_id() == ix.max_node_id()
+
+
+def test_read_batch():
+    b = ReadBatch.from_strings(["ACGT", "", "TT"])
+    assert len(b) == 3 and b.offsets.tolist() == [0, 4, 4, 6]
+    assert b.n_kmers(3) == 2 and b.uniform_length is None
+    u = ReadBatch.from_strings(["ACGT", "TTTT"])
+    assert u.uniform_length == 4
+    assert as_read_batch((b.bases, b.offsets)).offsets.tolist() == [0, 4, 4, 6]
+    with pytest.raises(ValueError):
+        ReadBatch(np.zeros(3, np.uint8), np.array([0, 2], np.int64))
+
+
+def test_synthetic_hit_rate(oracle):
+    ix, genome = syn.make_index(2000, seed=1)
+    bases, offs = syn.make_reads(genome, 2000, 150, seed=2)
+    counts, n = oracle.map_reads(ix, ix.max_node_id(), bases, offs, 31)
+    assert n == 2000 * 120
+    assert 0.12 < counts.sum() / n < 0.25               # p ~ 0.18
+    assert (bases == ord("N")).sum() > 0 and (bases >= ord("a")).sum() > 0
