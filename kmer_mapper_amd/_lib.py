@@ -66,6 +66,20 @@ def build(force=False, verbose=False):
 _lib = None
 
 
+def _share_hip_runtime_with_torch():
+    """One process must hold ONE HIP runtime.  PyTorch-ROCm wheels bundle their own
+    libamdhip64 (SONAME libamdhip64.so.7, the name libkmm.so links against); if libkmm.so were
+    loaded first it would pull /opt/rocm's copy and torch would then find "No HIP GPUs".  Importing
+    torch first makes the dynamic loader resolve libkmm.so's dependency to the copy torch already
+    mapped.  Without torch installed (or with KMM_NO_TORCH=1) /opt/rocm's runtime is used."""
+    if os.environ.get("KMM_NO_TORCH") == "1":
+        return
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
+
+
 def lib():
     """The loaded library; raises RuntimeError if it has not been built (no fallback)."""
     global _lib
@@ -75,6 +89,7 @@ def lib():
                 "kmer_mapper_amd: %s is missing — build it with "
                 "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc, gfx950). "
                 "There is no CPU fallback." % SO_PATH)
+        _share_hip_runtime_with_torch()
         L = ctypes.CDLL(SO_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)  # AttributeError if the symbol is not exported
