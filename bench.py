@@ -27,6 +27,16 @@ sys.path.insert(0, ROOT)
 # algorithmic bytes per k-mer of the fused path at alpha=0.5, p=0.18, d=1:
 # 150/120 read bytes + 8 bucket record + 8*(alpha + p*d) entry k-mers + 14*p*d (freq, node, count RMW)
 B_ALG_PER_KMER = 1.25 + 8.0 + 8.0 * (0.5 + 0.18) + 14.0 * 0.18      # = 17.21
+# per kernel (DESIGN.md "Measurement"): the fused kernel does all of it; on the partitioned path the
+# probe reads an 8-byte k-mer instead of 1.25 read bytes (SURVEY's 24.0 B operator figure), the
+# scatter reads 1.25 B and writes 8 B per k-mer, the histogram only reads.
+B_ALG = {
+    "k_map_reads": B_ALG_PER_KMER,
+    "k_map_kmers": B_ALG_PER_KMER - 1.25 + 8.0,
+    "k_part_probe": B_ALG_PER_KMER - 1.25 + 8.0,
+    "k_part_scatter": 1.25 + 8.0,
+    "k_part_hist": 1.25,
+}
 HBM_PEAK_GBPS = 8000.0                                               # MI355X_MICROARCH.md
 
 
@@ -45,7 +55,8 @@ def main():
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("-k", "--kmer-size", type=int, default=31)
     ap.add_argument("--skewed", action="store_true", help="node = i mod 1000 (atomic contention)")
-    ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--path", type=int, default=0, help="0 auto, 1 direct fused kernel, 2 radix-partitioned")
+    ap.add_argument("--part-shift", type=int, default=None)
     ap.add_argument("--general-path", action="store_true", help="use kmm_map_reads with an offsets array")
     ap.add_argument("--cpu-sample-reads", type=int, default=2_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -76,7 +87,9 @@ def main():
     log("index: %d entries, modulo %d, max_node_id %d (%.1fs)"
         % (len(index._kmers), index._modulo, mx, time.time() - t_setup))
     dev = DeviceIndex.from_index(index, mx, device=local_rank)
-    dev.set_variant(args.variant)
+    dev.set_param("path", args.path)
+    if args.part_shift is not None:
+        dev.set_param("part_shift", args.part_shift)
     counts = torch.zeros(mx + 1, dtype=torch.int32, device=dev_t)    # uint32 bits; wrap-add == int32 add
     dev.bind_counts(counts)
 
@@ -123,7 +136,7 @@ def main():
     fence()
     t1 = time.perf_counter()
     dev.set_timing(False)
-    kernel_ms, launches = dev.get_timing()
+    timing = dev.get_timing()
 
     elapsed = t1 - t0
     reduce_s = t1 - t_map
@@ -138,14 +151,20 @@ def main():
     result = None
     if rank == 0:
         value = total_kmers / elapsed / 1e6
+        # dominant kernel = the hot-path kernel with the largest summed HIP-event time
+        dom = max(timing, key=lambda n: timing[n][0])
+        kernel_ms, launches = timing[dom]
         avg_kernel_s = kernel_ms / 1e3 / max(launches, 1)
-        achieved = kmers_per_step * B_ALG_PER_KMER / avg_kernel_s / 1e9
+        kmers_per_launch = kmers_per_step * args.steps / max(launches, 1)
+        b_alg = B_ALG[dom]
+        achieved = kmers_per_launch * b_alg / avg_kernel_s / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                if tj.get("reads") == R and tj.get("index_kmers") == args.index_kmers and not args.skewed:
+                if (tj.get("reads") == R and tj.get("index_kmers") == args.index_kmers
+                        and tj.get("kernel") == dom and not args.skewed):
                     traffic = tj.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
@@ -170,22 +189,24 @@ def main():
                 "kmers_per_step_per_gpu": kmers_per_step,
                 "hit_rate": round(hits / max(total_kmers, 1), 4),
                 "nodes": "skewed(mod 1000)" if args.skewed else "uniform",
-                "variant": args.variant,
+                "path": {0: "auto", 1: "direct", 2: "partitioned"}[args.path],
+                "n_partitions": dev.get_param("n_partitions"),
                 "final_reduce_ms": round(reduce_s * 1e3, 3) if world > 1 else 0.0,
                 "parallelism": "reads sharded by batch over %d GPU(s), index replicated, one RCCL sum" % world,
+                "kernel_ms_per_step": {n: round(t[0] / args.steps, 3) for n, t in timing.items() if t[1]},
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "k_map_reads",
+                "kernel": dom,
                 "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4),
                 "traffic": traffic,
-                "algorithmic_bytes_per_kmer": round(B_ALG_PER_KMER, 2),
+                "algorithmic_bytes_per_kmer": round(b_alg, 2),
                 "avg_kernel_ms": round(avg_kernel_s * 1e3, 3),
                 "launches": launches,
-                "kernel_gkmers_per_s": round(kmers_per_step / avg_kernel_s / 1e9, 2),
+                "kernel_gkmers_per_s": round(kmers_per_launch / avg_kernel_s / 1e9, 2),
             },
         }
 

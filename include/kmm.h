@@ -123,16 +123,28 @@ int kmm_in_index(kmm_index_t *idx, const uint64_t *kmers, int64_t n, uint8_t *ou
 
 /*
  * Measurement hooks (the reference only logs perf_counter deltas,
- * command_line_interface.py:67-78).  With timing on, every launch of the dominant kernel
- * (map_reads / map_kmers) is bracketed by HIP events on the handle's stream;
- * kmm_get_timing drains the stream and returns the summed kernel milliseconds, the number of
- * launches and the number of k-mer windows those launches covered, then clears the totals.
+ * command_line_interface.py:67-78).  With timing on, every launch of a hot-path kernel is
+ * bracketed by HIP events on the handle's stream; kmm_get_timing drains the stream and returns,
+ * for one kernel id, the summed milliseconds and the number of launches since the last call for
+ * that id, then clears them.
  */
+#define KMM_KERNEL_MAP_READS 0    /* fused direct kernel (reads -> counts)                    */
+#define KMM_KERNEL_MAP_KMERS 1    /* operator kernel (uint64 k-mers -> counts)                */
+#define KMM_KERNEL_PART_HIST 2    /* partitioned path: reads -> per-partition histogram       */
+#define KMM_KERNEL_PART_SCATTER 3 /* partitioned path: reads -> k-mers grouped by hash range  */
+#define KMM_KERNEL_PART_PROBE 4   /* partitioned path: L2-local probe + count                 */
+#define KMM_N_KERNELS 5
 int kmm_set_timing(kmm_index_t *idx, int enabled);
-int kmm_get_timing(kmm_index_t *idx, double *kernel_ms, int64_t *n_launches);
+int kmm_get_timing(kmm_index_t *idx, int kernel_id, double *kernel_ms, int64_t *n_launches);
 
-/* Tuning knob, for experiments only: selects the kernel variant (0 = default). */
-int kmm_set_variant(kmm_index_t *idx, int variant);
+/*
+ * Tuning knobs, for experiments and benchmarks (defaults are chosen at index creation):
+ *   "path"        0 = auto, 1 = direct fused kernel, 2 = radix-partitioned (L2-local) path
+ *   "part_shift"  log2 of the number of hash buckets per partition (partitioned path)
+ * Unknown names return KMM_ERR_INVALID_ARG.
+ */
+int kmm_set_param(kmm_index_t *idx, const char *name, int64_t value);
+int kmm_get_param(kmm_index_t *idx, const char *name, int64_t *value);
 
 #ifdef __cplusplus
 }

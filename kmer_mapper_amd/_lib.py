@@ -20,6 +20,10 @@ KMM_ERR_INDEX = -3
 KMM_ERR_INVALID_BASE = -4
 KMM_ERR_NOMEM = -5
 
+# kernel ids of kmm_get_timing (include/kmm.h)
+KERNEL_MAP_READS, KERNEL_MAP_KMERS, KERNEL_PART_HIST, KERNEL_PART_SCATTER, KERNEL_PART_PROBE = range(5)
+KERNEL_NAMES = ("k_map_reads", "k_map_kmers", "k_part_hist", "k_part_scatter", "k_part_probe")
+
 _c = ctypes
 _P = ctypes.c_void_p
 
@@ -43,8 +47,9 @@ SIGNATURES = {
     "kmm_extract_kmers": (_c.c_int, [_c.c_int, _P, _P, _c.c_int64, _c.c_int, _P, _P, _c.c_int64]),
     "kmm_in_index": (_c.c_int, [_P, _P, _c.c_int64, _P]),
     "kmm_set_timing": (_c.c_int, [_P, _c.c_int]),
-    "kmm_get_timing": (_c.c_int, [_P, _P, _P]),
-    "kmm_set_variant": (_c.c_int, [_P, _c.c_int]),
+    "kmm_get_timing": (_c.c_int, [_P, _c.c_int, _P, _P]),
+    "kmm_set_param": (_c.c_int, [_P, _c.c_char_p, _c.c_int64]),
+    "kmm_get_param": (_c.c_int, [_P, _c.c_char_p, _P]),
 }
 
 

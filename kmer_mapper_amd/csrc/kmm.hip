@@ -55,11 +55,16 @@ int fail(int code, const char *fmt, ...)
 
 // ------------------------------------------------------------------------------------------------
 // device-side data layout (ours; the .npz surface is unchanged)
-//   bucket h : uint2 {start, count}           8 B  — one gather instead of the reference's two
-//   entry  l : uint4 {kmer_lo, kmer_hi, node, freq}  16 B — a hit touches one 16 B slot
+//   bucket h : uint4, 16 B — ONE gather resolves an empty or single-entry bucket:
+//        w & 3 == 0  empty
+//        w & 3 == 1  single entry stored inline: {x,y} = k-mer, z = node, w >> 16 = frequency
+//        w & 3 == 2  two or more entries: x = start, y = count into `entries`
+//   entry  l : uint4 {kmer_lo, kmer_hi, node, freq}, 16 B, in the index's own order (grouped by hash)
+// The MI355X random-access ceiling is ~55 G L2-missing requests/s whatever their width (8 or 16 B,
+// profiles/r01/gather_bench_mi355x.txt), so the layout minimises REQUESTS per k-mer, not bytes.
 // ------------------------------------------------------------------------------------------------
 struct IndexView {
-    const uint2 *buckets;
+    const uint4 *buckets;
     const uint4 *entries;
     uint32_t *counts;
     uint64_t modulo;
@@ -123,34 +128,50 @@ __device__ __forceinline__ void count_if_match(const IndexView &iv, uint4 e, uin
         atomicAdd(&iv.counts[e.z], 1u);
 }
 
-// The probe of mapper.pyx:53-69 for U k-mers per lane, arranged so that the U bucket gathers are
-// all in flight before any is consumed, then the U first-entry gathers likewise; only buckets
-// with more than one entry (hash collisions, duplicated k-mers) enter the serial tail.
+// The probe of mapper.pyx:53-69 for U k-mers per lane.  All U bucket gathers are in flight before
+// any is consumed; empty and single-entry buckets (the common cases) finish there.  Buckets with
+// two or more entries (hash collisions, k-mers present under several nodes) are handled in a
+// per-lane loop that takes one such bucket per trip and loads its first two entries together.
 template <int U>
 __device__ __forceinline__ void probe_batch(const IndexView &iv, const uint64_t (&q)[U],
                                             uint32_t valid, int max_freq)
 {
-    uint2 b[U];
+    uint4 b[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-        b[u] = make_uint2(0u, 0u);
+        b[u] = make_uint4(0u, 0u, 0u, 0u);
         if ((valid >> u) & 1u)
             b[u] = iv.buckets[fastmod(q[u], iv.modulo, iv.magic)];
     }
-    uint4 e[U];
+    uint32_t multi = 0;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-        e[u] = make_uint4(0u, 0u, 0u, 0u);
-        if (b[u].y)
-            e[u] = iv.entries[b[u].x];
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        if (b[u].y) {
-            count_if_match(iv, e[u], q[u], max_freq);
-            for (uint32_t j = 1; j < b[u].y; ++j)
-                count_if_match(iv, iv.entries[(uint64_t)b[u].x + j], q[u], max_freq);
+        const uint32_t kind = b[u].w & 3u;
+        if (kind == 1u) {
+            uint64_t ek = (uint64_t)b[u].x | ((uint64_t)b[u].y << 32);
+            if (ek == q[u] && (int)(b[u].w >> 16) <= max_freq)
+                atomicAdd(&iv.counts[b[u].z], 1u);
         }
+        multi |= (kind == 2u ? 1u : 0u) << u;
+    }
+    while (multi) {
+        const int u = __ffs((int)multi) - 1;
+        multi &= multi - 1u;
+        uint64_t qq = q[0];
+        uint32_t st = b[0].x, cn = b[0].y;
+#pragma unroll
+        for (int t = 1; t < U; ++t)
+            if (u == t) {
+                qq = q[t];
+                st = b[t].x;
+                cn = b[t].y;
+            }
+        const uint4 e0 = iv.entries[st];
+        const uint4 e1 = iv.entries[(uint64_t)st + 1]; // cn >= 2 by construction
+        count_if_match(iv, e0, qq, max_freq);
+        count_if_match(iv, e1, qq, max_freq);
+        for (uint32_t j = 2; j < cn; ++j)
+            count_if_match(iv, iv.entries[(uint64_t)st + j], qq, max_freq);
     }
 }
 
@@ -185,133 +206,163 @@ __global__ void __launch_bounds__(256) k_map_kmers(const uint64_t *__restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------
-// K1: fused reads -> counts.  One workgroup (4 wavefronts) owns tiles of T = 256*S consecutive
-// base positions of the chunk's flat byte stream:
+// Tile front end shared by every kernel that starts from read bytes.  A workgroup (4 wavefronts)
+// owns tiles of T = 256*S consecutive base positions of the chunk's flat byte stream:
 //   1. 16-byte coalesced loads of the T + 48 bytes the tile's windows can touch; each byte goes
 //      through the 256-entry LDS lookup table and 16 codes are packed into one 32-bit LDS word;
 //   2. read starts that fall inside the tile are marked in an LDS bitset (general path) so that
 //      no window spans two reads (bionumpy's ragged windowing, util.py:72);
 //   3. each lane takes S consecutive positions: three LDS words give it S+31 bases in a 128-bit
 //      register window, and successive k-mers are 2-bit funnel shifts of that window
-//      (first base in the lowest bits);
-//   4. probe_batch<S>.
+//      (first base in the lowest bits).
+// Returns the lane's S k-mers and the bitmask of those that are real windows.
+// ------------------------------------------------------------------------------------------------
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+template <int S>
+struct TileSmem {
+    static constexpr int T = 256 * S;
+    static constexpr int NV = T / 16 + 3; // 16-base words staged per tile (T + 48 positions)
+    static constexpr int NB = T / 32 + 3; // 32-position words of the read-start bitset
+    uint8_t lut[256];
+    uint32_t codes[NV + 1];
+    uint32_t bits[NB + 1];
+};
+
+struct TileConst {
+    uint64_t kmask; // low 2k bits
+    uint64_t bmask; // read starts in (p, p+k-1] kill the window at p
+    bool aligned;   // bases pointer is 16-byte aligned
+};
+
+__device__ __forceinline__ TileConst tile_const(const ReadsView &rv, int k)
+{
+    TileConst c;
+    c.kmask = (1ull << (2 * k)) - 1ull; // k <= 31
+    c.bmask = (1ull << (k - 1)) - 1ull;
+    c.aligned = (((uintptr_t)rv.bases) & 15u) == 0;
+    return c;
+}
+
+template <int S, bool UNIFORM>
+__device__ __forceinline__ uint32_t tile_kmers(const ReadsView &rv, const TileConst &tc, int64_t tile,
+                                               int k, TileSmem<S> &sm, uint64_t (&q)[S])
+{
+    constexpr int T = TileSmem<S>::T;
+    constexpr int NV = TileSmem<S>::NV;
+    constexpr int NB = TileSmem<S>::NB;
+    const int tid = threadIdx.x;
+    const int64_t total = rv.total;
+    const int64_t t0 = tile * T;
+    if (!UNIFORM)
+        for (int i = tid; i < NB + 1; i += 256)
+            sm.bits[i] = 0;
+    __syncthreads(); // LUT visible; bitset cleared; previous tile's LDS readers are done
+
+    // ---- stage 1: bytes -> 2-bit codes in LDS ----------------------------------------------
+    for (int v = tid; v < NV; v += 256) {
+        const int64_t p = t0 + (int64_t)v * 16;
+        uint32_t w[4];
+        if (tc.aligned && p + 16 <= total) {
+            // streamed once: non-temporal so the read bytes do not displace index lines in L2
+            u32x4 x = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(rv.bases + p));
+            w[0] = x[0]; w[1] = x[1]; w[2] = x[2]; w[3] = x[3];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                uint32_t acc = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    int64_t pp = p + i * 4 + j;
+                    uint32_t c = (pp < total) ? rv.bases[pp] : 0u;
+                    acc |= c << (8 * j);
+                }
+                w[i] = acc;
+            }
+        }
+        uint32_t code = 0;
+        int bad = -1;
+#pragma unroll
+        for (int i = 15; i >= 0; --i) {
+            uint32_t c = (w[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+            uint32_t l = sm.lut[c];
+            if (l == 0xFFu && p + i < total)
+                bad = i;
+            code |= (l & 3u) << (2 * i);
+        }
+        sm.codes[v] = code;
+        if (bad >= 0)
+            atomicMin(rv.first_bad, (unsigned long long)(p + bad));
+    }
+    // ---- stage 2: read starts inside (t0, t0 + T + k - 2] ----------------------------------
+    if (!UNIFORM) {
+        for (int64_t r = rv.tile_first[tile] + tid; r <= rv.n_reads; r += 256) {
+            int64_t o = rv.offsets[r] - t0;
+            if (o > (int64_t)T + k - 2)
+                break;
+            if (o >= 1)
+                atomicOr(&sm.bits[o >> 5], 1u << (o & 31));
+        }
+    }
+    __syncthreads();
+
+    // ---- stage 3: S consecutive windows per lane -------------------------------------------
+    const int q0 = tid * S;
+    const int64_t p0 = t0 + q0;
+    uint64_t lo, hi;
+    {
+        const int w = q0 >> 4;
+        const uint32_t c0 = sm.codes[w], c1 = sm.codes[w + 1], c2 = sm.codes[w + 2];
+        const int sh = (q0 & 15) * 2;
+        lo = ((uint64_t)c1 << 32) | c0;
+        hi = c2;
+        if (sh) {
+            lo = (lo >> sh) | (hi << (64 - sh));
+            hi >>= sh;
+        }
+    }
+    uint32_t valid = 0;
+    if (UNIFORM) {
+        uint64_t o;
+        (void)fastdiv((uint64_t)p0, rv.read_len, rv.read_len_magic, &o);
+#pragma unroll
+        for (int j = 0; j < S; ++j) {
+            uint64_t oj = o + j;
+            if (oj >= rv.read_len)
+                oj -= rv.read_len;
+            if (oj + k <= rv.read_len && p0 + j < total)
+                valid |= 1u << j;
+        }
+    } else {
+        const int sw = q0 >> 5, off = q0 & 31;
+        uint64_t B = ((uint64_t)sm.bits[sw + 1] << 32) | sm.bits[sw];
+        if (off)
+            B = (B >> off) | ((uint64_t)sm.bits[sw + 2] << (64 - off));
+#pragma unroll
+        for (int j = 0; j < S; ++j)
+            if (((B >> (j + 1)) & tc.bmask) == 0 && p0 + j + k <= total)
+                valid |= 1u << j;
+    }
+#pragma unroll
+    for (int j = 0; j < S; ++j)
+        q[j] = (j == 0 ? lo : ((lo >> (2 * j)) | (hi << (64 - 2 * j)))) & tc.kmask;
+    return valid;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1 (direct path): fused reads -> counts, every probe goes to HBM.  Used for small batches and for
+// indexes whose hash space cannot be cut into L2-sized partitions.
 // ------------------------------------------------------------------------------------------------
 template <int S, bool UNIFORM>
 __global__ void __launch_bounds__(256) k_map_reads(ReadsView rv, IndexView iv, int k, int max_freq,
-                                                   int also_rc)
+                                                   int also_rc, int64_t tile_begin, int64_t tile_end)
 {
-    constexpr int T = 256 * S;
-    constexpr int NV = T / 16 + 3; // 16-base words staged per tile (T + 48 positions)
-    constexpr int NB = T / 32 + 3; // 32-position words of the read-start bitset
-    __shared__ uint8_t s_lut[256];
-    __shared__ uint32_t s_codes[NV + 1];
-    __shared__ uint32_t s_bits[NB + 1];
-
-    const int tid = threadIdx.x;
-    s_lut[tid] = rv.lut[tid];
-
-    const uint64_t kmask = (1ull << (2 * k)) - 1ull; // k <= 31
-    const uint64_t bmask = (1ull << (k - 1)) - 1ull; // starts in (p, p+k-1] kill the window at p
-    const bool aligned = (((uintptr_t)rv.bases) & 15u) == 0;
-    const int64_t total = rv.total;
-    const int64_t n_tiles = (total + T - 1) / T;
-
-    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const int64_t t0 = tile * T;
-        if (!UNIFORM)
-            for (int i = tid; i < NB + 1; i += 256)
-                s_bits[i] = 0;
-        __syncthreads(); // LUT visible; bitset cleared; previous tile's LDS readers are done
-
-        // ---- stage 1: bytes -> 2-bit codes in LDS ------------------------------------------
-        for (int v = tid; v < NV; v += 256) {
-            const int64_t p = t0 + (int64_t)v * 16;
-            uint32_t w[4];
-            if (aligned && p + 16 <= total) {
-                uint4 x = *reinterpret_cast<const uint4 *>(rv.bases + p);
-                w[0] = x.x; w[1] = x.y; w[2] = x.z; w[3] = x.w;
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    uint32_t acc = 0;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        int64_t pp = p + i * 4 + j;
-                        uint32_t c = (pp < total) ? rv.bases[pp] : 0u;
-                        acc |= c << (8 * j);
-                    }
-                    w[i] = acc;
-                }
-            }
-            uint32_t code = 0;
-            int bad = -1;
-#pragma unroll
-            for (int i = 15; i >= 0; --i) {
-                uint32_t c = (w[i >> 2] >> (8 * (i & 3))) & 0xFFu;
-                uint32_t l = s_lut[c];
-                if (l == 0xFFu && p + i < total)
-                    bad = i;
-                code |= (l & 3u) << (2 * i);
-            }
-            s_codes[v] = code;
-            if (bad >= 0)
-                atomicMin(rv.first_bad, (unsigned long long)(p + bad));
-        }
-        // ---- stage 2: read starts inside (t0, t0 + T + k - 2] ------------------------------
-        if (!UNIFORM) {
-            for (int64_t r = rv.tile_first[tile] + tid; r <= rv.n_reads; r += 256) {
-                int64_t o = rv.offsets[r] - t0;
-                if (o > (int64_t)T + k - 2)
-                    break;
-                if (o >= 1)
-                    atomicOr(&s_bits[o >> 5], 1u << (o & 31));
-            }
-        }
-        __syncthreads();
-
-        // ---- stage 3: S consecutive windows per lane ---------------------------------------
-        const int q0 = tid * S;
-        const int64_t p0 = t0 + q0;
-        uint64_t lo, hi;
-        {
-            const int w = q0 >> 4;
-            const uint32_t c0 = s_codes[w], c1 = s_codes[w + 1], c2 = s_codes[w + 2];
-            const int sh = (q0 & 15) * 2;
-            lo = ((uint64_t)c1 << 32) | c0;
-            hi = c2;
-            if (sh) {
-                lo = (lo >> sh) | (hi << (64 - sh));
-                hi >>= sh;
-            }
-        }
-        uint32_t valid = 0;
-        if (UNIFORM) {
-            uint64_t o;
-            (void)fastdiv((uint64_t)p0, rv.read_len, rv.read_len_magic, &o);
-#pragma unroll
-            for (int j = 0; j < S; ++j) {
-                uint64_t oj = o + j;
-                if (oj >= rv.read_len)
-                    oj -= rv.read_len;
-                if (oj + k <= rv.read_len && p0 + j < total)
-                    valid |= 1u << j;
-            }
-        } else {
-            const int sw = q0 >> 5, off = q0 & 31;
-            uint64_t B = ((uint64_t)s_bits[sw + 1] << 32) | s_bits[sw];
-            if (off)
-                B = (B >> off) | ((uint64_t)s_bits[sw + 2] << (64 - off));
-#pragma unroll
-            for (int j = 0; j < S; ++j)
-                if (((B >> (j + 1)) & bmask) == 0 && p0 + j + k <= total)
-                    valid |= 1u << j;
-        }
+    __shared__ TileSmem<S> sm;
+    sm.lut[threadIdx.x] = rv.lut[threadIdx.x];
+    const TileConst tc = tile_const(rv, k);
+    for (int64_t tile = tile_begin + blockIdx.x; tile < tile_end; tile += gridDim.x) {
         uint64_t q[S];
-#pragma unroll
-        for (int j = 0; j < S; ++j)
-            q[j] = (j == 0 ? lo : ((lo >> (2 * j)) | (hi << (64 - 2 * j)))) & kmask;
-
-        // ---- stage 4: gather + count -------------------------------------------------------
+        const uint32_t valid = tile_kmers<S, UNIFORM>(rv, tc, tile, k, sm, q);
         if (__builtin_amdgcn_ballot_w64(valid != 0)) {
             probe_batch<S>(iv, q, valid, max_freq);
             if (also_rc) {
@@ -320,6 +371,259 @@ __global__ void __launch_bounds__(256) k_map_reads(ReadsView rv, IndexView iv, i
                     q[j] = revcomp(q[j], k);
                 probe_batch<S>(iv, q, valid, max_freq);
             }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Partitioned path.  Random probes that miss L2 are capped at ~55 G requests/s on MI355X while
+// L2-resident probes run ~4.6x faster, so large batches are first grouped by hash range
+// (partition = h >> shift, each partition's bucket-table slice ~1 MiB, i.e. L2-resident) and then
+// probed partition by partition, each XCD working on its own partitions so that the slice stays in
+// that XCD's 4 MiB L2.  Three kernels per sub-batch, all streaming except the L2-local gathers:
+//   k_part_hist     reads -> number of k-mers per partition            (exact sizes, no overflow)
+//   k_part_scan     sizes -> partition offsets, write cursors, per-XCD work lists
+//   k_part_scatter  reads -> k-mers written partition by partition (LDS counting sort per tile so
+//                   that runs of one partition leave the workgroup as contiguous stores)
+//   k_part_probe    persistent workgroups pull 2048-k-mer chunks from the queue of the XCD they
+//                   run on (read from HW_REG_XCC_ID — placement is only ever a speed matter: when
+//                   their own queue is empty they drain the other XCDs' queues) and run probe_batch.
+// ------------------------------------------------------------------------------------------------
+constexpr int KMM_MAX_PARTS = 1024;
+constexpr int KMM_N_XCD = 8;
+constexpr int KMM_CHUNK = 2048; // k-mers per probe work item (256 lanes x 8)
+
+struct PartView {
+    int shift; // partition = hash >> shift
+    int P;     // number of partitions, <= KMM_MAX_PARTS
+    int PX;    // max partitions per XCD = ceil(P / 8)
+    uint32_t *hist;      // [P]        k-mers per partition (zero between sub-batches)
+    uint32_t *part_off;  // [P + 1]    exclusive prefix of hist
+    uint32_t *cursor;    // [P]        next free slot per partition during the scatter
+    uint32_t *xcd_cum;   // [8][PX+1]  cumulative chunk counts over the partitions p = x, x+8, ...
+    uint32_t *xcd_queue; // [8]        next chunk to hand out per XCD
+    uint64_t *kmers;     // grouped k-mers of the sub-batch
+};
+
+__device__ __forceinline__ uint32_t part_of(const IndexView &iv, const PartView &pv, uint64_t q)
+{
+    return (uint32_t)(fastmod(q, iv.modulo, iv.magic) >> pv.shift);
+}
+
+template <int S, bool UNIFORM>
+__global__ void __launch_bounds__(256) k_part_hist(ReadsView rv, IndexView iv, int k, int also_rc,
+                                                   PartView pv, int64_t tile_begin, int64_t tile_end)
+{
+    __shared__ TileSmem<S> sm;
+    __shared__ uint32_t s_hist[KMM_MAX_PARTS];
+    sm.lut[threadIdx.x] = rv.lut[threadIdx.x];
+    for (int i = threadIdx.x; i < pv.P; i += 256)
+        s_hist[i] = 0;
+    const TileConst tc = tile_const(rv, k);
+    for (int64_t tile = tile_begin + blockIdx.x; tile < tile_end; tile += gridDim.x) {
+        uint64_t q[S];
+        const uint32_t valid = tile_kmers<S, UNIFORM>(rv, tc, tile, k, sm, q);
+#pragma unroll
+        for (int j = 0; j < S; ++j)
+            if ((valid >> j) & 1u) {
+                atomicAdd(&s_hist[part_of(iv, pv, q[j])], 1u);
+                if (also_rc)
+                    atomicAdd(&s_hist[part_of(iv, pv, revcomp(q[j], k))], 1u);
+            }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < pv.P; i += 256)
+        if (s_hist[i])
+            atomicAdd(&pv.hist[i], s_hist[i]);
+}
+
+// One workgroup of 1024 threads: exclusive scan of the P partition sizes + the per-XCD work lists.
+__global__ void __launch_bounds__(1024) k_part_scan(PartView pv)
+{
+    __shared__ uint32_t s_a[KMM_MAX_PARTS];
+    const int t = threadIdx.x;
+    const uint32_t c = t < pv.P ? pv.hist[t] : 0u;
+    s_a[t] = c;
+    __syncthreads();
+    for (int d = 1; d < KMM_MAX_PARTS; d <<= 1) { // Hillis-Steele inclusive scan
+        uint32_t v = t >= d ? s_a[t - d] : 0u;
+        __syncthreads();
+        s_a[t] += v;
+        __syncthreads();
+    }
+    if (t < pv.P) {
+        const uint32_t excl = s_a[t] - c;
+        pv.part_off[t] = excl;
+        pv.cursor[t] = excl;
+        pv.hist[t] = 0; // ready for the next sub-batch
+        if (t == pv.P - 1)
+            pv.part_off[pv.P] = s_a[t];
+    }
+    __syncthreads();
+    s_a[t] = (c + KMM_CHUNK - 1) / KMM_CHUNK; // chunks per partition
+    __syncthreads();
+    if (t < KMM_N_XCD) {
+        uint32_t *cum = pv.xcd_cum + t * (pv.PX + 1);
+        uint32_t acc = 0;
+        cum[0] = 0;
+        int j = 0;
+        for (int p = t; p < pv.P; p += KMM_N_XCD, ++j) {
+            acc += s_a[p];
+            cum[j + 1] = acc;
+        }
+        for (; j < pv.PX; ++j)
+            cum[j + 1] = acc;
+        pv.xcd_queue[t] = 0;
+    }
+}
+
+// Exclusive scan of s_cnt[0..P) into s_loc[0..P) by one 256-thread workgroup; returns the total.
+__device__ __forceinline__ uint32_t block_excl_scan(const uint32_t *s_cnt, uint32_t *s_loc, int P,
+                                                    uint32_t *s_wave)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int PER = KMM_MAX_PARTS / 256; // 4 consecutive partitions per thread
+    uint32_t v[PER], sum = 0;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int p = tid * PER + i;
+        v[i] = p < P ? s_cnt[p] : 0u;
+        sum += v[i];
+    }
+    uint32_t inc = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t o = __shfl_up(inc, d);
+        if (lane >= d)
+            inc += o;
+    }
+    if (lane == 63)
+        s_wave[wave] = inc;
+    __syncthreads();
+    uint32_t base = 0;
+    for (int w = 0; w < wave; ++w)
+        base += s_wave[w];
+    const uint32_t total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    uint32_t run = base + inc - sum;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int p = tid * PER + i;
+        if (p < P)
+            s_loc[p] = run;
+        run += v[i];
+    }
+    __syncthreads();
+    return total;
+}
+
+template <int S, bool UNIFORM>
+__global__ void __launch_bounds__(256) k_part_scatter(ReadsView rv, IndexView iv, int k, int also_rc,
+                                                      PartView pv, int64_t tile_begin,
+                                                      int64_t tile_end)
+{
+    constexpr int T = 256 * S;
+    __shared__ TileSmem<S> sm;
+    __shared__ uint32_t s_cnt[KMM_MAX_PARTS]; // k-mers of this tile per partition
+    __shared__ uint32_t s_loc[KMM_MAX_PARTS]; // where the partition's run starts in s_km
+    __shared__ uint32_t s_dst[KMM_MAX_PARTS]; // global slot of the run minus s_loc (mod 2^32)
+    __shared__ uint32_t s_wave[4];
+    __shared__ uint64_t s_km[T];
+    __shared__ uint16_t s_pd[T];
+    const int tid = threadIdx.x;
+    sm.lut[tid] = rv.lut[tid];
+    const TileConst tc = tile_const(rv, k);
+    for (int64_t tile = tile_begin + blockIdx.x; tile < tile_end; tile += gridDim.x) {
+        uint64_t q[S];
+        const uint32_t valid = tile_kmers<S, UNIFORM>(rv, tc, tile, k, sm, q);
+        for (int round = 0; round < (also_rc ? 2 : 1); ++round) {
+            if (round == 1) {
+#pragma unroll
+                for (int j = 0; j < S; ++j)
+                    q[j] = revcomp(q[j], k);
+            }
+            for (int i = tid; i < pv.P; i += 256)
+                s_cnt[i] = 0;
+            __syncthreads(); // also: the previous round's readers of s_km / s_pd are done
+            uint16_t pid[S], rk[S];
+#pragma unroll
+            for (int j = 0; j < S; ++j) {
+                pid[j] = 0;
+                rk[j] = 0;
+                if ((valid >> j) & 1u) {
+                    pid[j] = (uint16_t)part_of(iv, pv, q[j]);
+                    rk[j] = (uint16_t)atomicAdd(&s_cnt[pid[j]], 1u);
+                }
+            }
+            __syncthreads();
+            const uint32_t n_tile = block_excl_scan(s_cnt, s_loc, pv.P, s_wave);
+            for (int i = tid; i < pv.P; i += 256) {
+                const uint32_t c = s_cnt[i];
+                const uint32_t g = c ? atomicAdd(&pv.cursor[i], c) : 0u;
+                s_dst[i] = g - s_loc[i];
+            }
+#pragma unroll
+            for (int j = 0; j < S; ++j)
+                if ((valid >> j) & 1u) {
+                    const uint32_t pos = s_loc[pid[j]] + rk[j];
+                    s_km[pos] = q[j];
+                    s_pd[pos] = pid[j];
+                }
+            __syncthreads();
+            for (uint32_t i = tid; i < n_tile; i += 256)
+                pv.kmers[(uint32_t)(s_dst[s_pd[i]] + i)] = s_km[i];
+        }
+    }
+}
+
+__device__ __forceinline__ int xcc_id()
+{
+    // HW_REG_XCC_ID (hwreg 20), bits [3:0]: the XCD this wave runs on.
+    return (int)(__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u);
+}
+
+template <int U>
+__global__ void __launch_bounds__(256) k_part_probe(IndexView iv, PartView pv, int max_freq)
+{
+    static_assert(256 * U == KMM_CHUNK, "chunk = one k-mer per lane per unroll slot");
+    __shared__ uint32_t s_item;
+    const int tid = threadIdx.x;
+    const int home = xcc_id();
+    for (int step = 0; step < KMM_N_XCD; ++step) {
+        const int x = (home + step) & (KMM_N_XCD - 1);
+        const int n_px = pv.P > x ? (pv.P - x + KMM_N_XCD - 1) / KMM_N_XCD : 0;
+        const uint32_t *cum = pv.xcd_cum + x * (pv.PX + 1);
+        const uint32_t n_items = cum[n_px];
+        for (;;) {
+            if (tid == 0)
+                s_item = atomicAdd(&pv.xcd_queue[x], 1u);
+            __syncthreads();
+            const uint32_t item = s_item;
+            __syncthreads();
+            if (item >= n_items)
+                break;
+            int lo = 0, hi = n_px; // last j with cum[j] <= item
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (cum[mid] <= item)
+                    lo = mid;
+                else
+                    hi = mid;
+            }
+            const int p = x + lo * KMM_N_XCD;
+            const uint32_t begin = pv.part_off[p] + (item - cum[lo]) * KMM_CHUNK;
+            const uint32_t end = pv.part_off[p + 1];
+            uint64_t q[U];
+            uint32_t valid = 0;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t i = begin + u * 256 + tid;
+                q[u] = 0;
+                if (i < end) {
+                    q[u] = __builtin_nontemporal_load(&pv.kmers[i]);
+                    valid |= 1u << u;
+                }
+            }
+            probe_batch<U>(iv, q, valid, max_freq);
         }
     }
 }
@@ -391,13 +695,18 @@ __global__ void k_in_index(const uint64_t *__restrict__ kmers, int64_t n, IndexV
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (int64_t)gridDim.x * blockDim.x) {
         const uint64_t q = kmers[i];
-        const uint2 b = iv.buckets[fastmod(q, iv.modulo, iv.magic)];
+        const uint4 b = iv.buckets[fastmod(q, iv.modulo, iv.magic)];
+        const uint32_t kind = b.w & 3u;
         uint8_t hit = 0;
-        for (uint32_t j = 0; j < b.y; ++j) {
-            uint4 e = iv.entries[(uint64_t)b.x + j];
-            if (((uint64_t)e.x | ((uint64_t)e.y << 32)) == q) {
-                hit = 1;
-                break;
+        if (kind == 1u) {
+            hit = (((uint64_t)b.x | ((uint64_t)b.y << 32)) == q) ? 1 : 0;
+        } else if (kind == 2u) {
+            for (uint32_t j = 0; j < b.y; ++j) {
+                uint4 e = iv.entries[(uint64_t)b.x + j];
+                if (((uint64_t)e.x | ((uint64_t)e.y << 32)) == q) {
+                    hit = 1;
+                    break;
+                }
             }
         }
         out[i] = hit;
@@ -409,22 +718,30 @@ __global__ void k_in_index(const uint64_t *__restrict__ kmers, int64_t n, IndexV
 // err bit 0: bucket outside [0, n_entries); bit 1: node outside [0, max_node_id].
 // ------------------------------------------------------------------------------------------------
 __global__ void k_pack_buckets(const int32_t *__restrict__ h2i, const int32_t *__restrict__ nk,
-                               uint64_t modulo, int64_t n_entries, uint2 *__restrict__ buckets,
+                               const uint64_t *__restrict__ kmers, const int32_t *__restrict__ nodes,
+                               const uint16_t *__restrict__ freqs, uint64_t modulo,
+                               int64_t n_entries, int64_t max_node_id, uint4 *__restrict__ buckets,
                                uint32_t *err)
 {
     for (uint64_t h = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; h < modulo;
          h += (uint64_t)gridDim.x * blockDim.x) {
-        int32_t c = nk[h], s = h2i[h];
-        if (c <= 0) { // `for j in range(n_local_hits)` runs zero times (mapper.pyx:58)
-            buckets[h] = make_uint2(0u, 0u);
-            continue;
+        const int32_t c = nk[h], s = h2i[h];
+        uint4 b = make_uint4(0u, 0u, 0u, 0u);
+        if (c > 0) { // c <= 0: `for j in range(n_local_hits)` runs zero times (mapper.pyx:58)
+            if (s < 0 || (int64_t)s + c > n_entries) {
+                atomicOr(err, 1u);
+            } else if (c == 1) {
+                const uint64_t km = kmers[s];
+                int32_t nd = nodes[s];
+                if (nd < 0 || (int64_t)nd > max_node_id)
+                    nd = 0; // reported by k_pack_entries
+                b = make_uint4((uint32_t)km, (uint32_t)(km >> 32), (uint32_t)nd,
+                               ((uint32_t)freqs[s] << 16) | 1u);
+            } else {
+                b = make_uint4((uint32_t)s, (uint32_t)c, 0u, 2u);
+            }
         }
-        if (s < 0 || (int64_t)s + c > n_entries) {
-            atomicOr(err, 1u);
-            buckets[h] = make_uint2(0u, 0u);
-            continue;
-        }
-        buckets[h] = make_uint2((uint32_t)s, (uint32_t)c);
+        buckets[h] = b;
     }
 }
 
@@ -519,15 +836,19 @@ constexpr unsigned long long NO_BAD = ~0ull;
 
 } // namespace
 
+struct TimedEvent {
+    hipEvent_t start, stop;
+    int kernel_id;
+};
+
 struct kmm_index {
     int device = 0;
     hipStream_t stream = nullptr;      // kernels
     hipStream_t copy_stream = nullptr; // host -> HBM staging, overlaps the previous kernel
     hipEvent_t copied = nullptr;
-    uint2 *buckets = nullptr;
+    uint4 *buckets = nullptr;
     uint4 *entries = nullptr;
     uint32_t *counts = nullptr;
-    bool own_counts = true;
     uint32_t *own_counts_buf = nullptr;
     uint8_t *lut_default = nullptr;
     unsigned long long *first_bad = nullptr;
@@ -535,14 +856,19 @@ struct kmm_index {
     int64_t n_entries = 0, max_node_id = 0;
     Stage stage[2];
     int cur = 0;
-    int variant = 0;
     int n_cu = 256;
+    // path selection / partitioned path state
+    int path = 0;        // 0 auto, 1 direct, 2 partitioned
+    int part_shift = 16; // 2^16 buckets x 16 B = 1 MiB bucket-table slice per partition
+    int64_t part_min_positions = (int64_t)1 << 22; // auto: below this a batch takes the direct path
+    DevBuf part_meta;    // hist, part_off, cursor, xcd_cum, xcd_queue
+    DevBuf part_kmers;
     // timing
     bool timing = false;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_used;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_free;
-    double ms_total = 0.0;
-    int64_t launches = 0;
+    std::vector<TimedEvent> ev_used;
+    std::vector<TimedEvent> ev_free;
+    double ms_total[KMM_N_KERNELS] = {0};
+    int64_t launches[KMM_N_KERNELS] = {0};
 };
 
 namespace {
@@ -558,31 +884,39 @@ IndexView view_of(const kmm_index *ix)
     return v;
 }
 
-int timing_begin(kmm_index *ix, std::pair<hipEvent_t, hipEvent_t> &ev)
-{
-    if (!ix->timing)
+struct ScopedTimer {
+    kmm_index *ix;
+    TimedEvent ev{};
+    bool active = false;
+    int begin(kmm_index *ix_, int kernel_id)
+    {
+        ix = ix_;
+        if (!ix->timing)
+            return KMM_OK;
+        if (!ix->ev_free.empty()) {
+            ev = ix->ev_free.back();
+            ix->ev_free.pop_back();
+        } else {
+            HIPCHK(hipEventCreate(&ev.start));
+            HIPCHK(hipEventCreate(&ev.stop));
+        }
+        ev.kernel_id = kernel_id;
+        HIPCHK(hipEventRecord(ev.start, ix->stream));
+        active = true;
         return KMM_OK;
-    if (!ix->ev_free.empty()) {
-        ev = ix->ev_free.back();
-        ix->ev_free.pop_back();
-    } else {
-        HIPCHK(hipEventCreate(&ev.first));
-        HIPCHK(hipEventCreate(&ev.second));
     }
-    HIPCHK(hipEventRecord(ev.first, ix->stream));
-    return KMM_OK;
-}
-
-int timing_end(kmm_index *ix, std::pair<hipEvent_t, hipEvent_t> &ev)
-{
-    if (!ix->timing)
+    int end()
+    {
+        if (!active)
+            return KMM_OK;
+        HIPCHK(hipEventRecord(ev.stop, ix->stream));
+        ix->ev_used.push_back(ev);
+        active = false;
         return KMM_OK;
-    HIPCHK(hipEventRecord(ev.second, ix->stream));
-    ix->ev_used.push_back(ev);
-    return KMM_OK;
-}
+    }
+};
 
-// Drain the stream and surface deferred device-side errors (invalid bases).
+// Drain the streams and surface deferred device-side errors (invalid bases).
 int drain(kmm_index *ix)
 {
     HIPCHK(hipStreamSynchronize(ix->copy_stream));
@@ -633,8 +967,9 @@ Stage &next_stage(kmm_index *ix)
     return s;
 }
 
-// Common tail of every map call: kernels may start once the copies are in; the stage can be
-// overwritten once this call's kernels are done; host buffers are free once the copies are done.
+// Every map call: (1) the stage's buffers may be overwritten once the kernels of the call that
+// last used them are done; (2) kernels may start once the copies are in; (3) borrowed host buffers
+// are free again once the copies are done.
 int stage_acquire(kmm_index *ix, Stage &s)
 {
     if (s.used)
@@ -654,7 +989,7 @@ int stage_release(kmm_index *ix, Stage &s, bool staged)
     HIPCHK(hipEventRecord(s.done, ix->stream));
     s.used = true;
     if (staged)
-        HIPCHK(hipEventSynchronize(ix->copied)); // borrowed host pointers are free again
+        HIPCHK(hipEventSynchronize(ix->copied));
     return KMM_OK;
 }
 
@@ -667,36 +1002,91 @@ int resolve_lut(kmm_index *ix, Stage &s, const uint8_t *lut, const uint8_t **dev
     return stage_in<uint8_t>(ix, s.lut, lut, 256, dev, staged);
 }
 
+constexpr int TILE_S = 8;
+constexpr int TILE_T = 256 * TILE_S;
+
+int part_count(const kmm_index *ix)
+{
+    const uint64_t per = 1ull << ix->part_shift;
+    return (int)((ix->modulo + per - 1) / per);
+}
+
+bool use_partitioned(const kmm_index *ix, int64_t total_positions)
+{
+    if (ix->path == 1)
+        return false;
+    const uint64_t per = 1ull << ix->part_shift;
+    if ((ix->modulo + per - 1) / per > (uint64_t)KMM_MAX_PARTS)
+        return false; // hash space too large for L2-sized partitions in one pass
+    if (ix->path == 2)
+        return true;
+    return total_positions >= ix->part_min_positions && part_count(ix) >= 2 * KMM_N_XCD;
+}
+
+int part_view(kmm_index *ix, size_t kmer_capacity, PartView *pv)
+{
+    const int P = part_count(ix);
+    const int PX = (P + KMM_N_XCD - 1) / KMM_N_XCD;
+    const size_t words = (size_t)P + (P + 1) + P + (size_t)KMM_N_XCD * (PX + 1) + KMM_N_XCD;
+    const bool fresh = !ix->part_meta.p || ix->part_meta.cap < words * 4;
+    KMMCHK(ensure(ix->part_meta, words * 4));
+    if (fresh)
+        HIPCHK(hipMemsetAsync(ix->part_meta.p, 0, words * 4, ix->stream));
+    KMMCHK(ensure(ix->part_kmers, kmer_capacity * 8));
+    uint32_t *w = (uint32_t *)ix->part_meta.p;
+    pv->shift = ix->part_shift;
+    pv->P = P;
+    pv->PX = PX;
+    pv->hist = w; w += P;
+    pv->part_off = w; w += P + 1;
+    pv->cursor = w; w += P;
+    pv->xcd_cum = w; w += (size_t)KMM_N_XCD * (PX + 1);
+    pv->xcd_queue = w;
+    pv->kmers = (uint64_t *)ix->part_kmers.p;
+    return KMM_OK;
+}
+
 template <bool UNIFORM>
 int launch_map_reads(kmm_index *ix, const ReadsView &rv, int k, int max_freq, int also_rc)
 {
     const IndexView iv = view_of(ix);
-    std::pair<hipEvent_t, hipEvent_t> ev{};
-    KMMCHK(timing_begin(ix, ev));
-    switch (ix->variant) {
-    case 1: {
-        constexpr int S = 4;
-        int64_t n_tiles = (rv.total + 256 * S - 1) / (256 * S);
-        hipLaunchKernelGGL((k_map_reads<S, UNIFORM>), dim3(grid_for(ix, n_tiles, 64)), dim3(256), 0,
-                           ix->stream, rv, iv, k, max_freq, also_rc);
-        break;
+    const int64_t n_tiles = (rv.total + TILE_T - 1) / TILE_T;
+    if (!use_partitioned(ix, rv.total)) {
+        ScopedTimer tm;
+        KMMCHK(tm.begin(ix, KMM_KERNEL_MAP_READS));
+        hipLaunchKernelGGL((k_map_reads<TILE_S, UNIFORM>), dim3(grid_for(ix, n_tiles, 64)), dim3(256),
+                           0, ix->stream, rv, iv, k, max_freq, also_rc, (int64_t)0, n_tiles);
+        HIPCHK(hipGetLastError());
+        return tm.end();
     }
-    default: {
-        constexpr int S = 8;
-        int64_t n_tiles = (rv.total + 256 * S - 1) / (256 * S);
-        hipLaunchKernelGGL((k_map_reads<S, UNIFORM>), dim3(grid_for(ix, n_tiles, 64)), dim3(256), 0,
-                           ix->stream, rv, iv, k, max_freq, also_rc);
-        break;
+    // partitioned path, in sub-batches whose grouped k-mers fit 32-bit slots
+    const int64_t sub_tiles = ((int64_t)1 << 29) / TILE_T; // 2^29 positions -> <= 2^30 k-mers with -r
+    const int64_t max_tiles = n_tiles < sub_tiles ? n_tiles : sub_tiles;
+    PartView pv;
+    KMMCHK(part_view(ix, (size_t)max_tiles * TILE_T * (also_rc ? 2 : 1), &pv));
+    for (int64_t t0 = 0; t0 < n_tiles; t0 += sub_tiles) {
+        const int64_t t1 = t0 + sub_tiles < n_tiles ? t0 + sub_tiles : n_tiles;
+        const int grid = grid_for(ix, t1 - t0, 8);
+        ScopedTimer tm;
+        KMMCHK(tm.begin(ix, KMM_KERNEL_PART_HIST));
+        hipLaunchKernelGGL((k_part_hist<TILE_S, UNIFORM>), dim3(grid), dim3(256), 0, ix->stream, rv, iv,
+                           k, also_rc, pv, t0, t1);
+        HIPCHK(hipGetLastError());
+        KMMCHK(tm.end());
+        hipLaunchKernelGGL(k_part_scan, dim3(1), dim3(1024), 0, ix->stream, pv);
+        HIPCHK(hipGetLastError());
+        KMMCHK(tm.begin(ix, KMM_KERNEL_PART_SCATTER));
+        hipLaunchKernelGGL((k_part_scatter<TILE_S, UNIFORM>), dim3(grid), dim3(256), 0, ix->stream, rv,
+                           iv, k, also_rc, pv, t0, t1);
+        HIPCHK(hipGetLastError());
+        KMMCHK(tm.end());
+        KMMCHK(tm.begin(ix, KMM_KERNEL_PART_PROBE));
+        hipLaunchKernelGGL((k_part_probe<KMM_CHUNK / 256>), dim3(ix->n_cu * 8), dim3(256), 0,
+                           ix->stream, iv, pv, max_freq);
+        HIPCHK(hipGetLastError());
+        KMMCHK(tm.end());
     }
-    }
-    HIPCHK(hipGetLastError());
-    KMMCHK(timing_end(ix, ev));
     return KMM_OK;
-}
-
-int tile_size_for(const kmm_index *ix)
-{
-    return ix->variant == 1 ? 256 * 4 : 256 * 8;
 }
 
 int check_k(int k)
@@ -713,7 +1103,7 @@ int check_k(int k)
 // ================================================================================================
 extern "C" {
 
-const char *kmm_version(void) { return "kmm 0.1.0 (gfx950)"; }
+const char *kmm_version(void) { return "kmm 0.2.0 (gfx950)"; }
 
 const char *kmm_last_error(void) { return g_err.c_str(); }
 
@@ -749,13 +1139,15 @@ void kmm_index_destroy(kmm_index_t *ix)
         if (s.done)
             (void)hipEventDestroy(s.done);
     }
+    release(ix->part_meta);
+    release(ix->part_kmers);
     for (auto &ev : ix->ev_used) {
-        (void)hipEventDestroy(ev.first);
-        (void)hipEventDestroy(ev.second);
+        (void)hipEventDestroy(ev.start);
+        (void)hipEventDestroy(ev.stop);
     }
     for (auto &ev : ix->ev_free) {
-        (void)hipEventDestroy(ev.first);
-        (void)hipEventDestroy(ev.second);
+        (void)hipEventDestroy(ev.start);
+        (void)hipEventDestroy(ev.stop);
     }
     if (ix->copied)
         (void)hipEventDestroy(ix->copied);
@@ -791,7 +1183,7 @@ static int index_create_impl(kmm_index *ix, const int32_t *h2i, const int32_t *n
     for (Stage &s : ix->stage)
         HIPCHK(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
 
-    HIPCHK(hipMalloc(&ix->buckets, sizeof(uint2) * (size_t)M));
+    HIPCHK(hipMalloc(&ix->buckets, sizeof(uint4) * (size_t)M));
     HIPCHK(hipMalloc(&ix->entries, sizeof(uint4) * (size_t)(N > 0 ? N : 1)));
     HIPCHK(hipMalloc(&ix->own_counts_buf, sizeof(uint32_t) * (size_t)(ix->max_node_id + 1)));
     ix->counts = ix->own_counts_buf;
@@ -807,9 +1199,9 @@ static int index_create_impl(kmm_index *ix, const int32_t *h2i, const int32_t *n
     // raw arrays -> HBM (temporary), repack + validate on the GPU
     DevBuf d_h2i, d_nk, d_km, d_nd, d_fr, d_err;
     bool staged = false;
-    const int32_t *p_h2i, *p_nk, *p_nd;
-    const uint64_t *p_km;
-    const uint16_t *p_fr;
+    const int32_t *p_h2i = nullptr, *p_nk = nullptr, *p_nd = nullptr;
+    const uint64_t *p_km = nullptr;
+    const uint16_t *p_fr = nullptr;
     int rc = KMM_OK;
     do {
         if ((rc = stage_in<int32_t>(ix, d_h2i, h2i, (size_t)M, &p_h2i, &staged))) break;
@@ -828,8 +1220,8 @@ static int index_create_impl(kmm_index *ix, const int32_t *h2i, const int32_t *n
     uint32_t err = 0;
     if (rc == KMM_OK) {
         hipLaunchKernelGGL(k_pack_buckets, dim3(grid_for(ix, (int64_t)((M + 255) / 256), 16)),
-                           dim3(256), 0, ix->stream, p_h2i, p_nk, M, N, ix->buckets,
-                           (uint32_t *)d_err.p);
+                           dim3(256), 0, ix->stream, p_h2i, p_nk, p_km, p_nd, p_fr, M, N,
+                           ix->max_node_id, ix->buckets, (uint32_t *)d_err.p);
         if (N > 0)
             hipLaunchKernelGGL(k_pack_entries, dim3(grid_for(ix, (N + 255) / 256, 16)), dim3(256),
                                0, ix->stream, p_km, p_nd, p_fr, N, ix->max_node_id, ix->entries,
@@ -850,6 +1242,11 @@ static int index_create_impl(kmm_index *ix, const int32_t *h2i, const int32_t *n
     if (err & 2u)
         return fail(KMM_ERR_INDEX, "index inconsistent: a node id lies outside [0, max_node_id=%lld]",
                     (long long)ix->max_node_id);
+    // default partition granularity: 1 MiB bucket-table slices, coarser if that needs > 1024 parts
+    ix->part_shift = 16;
+    while (((M + (1ull << ix->part_shift) - 1) >> ix->part_shift) > (uint64_t)KMM_MAX_PARTS &&
+           ix->part_shift < 18)
+        ix->part_shift++;
     return KMM_OK;
 }
 
@@ -869,7 +1266,7 @@ int kmm_index_create(const int32_t *hashes_to_index, const int32_t *n_kmers, uin
                     (long long)n_entries, (long long)max_node_id);
     if (n_entries > 0 && (!kmers || !nodes || !frequencies))
         return fail(KMM_ERR_INVALID_ARG, "kmers / nodes / frequencies is NULL");
-    if (n_entries > 0xFFFFFFFFll)
+    if (n_entries > 0x7FFFFFFFll)
         return fail(KMM_ERR_INVALID_ARG, "n_entries exceeds the int32 bucket offsets of the index format");
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
@@ -968,13 +1365,13 @@ int kmm_map_kmers(kmm_index_t *ix, const uint64_t *kmers, int64_t n, int max_fre
     KMMCHK(stage_in<uint64_t>(ix, s.kmers, kmers, (size_t)n, &d_kmers, &staged));
     KMMCHK(stage_copies_done(ix));
     constexpr int U = 8;
-    std::pair<hipEvent_t, hipEvent_t> ev{};
-    KMMCHK(timing_begin(ix, ev));
+    ScopedTimer tm;
+    KMMCHK(tm.begin(ix, KMM_KERNEL_MAP_KMERS));
     hipLaunchKernelGGL((k_map_kmers<U>), dim3(grid_for(ix, (n + 256 * U - 1) / (256 * U), 64)),
                        dim3(256), 0, ix->stream, d_kmers, n, view_of(ix), max_freq,
                        also_revcomp ? 1 : 0, k);
     HIPCHK(hipGetLastError());
-    KMMCHK(timing_end(ix, ev));
+    KMMCHK(tm.end());
     return stage_release(ix, s, staged);
 }
 
@@ -1023,8 +1420,7 @@ static int map_reads_common(kmm_index_t *ix, const uint8_t *bases, const int64_t
     rv.total = total;
     rv.n_reads = n_reads;
     rv.first_bad = ix->first_bad;
-    const int T = tile_size_for(ix);
-    const int64_t n_tiles = (total + T - 1) / T;
+    const int64_t n_tiles = (total + TILE_T - 1) / TILE_T;
     // the uniform kernel's wrap-around handles one read boundary per lane: needs read_len >= S
     const bool uniform_kernel = uniform && read_len >= 16;
     if (uniform_kernel) {
@@ -1047,7 +1443,7 @@ static int map_reads_common(kmm_index_t *ix, const uint8_t *bases, const int64_t
         rv.tile_first = (const int64_t *)s.tile_first.p;
         KMMCHK(stage_copies_done(ix));
         hipLaunchKernelGGL(k_tile_first, dim3((unsigned)((n_tiles + 255) / 256)), dim3(256), 0,
-                           ix->stream, rv.offsets, n_reads, n_tiles, T, (int64_t *)s.tile_first.p);
+                           ix->stream, rv.offsets, n_reads, n_tiles, TILE_T, (int64_t *)s.tile_first.p);
         HIPCHK(hipGetLastError());
         KMMCHK(launch_map_reads<false>(ix, rv, k, max_freq, also_revcomp ? 1 : 0));
     }
@@ -1224,36 +1620,70 @@ int kmm_set_timing(kmm_index_t *ix, int enabled)
     return KMM_OK;
 }
 
-int kmm_get_timing(kmm_index_t *ix, double *kernel_ms, int64_t *n_launches)
+int kmm_get_timing(kmm_index_t *ix, int kernel_id, double *kernel_ms, int64_t *n_launches)
 {
     if (!ix)
         return fail(KMM_ERR_INVALID_ARG, "idx is NULL");
+    if (kernel_id < 0 || kernel_id >= KMM_N_KERNELS)
+        return fail(KMM_ERR_INVALID_ARG, "kernel_id %d outside [0, %d)", kernel_id, KMM_N_KERNELS);
     HIPCHK(hipSetDevice(ix->device));
     HIPCHK(hipStreamSynchronize(ix->stream));
     for (auto &ev : ix->ev_used) {
         float ms = 0.f;
-        HIPCHK(hipEventElapsedTime(&ms, ev.first, ev.second));
-        ix->ms_total += ms;
-        ix->launches += 1;
+        HIPCHK(hipEventElapsedTime(&ms, ev.start, ev.stop));
+        ix->ms_total[ev.kernel_id] += ms;
+        ix->launches[ev.kernel_id] += 1;
         ix->ev_free.push_back(ev);
     }
     ix->ev_used.clear();
     if (kernel_ms)
-        *kernel_ms = ix->ms_total;
+        *kernel_ms = ix->ms_total[kernel_id];
     if (n_launches)
-        *n_launches = ix->launches;
-    ix->ms_total = 0.0;
-    ix->launches = 0;
+        *n_launches = ix->launches[kernel_id];
+    ix->ms_total[kernel_id] = 0.0;
+    ix->launches[kernel_id] = 0;
     return KMM_OK;
 }
 
-int kmm_set_variant(kmm_index_t *ix, int variant)
+int kmm_set_param(kmm_index_t *ix, const char *name, int64_t value)
 {
-    if (!ix)
-        return fail(KMM_ERR_INVALID_ARG, "idx is NULL");
+    if (!ix || !name)
+        return fail(KMM_ERR_INVALID_ARG, "NULL argument");
     HIPCHK(hipSetDevice(ix->device));
-    HIPCHK(hipStreamSynchronize(ix->stream)); // tile size changes with the variant
-    ix->variant = variant;
+    HIPCHK(hipStreamSynchronize(ix->stream)); // scratch layouts depend on the knobs
+    if (!strcmp(name, "path")) {
+        if (value < 0 || value > 2)
+            return fail(KMM_ERR_INVALID_ARG, "path must be 0 (auto), 1 (direct) or 2 (partitioned)");
+        ix->path = (int)value;
+    } else if (!strcmp(name, "part_shift")) {
+        if (value < 4 || value > 30)
+            return fail(KMM_ERR_INVALID_ARG, "part_shift outside [4, 30]");
+        ix->part_shift = (int)value;
+        release(ix->part_meta); // re-laid out (and re-zeroed) on next use
+    } else if (!strcmp(name, "part_min_positions")) {
+        ix->part_min_positions = value;
+    } else {
+        return fail(KMM_ERR_INVALID_ARG, "unknown parameter '%s'", name);
+    }
+    return KMM_OK;
+}
+
+int kmm_get_param(kmm_index_t *ix, const char *name, int64_t *value)
+{
+    if (!ix || !name || !value)
+        return fail(KMM_ERR_INVALID_ARG, "NULL argument");
+    if (!strcmp(name, "path"))
+        *value = ix->path;
+    else if (!strcmp(name, "part_shift"))
+        *value = ix->part_shift;
+    else if (!strcmp(name, "part_min_positions"))
+        *value = ix->part_min_positions;
+    else if (!strcmp(name, "n_partitions"))
+        *value = part_count(ix);
+    else if (!strcmp(name, "partitioned_available"))
+        *value = part_count(ix) <= KMM_MAX_PARTS ? 1 : 0;
+    else
+        return fail(KMM_ERR_INVALID_ARG, "unknown parameter '%s'", name);
     return KMM_OK;
 }
 

@@ -162,14 +162,23 @@ class DeviceIndex:
     def set_timing(self, on=True):
         _lib.check(_lib.lib().kmm_set_timing(self._h, int(bool(on))))
 
-    def get_timing(self):
+    def get_timing(self, kernel_id=None):
+        """(milliseconds, launches) of one kernel id since the last call, or a dict over all ids."""
+        if kernel_id is None:
+            return {name: self.get_timing(i) for i, name in enumerate(_lib.KERNEL_NAMES)}
         ms = ctypes.c_double(0.0)
         n = ctypes.c_int64(0)
-        _lib.check(_lib.lib().kmm_get_timing(self._h, ctypes.byref(ms), ctypes.byref(n)))
+        _lib.check(_lib.lib().kmm_get_timing(self._h, int(kernel_id), ctypes.byref(ms), ctypes.byref(n)))
         return ms.value, n.value
 
-    def set_variant(self, v):
-        _lib.check(_lib.lib().kmm_set_variant(self._h, int(v)))
+    def set_param(self, name, value):
+        """Tuning knobs of include/kmm.h: "path" (0 auto, 1 direct, 2 partitioned), "part_shift"."""
+        _lib.check(_lib.lib().kmm_set_param(self._h, name.encode(), int(value)))
+
+    def get_param(self, name):
+        v = ctypes.c_int64(0)
+        _lib.check(_lib.lib().kmm_get_param(self._h, name.encode(), ctypes.byref(v)))
+        return v.value
 
 
 def extract_kmers(bases, read_offsets, k, lut=None, device=0):

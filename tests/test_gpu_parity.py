@@ -74,6 +74,12 @@ def test_goldens(kmm, name):
         assert np.array_equal(dev.get_node_counts(), d[name + "_counts_nofilter"])
         dev.reset(); dev.map_reads(bases, offs, k, also_revcomp=True)
         assert np.array_equal(dev.get_node_counts(), d[name + "_counts_revcomp"])
+        dev.set_param("path", 2); dev.set_param("part_shift", 5)      # radix-partitioned path
+        dev.reset(); dev.map_reads(bases, offs, k)
+        assert np.array_equal(dev.get_node_counts(), d[name + "_counts"])
+        dev.reset(); dev.map_reads(bases, offs, k, also_revcomp=True)
+        assert np.array_equal(dev.get_node_counts(), d[name + "_counts_revcomp"])
+        dev.set_param("path", 1)
         dev.reset(); dev.map_kmers(km, also_revcomp=True, k=k)
         assert np.array_equal(dev.get_node_counts(), d[name + "_counts_revcomp"])
         assert np.array_equal(dev.in_index(km), d[name + "_in_index"])
@@ -83,23 +89,26 @@ def test_goldens(kmm, name):
 
 
 # ---------------------------------------------------------------- seeded parity vs the oracle
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("path", [1, 2])
 @pytest.mark.parametrize("k", [1, 2, 5, 16, 31])
-def test_fused_vs_oracle_ragged(kmm, syn, oracle, k, variant):
+def test_fused_vs_oracle_ragged(kmm, syn, oracle, k, path):
     index, genome = syn.make_index(3000, k=k, seed=21 + k, plant=(k >= 16))
     mx = index.max_node_id()
     bases, offs = syn.make_ragged_reads(genome, 4000, 0, 220, seed=31 + k)
     expect, n = oracle.map_reads(index, mx, bases, offs, k, n_threads=4)
     with kmm.DeviceIndex.from_index(index, mx) as dev:
-        dev.set_variant(variant)
+        dev.set_param("path", path)
+        if path == 2:
+            dev.set_param("part_shift", 4)      # hundreds of partitions even for this small index
+            assert dev.get_param("n_partitions") > 64
         dev.map_reads(bases, offs, k)
         got = dev.get_node_counts()
     assert n > 0 and np.array_equal(got, expect)
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("path", [1, 2])
 @pytest.mark.parametrize("read_len", [5, 16, 31, 32, 100, 150, 151, 4096, 5000])
-def test_fused_vs_oracle_uniform(kmm, syn, oracle, read_len, variant):
+def test_fused_vs_oracle_uniform(kmm, syn, oracle, read_len, path):
     k = min(31, read_len)
     index, genome = syn.make_index(5000, k=k, seed=41, plant=True)
     mx = index.max_node_id()
@@ -107,7 +116,9 @@ def test_fused_vs_oracle_uniform(kmm, syn, oracle, read_len, variant):
     bases, offs = syn.make_reads(genome, n_reads, read_len, seed=43)
     expect, n = oracle.map_reads(index, mx, bases, offs, k, n_threads=4)
     with kmm.DeviceIndex.from_index(index, mx) as dev:
-        dev.set_variant(variant)
+        dev.set_param("path", path)
+        if path == 2:
+            dev.set_param("part_shift", 4)
         dev.map_reads_uniform(bases, n_reads, read_len, k)
         got_u = dev.get_node_counts()
         dev.reset()
@@ -282,12 +293,21 @@ def test_large_batch_properties(kmm, syn, oracle):
     d_offs = torch.arange(R + 1, dtype=torch.int64, device="cuda") * 150
     torch.cuda.synchronize()
     with kmm.DeviceIndex.from_index(index, mx) as dev:
+        dev.set_param("path", 1)
         dev.map_reads_uniform(d_bases, R, 150, 31)
         a = dev.get_node_counts()
         dev.reset()
+        dev.set_param("path", 2)
         dev.map_reads(d_bases, d_offs, 31)
         b = dev.get_node_counts()
         assert np.array_equal(a, b)
+        dev.reset()
+        dev.map_reads_uniform(d_bases, R, 150, 31, also_revcomp=True)
+        c = dev.get_node_counts()
+        dev.reset()
+        dev.set_param("path", 1)
+        dev.map_reads_uniform(d_bases, R, 150, 31, also_revcomp=True)
+        assert np.array_equal(c, dev.get_node_counts())
         # first 20 k reads against the oracle
         sample = d_bases[:20000 * 150].cpu().numpy()
         expect, _ = oracle.map_reads(index, mx, sample, np.arange(20001, dtype=np.int64) * 150, 31,
