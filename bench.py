@@ -60,6 +60,8 @@ def main():
     ap.add_argument("--general-path", action="store_true", help="use kmm_map_reads with an offsets array")
     ap.add_argument("--cpu-sample-reads", type=int, default=2_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--max-freq", type=int, default=1000,
+                    help="max_index_lookup_frequency (-1 filters every hit: timing ablation without atomics)")
     args = ap.parse_args()
 
     import torch
@@ -106,9 +108,9 @@ def main():
     def step(i):
         b = batches[i & 1]
         if offs is not None:
-            dev.map_reads(b, offs, k)
+            dev.map_reads(b, offs, k, args.max_freq)
         else:
-            dev.map_reads_uniform(b, R, L, k)
+            dev.map_reads_uniform(b, R, L, k, args.max_freq)
 
     def fence():
         dev.synchronize()

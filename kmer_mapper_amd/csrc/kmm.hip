@@ -380,34 +380,40 @@ __global__ void __launch_bounds__(256) k_map_reads(ReadsView rv, IndexView iv, i
 // L2-resident probes run ~4.6x faster, so large batches are first grouped by hash range
 // (partition = h >> shift, each partition's bucket-table slice ~1 MiB, i.e. L2-resident) and then
 // probed partition by partition, each XCD working on its own partitions so that the slice stays in
-// that XCD's 4 MiB L2.  Three kernels per sub-batch, all streaming except the L2-local gathers:
-//   k_part_hist     reads -> number of k-mers per partition            (exact sizes, no overflow)
-//   k_part_scan     sizes -> partition offsets, write cursors, per-XCD work lists
-//   k_part_scatter  reads -> k-mers written partition by partition (LDS counting sort per tile so
-//                   that runs of one partition leave the workgroup as contiguous stores)
-//   k_part_probe    persistent workgroups pull 2048-k-mer chunks from the queue of the XCD they
-//                   run on (read from HW_REG_XCC_ID — placement is only ever a speed matter: when
-//                   their own queue is empty they drain the other XCDs' queues) and run probe_batch.
+// that XCD's 4 MiB L2.  Per sub-batch, all streaming except the L2-local gathers:
+//   k_part_hist     reads -> k-mers per (partition, workgroup): every workgroup owns a fixed set
+//                   of tiles (grid-stride), so its histogram row is private — no global atomics
+//   k_part_scan1/2  exclusive scan over (partition, workgroup) -> a private, exactly sized output
+//                   range per workgroup inside every partition
+//   k_part_scatter  same tiles again: k-mers are counting-sorted by partition inside LDS so that
+//                   each partition's run leaves the workgroup as contiguous 8-byte stores at the
+//                   workgroup's private cursor (kept in LDS)
+//   k_part_probe    workgroup b takes chunks of the k-mers of XCD (b mod 8) — partitions are laid
+//                   out XCD-major, p mod 8 = XCD — in lock step with the other workgroups of that
+//                   XCD.  blockIdx mod 8 is where the dispatcher has been observed to place a
+//                   workgroup; it is used for L2 affinity only — every chunk is processed exactly
+//                   once whatever the placement.
 // ------------------------------------------------------------------------------------------------
 constexpr int KMM_MAX_PARTS = 1024;
 constexpr int KMM_N_XCD = 8;
-constexpr int KMM_CHUNK = 2048; // k-mers per probe work item (256 lanes x 8)
+constexpr int KMM_CHUNK = 2048;    // k-mers per probe work item (256 lanes x 8)
+constexpr int KMM_PART_GRID = 2048; // workgroups of the hist / scatter kernels (fixed: rows of wg_hist)
 
 struct PartView {
     int shift; // partition = hash >> shift
     int P;     // number of partitions, <= KMM_MAX_PARTS
-    int PX;    // max partitions per XCD = ceil(P / 8)
-    uint32_t *hist;      // [P]        k-mers per partition (zero between sub-batches)
-    uint32_t *part_off;  // [P + 1]    exclusive prefix of hist
-    uint32_t *cursor;    // [P]        next free slot per partition during the scatter
-    uint32_t *xcd_cum;   // [8][PX+1]  cumulative chunk counts over the partitions p = x, x+8, ...
-    uint32_t *xcd_queue; // [8]        next chunk to hand out per XCD
-    uint64_t *kmers;     // grouped k-mers of the sub-batch
+    int PX;    // partition slots per XCD = ceil(P / 8); slot(p) = (p % 8) * PX + p / 8
+    uint32_t *wg_hist;  // [8*PX][KMM_PART_GRID] k-mers per (slot, workgroup); after scan1: exclusive
+                        //                       prefix over the workgroups of the slot
+    uint32_t *slot_tot; // [8*PX]     k-mers per slot
+    uint32_t *slot_off; // [8*PX + 1] exclusive prefix of slot_tot (XCD x owns [x*PX, (x+1)*PX))
+    uint64_t *kmers;    // grouped k-mers of the sub-batch
 };
 
-__device__ __forceinline__ uint32_t part_of(const IndexView &iv, const PartView &pv, uint64_t q)
+__device__ __forceinline__ uint32_t slot_of(const IndexView &iv, const PartView &pv, uint64_t q)
 {
-    return (uint32_t)(fastmod(q, iv.modulo, iv.magic) >> pv.shift);
+    const uint32_t p = (uint32_t)(fastmod(q, iv.modulo, iv.magic) >> pv.shift);
+    return (p & (KMM_N_XCD - 1)) * pv.PX + (p >> 3);
 }
 
 template <int S, bool UNIFORM>
@@ -415,9 +421,10 @@ __global__ void __launch_bounds__(256) k_part_hist(ReadsView rv, IndexView iv, i
                                                    PartView pv, int64_t tile_begin, int64_t tile_end)
 {
     __shared__ TileSmem<S> sm;
-    __shared__ uint32_t s_hist[KMM_MAX_PARTS];
+    __shared__ uint32_t s_hist[KMM_MAX_PARTS + KMM_N_XCD];
+    const int n_slots = KMM_N_XCD * pv.PX;
     sm.lut[threadIdx.x] = rv.lut[threadIdx.x];
-    for (int i = threadIdx.x; i < pv.P; i += 256)
+    for (int i = threadIdx.x; i < n_slots; i += 256)
         s_hist[i] = 0;
     const TileConst tc = tile_const(rv, k);
     for (int64_t tile = tile_begin + blockIdx.x; tile < tile_end; tile += gridDim.x) {
@@ -426,68 +433,27 @@ __global__ void __launch_bounds__(256) k_part_hist(ReadsView rv, IndexView iv, i
 #pragma unroll
         for (int j = 0; j < S; ++j)
             if ((valid >> j) & 1u) {
-                atomicAdd(&s_hist[part_of(iv, pv, q[j])], 1u);
+                atomicAdd(&s_hist[slot_of(iv, pv, q[j])], 1u);
                 if (also_rc)
-                    atomicAdd(&s_hist[part_of(iv, pv, revcomp(q[j], k))], 1u);
+                    atomicAdd(&s_hist[slot_of(iv, pv, revcomp(q[j], k))], 1u);
             }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < pv.P; i += 256)
-        if (s_hist[i])
-            atomicAdd(&pv.hist[i], s_hist[i]);
+    for (int i = threadIdx.x; i < n_slots; i += 256)
+        pv.wg_hist[(size_t)i * KMM_PART_GRID + blockIdx.x] = s_hist[i];
 }
 
-// One workgroup of 1024 threads: exclusive scan of the P partition sizes + the per-XCD work lists.
-__global__ void __launch_bounds__(1024) k_part_scan(PartView pv)
+// One workgroup per slot: exclusive scan of the slot's KMM_PART_GRID per-workgroup counts, in place.
+__global__ void __launch_bounds__(256) k_part_scan1(PartView pv)
 {
-    __shared__ uint32_t s_a[KMM_MAX_PARTS];
-    const int t = threadIdx.x;
-    const uint32_t c = t < pv.P ? pv.hist[t] : 0u;
-    s_a[t] = c;
-    __syncthreads();
-    for (int d = 1; d < KMM_MAX_PARTS; d <<= 1) { // Hillis-Steele inclusive scan
-        uint32_t v = t >= d ? s_a[t - d] : 0u;
-        __syncthreads();
-        s_a[t] += v;
-        __syncthreads();
-    }
-    if (t < pv.P) {
-        const uint32_t excl = s_a[t] - c;
-        pv.part_off[t] = excl;
-        pv.cursor[t] = excl;
-        pv.hist[t] = 0; // ready for the next sub-batch
-        if (t == pv.P - 1)
-            pv.part_off[pv.P] = s_a[t];
-    }
-    __syncthreads();
-    s_a[t] = (c + KMM_CHUNK - 1) / KMM_CHUNK; // chunks per partition
-    __syncthreads();
-    if (t < KMM_N_XCD) {
-        uint32_t *cum = pv.xcd_cum + t * (pv.PX + 1);
-        uint32_t acc = 0;
-        cum[0] = 0;
-        int j = 0;
-        for (int p = t; p < pv.P; p += KMM_N_XCD, ++j) {
-            acc += s_a[p];
-            cum[j + 1] = acc;
-        }
-        for (; j < pv.PX; ++j)
-            cum[j + 1] = acc;
-        pv.xcd_queue[t] = 0;
-    }
-}
-
-// Exclusive scan of s_cnt[0..P) into s_loc[0..P) by one 256-thread workgroup; returns the total.
-__device__ __forceinline__ uint32_t block_excl_scan(const uint32_t *s_cnt, uint32_t *s_loc, int P,
-                                                    uint32_t *s_wave)
-{
+    __shared__ uint32_t s_wave[4];
+    constexpr int PER = KMM_PART_GRID / 256;
+    uint32_t *row = pv.wg_hist + (size_t)blockIdx.x * KMM_PART_GRID;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    constexpr int PER = KMM_MAX_PARTS / 256; // 4 consecutive partitions per thread
     uint32_t v[PER], sum = 0;
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
-        const int p = tid * PER + i;
-        v[i] = p < P ? s_cnt[p] : 0u;
+        v[i] = row[tid * PER + i];
         sum += v[i];
     }
     uint32_t inc = sum;
@@ -503,12 +469,77 @@ __device__ __forceinline__ uint32_t block_excl_scan(const uint32_t *s_cnt, uint3
     uint32_t base = 0;
     for (int w = 0; w < wave; ++w)
         base += s_wave[w];
+    uint32_t run = base + inc - sum;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        row[tid * PER + i] = run;
+        run += v[i];
+    }
+    if (tid == 255)
+        pv.slot_tot[blockIdx.x] = run;
+}
+
+// One workgroup of 1024 threads: exclusive scan of the (<= 1032) slot totals.
+__global__ void __launch_bounds__(1024) k_part_scan2(PartView pv)
+{
+    __shared__ uint32_t s_a[2048];
+    const int n_slots = KMM_N_XCD * pv.PX;
+    const int t = threadIdx.x;
+    const uint32_t c0 = t < n_slots ? pv.slot_tot[t] : 0u;
+    const uint32_t c1 = t + 1024 < n_slots ? pv.slot_tot[t + 1024] : 0u;
+    s_a[t] = c0;
+    s_a[t + 1024] = c1;
+    __syncthreads();
+    for (int d = 1; d < 2048; d <<= 1) { // Hillis-Steele inclusive scan over 2048 slots
+        uint32_t v0 = t >= d ? s_a[t - d] : 0u;
+        uint32_t v1 = s_a[t + 1024 - d];
+        __syncthreads();
+        s_a[t] += v0;
+        s_a[t + 1024] += v1;
+        __syncthreads();
+    }
+    if (t < n_slots)
+        pv.slot_off[t] = s_a[t] - c0;
+    if (t + 1024 < n_slots)
+        pv.slot_off[t + 1024] = s_a[t + 1024] - c1;
+    if (t == 0)
+        pv.slot_off[n_slots] = s_a[2047];
+}
+
+// Exclusive scan of s_cnt[0..n) into s_loc[0..n) (n <= 1280) by one 256-thread workgroup; returns
+// the total.
+__device__ __forceinline__ uint32_t block_excl_scan(const uint32_t *s_cnt, uint32_t *s_loc, int n,
+                                                    uint32_t *s_wave)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int PER = 5; // 256 x 5 = 1280 >= KMM_MAX_PARTS + 8
+    uint32_t v[PER], sum = 0;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int p = tid * PER + i;
+        v[i] = p < n ? s_cnt[p] : 0u;
+        sum += v[i];
+    }
+    uint32_t inc = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t o = __shfl_up(inc, d);
+        if (lane >= d)
+            inc += o;
+    }
+    __syncthreads(); // s_wave may still be read by the previous call
+    if (lane == 63)
+        s_wave[wave] = inc;
+    __syncthreads();
+    uint32_t base = 0;
+    for (int w = 0; w < wave; ++w)
+        base += s_wave[w];
     const uint32_t total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
     uint32_t run = base + inc - sum;
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
         const int p = tid * PER + i;
-        if (p < P)
+        if (p < n)
             s_loc[p] = run;
         run += v[i];
     }
@@ -522,15 +553,19 @@ __global__ void __launch_bounds__(256) k_part_scatter(ReadsView rv, IndexView iv
                                                       int64_t tile_end)
 {
     constexpr int T = 256 * S;
+    constexpr int NS = KMM_MAX_PARTS + KMM_N_XCD;
     __shared__ TileSmem<S> sm;
-    __shared__ uint32_t s_cnt[KMM_MAX_PARTS]; // k-mers of this tile per partition
-    __shared__ uint32_t s_loc[KMM_MAX_PARTS]; // where the partition's run starts in s_km
-    __shared__ uint32_t s_dst[KMM_MAX_PARTS]; // global slot of the run minus s_loc (mod 2^32)
+    __shared__ uint32_t s_cur[NS]; // this workgroup's next free slot per partition (private range)
+    __shared__ uint32_t s_cnt[NS]; // k-mers of this tile per partition
+    __shared__ uint32_t s_loc[NS]; // where the partition's run starts in s_km
     __shared__ uint32_t s_wave[4];
     __shared__ uint64_t s_km[T];
     __shared__ uint16_t s_pd[T];
     const int tid = threadIdx.x;
+    const int n_slots = KMM_N_XCD * pv.PX;
     sm.lut[tid] = rv.lut[tid];
+    for (int i = tid; i < n_slots; i += 256)
+        s_cur[i] = pv.slot_off[i] + pv.wg_hist[(size_t)i * KMM_PART_GRID + blockIdx.x];
     const TileConst tc = tile_const(rv, k);
     for (int64_t tile = tile_begin + blockIdx.x; tile < tile_end; tile += gridDim.x) {
         uint64_t q[S];
@@ -541,26 +576,21 @@ __global__ void __launch_bounds__(256) k_part_scatter(ReadsView rv, IndexView iv
                 for (int j = 0; j < S; ++j)
                     q[j] = revcomp(q[j], k);
             }
-            for (int i = tid; i < pv.P; i += 256)
+            for (int i = tid; i < n_slots; i += 256)
                 s_cnt[i] = 0;
-            __syncthreads(); // also: the previous round's readers of s_km / s_pd are done
+            __syncthreads(); // also: the previous round's readers of s_km / s_pd / s_loc are done
             uint16_t pid[S], rk[S];
 #pragma unroll
             for (int j = 0; j < S; ++j) {
                 pid[j] = 0;
                 rk[j] = 0;
                 if ((valid >> j) & 1u) {
-                    pid[j] = (uint16_t)part_of(iv, pv, q[j]);
+                    pid[j] = (uint16_t)slot_of(iv, pv, q[j]);
                     rk[j] = (uint16_t)atomicAdd(&s_cnt[pid[j]], 1u);
                 }
             }
             __syncthreads();
-            const uint32_t n_tile = block_excl_scan(s_cnt, s_loc, pv.P, s_wave);
-            for (int i = tid; i < pv.P; i += 256) {
-                const uint32_t c = s_cnt[i];
-                const uint32_t g = c ? atomicAdd(&pv.cursor[i], c) : 0u;
-                s_dst[i] = g - s_loc[i];
-            }
+            const uint32_t n_tile = block_excl_scan(s_cnt, s_loc, n_slots, s_wave);
 #pragma unroll
             for (int j = 0; j < S; ++j)
                 if ((valid >> j) & 1u) {
@@ -569,62 +599,40 @@ __global__ void __launch_bounds__(256) k_part_scatter(ReadsView rv, IndexView iv
                     s_pd[pos] = pid[j];
                 }
             __syncthreads();
-            for (uint32_t i = tid; i < n_tile; i += 256)
-                pv.kmers[(uint32_t)(s_dst[s_pd[i]] + i)] = s_km[i];
+            for (uint32_t i = tid; i < n_tile; i += 256) {
+                const uint32_t sl = s_pd[i];
+                pv.kmers[s_cur[sl] + (i - s_loc[sl])] = s_km[i];
+            }
+            __syncthreads();
+            for (int i = tid; i < n_slots; i += 256)
+                s_cur[i] += s_cnt[i];
         }
     }
-}
-
-__device__ __forceinline__ int xcc_id()
-{
-    // HW_REG_XCC_ID (hwreg 20), bits [3:0]: the XCD this wave runs on.
-    return (int)(__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u);
 }
 
 template <int U>
 __global__ void __launch_bounds__(256) k_part_probe(IndexView iv, PartView pv, int max_freq)
 {
     static_assert(256 * U == KMM_CHUNK, "chunk = one k-mer per lane per unroll slot");
-    __shared__ uint32_t s_item;
     const int tid = threadIdx.x;
-    const int home = xcc_id();
-    for (int step = 0; step < KMM_N_XCD; ++step) {
-        const int x = (home + step) & (KMM_N_XCD - 1);
-        const int n_px = pv.P > x ? (pv.P - x + KMM_N_XCD - 1) / KMM_N_XCD : 0;
-        const uint32_t *cum = pv.xcd_cum + x * (pv.PX + 1);
-        const uint32_t n_items = cum[n_px];
-        for (;;) {
-            if (tid == 0)
-                s_item = atomicAdd(&pv.xcd_queue[x], 1u);
-            __syncthreads();
-            const uint32_t item = s_item;
-            __syncthreads();
-            if (item >= n_items)
-                break;
-            int lo = 0, hi = n_px; // last j with cum[j] <= item
-            while (hi - lo > 1) {
-                const int mid = (lo + hi) >> 1;
-                if (cum[mid] <= item)
-                    lo = mid;
-                else
-                    hi = mid;
-            }
-            const int p = x + lo * KMM_N_XCD;
-            const uint32_t begin = pv.part_off[p] + (item - cum[lo]) * KMM_CHUNK;
-            const uint32_t end = pv.part_off[p + 1];
-            uint64_t q[U];
-            uint32_t valid = 0;
+    const int x = blockIdx.x & (KMM_N_XCD - 1); // expected XCD of this workgroup (speed only)
+    const uint32_t j = blockIdx.x >> 3, nj = gridDim.x >> 3;
+    const uint32_t begin_x = pv.slot_off[x * pv.PX], end_x = pv.slot_off[(x + 1) * pv.PX];
+    const uint32_t n_chunks = (end_x - begin_x + KMM_CHUNK - 1) / KMM_CHUNK;
+    for (uint32_t c = j; c < n_chunks; c += nj) {
+        const uint32_t begin = begin_x + c * KMM_CHUNK;
+        uint64_t q[U];
+        uint32_t valid = 0;
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const uint32_t i = begin + u * 256 + tid;
-                q[u] = 0;
-                if (i < end) {
-                    q[u] = __builtin_nontemporal_load(&pv.kmers[i]);
-                    valid |= 1u << u;
-                }
+        for (int u = 0; u < U; ++u) {
+            const uint32_t i = begin + u * 256 + tid;
+            q[u] = 0;
+            if (i < end_x) {
+                q[u] = __builtin_nontemporal_load(&pv.kmers[i]);
+                valid |= 1u << u;
             }
-            probe_batch<U>(iv, q, valid, max_freq);
         }
+        probe_batch<U>(iv, q, valid, max_freq);
     }
 }
 
@@ -1027,21 +1035,17 @@ int part_view(kmm_index *ix, size_t kmer_capacity, PartView *pv)
 {
     const int P = part_count(ix);
     const int PX = (P + KMM_N_XCD - 1) / KMM_N_XCD;
-    const size_t words = (size_t)P + (P + 1) + P + (size_t)KMM_N_XCD * (PX + 1) + KMM_N_XCD;
-    const bool fresh = !ix->part_meta.p || ix->part_meta.cap < words * 4;
+    const size_t n_slots = (size_t)KMM_N_XCD * PX;
+    const size_t words = n_slots * KMM_PART_GRID + n_slots + (n_slots + 1);
     KMMCHK(ensure(ix->part_meta, words * 4));
-    if (fresh)
-        HIPCHK(hipMemsetAsync(ix->part_meta.p, 0, words * 4, ix->stream));
     KMMCHK(ensure(ix->part_kmers, kmer_capacity * 8));
     uint32_t *w = (uint32_t *)ix->part_meta.p;
     pv->shift = ix->part_shift;
     pv->P = P;
     pv->PX = PX;
-    pv->hist = w; w += P;
-    pv->part_off = w; w += P + 1;
-    pv->cursor = w; w += P;
-    pv->xcd_cum = w; w += (size_t)KMM_N_XCD * (PX + 1);
-    pv->xcd_queue = w;
+    pv->wg_hist = w; w += n_slots * KMM_PART_GRID;
+    pv->slot_tot = w; w += n_slots;
+    pv->slot_off = w;
     pv->kmers = (uint64_t *)ix->part_kmers.p;
     return KMM_OK;
 }
@@ -1066,14 +1070,17 @@ int launch_map_reads(kmm_index *ix, const ReadsView &rv, int k, int max_freq, in
     KMMCHK(part_view(ix, (size_t)max_tiles * TILE_T * (also_rc ? 2 : 1), &pv));
     for (int64_t t0 = 0; t0 < n_tiles; t0 += sub_tiles) {
         const int64_t t1 = t0 + sub_tiles < n_tiles ? t0 + sub_tiles : n_tiles;
-        const int grid = grid_for(ix, t1 - t0, 8);
+        // every workgroup writes its (possibly all-zero) histogram row: the grid is always full
+        const int grid = KMM_PART_GRID;
+        const int n_slots = KMM_N_XCD * pv.PX;
         ScopedTimer tm;
         KMMCHK(tm.begin(ix, KMM_KERNEL_PART_HIST));
         hipLaunchKernelGGL((k_part_hist<TILE_S, UNIFORM>), dim3(grid), dim3(256), 0, ix->stream, rv, iv,
                            k, also_rc, pv, t0, t1);
         HIPCHK(hipGetLastError());
         KMMCHK(tm.end());
-        hipLaunchKernelGGL(k_part_scan, dim3(1), dim3(1024), 0, ix->stream, pv);
+        hipLaunchKernelGGL(k_part_scan1, dim3(n_slots), dim3(256), 0, ix->stream, pv);
+        hipLaunchKernelGGL(k_part_scan2, dim3(1), dim3(1024), 0, ix->stream, pv);
         HIPCHK(hipGetLastError());
         KMMCHK(tm.begin(ix, KMM_KERNEL_PART_SCATTER));
         hipLaunchKernelGGL((k_part_scatter<TILE_S, UNIFORM>), dim3(grid), dim3(256), 0, ix->stream, rv,
@@ -1662,6 +1669,7 @@ int kmm_set_param(kmm_index_t *ix, const char *name, int64_t value)
         release(ix->part_meta); // re-laid out (and re-zeroed) on next use
     } else if (!strcmp(name, "part_min_positions")) {
         ix->part_min_positions = value;
+
     } else {
         return fail(KMM_ERR_INVALID_ARG, "unknown parameter '%s'", name);
     }
