@@ -119,21 +119,66 @@ __device__ __forceinline__ uint64_t revcomp(uint64_t x, int k)
     return x >> (64 - 2 * k);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Node-count accumulation (mapper.pyx:68: node_counts[nodes[l]] += 1).
+// Real graph indexes map many k-mers to few nodes, so hits are first aggregated in a small
+// direct-mapped table in LDS that lives as long as the workgroup: a hit claims the slot of its
+// node (ds_cmpst) and bumps the slot's counter (ds_add); a hit whose slot belongs to another node
+// falls through to one global atomicAdd.  The table is flushed with one global atomicAdd per used
+// slot when the workgroup retires.  uint32 wrap-around is preserved (sums of sums mod 2^32).
+// ------------------------------------------------------------------------------------------------
+constexpr int AGG_LOG_SLOTS = 11;
+constexpr int AGG_SLOTS = 1 << AGG_LOG_SLOTS;
+constexpr uint32_t AGG_EMPTY = 0xFFFFFFFFu; // node ids are < 2^31
+
+struct NodeAgg {
+    uint32_t key[AGG_SLOTS];
+    uint32_t val[AGG_SLOTS];
+};
+
+__device__ __forceinline__ void agg_init(NodeAgg &agg)
+{
+    for (int i = threadIdx.x; i < AGG_SLOTS; i += blockDim.x) {
+        agg.key[i] = AGG_EMPTY;
+        agg.val[i] = 0;
+    }
+}
+
+__device__ __forceinline__ void agg_add(const IndexView &iv, NodeAgg &agg, uint32_t node)
+{
+    const uint32_t slot = (node * 2654435761u) >> (32 - AGG_LOG_SLOTS);
+    const uint32_t prev = atomicCAS(&agg.key[slot], AGG_EMPTY, node);
+    if (prev == AGG_EMPTY || prev == node)
+        atomicAdd(&agg.val[slot], 1u);
+    else
+        atomicAdd(&iv.counts[node], 1u);
+}
+
+// Call after a __syncthreads() that follows the workgroup's last agg_add.
+__device__ __forceinline__ void agg_flush(const IndexView &iv, NodeAgg &agg)
+{
+    for (int i = threadIdx.x; i < AGG_SLOTS; i += blockDim.x) {
+        const uint32_t v = agg.val[i];
+        if (v)
+            atomicAdd(&iv.counts[agg.key[i]], v);
+    }
+}
+
 // mapper.pyx:60-68 for one entry.
-__device__ __forceinline__ void count_if_match(const IndexView &iv, uint4 e, uint64_t q,
+__device__ __forceinline__ void count_if_match(const IndexView &iv, NodeAgg &agg, uint4 e, uint64_t q,
                                                int max_freq)
 {
     uint64_t ek = (uint64_t)e.x | ((uint64_t)e.y << 32);
     if (ek == q && (int)e.w <= max_freq)
-        atomicAdd(&iv.counts[e.z], 1u);
+        agg_add(iv, agg, e.z);
 }
 
 // The probe of mapper.pyx:53-69 for U k-mers per lane.  All U bucket gathers are in flight before
 // any is consumed; empty and single-entry buckets (the common cases) finish there.  Buckets with
-// two or more entries (hash collisions, k-mers present under several nodes) are handled in a
-// per-lane loop that takes one such bucket per trip and loads its first two entries together.
+// two or more entries (hash collisions, k-mers present under several nodes) then load their first
+// two entries together and walk the rest.
 template <int U>
-__device__ __forceinline__ void probe_batch(const IndexView &iv, const uint64_t (&q)[U],
+__device__ __forceinline__ void probe_batch(const IndexView &iv, NodeAgg &agg, const uint64_t (&q)[U],
                                             uint32_t valid, int max_freq)
 {
     uint4 b[U];
@@ -143,35 +188,26 @@ __device__ __forceinline__ void probe_batch(const IndexView &iv, const uint64_t 
         if ((valid >> u) & 1u)
             b[u] = iv.buckets[fastmod(q[u], iv.modulo, iv.magic)];
     }
-    uint32_t multi = 0;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const uint32_t kind = b[u].w & 3u;
         if (kind == 1u) {
             uint64_t ek = (uint64_t)b[u].x | ((uint64_t)b[u].y << 32);
             if (ek == q[u] && (int)(b[u].w >> 16) <= max_freq)
-                atomicAdd(&iv.counts[b[u].z], 1u);
+                agg_add(iv, agg, b[u].z);
         }
-        multi |= (kind == 2u ? 1u : 0u) << u;
     }
-    while (multi) {
-        const int u = __ffs((int)multi) - 1;
-        multi &= multi - 1u;
-        uint64_t qq = q[0];
-        uint32_t st = b[0].x, cn = b[0].y;
 #pragma unroll
-        for (int t = 1; t < U; ++t)
-            if (u == t) {
-                qq = q[t];
-                st = b[t].x;
-                cn = b[t].y;
-            }
-        const uint4 e0 = iv.entries[st];
-        const uint4 e1 = iv.entries[(uint64_t)st + 1]; // cn >= 2 by construction
-        count_if_match(iv, e0, qq, max_freq);
-        count_if_match(iv, e1, qq, max_freq);
-        for (uint32_t j = 2; j < cn; ++j)
-            count_if_match(iv, iv.entries[(uint64_t)st + j], qq, max_freq);
+    for (int u = 0; u < U; ++u) {
+        if ((b[u].w & 3u) == 2u) {
+            const uint32_t st = b[u].x, cn = b[u].y; // cn >= 2 by construction
+            const uint4 e0 = iv.entries[st];
+            const uint4 e1 = iv.entries[(uint64_t)st + 1];
+            count_if_match(iv, agg, e0, q[u], max_freq);
+            count_if_match(iv, agg, e1, q[u], max_freq);
+            for (uint32_t j = 2; j < cn; ++j)
+                count_if_match(iv, agg, iv.entries[(uint64_t)st + j], q[u], max_freq);
+        }
     }
 }
 
@@ -182,6 +218,9 @@ template <int U>
 __global__ void __launch_bounds__(256) k_map_kmers(const uint64_t *__restrict__ kmers, int64_t n,
                                                    IndexView iv, int max_freq, int also_rc, int k)
 {
+    __shared__ NodeAgg agg;
+    agg_init(agg);
+    __syncthreads();
     const int64_t span = (int64_t)256 * U;
     for (int64_t base = (int64_t)blockIdx.x * span; base < n; base += (int64_t)gridDim.x * span) {
         uint64_t q[U];
@@ -195,14 +234,16 @@ __global__ void __launch_bounds__(256) k_map_kmers(const uint64_t *__restrict__ 
                 valid |= 1u << u;
             }
         }
-        probe_batch<U>(iv, q, valid, max_freq);
+        probe_batch<U>(iv, agg, q, valid, max_freq);
         if (also_rc) {
 #pragma unroll
             for (int u = 0; u < U; ++u)
                 q[u] = revcomp(q[u], k);
-            probe_batch<U>(iv, q, valid, max_freq);
+            probe_batch<U>(iv, agg, q, valid, max_freq);
         }
     }
+    __syncthreads();
+    agg_flush(iv, agg);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -358,21 +399,25 @@ __global__ void __launch_bounds__(256) k_map_reads(ReadsView rv, IndexView iv, i
                                                    int also_rc, int64_t tile_begin, int64_t tile_end)
 {
     __shared__ TileSmem<S> sm;
+    __shared__ NodeAgg agg;
     sm.lut[threadIdx.x] = rv.lut[threadIdx.x];
+    agg_init(agg); // ordered before the first agg_add by the barriers inside tile_kmers
     const TileConst tc = tile_const(rv, k);
     for (int64_t tile = tile_begin + blockIdx.x; tile < tile_end; tile += gridDim.x) {
         uint64_t q[S];
         const uint32_t valid = tile_kmers<S, UNIFORM>(rv, tc, tile, k, sm, q);
         if (__builtin_amdgcn_ballot_w64(valid != 0)) {
-            probe_batch<S>(iv, q, valid, max_freq);
+            probe_batch<S>(iv, agg, q, valid, max_freq);
             if (also_rc) {
 #pragma unroll
                 for (int j = 0; j < S; ++j)
                     q[j] = revcomp(q[j], k);
-                probe_batch<S>(iv, q, valid, max_freq);
+                probe_batch<S>(iv, agg, q, valid, max_freq);
             }
         }
     }
+    __syncthreads();
+    agg_flush(iv, agg);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -614,6 +659,9 @@ template <int U>
 __global__ void __launch_bounds__(256) k_part_probe(IndexView iv, PartView pv, int max_freq)
 {
     static_assert(256 * U == KMM_CHUNK, "chunk = one k-mer per lane per unroll slot");
+    __shared__ NodeAgg agg;
+    agg_init(agg);
+    __syncthreads();
     const int tid = threadIdx.x;
     const int x = blockIdx.x & (KMM_N_XCD - 1); // expected XCD of this workgroup (speed only)
     const uint32_t j = blockIdx.x >> 3, nj = gridDim.x >> 3;
@@ -632,8 +680,10 @@ __global__ void __launch_bounds__(256) k_part_probe(IndexView iv, PartView pv, i
                 valid |= 1u << u;
             }
         }
-        probe_batch<U>(iv, q, valid, max_freq);
+        probe_batch<U>(iv, agg, q, valid, max_freq);
     }
+    __syncthreads();
+    agg_flush(iv, agg);
 }
 
 // General path helper: for every tile, the first read index r in [0, n_reads+1] whose start lies
