@@ -1,0 +1,181 @@
+"""`kmer_mapper map …` — the reference's CLI surface (kmer_mapper/command_line_interface.py:155-192)
+on the MI355X engine.  Same flags, defaults and output file; the work runs in libkmm.so.
+
+Differences that follow from replacing the engine (all documented in DESIGN.md):
+  * there is one engine, the GPU: `-g/--gpu` and `-t/--n-threads` are accepted and ignored
+    (`-t` is still echoed in the final log line); `-s/--gpu-hash-map-size` is ignored (the index's own
+    modulo is the hash table);
+  * results follow the reference's CPU path (uint32 node counts with the frequency filter of
+    mapper.pyx:64-66).  The reference parses `-I/--max-hits-per-kmer` but never forwards it
+    (command_line_interface.py:51 passes 3 arguments), so its effective filter is always 1000; the same
+    holds here unless `--apply-max-hits-per-kmer` is given;
+  * `-r` works (the reference only supports it in its experimental GPU mode, :107);
+  * `-b/--index-bundle`, Minimal/Counter index variants (util.py:52-66) are out of scope -> error.
+  * launched under torchrun (WORLD_SIZE > 1) chunk i goes to rank i mod WORLD_SIZE and the count
+    vectors are summed with one RCCL reduce; rank 0 writes the output.
+"""
+import argparse
+import logging
+import os
+import sys
+import time
+
+import numpy as np
+
+from .distributed import chunk_owner
+from .engine import DeviceIndex
+from .kmer_index import KmerIndex
+from .reads_io import prefetch, read_chunks
+
+
+def main():
+    run_argument_parser(sys.argv[1:])
+
+
+def _get_kmer_index_from_args(args):
+    """util.py:38-68, restricted to plain KmerIndex (.npz) or an in-memory index object."""
+    if args.kmer_index is None:
+        if getattr(args, "index_bundle", None) is None:
+            logging.error("Either a kmer index (-i) or an index bundle (-b) needs to be specified")
+            sys.exit(1)
+        logging.error("Index bundles (-b) are not supported by this build: pass the kmer index with -i")
+        sys.exit(1)
+    if not isinstance(args.kmer_index, (str, os.PathLike)):
+        kmer_index = args.kmer_index          # already an index object (util.py:40-44), duck-typed
+    else:
+        if "minimal" in os.path.basename(str(args.kmer_index)):
+            logging.error("MinimalKmerIndex files are not supported by this build")
+            sys.exit(1)
+        kmer_index = KmerIndex.from_file(args.kmer_index)
+    if hasattr(kmer_index, "convert_to_int32"):
+        kmer_index.convert_to_int32()
+    if hasattr(kmer_index, "remove_ref_offsets"):
+        kmer_index.remove_ref_offsets()
+    return kmer_index
+
+
+def map_gpu(index, chunks, k, hash_map_size=0, map_reverse_complements=False,
+            max_index_lookup_frequency=1000, device=0, rank=0, world_size=1):
+    """command_line_interface.py:59-79 on the HIP engine: chunks -> fused kmm_map_reads calls."""
+    max_node_id = index.max_node_id() if hasattr(index, "max_node_id") else int(np.max(index._nodes))
+    dev = DeviceIndex.from_index(index, max_node_id, device=device)
+    t_start = time.perf_counter()
+    n_kmers = 0
+    try:
+        for i, chunk in enumerate(chunks):
+            if chunk_owner(i, world_size) != rank:
+                continue
+            t0 = time.perf_counter()
+            L = chunk.uniform_length
+            if L is not None:
+                dev.map_reads_uniform(chunk.bases, len(chunk), L, k, max_index_lookup_frequency,
+                                      also_revcomp=map_reverse_complements)
+            else:
+                dev.map_reads(chunk.bases, chunk.offsets, k, max_index_lookup_frequency,
+                              also_revcomp=map_reverse_complements)
+            n_kmers += chunk.n_kmers(k)
+            logging.debug("GPU: chunk %d (%d reads) submitted in %.5f sec", i, len(chunk),
+                          time.perf_counter() - t0)
+        node_counts = dev.get_node_counts()
+    finally:
+        dev.close()
+    dt = time.perf_counter() - t_start
+    logging.info("Time spent only on hashing and counting hashes: %.5f" % dt)
+    logging.info("Mapped %d k-mers (%.1f M k-mers/s)" % (n_kmers, n_kmers / max(dt, 1e-9) / 1e6))
+    return node_counts
+
+
+def map_bnp(args):
+    if args.debug:
+        logging.info("Will print debug log")
+        logging.getLogger().setLevel(logging.DEBUG)
+
+    k = args.kmer_size
+    start_time = time.perf_counter()
+    kmer_index = _get_kmer_index_from_args(args)
+
+    n_bytes = os.stat(args.reads).st_size
+    if str(args.reads).endswith(".gz"):
+        n_bytes *= 6.5  # rough estimate for gzipped to give a progress (reference :92-93)
+    logging.info("N bytes of reads: %d" % n_bytes)
+    logging.info("Approx number of chunks of %d bytes: %d" % (args.chunk_size, int(n_bytes / args.chunk_size)))
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    max_freq = args.max_hits_per_kmer if getattr(args, "apply_max_hits_per_kmer", False) else 1000
+
+    chunks = prefetch(read_chunks(args.reads, min_chunk_size=args.chunk_size))
+    node_counts = map_gpu(kmer_index, chunks, k, getattr(args, "gpu_hash_map_size", 0),
+                          bool(getattr(args, "map_reverse_complements", False)), max_freq,
+                          device=local_rank if world > 1 else getattr(args, "device", 0),
+                          rank=rank, world_size=world)
+
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        from .distributed import reduce_node_counts
+        if not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("nccl" if torch.cuda.is_available() else "gloo")
+        t = torch.from_numpy(node_counts.view(np.int32))
+        if dist.get_backend() == "nccl":
+            t = t.cuda(local_rank)
+        reduce_node_counts(t, dst=0)
+        node_counts = t.cpu().numpy().view(np.uint32)
+        if rank != 0:
+            return node_counts
+
+    if args.output_file is None:
+        return node_counts
+
+    np.save(args.output_file, node_counts)
+    logging.info("Saved node counts to %s.npy" % args.output_file)
+    logging.info("Spent %.3f sec in total mapping kmers using %d threads"
+                 % (time.perf_counter() - start_time, args.n_threads))
+    return node_counts
+
+
+def run_argument_parser(args):
+    logging.basicConfig(stream=sys.stdout, level=logging.INFO,
+                        format='%(asctime)s %(levelname)s: %(message)s')
+    parser = argparse.ArgumentParser(
+        description='Kmer Mapper',
+        prog='kmer_mapper',
+        formatter_class=lambda prog: argparse.HelpFormatter(prog, max_help_position=50, width=100))
+
+    subparsers = parser.add_subparsers()
+    subparser = subparsers.add_parser("map", help="Map reads to a kmer index")
+    subparser.add_argument("-i", "--kmer-index", required=False)
+    subparser.add_argument("-b", "--index-bundle", required=False)
+    subparser.add_argument("-f", "--reads", required=True, help="Reads in .fa, .fq, .fa.gz, or fq.gz format")
+    subparser.add_argument("-k", "--kmer-size", required=False, default=31, type=int)
+    subparser.add_argument("-t", "--n-threads", required=False, default=16, type=int)
+    subparser.add_argument("-c", "--chunk-size", required=False, type=int, default=2500000,
+                           help="N bytes to process in each chunk")
+    subparser.add_argument("-o", "--output-file", required=True)
+    subparser.add_argument("-d", "--debug", required=False, help="Set to True to print debug log")
+    subparser.add_argument("-I", "--max-hits-per-kmer", required=False, default=1000, type=int,
+                           help="Ignore kmers that have more than this amount of hits in index")
+    subparser.add_argument("-g", "--gpu", default=False, type=bool,
+                           help="Accepted for compatibility: this build always maps on the GPU.")
+    subparser.add_argument("-s", "--gpu-hash-map-size", default=0, type=int,
+                           help="Accepted for compatibility; the index's own modulo is used.")
+    subparser.add_argument("-r", "--map-reverse-complements", default=False, type=bool,
+                           help="Also count kmers in reverse complement of reads. "
+                                "Default False. Not necessary if index contains reverse complements.")
+    subparser.add_argument("--apply-max-hits-per-kmer", action="store_true",
+                           help="Extension: actually apply -I (the reference parses it but always uses 1000).")
+    subparser.add_argument("--device", default=0, type=int, help="Extension: GPU ordinal (single process).")
+    subparser.set_defaults(func=map_bnp)
+
+    if len(args) == 0:
+        parser.print_help()
+        sys.exit(1)
+
+    args = parser.parse_args(args)
+    return args.func(args)
+
+
+if __name__ == "__main__":
+    main()

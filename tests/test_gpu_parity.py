@@ -317,3 +317,34 @@ def test_large_batch_properties(kmm, syn, oracle):
         assert np.array_equal(dev.get_node_counts(), expect)
     rate = a.sum() / (R * 120)
     assert 0.12 < rate < 0.25
+
+
+# ---------------------------------------------------------------- CLI end to end (row f-1)
+@pytest.mark.parametrize("fmt,gz", [("fa", False), ("fq", True)])
+def test_cli_map_end_to_end(kmm, syn, oracle, tmp_path, fmt, gz):
+    """`kmer_mapper map -i idx.npz -f reads -o out`: output <out>.npy equals the oracle's counts."""
+    from kmer_mapper_amd import reads_io
+    from kmer_mapper_amd.command_line_interface import run_argument_parser
+    from kmer_mapper_amd.util import ReadBatch
+    index, genome = syn.make_index(5000, seed=101)
+    bases, offs = syn.make_ragged_reads(genome, 3000, 20, 200, seed=102)
+    batch = ReadBatch(bases, offs)
+    idx_path = str(tmp_path / "index.npz")
+    index.to_file(idx_path)
+    reads_path = str(tmp_path / ("reads." + fmt + (".gz" if gz else "")))
+    (reads_io.write_fasta if fmt == "fa" else reads_io.write_fastq)(reads_path, batch, gz=gz)
+    out = str(tmp_path / "node_counts")
+    run_argument_parser(["map", "-i", idx_path, "-f", reads_path, "-o", out, "-k", "31", "-c", "20000"])
+    got = np.load(out + ".npy")
+    expect, _ = oracle.map_reads(index, index.max_node_id(), bases, offs, 31, n_threads=4)
+    assert got.dtype == np.uint32 and np.array_equal(got, expect)
+    # in-memory index object + output_file=None returns the array (command_line_interface.py:146-147)
+    import argparse
+    from kmer_mapper_amd.command_line_interface import map_bnp
+    ns = argparse.Namespace(kmer_index=index, index_bundle=None, reads=reads_path, kmer_size=31,
+                            n_threads=16, chunk_size=2500000, output_file=None, debug=None,
+                            max_hits_per_kmer=1000, gpu=False, gpu_hash_map_size=0,
+                            map_reverse_complements=True)
+    got_rc = map_bnp(ns)
+    expect_rc, _ = oracle.map_reads(index, index.max_node_id(), bases, offs, 31, also_revcomp=True)
+    assert np.array_equal(got_rc, expect_rc)

@@ -91,3 +91,29 @@ def test_synthetic_hit_rate(oracle):
     assert n == 2000 * 120
     assert 0.12 < counts.sum() / n < 0.25               # p ~ 0.18
     assert (bases == ord("N")).sum() > 0 and (bases >= ord("a")).sum() > 0
+
+
+def test_cli_flags_match_reference(monkeypatch):
+    """Flags and defaults of `kmer_mapper map` (reference command_line_interface.py:163-183)."""
+    from kmer_mapper_amd import command_line_interface as cli
+    seen = {}
+    monkeypatch.setattr(cli, "map_bnp", lambda a: seen.update(vars(a)) or "ret")
+    # set_defaults(func=map_bnp) captured the original; patch through the parser instead
+    import argparse
+    real = argparse.ArgumentParser.parse_args
+
+    def fake(self, args=None, namespace=None):
+        ns = real(self, args, namespace)
+        ns.func = lambda a: seen.update({k: v for k, v in vars(a).items() if k != "func"})
+        return ns
+    monkeypatch.setattr(argparse.ArgumentParser, "parse_args", fake)
+    cli.run_argument_parser(["map", "-i", "x.npz", "-f", "r.fa", "-o", "out"])
+    assert seen["kmer_size"] == 31 and seen["n_threads"] == 16 and seen["chunk_size"] == 2500000
+    assert seen["max_hits_per_kmer"] == 1000 and seen["gpu"] is False and seen["gpu_hash_map_size"] == 0
+    assert seen["map_reverse_complements"] is False and seen["index_bundle"] is None
+    cli.run_argument_parser(["map", "-i", "x", "-f", "r", "-o", "o", "-k", "21", "-t", "4", "-c", "100",
+                             "-I", "5", "-g", "True", "-s", "7", "-r", "True", "-d", "True", "-b", "bundle"])
+    assert (seen["kmer_size"], seen["n_threads"], seen["chunk_size"], seen["max_hits_per_kmer"]) == (21, 4, 100, 5)
+    assert seen["gpu"] is True and seen["map_reverse_complements"] is True and seen["index_bundle"] == "bundle"
+    with pytest.raises(SystemExit):
+        cli.run_argument_parser([])
