@@ -57,6 +57,7 @@ def main():
     ap.add_argument("--skewed", action="store_true", help="node = i mod 1000 (atomic contention)")
     ap.add_argument("--path", type=int, default=0, help="0 auto, 1 direct fused kernel, 2 radix-partitioned")
     ap.add_argument("--part-shift", type=int, default=None)
+    ap.add_argument("--no-filter", action="store_true", help="disable the L2 occupancy-bitmap prefilter")
     ap.add_argument("--general-path", action="store_true", help="use kmm_map_reads with an offsets array")
     ap.add_argument("--cpu-sample-reads", type=int, default=2_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -90,6 +91,8 @@ def main():
         % (len(index._kmers), index._modulo, mx, time.time() - t_setup))
     dev = DeviceIndex.from_index(index, mx, device=local_rank)
     dev.set_param("path", args.path)
+    if args.no_filter:
+        dev.set_param("occupancy_filter", 0)
     if args.part_shift is not None:
         dev.set_param("part_shift", args.part_shift)
     counts = torch.zeros(mx + 1, dtype=torch.int32, device=dev_t)    # uint32 bits; wrap-add == int32 add
@@ -193,6 +196,7 @@ def main():
                 "nodes": "skewed(mod 1000)" if args.skewed else "uniform",
                 "path": {0: "auto", 1: "direct", 2: "partitioned"}[args.path],
                 "n_partitions": dev.get_param("n_partitions"),
+                "occupancy_filter": bool(dev.get_param("occupancy_filter")),
                 "final_reduce_ms": round(reduce_s * 1e3, 3) if world > 1 else 0.0,
                 "parallelism": "reads sharded by batch over %d GPU(s), index replicated, one RCCL sum" % world,
                 "kernel_ms_per_step": {n: round(t[0] / args.steps, 3) for n, t in timing.items() if t[1]},

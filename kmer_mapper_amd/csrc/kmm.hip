@@ -63,9 +63,12 @@ int fail(int code, const char *fmt, ...)
 // The MI355X random-access ceiling is ~55 G L2-missing requests/s whatever their width (8 or 16 B,
 // profiles/r01/gather_bench_mi355x.txt), so the layout minimises REQUESTS per k-mer, not bytes.
 // ------------------------------------------------------------------------------------------------
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
 struct IndexView {
     const uint4 *buckets;
     const uint4 *entries;
+    const uint32_t *occ; // optional L2-resident occupancy bitmap (bit h = bucket h non-empty), or null
     uint32_t *counts;
     uint64_t modulo;
     uint64_t magic; // floor(2^64 / modulo) (all ones for modulo == 1)
@@ -177,16 +180,38 @@ __device__ __forceinline__ void count_if_match(const IndexView &iv, NodeAgg &agg
 // any is consumed; empty and single-entry buckets (the common cases) finish there.  Buckets with
 // two or more entries (hash collisions, k-mers present under several nodes) then load their first
 // two entries together and walk the rest.
-template <int U>
-__device__ __forceinline__ void probe_batch(const IndexView &iv, NodeAgg &agg, const uint64_t (&q)[U],
-                                            uint32_t valid, int max_freq)
+template <int U, bool FILTER>
+__device__ __forceinline__ void probe_batch_impl(const IndexView &iv, NodeAgg &agg,
+                                                 const uint64_t (&q)[U], uint32_t valid, int max_freq)
 {
+    uint64_t h[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+        h[u] = fastmod(q[u], iv.modulo, iv.magic);
+    if (FILTER) {
+        // Small indexes: one bit per bucket fits the XCD's L2 (4 MiB), and an L2 hit is ~4.6x cheaper
+        // than the HBM request it saves for every k-mer whose bucket is empty.
+        uint32_t w[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            w[u] = ((valid >> u) & 1u) ? iv.occ[h[u] >> 5] : 0u;
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (!((w[u] >> (h[u] & 31u)) & 1u))
+                valid &= ~(1u << u);
+    }
     uint4 b[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         b[u] = make_uint4(0u, 0u, 0u, 0u);
-        if ((valid >> u) & 1u)
-            b[u] = iv.buckets[fastmod(q[u], iv.modulo, iv.magic)];
+        if ((valid >> u) & 1u) {
+            if (FILTER) { // streamed once: keep the bitmap, not these lines, in L2
+                u32x4 x = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(&iv.buckets[h[u]]));
+                b[u] = make_uint4(x[0], x[1], x[2], x[3]);
+            } else {
+                b[u] = iv.buckets[h[u]];
+            }
+        }
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -209,6 +234,16 @@ __device__ __forceinline__ void probe_batch(const IndexView &iv, NodeAgg &agg, c
                 count_if_match(iv, agg, iv.entries[(uint64_t)st + j], q[u], max_freq);
         }
     }
+}
+
+template <int U>
+__device__ __forceinline__ void probe_batch(const IndexView &iv, NodeAgg &agg, const uint64_t (&q)[U],
+                                            uint32_t valid, int max_freq)
+{
+    if (iv.occ) // wave-uniform
+        probe_batch_impl<U, true>(iv, agg, q, valid, max_freq);
+    else
+        probe_batch_impl<U, false>(iv, agg, q, valid, max_freq);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -258,8 +293,6 @@ __global__ void __launch_bounds__(256) k_map_kmers(const uint64_t *__restrict__ 
 //      (first base in the lowest bits).
 // Returns the lane's S k-mers and the bitmask of those that are real windows.
 // ------------------------------------------------------------------------------------------------
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-
 template <int S>
 struct TileSmem {
     static constexpr int T = 256 * S;
@@ -819,6 +852,22 @@ __global__ void k_pack_entries(const uint64_t *__restrict__ kmers, const int32_t
     }
 }
 
+// One bit per bucket: set iff the bucket holds at least one entry.
+__global__ void k_build_occ(const uint4 *__restrict__ buckets, uint64_t modulo, uint32_t *__restrict__ occ)
+{
+    const uint64_t n_words = (modulo + 31) / 32;
+    for (uint64_t wd = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; wd < n_words;
+         wd += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t bits = 0;
+        for (int i = 0; i < 32; ++i) {
+            const uint64_t h = wd * 32 + i;
+            if (h < modulo && (buckets[h].w & 3u))
+                bits |= 1u << i;
+        }
+        occ[wd] = bits;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
@@ -906,6 +955,8 @@ struct kmm_index {
     hipEvent_t copied = nullptr;
     uint4 *buckets = nullptr;
     uint4 *entries = nullptr;
+    uint32_t *occ = nullptr;           // occupancy bitmap, only for indexes small enough (see occ_max_bytes)
+    bool use_occ = true;
     uint32_t *counts = nullptr;
     uint32_t *own_counts_buf = nullptr;
     uint8_t *lut_default = nullptr;
@@ -936,6 +987,7 @@ IndexView view_of(const kmm_index *ix)
     IndexView v;
     v.buckets = ix->buckets;
     v.entries = ix->entries;
+    v.occ = ix->use_occ ? ix->occ : nullptr;
     v.counts = ix->counts;
     v.modulo = ix->modulo;
     v.magic = ix->magic;
@@ -1060,7 +1112,8 @@ int resolve_lut(kmm_index *ix, Stage &s, const uint8_t *lut, const uint8_t **dev
     return stage_in<uint8_t>(ix, s.lut, lut, 256, dev, staged);
 }
 
-constexpr int TILE_S = 8;
+constexpr size_t KMM_OCC_MAX_BYTES = (size_t)3 << 20; // 25 M buckets
+constexpr int TILE_S = 4;
 constexpr int TILE_T = 256 * TILE_S;
 
 int part_count(const kmm_index *ix)
@@ -1138,8 +1191,10 @@ int launch_map_reads(kmm_index *ix, const ReadsView &rv, int k, int max_freq, in
         HIPCHK(hipGetLastError());
         KMMCHK(tm.end());
         KMMCHK(tm.begin(ix, KMM_KERNEL_PART_PROBE));
+        IndexView iv_nofilter = iv; // bucket gathers are L2 hits here: the bitmap would only add requests
+        iv_nofilter.occ = nullptr;
         hipLaunchKernelGGL((k_part_probe<KMM_CHUNK / 256>), dim3(ix->n_cu * 8), dim3(256), 0,
-                           ix->stream, iv, pv, max_freq);
+                           ix->stream, iv_nofilter, pv, max_freq);
         HIPCHK(hipGetLastError());
         KMMCHK(tm.end());
     }
@@ -1212,6 +1267,8 @@ void kmm_index_destroy(kmm_index_t *ix)
         (void)hipFree(ix->buckets);
     if (ix->entries)
         (void)hipFree(ix->entries);
+    if (ix->occ)
+        (void)hipFree(ix->occ);
     if (ix->own_counts_buf)
         (void)hipFree(ix->own_counts_buf);
     if (ix->lut_default)
@@ -1299,6 +1356,15 @@ static int index_create_impl(kmm_index *ix, const int32_t *h2i, const int32_t *n
     if (err & 2u)
         return fail(KMM_ERR_INDEX, "index inconsistent: a node id lies outside [0, max_node_id=%lld]",
                     (long long)ix->max_node_id);
+    // occupancy bitmap for indexes whose bitmap stays resident in one XCD's 4 MiB L2
+    const size_t occ_bytes = (size_t)((M + 31) / 32) * 4;
+    if (occ_bytes <= KMM_OCC_MAX_BYTES) {
+        HIPCHK(hipMalloc(&ix->occ, occ_bytes));
+        hipLaunchKernelGGL(k_build_occ, dim3(grid_for(ix, (int64_t)((M / 32 + 256) / 256), 16)), dim3(256),
+                           0, ix->stream, ix->buckets, M, ix->occ);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(ix->stream));
+    }
     // default partition granularity: 1 MiB bucket-table slices, coarser if that needs > 1024 parts
     ix->part_shift = 16;
     while (((M + (1ull << ix->part_shift) - 1) >> ix->part_shift) > (uint64_t)KMM_MAX_PARTS &&
@@ -1719,6 +1785,8 @@ int kmm_set_param(kmm_index_t *ix, const char *name, int64_t value)
         release(ix->part_meta); // re-laid out (and re-zeroed) on next use
     } else if (!strcmp(name, "part_min_positions")) {
         ix->part_min_positions = value;
+    } else if (!strcmp(name, "occupancy_filter")) {
+        ix->use_occ = value != 0;
 
     } else {
         return fail(KMM_ERR_INVALID_ARG, "unknown parameter '%s'", name);
@@ -1736,6 +1804,8 @@ int kmm_get_param(kmm_index_t *ix, const char *name, int64_t *value)
         *value = ix->part_shift;
     else if (!strcmp(name, "part_min_positions"))
         *value = ix->part_min_positions;
+    else if (!strcmp(name, "occupancy_filter"))
+        *value = (ix->use_occ && ix->occ) ? 1 : 0;
     else if (!strcmp(name, "n_partitions"))
         *value = part_count(ix);
     else if (!strcmp(name, "partitioned_available"))
