@@ -969,7 +969,6 @@ struct kmm_index {
     // path selection / partitioned path state
     int path = 0;        // 0 auto, 1 direct, 2 partitioned
     int part_shift = 16; // 2^16 buckets x 16 B = 1 MiB bucket-table slice per partition
-    int64_t part_min_positions = (int64_t)1 << 22; // auto: below this a batch takes the direct path
     DevBuf part_meta;    // hist, part_off, cursor, xcd_cum, xcd_queue
     DevBuf part_kmers;
     // timing
@@ -1124,14 +1123,13 @@ int part_count(const kmm_index *ix)
 
 bool use_partitioned(const kmm_index *ix, int64_t total_positions)
 {
-    if (ix->path == 1)
+    (void)total_positions;
+    // r01 measurements (profiles/r01/partitioned_path_ablation.md): the direct kernel is faster on
+    // every configuration tried, so "auto" (0) means direct; the partitioned path is opt-in.
+    if (ix->path != 2)
         return false;
     const uint64_t per = 1ull << ix->part_shift;
-    if ((ix->modulo + per - 1) / per > (uint64_t)KMM_MAX_PARTS)
-        return false; // hash space too large for L2-sized partitions in one pass
-    if (ix->path == 2)
-        return true;
-    return total_positions >= ix->part_min_positions && part_count(ix) >= 2 * KMM_N_XCD;
+    return (ix->modulo + per - 1) / per <= (uint64_t)KMM_MAX_PARTS;
 }
 
 int part_view(kmm_index *ix, size_t kmer_capacity, PartView *pv)
@@ -1783,8 +1781,6 @@ int kmm_set_param(kmm_index_t *ix, const char *name, int64_t value)
             return fail(KMM_ERR_INVALID_ARG, "part_shift outside [4, 30]");
         ix->part_shift = (int)value;
         release(ix->part_meta); // re-laid out (and re-zeroed) on next use
-    } else if (!strcmp(name, "part_min_positions")) {
-        ix->part_min_positions = value;
     } else if (!strcmp(name, "occupancy_filter")) {
         ix->use_occ = value != 0;
 
@@ -1802,8 +1798,6 @@ int kmm_get_param(kmm_index_t *ix, const char *name, int64_t *value)
         *value = ix->path;
     else if (!strcmp(name, "part_shift"))
         *value = ix->part_shift;
-    else if (!strcmp(name, "part_min_positions"))
-        *value = ix->part_min_positions;
     else if (!strcmp(name, "occupancy_filter"))
         *value = (ix->use_occ && ix->occ) ? 1 : 0;
     else if (!strcmp(name, "n_partitions"))
