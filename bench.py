@@ -59,7 +59,7 @@ def main():
     ap.add_argument("--part-shift", type=int, default=None)
     ap.add_argument("--no-filter", action="store_true", help="disable the L2 occupancy-bitmap prefilter")
     ap.add_argument("--general-path", action="store_true", help="use kmm_map_reads with an offsets array")
-    ap.add_argument("--cpu-sample-reads", type=int, default=2_000_000)
+    ap.add_argument("--cpu-sample-reads", type=int, default=5_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--max-freq", type=int, default=1000,
                     help="max_index_lookup_frequency (-1 filters every hit: timing ablation without atomics)")
