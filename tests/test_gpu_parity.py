@@ -348,3 +348,113 @@ def test_cli_map_end_to_end(kmm, syn, oracle, tmp_path, fmt, gz):
     got_rc = map_bnp(ns)
     expect_rc, _ = oracle.map_reads(index, index.max_node_id(), bases, offs, 31, also_revcomp=True)
     assert np.array_equal(got_rc, expect_rc)
+
+
+# ---------------------------------------------------------------- more edge cases
+def _flat_index(syn, kmers, nodes, modulo):
+    from kmer_mapper_amd.kmer_index import KmerIndex
+    return KmerIndex.from_flat_kmers(np.asarray(kmers, dtype=np.uint64), np.asarray(nodes, dtype=np.int64), modulo)
+
+
+@pytest.mark.parametrize("modulo", [1, 2, 64, 1009, 2 ** 20, 2147483629])
+def test_fastmod_exact_for_every_modulo_and_full_uint64_range(kmm, oracle, modulo):
+    """kmers[i] % modulo (mapper.pyx:54) for k-mers over the whole uint64 range, odd moduli,
+    powers of two, modulo 1 and a prime just below 2^31."""
+    rng = np.random.default_rng(modulo)
+    idx_kmers = rng.integers(0, 2 ** 64, size=300, dtype=np.uint64)
+    idx_kmers[:5] = [0, 1, 2 ** 64 - 1, 2 ** 63, modulo]
+    if modulo > 10 ** 6:                      # keep hashes_to_index small enough to build on the host
+        pytest.skip("covered by test_large_modulo_table") if modulo > 2 ** 22 else None
+    index = _flat_index(None, idx_kmers, np.arange(300), modulo)
+    q = np.concatenate([idx_kmers, rng.integers(0, 2 ** 64, size=5000, dtype=np.uint64),
+                        idx_kmers + np.uint64(modulo)])
+    expect = oracle.map_kmers(index, 299, q)
+    with kmm.DeviceIndex.from_index(index, 299) as dev:
+        dev.map_kmers(q)
+        assert np.array_equal(dev.get_node_counts(), expect)
+        assert np.array_equal(dev.in_index(q), oracle.in_index(index, q))
+
+
+def test_large_modulo_table(kmm, oracle):
+    """A 2^31-sized hash space is too big for CI; 50 M buckets still exercises 64-bit indexing."""
+    modulo = 50_000_017
+    rng = np.random.default_rng(9)
+    idx_kmers = rng.integers(0, 2 ** 62, size=2000, dtype=np.uint64)
+    index = _flat_index(None, idx_kmers, rng.integers(0, 77, size=2000), modulo)
+    q = np.concatenate([idx_kmers, rng.integers(0, 2 ** 62, size=20000, dtype=np.uint64)])
+    expect = oracle.map_kmers(index, 76, q)
+    with kmm.DeviceIndex.from_index(index, 76) as dev:
+        dev.map_kmers(q)
+        assert np.array_equal(dev.get_node_counts(), expect)
+
+
+def test_long_buckets_frequency_filter_and_poly_a(kmm, syn, oracle):
+    """One bucket holding every entry (modulo 1), a k-mer present 1500x (> 1000: filtered) and 700x
+    (kept), queried by poly-A reads."""
+    k = 31
+    a_kmer = np.uint64(0)                                   # AAAA...A
+    c_kmer = np.uint64(int("01" * 31, 2))                   # CCCC...C
+    kmers = np.concatenate([np.full(1500, a_kmer), np.full(700, c_kmer),
+                            np.arange(1, 200, dtype=np.uint64)])
+    nodes = np.arange(kmers.shape[0]) % 50
+    for modulo in (1, 7):
+        index = _flat_index(None, kmers, nodes, modulo)
+        reads = ["A" * 100, "C" * 64, "A" * 31 + "C" * 31, "N" * 40]
+        b = batch(reads)
+        for mf in (1000, 699, 65535):
+            expect, _ = oracle.map_reads(index, 49, b.bases, b.offsets, k, max_index_lookup_frequency=mf)
+            with kmm.DeviceIndex.from_index(index, 49) as dev:
+                dev.map_reads(b.bases, b.offsets, k, max_index_lookup_frequency=mf)
+                assert np.array_equal(dev.get_node_counts(), expect)
+                if mf == 1000:
+                    assert expect.sum() == 35 * 700      # only the 34 + 1 all-C windows (frequency 700) count
+
+
+@pytest.mark.parametrize("path", [1, 2])
+def test_many_tiny_reads_and_very_long_reads(kmm, syn, oracle, path):
+    index, genome = syn.make_index(4000, k=3, seed=111, plant=False, modulo=67)
+    mx = index.max_node_id()
+    # thousands of reads of length 0..5: far more than 256 read starts inside one tile
+    bases, offs = syn.make_ragged_reads(genome, 20000, 0, 5, seed=112)
+    expect, n = oracle.map_reads(index, mx, bases, offs, 3)
+    with kmm.DeviceIndex.from_index(index, mx) as dev:
+        dev.set_param("path", path)
+        if path == 2:
+            dev.set_param("part_shift", 4)
+        dev.map_reads(bases, offs, 3)
+        assert n > 0 and np.array_equal(dev.get_node_counts(), expect)
+    # a few reads of 23-100 kbp (windows spanning many tiles, no boundary for whole tiles)
+    index, genome = syn.make_index(30000, k=31, seed=113)
+    mx = index.max_node_id()
+    rng = np.random.default_rng(114)
+    lens = np.array([100000, 1, 50000, 0, 31, 30, 23457], dtype=np.int64)
+    offs = np.zeros(lens.shape[0] + 1, dtype=np.int64)
+    np.cumsum(lens, out=offs[1:])
+    starts = rng.integers(0, genome.shape[0] - 100000, size=lens.shape[0])
+    bases = np.concatenate([syn.ACGT[genome[s:s + l]] for s, l in zip(starts, lens)])
+    expect, n = oracle.map_reads(index, mx, bases, offs, 31)
+    with kmm.DeviceIndex.from_index(index, mx) as dev:
+        dev.set_param("path", path)
+        dev.map_reads(bases, offs, 31)
+        got = dev.get_node_counts()
+    assert expect.sum() > 1000 and np.array_equal(got, expect)
+
+
+@pytest.mark.parametrize("total_mod", [1, 15, 16, 17, 1023, 1024, 1025])
+def test_tail_and_alignment(kmm, syn, oracle, total_mod):
+    """Batches whose byte count is just below / at / above the 16-byte vector and 1024-position tile."""
+    index, genome = syn.make_index(2000, k=5, seed=121, plant=False)
+    mx = index.max_node_id()
+    total = 3 * 1024 + total_mod
+    bases = syn.ACGT[genome[:total]]
+    offs = np.array([0, 7, 7, 1500, total], dtype=np.int64)
+    expect, _ = oracle.map_reads(index, mx, bases, offs, 5)
+    with kmm.DeviceIndex.from_index(index, mx) as dev:
+        dev.map_reads(bases, offs, 5)
+        assert np.array_equal(dev.get_node_counts(), expect)
+        # one read of exactly k bases, and one of k-1
+        dev.reset(); dev.map_reads(bases[:5], np.array([0, 5], dtype=np.int64), 5)
+        e1, n1 = oracle.map_reads(index, mx, bases[:5], np.array([0, 5], dtype=np.int64), 5)
+        assert n1 == 1 and np.array_equal(dev.get_node_counts(), e1)
+        dev.reset(); dev.map_reads(bases[:4], np.array([0, 4], dtype=np.int64), 5)
+        assert dev.get_node_counts().sum() == 0
