@@ -61,6 +61,9 @@ def main():
     ap.add_argument("--general-path", action="store_true", help="use kmm_map_reads with an offsets array")
     ap.add_argument("--cpu-sample-reads", type=int, default=5_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl",
+                    help="nccl (= RCCL, the real multi-GPU path) or gloo (rehearsal on a 1-GPU box: all "
+                         "ranks share device LOCAL_RANK %% device_count, the reduce runs on host copies)")
     ap.add_argument("--max-freq", type=int, default=1000,
                     help="max_index_lookup_frequency (-1 filters every hit: timing ablation without atomics)")
     args = ap.parse_args()
@@ -73,11 +76,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         log("note: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world))
+    if args.dist_backend == "gloo":
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev_t = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev_t)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev_t)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     from kmer_mapper_amd import synthetic as syn
     from kmer_mapper_amd.distributed import reduce_node_counts
@@ -122,10 +130,18 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    def reduce_counts(t):
+        if args.dist_backend == "nccl":
+            reduce_node_counts(t, dst=0)            # RCCL sum of the uint32 count vectors over xGMI
+        else:                                        # rehearsal only
+            h = t.cpu()
+            reduce_node_counts(h, dst=0)
+            t.copy_(h)
+
     for i in range(args.warmup):
         step(i)
     if world > 1:                                   # warm the RCCL communicator too
-        reduce_node_counts(torch.zeros_like(counts), dst=0)
+        reduce_counts(torch.zeros_like(counts))
     fence()
     counts.zero_()
     fence()
@@ -137,7 +153,7 @@ def main():
     dev.synchronize()
     t_map = time.perf_counter()
     if world > 1:
-        reduce_node_counts(counts, dst=0)           # RCCL sum of the uint32 count vectors over xGMI
+        reduce_counts(counts)
     fence()
     t1 = time.perf_counter()
     dev.set_timing(False)
@@ -146,7 +162,8 @@ def main():
     elapsed = t1 - t0
     reduce_s = t1 - t_map
     if world > 1:
-        tt = torch.tensor([elapsed, reduce_s], dtype=torch.float64, device=dev_t)
+        tt = torch.tensor([elapsed, reduce_s], dtype=torch.float64,
+                          device=dev_t if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed, reduce_s = tt[0].item(), tt[1].item()
 
