@@ -57,6 +57,7 @@ def main():
     ap.add_argument("--skewed", action="store_true", help="node = i mod 1000 (atomic contention)")
     ap.add_argument("--path", type=int, default=0, help="0 auto, 1 direct fused kernel, 2 radix-partitioned")
     ap.add_argument("--part-shift", type=int, default=None)
+    ap.add_argument("--grid-per-cu", type=int, default=None)
     ap.add_argument("--no-filter", action="store_true", help="disable the L2 occupancy-bitmap prefilter")
     ap.add_argument("--general-path", action="store_true", help="use kmm_map_reads with an offsets array")
     ap.add_argument("--cpu-sample-reads", type=int, default=5_000_000)
@@ -101,6 +102,8 @@ def main():
     dev.set_param("path", args.path)
     if args.no_filter:
         dev.set_param("occupancy_filter", 0)
+    if args.grid_per_cu is not None:
+        dev.set_param("grid_per_cu", args.grid_per_cu)
     if args.part_shift is not None:
         dev.set_param("part_shift", args.part_shift)
     counts = torch.zeros(mx + 1, dtype=torch.int32, device=dev_t)    # uint32 bits; wrap-add == int32 add

@@ -968,6 +968,7 @@ struct kmm_index {
     int n_cu = 256;
     // path selection / partitioned path state
     int path = 0;        // 0 auto, 1 direct, 2 partitioned
+    int grid_per_cu = 64; // workgroups per CU of the grid-stride fused kernel
     int part_shift = 16; // 2^16 buckets x 16 B = 1 MiB bucket-table slice per partition
     DevBuf part_meta;    // hist, part_off, cursor, xcd_cum, xcd_queue
     DevBuf part_kmers;
@@ -1159,7 +1160,7 @@ int launch_map_reads(kmm_index *ix, const ReadsView &rv, int k, int max_freq, in
     if (!use_partitioned(ix, rv.total)) {
         ScopedTimer tm;
         KMMCHK(tm.begin(ix, KMM_KERNEL_MAP_READS));
-        hipLaunchKernelGGL((k_map_reads<TILE_S, UNIFORM>), dim3(grid_for(ix, n_tiles, 64)), dim3(256),
+        hipLaunchKernelGGL((k_map_reads<TILE_S, UNIFORM>), dim3(grid_for(ix, n_tiles, ix->grid_per_cu)), dim3(256),
                            0, ix->stream, rv, iv, k, max_freq, also_rc, (int64_t)0, n_tiles);
         HIPCHK(hipGetLastError());
         return tm.end();
@@ -1781,6 +1782,10 @@ int kmm_set_param(kmm_index_t *ix, const char *name, int64_t value)
             return fail(KMM_ERR_INVALID_ARG, "part_shift outside [4, 30]");
         ix->part_shift = (int)value;
         release(ix->part_meta); // re-laid out (and re-zeroed) on next use
+    } else if (!strcmp(name, "grid_per_cu")) {
+        if (value < 1 || value > 1024)
+            return fail(KMM_ERR_INVALID_ARG, "grid_per_cu outside [1, 1024]");
+        ix->grid_per_cu = (int)value;
     } else if (!strcmp(name, "occupancy_filter")) {
         ix->use_occ = value != 0;
 
@@ -1798,6 +1803,8 @@ int kmm_get_param(kmm_index_t *ix, const char *name, int64_t *value)
         *value = ix->path;
     else if (!strcmp(name, "part_shift"))
         *value = ix->part_shift;
+    else if (!strcmp(name, "grid_per_cu"))
+        *value = ix->grid_per_cu;
     else if (!strcmp(name, "occupancy_filter"))
         *value = (ix->use_occ && ix->occ) ? 1 : 0;
     else if (!strcmp(name, "n_partitions"))
