@@ -36,6 +36,7 @@ extern "C" {
 #define KMM_ERR_INDEX (-3)         /* index arrays inconsistent (bucket out of range, bad node)  */
 #define KMM_ERR_INVALID_BASE (-4)  /* a read byte is not a nucleotide under the lookup table     */
 #define KMM_ERR_NOMEM (-5)
+#define KMM_ERR_MALFORMED (-6)     /* raw FASTA/FASTQ chunk does not have the expected line structure */
 
 #define KMM_MAX_K 31               /* a k-mer is packed 2 bits/base into a uint64; bionumpy's
                                       get_kmers (util.py:72) is used with k <= 31                */
@@ -105,6 +106,26 @@ int kmm_map_reads(kmm_index_t *idx, const uint8_t *bases, const int64_t *read_of
 int kmm_map_reads_uniform(kmm_index_t *idx, const uint8_t *bases, int64_t n_reads,
                           int64_t read_len, int k, int max_index_lookup_frequency,
                           int also_revcomp, const uint8_t *lut);
+
+/*
+ * kmm_map_records — maps a RAW chunk of a FASTQ (format = 4 lines per record) or two-line FASTA
+ * (format = 2) file: replaces `bnp.open(reads).read_chunks(...)` + the per-chunk map
+ * (command_line_interface.py:102-103,109-111 and :32-56) — record parsing happens on the GPU, the host
+ * only reads (and, for .gz, inflates) bytes.  `raw` must start at the first byte of a record.  The
+ * library finds the end of the last COMPLETE record inside the chunk, maps every base of the sequence
+ * lines up to there exactly like kmm_map_reads, and returns in *consumed how many bytes it used (the
+ * caller prepends the remaining raw[consumed:] to the next chunk; at end of file the last line must end
+ * with a newline) and in *n_records the number of reads mapped.  '\r' before '\n' is tolerated.
+ * The call returns once the chunk is staged and scanned (so *consumed is valid and the host buffer is
+ * free); the mapping kernels run asynchronously like every other map call.  n_bytes <= 2^30.
+ * A line that should start a record ('@' / '>') or the FASTQ '+' line but does not (e.g. multi-line
+ * FASTA) makes the next synchronising call fail with KMM_ERR_MALFORMED.
+ */
+#define KMM_FORMAT_FASTA2 2
+#define KMM_FORMAT_FASTQ 4
+int kmm_map_records(kmm_index_t *idx, const uint8_t *raw, int64_t n_bytes, int format, int k,
+                    int max_index_lookup_frequency, int also_revcomp, const uint8_t *lut,
+                    int64_t *consumed, int64_t *n_records);
 
 /*
  * kmm_extract_kmers — replaces get_kmer_hashes_from_chunk_sequence (util.py:71-75) as an

@@ -19,6 +19,8 @@ KMM_ERR_HIP = -2
 KMM_ERR_INDEX = -3
 KMM_ERR_INVALID_BASE = -4
 KMM_ERR_NOMEM = -5
+KMM_ERR_MALFORMED = -6
+FORMAT_FASTA2, FORMAT_FASTQ = 2, 4
 
 # kernel ids of kmm_get_timing (include/kmm.h)
 KERNEL_MAP_READS, KERNEL_MAP_KMERS, KERNEL_PART_HIST, KERNEL_PART_SCATTER, KERNEL_PART_PROBE = range(5)
@@ -44,6 +46,7 @@ SIGNATURES = {
     "kmm_map_reads": (_c.c_int, [_P, _P, _P, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _P]),
     "kmm_map_reads_uniform": (_c.c_int, [_P, _P, _c.c_int64, _c.c_int64, _c.c_int, _c.c_int,
                                          _c.c_int, _P]),
+    "kmm_map_records": (_c.c_int, [_P, _P, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _P, _P, _P]),
     "kmm_extract_kmers": (_c.c_int, [_c.c_int, _P, _P, _c.c_int64, _c.c_int, _P, _P, _c.c_int64]),
     "kmm_in_index": (_c.c_int, [_P, _P, _c.c_int64, _P]),
     "kmm_set_timing": (_c.c_int, [_P, _c.c_int]),
@@ -113,7 +116,7 @@ def check(rc):
     if rc == KMM_OK:
         return
     msg = lib().kmm_last_error().decode("utf-8", "replace")
-    if rc in (KMM_ERR_INVALID_ARG, KMM_ERR_INDEX, KMM_ERR_INVALID_BASE):
+    if rc in (KMM_ERR_INVALID_ARG, KMM_ERR_INDEX, KMM_ERR_INVALID_BASE, KMM_ERR_MALFORMED):
         raise ValueError(msg)       # Cython buffer / bionumpy encoding errors are ValueError-like
     if rc == KMM_ERR_NOMEM:
         raise MemoryError(msg)

@@ -25,7 +25,8 @@ import numpy as np
 from .distributed import chunk_owner
 from .engine import DeviceIndex
 from .kmer_index import KmerIndex
-from .reads_io import prefetch, read_chunks
+from . import _lib
+from .reads_io import RawChunker, prefetch, read_chunks, sniff_format
 
 
 def main():
@@ -85,6 +86,50 @@ def map_gpu(index, chunks, k, hash_map_size=0, map_reverse_complements=False,
     return node_counts
 
 
+def map_gpu_raw(index, path, chunk_size, fmt, k, map_reverse_complements=False,
+                max_index_lookup_frequency=1000, device=0, rank=0, world_size=1):
+    """Same job as map_gpu, but the FASTQ / two-line FASTA records are parsed ON THE GPU
+    (kmm_map_records): the host only reads (and for .gz inflates) raw bytes."""
+    max_node_id = index.max_node_id() if hasattr(index, "max_node_id") else int(np.max(index._nodes))
+    dev = DeviceIndex.from_index(index, max_node_id, device=device)
+    chunker = RawChunker(path, chunk_size)
+    kfmt = _lib.FORMAT_FASTQ if fmt == "fastq" else _lib.FORMAT_FASTA2
+    t_start = time.perf_counter()
+    n_reads = n_bytes = 0
+    try:
+        i = 0
+        while True:
+            buf = chunker.next_chunk()
+            if buf is None:
+                break
+            if chunk_owner(i, world_size) == rank:
+                used, n_rec = dev.map_records(buf, buf.shape[0], kfmt, k, max_index_lookup_frequency,
+                                              also_revcomp=map_reverse_complements)
+            else:   # other ranks still need the record boundary: count lines on the host
+                nl = np.flatnonzero(buf == 10)
+                per = 4 if fmt == "fastq" else 2
+                whole = (nl.shape[0] // per) * per
+                used, n_rec = (int(nl[whole - 1]) + 1, whole // per) if whole else (0, 0)
+            if used == 0:
+                if chunker.eof:
+                    raise ValueError("trailing bytes at end of %s do not form a complete record" % path)
+                chunker.chunk_size *= 2          # a record longer than the chunk: read more
+                continue
+            n_reads += n_rec if chunk_owner(i, world_size) == rank else 0
+            n_bytes += used
+            chunker.consumed(used)
+            i += 1
+        node_counts = dev.get_node_counts()
+    finally:
+        chunker.close()
+        dev.close()
+    dt = time.perf_counter() - t_start
+    logging.info("Time spent only on hashing and counting hashes: %.5f" % dt)
+    logging.info("Mapped %d reads from %d bytes (%.1f MB/s, GPU record parser)"
+                 % (n_reads, n_bytes, n_bytes / max(dt, 1e-9) / 1e6))
+    return node_counts
+
+
 def map_bnp(args):
     if args.debug:
         logging.info("Will print debug log")
@@ -105,11 +150,17 @@ def map_bnp(args):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     max_freq = args.max_hits_per_kmer if getattr(args, "apply_max_hits_per_kmer", False) else 1000
 
-    chunks = prefetch(read_chunks(args.reads, min_chunk_size=args.chunk_size))
-    node_counts = map_gpu(kmer_index, chunks, k, getattr(args, "gpu_hash_map_size", 0),
-                          bool(getattr(args, "map_reverse_complements", False)), max_freq,
-                          device=local_rank if world > 1 else getattr(args, "device", 0),
-                          rank=rank, world_size=world)
+    device = local_rank if world > 1 else getattr(args, "device", 0)
+    revcomp = bool(getattr(args, "map_reverse_complements", False))
+    fmt, gpu_parsable = sniff_format(args.reads)
+    if gpu_parsable and not getattr(args, "host_parser", False):
+        node_counts = map_gpu_raw(kmer_index, args.reads, args.chunk_size, fmt, k, revcomp, max_freq,
+                                  device=device, rank=rank, world_size=world)
+    else:
+        logging.info("Using the host FASTA/FASTQ parser")
+        chunks = prefetch(read_chunks(args.reads, min_chunk_size=args.chunk_size))
+        node_counts = map_gpu(kmer_index, chunks, k, getattr(args, "gpu_hash_map_size", 0), revcomp,
+                              max_freq, device=device, rank=rank, world_size=world)
 
     if world > 1:
         import torch
@@ -166,6 +217,8 @@ def run_argument_parser(args):
                                 "Default False. Not necessary if index contains reverse complements.")
     subparser.add_argument("--apply-max-hits-per-kmer", action="store_true",
                            help="Extension: actually apply -I (the reference parses it but always uses 1000).")
+    subparser.add_argument("--host-parser", action="store_true",
+                           help="Extension: parse records on the host (always used for multi-line FASTA).")
     subparser.add_argument("--device", default=0, type=int, help="Extension: GPU ordinal (single process).")
     subparser.set_defaults(func=map_bnp)
 

@@ -83,8 +83,16 @@ struct ReadsView {
     uint64_t read_len;         // uniform path
     uint64_t read_len_magic;   // floor(2^64 / read_len)
     const uint8_t *lut;        // 256 bytes in HBM
-    unsigned long long *first_bad; // min position of a non-nucleotide byte (init ~0)
+    unsigned long long *first_bad; // [0] min position of a non-nucleotide byte, [1] of a malformed
+                                   //     record line (both init ~0)
+    // records mode (raw FASTQ / two-line FASTA bytes): newlines before every tile
+    const uint32_t *tile_nl;   // per tile: newlines before the tile inside its super-tile (1024 tiles)
+    const uint32_t *super_nl;  // per super-tile: newlines before it
+    uint32_t period_mask;      // lines per record - 1 (3 for FASTQ, 1 for two-line FASTA)
+    uint32_t header_char;      // '@' or '>'
 };
+
+enum { MODE_GENERAL = 0, MODE_UNIFORM = 1, MODE_RECORDS = 2 };
 
 // Exact x % m for any m >= 1 with one 64x64->hi multiply: q = hi64(x * floor(2^64/m)) is either
 // floor(x/m) or one less (x * (2^64/m - magic) / 2^64 < 1), so a single conditional subtract
@@ -318,20 +326,107 @@ __device__ __forceinline__ TileConst tile_const(const ReadsView &rv, int k)
     return c;
 }
 
-template <int S, bool UNIFORM>
+// SWAR: 0x80 in every byte of x that equals the byte value c (exact, no cross-byte carries).
+__device__ __forceinline__ uint32_t bytes_equal(uint32_t x, uint32_t c)
+{
+    const uint32_t y = x ^ (c * 0x01010101u);
+    return ~(((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y | 0x7F7F7F7Fu);
+}
+
+// 0x80-per-byte flags of four bytes -> 4-bit mask (bit i = byte i).
+__device__ __forceinline__ uint32_t flags_to_bits(uint32_t f)
+{
+    return ((f >> 7) & 1u) | ((f >> 14) & 2u) | ((f >> 21) & 4u) | ((f >> 28) & 8u);
+}
+
+template <int S, int MODE>
 __device__ __forceinline__ uint32_t tile_kmers(const ReadsView &rv, const TileConst &tc, int64_t tile,
                                                int k, TileSmem<S> &sm, uint64_t (&q)[S])
 {
+    constexpr bool UNIFORM = MODE == MODE_UNIFORM;
+    constexpr bool RECORDS = MODE == MODE_RECORDS;
     constexpr int T = TileSmem<S>::T;
     constexpr int NV = TileSmem<S>::NV;
     constexpr int NB = TileSmem<S>::NB;
+    static_assert(NV <= 256, "one staged 16-byte vector per thread");
     const int tid = threadIdx.x;
     const int64_t total = rv.total;
     const int64_t t0 = tile * T;
-    if (!UNIFORM)
+    if (MODE == MODE_GENERAL)
         for (int i = tid; i < NB + 1; i += 256)
             sm.bits[i] = 0;
     __syncthreads(); // LUT visible; bitset cleared; previous tile's LDS readers are done
+
+    if (RECORDS) {
+        // ---- records mode, stage 1: raw file bytes.  A byte is a base iff it lies on the sequence
+        // line of its record (line index mod period == 1) and is not a line terminator; every other
+        // byte is a "break" that no window may contain, so k-mers never leave their read.
+        uint32_t w[4] = {0u, 0u, 0u, 0u};
+        uint32_t nl = 0, cr = 0; // 16-bit masks: byte i is '\n' / '\r'
+        const int v = tid;
+        const int64_t p = t0 + (int64_t)v * 16;
+        if (v < NV) {
+            if (tc.aligned && p + 16 <= total) {
+                u32x4 x = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(rv.bases + p));
+                w[0] = x[0]; w[1] = x[1]; w[2] = x[2]; w[3] = x[3];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    uint32_t acc = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        int64_t pp = p + i * 4 + j;
+                        uint32_t c = (pp < total) ? rv.bases[pp] : 0u;
+                        acc |= c << (8 * j);
+                    }
+                    w[i] = acc;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                nl |= flags_to_bits(bytes_equal(w[i], 10u)) << (4 * i);
+                cr |= flags_to_bits(bytes_equal(w[i], 13u)) << (4 * i);
+            }
+            sm.codes[v] = (uint32_t)__popc(nl); // borrowed as the per-vector newline count
+        }
+        __syncthreads();
+        uint32_t brk = 0, code = 0;
+        int bad = -1, malformed = -1;
+        if (v < NV) {
+            uint32_t line0 = rv.super_nl[tile >> 10] + rv.tile_nl[tile]; // newlines before the tile
+            for (int i = 0; i < v; ++i)
+                line0 += sm.codes[i];
+            // first byte of a line: preceded by '\n' (or the very first byte of the chunk)
+            const uint32_t prev_nl = (p == 0) ? 1u : (p - 1 < total ? (rv.bases[p - 1] == 10u) : 0u);
+            const uint32_t first = ((nl << 1) | prev_nl) & 0xFFFFu;
+#pragma unroll
+            for (int i = 15; i >= 0; --i) {
+                const uint32_t c = (w[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+                const uint32_t line = line0 + (uint32_t)__popc(nl & ((1u << i) - 1u));
+                const uint32_t phase = line & rv.period_mask;
+                const bool term = ((nl | cr) >> i) & 1u;
+                const bool is_seq = phase == 1u && !term && p + i < total;
+                const uint32_t l = sm.lut[c];
+                if (is_seq && l == 0xFFu)
+                    bad = i;
+                if (((first >> i) & 1u) && p + i < total &&
+                    ((phase == 0u && c != rv.header_char) || (phase == 2u && c != '+')))
+                    malformed = i;
+                brk |= (is_seq ? 0u : 1u) << i;
+                code |= (l & 3u) << (2 * i);
+            }
+        }
+        __syncthreads(); // every thread has read the borrowed per-vector counts
+        if (v < NV) {
+            sm.codes[v] = code;
+            reinterpret_cast<uint16_t *>(sm.bits)[v] = (uint16_t)brk;
+            if (bad >= 0)
+                atomicMin(&rv.first_bad[0], (unsigned long long)(p + bad));
+            if (malformed >= 0)
+                atomicMin(&rv.first_bad[1], (unsigned long long)(p + malformed));
+        }
+        __syncthreads();
+    } else {
 
     // ---- stage 1: bytes -> 2-bit codes in LDS ----------------------------------------------
     for (int v = tid; v < NV; v += 256) {
@@ -369,7 +464,7 @@ __device__ __forceinline__ uint32_t tile_kmers(const ReadsView &rv, const TileCo
             atomicMin(rv.first_bad, (unsigned long long)(p + bad));
     }
     // ---- stage 2: read starts inside (t0, t0 + T + k - 2] ----------------------------------
-    if (!UNIFORM) {
+    if (MODE == MODE_GENERAL) {
         for (int64_t r = rv.tile_first[tile] + tid; r <= rv.n_reads; r += 256) {
             int64_t o = rv.offsets[r] - t0;
             if (o > (int64_t)T + k - 2)
@@ -379,6 +474,7 @@ __device__ __forceinline__ uint32_t tile_kmers(const ReadsView &rv, const TileCo
         }
     }
     __syncthreads();
+    } // !RECORDS
 
     // ---- stage 3: S consecutive windows per lane -------------------------------------------
     const int q0 = tid * S;
@@ -412,10 +508,18 @@ __device__ __forceinline__ uint32_t tile_kmers(const ReadsView &rv, const TileCo
         uint64_t B = ((uint64_t)sm.bits[sw + 1] << 32) | sm.bits[sw];
         if (off)
             B = (B >> off) | ((uint64_t)sm.bits[sw + 2] << (64 - off));
+        if (RECORDS) { // no break byte inside [p, p+k-1]
+            const uint64_t wmask = (1ull << k) - 1ull;
 #pragma unroll
-        for (int j = 0; j < S; ++j)
-            if (((B >> (j + 1)) & tc.bmask) == 0 && p0 + j + k <= total)
-                valid |= 1u << j;
+            for (int j = 0; j < S; ++j)
+                if (((B >> j) & wmask) == 0 && p0 + j + k <= total)
+                    valid |= 1u << j;
+        } else {       // no read start inside (p, p+k-1]
+#pragma unroll
+            for (int j = 0; j < S; ++j)
+                if (((B >> (j + 1)) & tc.bmask) == 0 && p0 + j + k <= total)
+                    valid |= 1u << j;
+        }
     }
 #pragma unroll
     for (int j = 0; j < S; ++j)
@@ -427,7 +531,7 @@ __device__ __forceinline__ uint32_t tile_kmers(const ReadsView &rv, const TileCo
 // K1 (direct path): fused reads -> counts, every probe goes to HBM.  Used for small batches and for
 // indexes whose hash space cannot be cut into L2-sized partitions.
 // ------------------------------------------------------------------------------------------------
-template <int S, bool UNIFORM>
+template <int S, int MODE>
 __global__ void __launch_bounds__(256) k_map_reads(ReadsView rv, IndexView iv, int k, int max_freq,
                                                    int also_rc, int64_t tile_begin, int64_t tile_end)
 {
@@ -438,7 +542,7 @@ __global__ void __launch_bounds__(256) k_map_reads(ReadsView rv, IndexView iv, i
     const TileConst tc = tile_const(rv, k);
     for (int64_t tile = tile_begin + blockIdx.x; tile < tile_end; tile += gridDim.x) {
         uint64_t q[S];
-        const uint32_t valid = tile_kmers<S, UNIFORM>(rv, tc, tile, k, sm, q);
+        const uint32_t valid = tile_kmers<S, MODE>(rv, tc, tile, k, sm, q);
         if (__builtin_amdgcn_ballot_w64(valid != 0)) {
             probe_batch<S>(iv, agg, q, valid, max_freq);
             if (also_rc) {
@@ -494,7 +598,7 @@ __device__ __forceinline__ uint32_t slot_of(const IndexView &iv, const PartView 
     return (p & (KMM_N_XCD - 1)) * pv.PX + (p >> 3);
 }
 
-template <int S, bool UNIFORM>
+template <int S, int MODE>
 __global__ void __launch_bounds__(256) k_part_hist(ReadsView rv, IndexView iv, int k, int also_rc,
                                                    PartView pv, int64_t tile_begin, int64_t tile_end)
 {
@@ -507,7 +611,7 @@ __global__ void __launch_bounds__(256) k_part_hist(ReadsView rv, IndexView iv, i
     const TileConst tc = tile_const(rv, k);
     for (int64_t tile = tile_begin + blockIdx.x; tile < tile_end; tile += gridDim.x) {
         uint64_t q[S];
-        const uint32_t valid = tile_kmers<S, UNIFORM>(rv, tc, tile, k, sm, q);
+        const uint32_t valid = tile_kmers<S, MODE>(rv, tc, tile, k, sm, q);
 #pragma unroll
         for (int j = 0; j < S; ++j)
             if ((valid >> j) & 1u) {
@@ -625,7 +729,7 @@ __device__ __forceinline__ uint32_t block_excl_scan(const uint32_t *s_cnt, uint3
     return total;
 }
 
-template <int S, bool UNIFORM>
+template <int S, int MODE>
 __global__ void __launch_bounds__(256) k_part_scatter(ReadsView rv, IndexView iv, int k, int also_rc,
                                                       PartView pv, int64_t tile_begin,
                                                       int64_t tile_end)
@@ -647,7 +751,7 @@ __global__ void __launch_bounds__(256) k_part_scatter(ReadsView rv, IndexView iv
     const TileConst tc = tile_const(rv, k);
     for (int64_t tile = tile_begin + blockIdx.x; tile < tile_end; tile += gridDim.x) {
         uint64_t q[S];
-        const uint32_t valid = tile_kmers<S, UNIFORM>(rv, tc, tile, k, sm, q);
+        const uint32_t valid = tile_kmers<S, MODE>(rv, tc, tile, k, sm, q);
         for (int round = 0; round < (also_rc ? 2 : 1); ++round) {
             if (round == 1) {
 #pragma unroll
@@ -717,6 +821,119 @@ __global__ void __launch_bounds__(256) k_part_probe(IndexView iv, PartView pv, i
     }
     __syncthreads();
     agg_flush(iv, agg);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Records mode pre-pass: newline census of a raw FASTQ / two-line FASTA chunk (tile = 1024 bytes,
+// super-tile = 1024 tiles), so that every tile knows the line number of its first byte, and the
+// position where the last complete record ends.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_rec_count(const uint8_t *__restrict__ raw, int64_t n,
+                                                   int64_t n_tiles, uint32_t *__restrict__ tile_cnt)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); // one wavefront per tile
+    if (tile >= n_tiles)
+        return;
+    const int64_t p = tile * 1024 + lane * 16;
+    uint32_t c = 0;
+    if ((((uintptr_t)raw) & 15u) == 0 && p + 16 <= n) {
+        u32x4 x = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(raw + p));
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            c += (uint32_t)__popc(bytes_equal(x[i], 10u));
+    } else {
+        for (int i = 0; i < 16; ++i)
+            if (p + i < n && raw[p + i] == 10u)
+                ++c;
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1)
+        c += __shfl_xor(c, d);
+    if (lane == 0)
+        tile_cnt[tile] = c;
+}
+
+// Inclusive Hillis-Steele scan of s_a[0..1024) by a 1024-thread workgroup.
+__device__ __forceinline__ void block_scan_1024(uint32_t *s_a)
+{
+    const int t = threadIdx.x;
+    for (int d = 1; d < 1024; d <<= 1) {
+        const uint32_t v = t >= d ? s_a[t - d] : 0u;
+        __syncthreads();
+        s_a[t] += v;
+        __syncthreads();
+    }
+}
+
+// One workgroup per super-tile: counts -> exclusive prefix inside the super-tile (in place) + total.
+__global__ void __launch_bounds__(1024) k_rec_scan1(uint32_t *tile_cnt, uint32_t *super_tot)
+{
+    __shared__ uint32_t s_a[1024];
+    const int t = threadIdx.x;
+    const size_t idx = (size_t)blockIdx.x * 1024 + t;
+    const uint32_t c = tile_cnt[idx];
+    s_a[t] = c;
+    __syncthreads();
+    block_scan_1024(s_a);
+    tile_cnt[idx] = s_a[t] - c;
+    if (t == 1023)
+        super_tot[blockIdx.x] = s_a[t];
+}
+
+// One workgroup: exclusive prefix over the super-tiles, then the byte position just after the last
+// newline that completes a record (records have `period` lines).  out = {consumed, n_records, n_lines}.
+__global__ void __launch_bounds__(1024) k_rec_scan2(const uint8_t *__restrict__ raw, int64_t n,
+                                                    int n_super, const uint32_t *__restrict__ tile_pre,
+                                                    uint32_t *super_tot, uint32_t period, int64_t *out)
+{
+    __shared__ uint32_t s_a[1024];
+    __shared__ uint32_t s_super, s_rem, s_super_cnt;
+    __shared__ int64_t s_tile;
+    const int t = threadIdx.x;
+    const uint32_t c = t < n_super ? super_tot[t] : 0u;
+    s_a[t] = c;
+    __syncthreads();
+    block_scan_1024(s_a);
+    const uint32_t excl = s_a[t] - c;
+    const uint32_t total = s_a[1023];
+    __syncthreads();
+    if (t < n_super)
+        super_tot[t] = excl;
+    const uint32_t target = total - total % period;
+    if (target == 0) { // same for every thread
+        if (t == 0) {
+            out[0] = 0;
+            out[1] = 0;
+            out[2] = total;
+        }
+        return;
+    }
+    if (t < n_super && excl < target && target <= excl + c) {
+        s_super = (uint32_t)t;
+        s_rem = target - excl;
+        s_super_cnt = c;
+    }
+    __syncthreads();
+    const uint32_t sup = s_super, rem = s_rem;
+    const uint32_t pre = tile_pre[(size_t)sup * 1024 + t];
+    const uint32_t nxt = t < 1023 ? tile_pre[(size_t)sup * 1024 + t + 1] : s_super_cnt;
+    if (pre < rem && rem <= nxt)
+        s_tile = (int64_t)sup * 1024 + t;
+    __syncthreads();
+    const int64_t tile = s_tile;
+    const uint32_t r = rem - tile_pre[tile];
+    const int64_t pos = tile * 1024 + t;
+    const uint32_t is_nl = (pos < n && raw[pos] == 10u) ? 1u : 0u;
+    s_a[t] = is_nl;
+    __syncthreads();
+    block_scan_1024(s_a);
+    if (is_nl && s_a[t] == r)
+        out[0] = pos + 1;
+    if (t == 0) {
+        out[1] = target / period;
+        out[2] = total;
+    }
 }
 
 // General path helper: for every tile, the first read index r in [0, n_reads+1] whose start lies
@@ -1031,14 +1248,19 @@ int drain(kmm_index *ix)
 {
     HIPCHK(hipStreamSynchronize(ix->copy_stream));
     HIPCHK(hipStreamSynchronize(ix->stream));
-    unsigned long long bad = NO_BAD;
-    HIPCHK(hipMemcpy(&bad, ix->first_bad, sizeof bad, hipMemcpyDeviceToHost));
-    if (bad != NO_BAD) {
-        unsigned long long reset = NO_BAD;
-        HIPCHK(hipMemcpy(ix->first_bad, &reset, sizeof reset, hipMemcpyHostToDevice));
+    unsigned long long bad[2] = {NO_BAD, NO_BAD};
+    HIPCHK(hipMemcpy(bad, ix->first_bad, sizeof bad, hipMemcpyDeviceToHost));
+    if (bad[0] != NO_BAD || bad[1] != NO_BAD) {
+        unsigned long long reset[2] = {NO_BAD, NO_BAD};
+        HIPCHK(hipMemcpy(ix->first_bad, reset, sizeof reset, hipMemcpyHostToDevice));
+        if (bad[1] != NO_BAD)
+            return fail(KMM_ERR_MALFORMED,
+                        "record structure violated at byte offset %llu of a mapped chunk (a record line "
+                        "does not start with '@' / '+' / '>'): multi-line FASTA/FASTQ is not supported by "
+                        "the GPU reader", bad[1]);
         return fail(KMM_ERR_INVALID_BASE,
                     "read byte at offset %llu of a mapped chunk is not a nucleotide under the "
-                    "lookup table (the reference's DNA encoder raises here)", bad);
+                    "lookup table (the reference's DNA encoder raises here)", bad[0]);
     }
     return KMM_OK;
 }
@@ -1152,7 +1374,7 @@ int part_view(kmm_index *ix, size_t kmer_capacity, PartView *pv)
     return KMM_OK;
 }
 
-template <bool UNIFORM>
+template <int MODE>
 int launch_map_reads(kmm_index *ix, const ReadsView &rv, int k, int max_freq, int also_rc)
 {
     const IndexView iv = view_of(ix);
@@ -1160,7 +1382,7 @@ int launch_map_reads(kmm_index *ix, const ReadsView &rv, int k, int max_freq, in
     if (!use_partitioned(ix, rv.total)) {
         ScopedTimer tm;
         KMMCHK(tm.begin(ix, KMM_KERNEL_MAP_READS));
-        hipLaunchKernelGGL((k_map_reads<TILE_S, UNIFORM>), dim3(grid_for(ix, n_tiles, ix->grid_per_cu)), dim3(256),
+        hipLaunchKernelGGL((k_map_reads<TILE_S, MODE>), dim3(grid_for(ix, n_tiles, ix->grid_per_cu)), dim3(256),
                            0, ix->stream, rv, iv, k, max_freq, also_rc, (int64_t)0, n_tiles);
         HIPCHK(hipGetLastError());
         return tm.end();
@@ -1177,7 +1399,7 @@ int launch_map_reads(kmm_index *ix, const ReadsView &rv, int k, int max_freq, in
         const int n_slots = KMM_N_XCD * pv.PX;
         ScopedTimer tm;
         KMMCHK(tm.begin(ix, KMM_KERNEL_PART_HIST));
-        hipLaunchKernelGGL((k_part_hist<TILE_S, UNIFORM>), dim3(grid), dim3(256), 0, ix->stream, rv, iv,
+        hipLaunchKernelGGL((k_part_hist<TILE_S, MODE>), dim3(grid), dim3(256), 0, ix->stream, rv, iv,
                            k, also_rc, pv, t0, t1);
         HIPCHK(hipGetLastError());
         KMMCHK(tm.end());
@@ -1185,7 +1407,7 @@ int launch_map_reads(kmm_index *ix, const ReadsView &rv, int k, int max_freq, in
         hipLaunchKernelGGL(k_part_scan2, dim3(1), dim3(1024), 0, ix->stream, pv);
         HIPCHK(hipGetLastError());
         KMMCHK(tm.begin(ix, KMM_KERNEL_PART_SCATTER));
-        hipLaunchKernelGGL((k_part_scatter<TILE_S, UNIFORM>), dim3(grid), dim3(256), 0, ix->stream, rv,
+        hipLaunchKernelGGL((k_part_scatter<TILE_S, MODE>), dim3(grid), dim3(256), 0, ix->stream, rv,
                            iv, k, also_rc, pv, t0, t1);
         HIPCHK(hipGetLastError());
         KMMCHK(tm.end());
@@ -1302,12 +1524,12 @@ static int index_create_impl(kmm_index *ix, const int32_t *h2i, const int32_t *n
     ix->counts = ix->own_counts_buf;
     HIPCHK(hipMemsetAsync(ix->counts, 0, sizeof(uint32_t) * (size_t)(ix->max_node_id + 1), ix->stream));
     HIPCHK(hipMalloc(&ix->lut_default, 256));
-    HIPCHK(hipMalloc(&ix->first_bad, sizeof(unsigned long long)));
+    HIPCHK(hipMalloc(&ix->first_bad, 2 * sizeof(unsigned long long)));
     uint8_t lut[256];
     default_lut(lut);
     HIPCHK(hipMemcpy(ix->lut_default, lut, 256, hipMemcpyHostToDevice));
-    unsigned long long nb = NO_BAD;
-    HIPCHK(hipMemcpy(ix->first_bad, &nb, sizeof nb, hipMemcpyHostToDevice));
+    unsigned long long nb[2] = {NO_BAD, NO_BAD};
+    HIPCHK(hipMemcpy(ix->first_bad, nb, sizeof nb, hipMemcpyHostToDevice));
 
     // raw arrays -> HBM (temporary), repack + validate on the GPU
     DevBuf d_h2i, d_nk, d_km, d_nd, d_fr, d_err;
@@ -1549,7 +1771,7 @@ static int map_reads_common(kmm_index_t *ix, const uint8_t *bases, const int64_t
         rv.read_len = (uint64_t)read_len;
         rv.read_len_magic = magic_for((uint64_t)read_len);
         KMMCHK(stage_copies_done(ix));
-        KMMCHK(launch_map_reads<true>(ix, rv, k, max_freq, also_revcomp ? 1 : 0));
+        KMMCHK(launch_map_reads<MODE_UNIFORM>(ix, rv, k, max_freq, also_revcomp ? 1 : 0));
     } else {
         if (uniform) {
             KMMCHK(ensure(s.offsets, (size_t)(n_reads + 1) * 8));
@@ -1567,7 +1789,7 @@ static int map_reads_common(kmm_index_t *ix, const uint8_t *bases, const int64_t
         hipLaunchKernelGGL(k_tile_first, dim3((unsigned)((n_tiles + 255) / 256)), dim3(256), 0,
                            ix->stream, rv.offsets, n_reads, n_tiles, TILE_T, (int64_t *)s.tile_first.p);
         HIPCHK(hipGetLastError());
-        KMMCHK(launch_map_reads<false>(ix, rv, k, max_freq, also_revcomp ? 1 : 0));
+        KMMCHK(launch_map_reads<MODE_GENERAL>(ix, rv, k, max_freq, also_revcomp ? 1 : 0));
     }
     return stage_release(ix, s, staged);
 }
@@ -1598,6 +1820,68 @@ int kmm_map_reads_uniform(kmm_index_t *ix, const uint8_t *bases, int64_t n_reads
     if (n_reads == 0 || read_len == 0)
         return KMM_OK;
     return map_reads_common(ix, bases, nullptr, n_reads, read_len, k, max_freq, also_revcomp, lut);
+}
+
+int kmm_map_records(kmm_index_t *ix, const uint8_t *raw, int64_t n_bytes, int format, int k,
+                    int max_freq, int also_revcomp, const uint8_t *lut, int64_t *consumed,
+                    int64_t *n_records)
+{
+    static_assert(TILE_T == 1024, "records mode counts newlines per 1024-byte tile");
+    if (!ix)
+        return fail(KMM_ERR_INVALID_ARG, "idx is NULL");
+    KMMCHK(check_k(k));
+    if (format != KMM_FORMAT_FASTQ && format != KMM_FORMAT_FASTA2)
+        return fail(KMM_ERR_INVALID_ARG, "format must be KMM_FORMAT_FASTQ (4) or KMM_FORMAT_FASTA2 (2)");
+    if (n_bytes < 0 || n_bytes > ((int64_t)1 << 30))
+        return fail(KMM_ERR_INVALID_ARG, "n_bytes outside [0, 2^30]: cut the file into smaller chunks");
+    if (consumed)
+        *consumed = 0;
+    if (n_records)
+        *n_records = 0;
+    if (n_bytes == 0)
+        return KMM_OK;
+    if (!raw)
+        return fail(KMM_ERR_INVALID_ARG, "raw is NULL");
+    HIPCHK(hipSetDevice(ix->device));
+    Stage &s = next_stage(ix);
+    KMMCHK(stage_acquire(ix, s));
+    bool staged = false;
+    ReadsView rv;
+    memset(&rv, 0, sizeof rv);
+    KMMCHK(stage_in<uint8_t>(ix, s.bases, raw, (size_t)n_bytes, &rv.bases, &staged));
+    KMMCHK(resolve_lut(ix, s, lut, &rv.lut, &staged));
+    const int64_t n_tiles = (n_bytes + TILE_T - 1) / TILE_T;
+    const int n_super = (int)((n_tiles + 1023) / 1024);
+    KMMCHK(ensure(s.tile_first, (size_t)n_super * 1024 * 4));
+    KMMCHK(ensure(s.offsets, (size_t)n_super * 4 + 64));
+    uint32_t *tile_cnt = (uint32_t *)s.tile_first.p;
+    uint32_t *super_tot = (uint32_t *)s.offsets.p;
+    int64_t *d_out = (int64_t *)((uint8_t *)s.offsets.p + (((size_t)n_super * 4 + 15) & ~(size_t)15));
+    HIPCHK(hipMemsetAsync(tile_cnt, 0, (size_t)n_super * 1024 * 4, ix->copy_stream));
+    hipLaunchKernelGGL(k_rec_count, dim3((unsigned)((n_tiles + 3) / 4)), dim3(256), 0, ix->copy_stream,
+                       rv.bases, n_bytes, n_tiles, tile_cnt);
+    hipLaunchKernelGGL(k_rec_scan1, dim3(n_super), dim3(1024), 0, ix->copy_stream, tile_cnt, super_tot);
+    hipLaunchKernelGGL(k_rec_scan2, dim3(1), dim3(1024), 0, ix->copy_stream, rv.bases, n_bytes, n_super,
+                       tile_cnt, super_tot, (uint32_t)format, d_out);
+    HIPCHK(hipGetLastError());
+    int64_t out[3] = {0, 0, 0};
+    HIPCHK(hipMemcpyAsync(out, d_out, sizeof out, hipMemcpyDeviceToHost, ix->copy_stream));
+    HIPCHK(hipStreamSynchronize(ix->copy_stream)); // the borrowed host buffer is free from here on
+    if (consumed)
+        *consumed = out[0];
+    if (n_records)
+        *n_records = out[1];
+    if (out[0] > 0) {
+        rv.total = out[0];
+        rv.first_bad = ix->first_bad;
+        rv.tile_nl = tile_cnt;
+        rv.super_nl = super_tot;
+        rv.period_mask = (uint32_t)format - 1u;
+        rv.header_char = format == KMM_FORMAT_FASTQ ? (uint32_t)'@' : (uint32_t)'>';
+        KMMCHK(stage_copies_done(ix));
+        KMMCHK(launch_map_reads<MODE_RECORDS>(ix, rv, k, max_freq, also_revcomp ? 1 : 0));
+    }
+    return stage_release(ix, s, false);
 }
 
 int kmm_in_index(kmm_index_t *ix, const uint64_t *kmers, int64_t n, uint8_t *out)

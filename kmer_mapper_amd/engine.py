@@ -152,6 +152,22 @@ class DeviceIndex:
                                                     int(k), int(max_index_lookup_frequency),
                                                     int(bool(also_revcomp)), t.ptr))
 
+    def map_records(self, raw, n_bytes=None, fmt=_lib.FORMAT_FASTQ, k=31, max_index_lookup_frequency=1000,
+                    also_revcomp=False, lut=None):
+        """Map a raw FASTQ (fmt=4) / two-line FASTA (fmt=2) chunk parsed on the GPU.
+        Returns (consumed_bytes, n_records); the caller carries raw[consumed:] to the next chunk."""
+        b = _Arg(raw, np.uint8, "raw")
+        t = _Arg(lut, np.uint8, "lut")
+        n = b.n if n_bytes is None else int(n_bytes)
+        if n > b.n:
+            raise ValueError("n_bytes exceeds the buffer")
+        consumed = ctypes.c_int64(0)
+        n_rec = ctypes.c_int64(0)
+        _lib.check(_lib.lib().kmm_map_records(self._h, b.ptr, n, int(fmt), int(k),
+                                              int(max_index_lookup_frequency), int(bool(also_revcomp)),
+                                              t.ptr, ctypes.byref(consumed), ctypes.byref(n_rec)))
+        return consumed.value, n_rec.value
+
     def in_index(self, kmers):
         a = _Arg(kmers, np.uint64, "kmers")
         out = np.zeros(a.n, dtype=np.uint8)

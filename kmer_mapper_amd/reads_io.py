@@ -199,3 +199,62 @@ def write_fastq(path, batch, gz=False):
         for i in range(len(batch)):
             seq = batch.bases[batch.offsets[i]:batch.offsets[i + 1]].tobytes()
             f.write(b"@r%d\n" % i + seq + b"\n+\n" + b"I" * len(seq) + b"\n")
+
+
+# ------------------------------------------------------------------------------------------------
+# Raw-chunk reader for the GPU record parser (kmm_map_records): the host only moves bytes.
+# ------------------------------------------------------------------------------------------------
+def sniff_format(path, probe_bytes=1 << 16):
+    """Returns ("fastq" | "fasta", gpu_parsable).  Two-line FASTA and 4-line FASTQ can be parsed on
+    the GPU; FASTA whose sequences are wrapped over several lines needs the host parser."""
+    with _open(path) as f:
+        head = f.read(probe_bytes)
+    if not head:
+        return "fasta", True
+    fmt = _detect_format(head[0], path)
+    if fmt == "fastq":
+        return fmt, True
+    lines = head.split(b"\n")
+    complete = lines[:-1] if len(lines) > 1 else lines
+    ok = all((ln[:1] == b">") == (i % 2 == 0) for i, ln in enumerate(complete) if ln or i % 2 == 0)
+    return fmt, ok
+
+
+class RawChunker:
+    """Feeds successive raw file chunks of ~chunk_size bytes to a consumer that reports how many
+    bytes it used (the end of the last complete record); the unused tail is carried over."""
+
+    def __init__(self, path, chunk_size):
+        self.f = _open(path)
+        self.chunk_size = int(chunk_size)
+        self.buf = np.empty(self.chunk_size + (1 << 20), dtype=np.uint8)
+        self.fill = 0
+        self.eof = False
+
+    def next_chunk(self):
+        """Returns a uint8 view (valid until the next call) or None at end of input."""
+        if self.eof and self.fill == 0:
+            return None
+        if self.fill == self.buf.shape[0]:          # one record larger than the buffer: grow
+            self.buf = np.concatenate([self.buf, np.empty_like(self.buf)])
+        while not self.eof and self.fill < min(self.chunk_size, self.buf.shape[0]):
+            got = self.f.readinto(memoryview(self.buf)[self.fill:])
+            if not got:
+                self.eof = True
+                if self.fill and self.buf[self.fill - 1] != _NL:     # last line without newline
+                    if self.fill == self.buf.shape[0]:
+                        self.buf = np.concatenate([self.buf, np.empty(16, np.uint8)])
+                    self.buf[self.fill] = _NL
+                    self.fill += 1
+                break
+            self.fill += got
+        return self.buf[:self.fill] if self.fill else None
+
+    def consumed(self, n):
+        rest = self.fill - n
+        if rest:
+            self.buf[:rest] = self.buf[n:self.fill].copy() if rest > n else self.buf[n:self.fill]
+        self.fill = rest
+
+    def close(self):
+        self.f.close()

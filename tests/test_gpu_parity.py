@@ -458,3 +458,117 @@ def test_tail_and_alignment(kmm, syn, oracle, total_mod):
         assert n1 == 1 and np.array_equal(dev.get_node_counts(), e1)
         dev.reset(); dev.map_reads(bases[:4], np.array([0, 4], dtype=np.int64), 5)
         assert dev.get_node_counts().sum() == 0
+
+
+# ---------------------------------------------------------------- GPU record parser (kmm_map_records)
+def _fastq_bytes(batch_, crlf=False, tricky_quality=True):
+    eol = b"\r\n" if crlf else b"\n"
+    out = []
+    for i in range(len(batch_)):
+        seq = batch_.bases[batch_.offsets[i]:batch_.offsets[i + 1]].tobytes()
+        qual = (b"@+>" * len(seq))[:len(seq)] if tricky_quality else b"I" * len(seq)
+        out.append(b"@read" + str(i).encode() + b" len=" + str(len(seq)).encode() + eol + seq + eol + b"+" + eol + qual + eol)
+    return np.frombuffer(b"".join(out), dtype=np.uint8)
+
+
+def _fasta2_bytes(batch_):
+    out = []
+    for i in range(len(batch_)):
+        seq = batch_.bases[batch_.offsets[i]:batch_.offsets[i + 1]].tobytes()
+        out.append(b">r" + str(i).encode() + b" ACGTNXYZ\n" + seq + b"\n")
+    return np.frombuffer(b"".join(out), dtype=np.uint8)
+
+
+@pytest.mark.parametrize("path", [1, 2])
+@pytest.mark.parametrize("crlf", [False, True])
+def test_map_records_fastq_whole_and_chunked(kmm, syn, oracle, crlf, path):
+    from kmer_mapper_amd import _lib
+    from kmer_mapper_amd.util import ReadBatch
+    index, genome = syn.make_index(4000, seed=131)
+    mx = index.max_node_id()
+    bases, offs = syn.make_ragged_reads(genome, 3000, 0, 200, seed=132)
+    rb = ReadBatch(bases, offs)
+    raw = _fastq_bytes(rb, crlf=crlf)
+    expect, _ = oracle.map_reads(index, mx, bases, offs, 31)
+    with kmm.DeviceIndex.from_index(index, mx) as dev:
+        dev.set_param("path", path)
+        if path == 2:
+            dev.set_param("part_shift", 5)
+        used, n_rec = dev.map_records(raw, fmt=_lib.FORMAT_FASTQ)
+        assert used == raw.shape[0] and n_rec == 3000
+        assert np.array_equal(dev.get_node_counts(), expect)
+        # arbitrary cuts: the library reports where the last complete record ends
+        dev.reset()
+        pos, total_rec, step = 0, 0, 70001
+        while pos < raw.shape[0]:
+            end = min(pos + step, raw.shape[0])
+            used, n_rec = dev.map_records(np.ascontiguousarray(raw[pos:end]), fmt=_lib.FORMAT_FASTQ)
+            assert used > 0 and raw[pos + used - 1] == 10
+            assert pos + used == raw.shape[0] or raw[pos + used] == ord("@")
+            pos += used
+            total_rec += n_rec
+        assert total_rec == 3000
+        assert np.array_equal(dev.get_node_counts(), expect)
+
+
+def test_map_records_fasta2_and_errors(kmm, syn, oracle):
+    from kmer_mapper_amd import _lib
+    from kmer_mapper_amd.util import ReadBatch
+    index, genome = syn.make_index(2000, seed=141)
+    mx = index.max_node_id()
+    bases, offs = syn.make_ragged_reads(genome, 1000, 0, 180, seed=142)
+    raw = _fasta2_bytes(ReadBatch(bases, offs))
+    expect, _ = oracle.map_reads(index, mx, bases, offs, 31)
+    with kmm.DeviceIndex.from_index(index, mx) as dev:
+        used, n_rec = dev.map_records(raw, fmt=_lib.FORMAT_FASTA2)
+        assert (used, n_rec) == (raw.shape[0], 1000)
+        assert np.array_equal(dev.get_node_counts(), expect)
+        # incomplete record at the end is left to the caller
+        dev.reset()
+        used, n_rec = dev.map_records(np.ascontiguousarray(raw[:-5]), fmt=_lib.FORMAT_FASTA2)
+        assert n_rec == 999 and raw[used - 1] == 10 and raw[used] == ord(">")
+        dev.get_node_counts()
+        # a chunk without a complete record consumes nothing
+        used, n_rec = dev.map_records(np.frombuffer(b">r1\nACGT", dtype=np.uint8), fmt=_lib.FORMAT_FASTA2)
+        assert (used, n_rec) == (0, 0)
+        # multi-line FASTA is rejected, not silently mis-parsed
+        dev.reset()
+        dev.map_records(np.frombuffer(b">r1\nACGT\nACGT\n>r2\nAC\n", dtype=np.uint8), fmt=_lib.FORMAT_FASTA2)
+        with pytest.raises(ValueError, match="record structure"):
+            dev.get_node_counts()
+        # a non-nucleotide in a SEQUENCE line is an error; in headers / quality it is not
+        dev.reset()
+        dev.map_records(np.frombuffer(b"@r1 XYZ\nACGTACGTAC\n+\n!!!!XYZ!!!\n", dtype=np.uint8), k=5)
+        dev.get_node_counts()
+        dev.map_records(np.frombuffer(b"@r1\nACGTXCGTAC\n+\nIIIIIIIIII\n", dtype=np.uint8), k=5)
+        with pytest.raises(ValueError, match="offset 8"):
+            dev.get_node_counts()
+        # FASTQ whose third line is not '+'
+        dev.reset()
+        dev.map_records(np.frombuffer(b"@r1\nACGT\nACGT\nIIII\n", dtype=np.uint8), k=3)
+        with pytest.raises(ValueError, match="record structure"):
+            dev.get_node_counts()
+
+
+def test_map_records_device_buffer_large(kmm, syn, oracle):
+    """A 150 MB raw FASTQ chunk already in HBM (several super-tiles of the newline census)."""
+    import torch
+    from kmer_mapper_amd import _lib
+    index, genome = syn.make_index(50000, seed=151)
+    mx = index.max_node_id()
+    n, L = 480000, 150
+    bases, offs = syn.make_reads(genome, n, L, seed=152)
+    rec = np.empty((n, 4 + L + 3 + L + 1), dtype=np.uint8)
+    rec[:, 0:4] = np.frombuffer(b"@rd\n", dtype=np.uint8)
+    rec[:, 4:4 + L] = bases.reshape(n, L)
+    rec[:, 4 + L:4 + L + 3] = np.frombuffer(b"\n+\n", dtype=np.uint8)
+    rec[:, 4 + L + 3:4 + L + 3 + L] = ord("F")
+    rec[:, -1] = 10
+    raw = rec.reshape(-1)
+    expect, _ = oracle.map_reads(index, mx, bases, offs, 31, n_threads=4)
+    d_raw = torch.from_numpy(raw).cuda()
+    torch.cuda.synchronize()
+    with kmm.DeviceIndex.from_index(index, mx) as dev:
+        used, n_rec = dev.map_records(d_raw, fmt=_lib.FORMAT_FASTQ)
+        assert (used, n_rec) == (raw.shape[0], n)
+        assert np.array_equal(dev.get_node_counts(), expect)
