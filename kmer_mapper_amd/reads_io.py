@@ -253,7 +253,7 @@ class RawChunker:
     def consumed(self, n):
         rest = self.fill - n
         if rest:
-            self.buf[:rest] = self.buf[n:self.fill].copy() if rest > n else self.buf[n:self.fill]
+            self.buf[:rest] = self.buf[n:self.fill]      # numpy handles the overlap
         self.fill = rest
 
     def close(self):

@@ -62,3 +62,46 @@ def test_malformed_raises(tmp_path):
     e = tmp_path / "empty.fa"
     e.write_bytes(b"")
     assert list(reads_io.read_chunks(str(e))) == []
+
+
+def test_sniff_format_and_raw_chunker(tmp_path, ragged):
+    fq = str(tmp_path / "a.fq")
+    reads_io.write_fastq(fq, ragged)
+    assert reads_io.sniff_format(fq) == ("fastq", True)
+    fa2 = str(tmp_path / "a.fa")
+    reads_io.write_fasta(fa2, ragged)
+    assert reads_io.sniff_format(fa2) == ("fasta", True)
+    fam = str(tmp_path / "m.fa")
+    reads_io.write_fasta(fam, ragged, line_width=50)
+    assert reads_io.sniff_format(fam) == ("fasta", False)           # wrapped sequences -> host parser
+    gz = str(tmp_path / "a.fq.gz")
+    reads_io.write_fastq(gz, ragged, gz=True)
+    assert reads_io.sniff_format(gz) == ("fastq", True)
+
+    # the chunker hands out raw bytes; a fake consumer cuts at the last complete 4-line record
+    whole = open(fq, "rb").read()
+    for path in (fq, gz):
+        ch = reads_io.RawChunker(path, 5000)
+        seen = bytearray()
+        while True:
+            buf = ch.next_chunk()
+            if buf is None:
+                break
+            nl = np.flatnonzero(buf == 10)
+            n_whole = (nl.shape[0] // 4) * 4
+            assert n_whole > 0
+            used = int(nl[n_whole - 1]) + 1
+            seen += buf[:used].tobytes()
+            ch.consumed(used)
+        ch.close()
+        assert bytes(seen) == whole
+
+
+def test_raw_chunker_adds_final_newline(tmp_path):
+    p = tmp_path / "x.fq"
+    p.write_bytes(b"@a\nACGT\n+\nIIII\n@b\nTT\n+\nII")
+    ch = reads_io.RawChunker(str(p), 1000)
+    buf = ch.next_chunk()
+    assert buf.tobytes().endswith(b"II\n")
+    ch.consumed(buf.shape[0])
+    assert ch.next_chunk() is None
