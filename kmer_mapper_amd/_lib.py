@@ -58,9 +58,10 @@ SIGNATURES = {
 
 def build(force=False, verbose=False):
     """Compile csrc/kmm.hip for gfx950 into kmer_mapper_amd/libkmm.so (cross-compiles on CPU)."""
-    hdr = os.path.join(INCLUDE, "kmm.h")
+    csrc = os.path.dirname(SRC)
+    deps = [os.path.join(INCLUDE, "kmm.h")] + [os.path.join(csrc, f) for f in os.listdir(csrc)]
     if (not force and os.path.exists(SO_PATH)
-            and os.path.getmtime(SO_PATH) >= max(os.path.getmtime(SRC), os.path.getmtime(hdr))):
+            and os.path.getmtime(SO_PATH) >= max(os.path.getmtime(d) for d in deps)):
         return SO_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",

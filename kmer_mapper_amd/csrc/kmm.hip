@@ -53,1037 +53,11 @@ int fail(int code, const char *fmt, ...)
             return r_;                                                                             \
     } while (0)
 
-// ------------------------------------------------------------------------------------------------
-// device-side data layout (ours; the .npz surface is unchanged)
-//   bucket h : uint4, 16 B — ONE gather resolves an empty or single-entry bucket:
-//        w & 3 == 0  empty
-//        w & 3 == 1  single entry stored inline: {x,y} = k-mer, z = node, w >> 16 = frequency
-//        w & 3 == 2  two or more entries: x = start, y = count into `entries`
-//   entry  l : uint4 {kmer_lo, kmer_hi, node, freq}, 16 B, in the index's own order (grouped by hash)
-// The MI355X random-access ceiling is ~55 G L2-missing requests/s whatever their width (8 or 16 B,
-// profiles/r01/gather_bench_mi355x.txt), so the layout minimises REQUESTS per k-mer, not bytes.
-// ------------------------------------------------------------------------------------------------
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-
-struct IndexView {
-    const uint4 *buckets;
-    const uint4 *entries;
-    const uint32_t *occ; // optional L2-resident occupancy bitmap (bit h = bucket h non-empty), or null
-    uint32_t *counts;
-    uint64_t modulo;
-    uint64_t magic; // floor(2^64 / modulo) (all ones for modulo == 1)
-};
-
-struct ReadsView {
-    const uint8_t *bases;
-    int64_t total;             // number of base bytes
-    const int64_t *offsets;    // n_reads + 1 (general path)
-    int64_t n_reads;
-    const int64_t *tile_first; // per tile: first r with offsets[r] > tile start (general path)
-    uint64_t read_len;         // uniform path
-    uint64_t read_len_magic;   // floor(2^64 / read_len)
-    const uint8_t *lut;        // 256 bytes in HBM
-    unsigned long long *first_bad; // [0] min position of a non-nucleotide byte, [1] of a malformed
-                                   //     record line (both init ~0)
-    // records mode (raw FASTQ / two-line FASTA bytes): newlines before every tile
-    const uint32_t *tile_nl;   // per tile: newlines before the tile inside its super-tile (1024 tiles)
-    const uint32_t *super_nl;  // per super-tile: newlines before it
-    uint32_t period_mask;      // lines per record - 1 (3 for FASTQ, 1 for two-line FASTA)
-    uint32_t header_char;      // '@' or '>'
-};
-
-enum { MODE_GENERAL = 0, MODE_UNIFORM = 1, MODE_RECORDS = 2 };
-
-// Exact x % m for any m >= 1 with one 64x64->hi multiply: q = hi64(x * floor(2^64/m)) is either
-// floor(x/m) or one less (x * (2^64/m - magic) / 2^64 < 1), so a single conditional subtract
-// restores the remainder.  The reference computes kmers[i] % modulo with a hardware divide
-// (mapper.pyx:54); results are identical for every x.
-__device__ __forceinline__ uint64_t fastmod(uint64_t x, uint64_t m, uint64_t magic)
-{
-    uint64_t q = __umul64hi(x, magic);
-    uint64_t r = x - q * m;
-    return r >= m ? r - m : r;
-}
-
-__device__ __forceinline__ uint64_t fastdiv(uint64_t x, uint64_t m, uint64_t magic, uint64_t *rem)
-{
-    uint64_t q = __umul64hi(x, magic);
-    uint64_t r = x - q * m;
-    if (r >= m) {
-        r -= m;
-        q += 1;
-    }
-    *rem = r;
-    return q;
-}
-
-// Reverse complement under A,C,G,T = 0,1,2,3, first base in the lowest bits: complement every
-// 2-bit group (NOT), reverse the groups, realign (the `-r` operation).
-__device__ __forceinline__ uint64_t revcomp(uint64_t x, int k)
-{
-    x = ~x;
-    x = ((x >> 2) & 0x3333333333333333ull) | ((x & 0x3333333333333333ull) << 2);
-    x = ((x >> 4) & 0x0F0F0F0F0F0F0F0Full) | ((x & 0x0F0F0F0F0F0F0F0Full) << 4);
-    x = ((x >> 8) & 0x00FF00FF00FF00FFull) | ((x & 0x00FF00FF00FF00FFull) << 8);
-    x = ((x >> 16) & 0x0000FFFF0000FFFFull) | ((x & 0x0000FFFF0000FFFFull) << 16);
-    x = (x >> 32) | (x << 32);
-    return x >> (64 - 2 * k);
-}
-
-// ------------------------------------------------------------------------------------------------
-// Node-count accumulation (mapper.pyx:68: node_counts[nodes[l]] += 1).
-// Real graph indexes map many k-mers to few nodes, so hits are first aggregated in a small
-// direct-mapped table in LDS that lives as long as the workgroup: a hit claims the slot of its
-// node (ds_cmpst) and bumps the slot's counter (ds_add); a hit whose slot belongs to another node
-// falls through to one global atomicAdd.  The table is flushed with one global atomicAdd per used
-// slot when the workgroup retires.  uint32 wrap-around is preserved (sums of sums mod 2^32).
-// ------------------------------------------------------------------------------------------------
-constexpr int AGG_LOG_SLOTS = 11;
-constexpr int AGG_SLOTS = 1 << AGG_LOG_SLOTS;
-constexpr uint32_t AGG_EMPTY = 0xFFFFFFFFu; // node ids are < 2^31
-
-struct NodeAgg {
-    uint32_t key[AGG_SLOTS];
-    uint32_t val[AGG_SLOTS];
-};
-
-__device__ __forceinline__ void agg_init(NodeAgg &agg)
-{
-    for (int i = threadIdx.x; i < AGG_SLOTS; i += blockDim.x) {
-        agg.key[i] = AGG_EMPTY;
-        agg.val[i] = 0;
-    }
-}
-
-__device__ __forceinline__ void agg_add(const IndexView &iv, NodeAgg &agg, uint32_t node)
-{
-    const uint32_t slot = (node * 2654435761u) >> (32 - AGG_LOG_SLOTS);
-    const uint32_t prev = atomicCAS(&agg.key[slot], AGG_EMPTY, node);
-    if (prev == AGG_EMPTY || prev == node)
-        atomicAdd(&agg.val[slot], 1u);
-    else
-        atomicAdd(&iv.counts[node], 1u);
-}
-
-// Call after a __syncthreads() that follows the workgroup's last agg_add.
-__device__ __forceinline__ void agg_flush(const IndexView &iv, NodeAgg &agg)
-{
-    for (int i = threadIdx.x; i < AGG_SLOTS; i += blockDim.x) {
-        const uint32_t v = agg.val[i];
-        if (v)
-            atomicAdd(&iv.counts[agg.key[i]], v);
-    }
-}
-
-// mapper.pyx:60-68 for one entry.
-__device__ __forceinline__ void count_if_match(const IndexView &iv, NodeAgg &agg, uint4 e, uint64_t q,
-                                               int max_freq)
-{
-    uint64_t ek = (uint64_t)e.x | ((uint64_t)e.y << 32);
-    if (ek == q && (int)e.w <= max_freq)
-        agg_add(iv, agg, e.z);
-}
-
-// The probe of mapper.pyx:53-69 for U k-mers per lane.  All U bucket gathers are in flight before
-// any is consumed; empty and single-entry buckets (the common cases) finish there.  Buckets with
-// two or more entries (hash collisions, k-mers present under several nodes) then load their first
-// two entries together and walk the rest.
-template <int U, bool FILTER>
-__device__ __forceinline__ void probe_batch_impl(const IndexView &iv, NodeAgg &agg,
-                                                 const uint64_t (&q)[U], uint32_t valid, int max_freq)
-{
-    uint64_t h[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-        h[u] = fastmod(q[u], iv.modulo, iv.magic);
-    if (FILTER) {
-        // Small indexes: one bit per bucket fits the XCD's L2 (4 MiB), and an L2 hit is ~4.6x cheaper
-        // than the HBM request it saves for every k-mer whose bucket is empty.
-        uint32_t w[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-            w[u] = ((valid >> u) & 1u) ? iv.occ[h[u] >> 5] : 0u;
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-            if (!((w[u] >> (h[u] & 31u)) & 1u))
-                valid &= ~(1u << u);
-    }
-    uint4 b[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        b[u] = make_uint4(0u, 0u, 0u, 0u);
-        if ((valid >> u) & 1u) {
-            if (FILTER) { // streamed once: keep the bitmap, not these lines, in L2
-                u32x4 x = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(&iv.buckets[h[u]]));
-                b[u] = make_uint4(x[0], x[1], x[2], x[3]);
-            } else {
-                b[u] = iv.buckets[h[u]];
-            }
-        }
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const uint32_t kind = b[u].w & 3u;
-        if (kind == 1u) {
-            uint64_t ek = (uint64_t)b[u].x | ((uint64_t)b[u].y << 32);
-            if (ek == q[u] && (int)(b[u].w >> 16) <= max_freq)
-                agg_add(iv, agg, b[u].z);
-        }
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        if ((b[u].w & 3u) == 2u) {
-            const uint32_t st = b[u].x, cn = b[u].y; // cn >= 2 by construction
-            const uint4 e0 = iv.entries[st];
-            const uint4 e1 = iv.entries[(uint64_t)st + 1];
-            count_if_match(iv, agg, e0, q[u], max_freq);
-            count_if_match(iv, agg, e1, q[u], max_freq);
-            for (uint32_t j = 2; j < cn; ++j)
-                count_if_match(iv, agg, iv.entries[(uint64_t)st + j], q[u], max_freq);
-        }
-    }
-}
-
-template <int U>
-__device__ __forceinline__ void probe_batch(const IndexView &iv, NodeAgg &agg, const uint64_t (&q)[U],
-                                            uint32_t valid, int max_freq)
-{
-    if (iv.occ) // wave-uniform
-        probe_batch_impl<U, true>(iv, agg, q, valid, max_freq);
-    else
-        probe_batch_impl<U, false>(iv, agg, q, valid, max_freq);
-}
-
-// ------------------------------------------------------------------------------------------------
-// K2: operator-level lookup, uint64 k-mers already in HBM (drop-in for map_kmers_to_graph_index).
-// ------------------------------------------------------------------------------------------------
-template <int U>
-__global__ void __launch_bounds__(256) k_map_kmers(const uint64_t *__restrict__ kmers, int64_t n,
-                                                   IndexView iv, int max_freq, int also_rc, int k)
-{
-    __shared__ NodeAgg agg;
-    agg_init(agg);
-    __syncthreads();
-    const int64_t span = (int64_t)256 * U;
-    for (int64_t base = (int64_t)blockIdx.x * span; base < n; base += (int64_t)gridDim.x * span) {
-        uint64_t q[U];
-        uint32_t valid = 0;
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            int64_t i = base + (int64_t)u * 256 + threadIdx.x;
-            q[u] = 0;
-            if (i < n) {
-                q[u] = kmers[i];
-                valid |= 1u << u;
-            }
-        }
-        probe_batch<U>(iv, agg, q, valid, max_freq);
-        if (also_rc) {
-#pragma unroll
-            for (int u = 0; u < U; ++u)
-                q[u] = revcomp(q[u], k);
-            probe_batch<U>(iv, agg, q, valid, max_freq);
-        }
-    }
-    __syncthreads();
-    agg_flush(iv, agg);
-}
-
-// ------------------------------------------------------------------------------------------------
-// Tile front end shared by every kernel that starts from read bytes.  A workgroup (4 wavefronts)
-// owns tiles of T = 256*S consecutive base positions of the chunk's flat byte stream:
-//   1. 16-byte coalesced loads of the T + 48 bytes the tile's windows can touch; each byte goes
-//      through the 256-entry LDS lookup table and 16 codes are packed into one 32-bit LDS word;
-//   2. read starts that fall inside the tile are marked in an LDS bitset (general path) so that
-//      no window spans two reads (bionumpy's ragged windowing, util.py:72);
-//   3. each lane takes S consecutive positions: three LDS words give it S+31 bases in a 128-bit
-//      register window, and successive k-mers are 2-bit funnel shifts of that window
-//      (first base in the lowest bits).
-// Returns the lane's S k-mers and the bitmask of those that are real windows.
-// ------------------------------------------------------------------------------------------------
-template <int S>
-struct TileSmem {
-    static constexpr int T = 256 * S;
-    static constexpr int NV = T / 16 + 3; // 16-base words staged per tile (T + 48 positions)
-    static constexpr int NB = T / 32 + 3; // 32-position words of the read-start bitset
-    uint8_t lut[256];
-    uint32_t codes[NV + 1];
-    uint32_t bits[NB + 1];
-};
-
-struct TileConst {
-    uint64_t kmask; // low 2k bits
-    uint64_t bmask; // read starts in (p, p+k-1] kill the window at p
-    bool aligned;   // bases pointer is 16-byte aligned
-};
-
-__device__ __forceinline__ TileConst tile_const(const ReadsView &rv, int k)
-{
-    TileConst c;
-    c.kmask = (1ull << (2 * k)) - 1ull; // k <= 31
-    c.bmask = (1ull << (k - 1)) - 1ull;
-    c.aligned = (((uintptr_t)rv.bases) & 15u) == 0;
-    return c;
-}
-
-// SWAR: 0x80 in every byte of x that equals the byte value c (exact, no cross-byte carries).
-__device__ __forceinline__ uint32_t bytes_equal(uint32_t x, uint32_t c)
-{
-    const uint32_t y = x ^ (c * 0x01010101u);
-    return ~(((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y | 0x7F7F7F7Fu);
-}
-
-// 0x80-per-byte flags of four bytes -> 4-bit mask (bit i = byte i).
-__device__ __forceinline__ uint32_t flags_to_bits(uint32_t f)
-{
-    return ((f >> 7) & 1u) | ((f >> 14) & 2u) | ((f >> 21) & 4u) | ((f >> 28) & 8u);
-}
-
-template <int S, int MODE>
-__device__ __forceinline__ uint32_t tile_kmers(const ReadsView &rv, const TileConst &tc, int64_t tile,
-                                               int k, TileSmem<S> &sm, uint64_t (&q)[S])
-{
-    constexpr bool UNIFORM = MODE == MODE_UNIFORM;
-    constexpr bool RECORDS = MODE == MODE_RECORDS;
-    constexpr int T = TileSmem<S>::T;
-    constexpr int NV = TileSmem<S>::NV;
-    constexpr int NB = TileSmem<S>::NB;
-    static_assert(NV <= 256, "one staged 16-byte vector per thread");
-    const int tid = threadIdx.x;
-    const int64_t total = rv.total;
-    const int64_t t0 = tile * T;
-    if (MODE == MODE_GENERAL)
-        for (int i = tid; i < NB + 1; i += 256)
-            sm.bits[i] = 0;
-    __syncthreads(); // LUT visible; bitset cleared; previous tile's LDS readers are done
-
-    if (RECORDS) {
-        // ---- records mode, stage 1: raw file bytes.  A byte is a base iff it lies on the sequence
-        // line of its record (line index mod period == 1) and is not a line terminator; every other
-        // byte is a "break" that no window may contain, so k-mers never leave their read.
-        uint32_t w[4] = {0u, 0u, 0u, 0u};
-        uint32_t nl = 0, cr = 0; // 16-bit masks: byte i is '\n' / '\r'
-        const int v = tid;
-        const int64_t p = t0 + (int64_t)v * 16;
-        if (v < NV) {
-            if (tc.aligned && p + 16 <= total) {
-                u32x4 x = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(rv.bases + p));
-                w[0] = x[0]; w[1] = x[1]; w[2] = x[2]; w[3] = x[3];
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    uint32_t acc = 0;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        int64_t pp = p + i * 4 + j;
-                        uint32_t c = (pp < total) ? rv.bases[pp] : 0u;
-                        acc |= c << (8 * j);
-                    }
-                    w[i] = acc;
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                nl |= flags_to_bits(bytes_equal(w[i], 10u)) << (4 * i);
-                cr |= flags_to_bits(bytes_equal(w[i], 13u)) << (4 * i);
-            }
-            sm.codes[v] = (uint32_t)__popc(nl); // borrowed as the per-vector newline count
-        }
-        __syncthreads();
-        uint32_t brk = 0, code = 0;
-        int bad = -1, malformed = -1;
-        if (v < NV) {
-            uint32_t line0 = rv.super_nl[tile >> 10] + rv.tile_nl[tile]; // newlines before the tile
-            for (int i = 0; i < v; ++i)
-                line0 += sm.codes[i];
-            // first byte of a line: preceded by '\n' (or the very first byte of the chunk)
-            const uint32_t prev_nl = (p == 0) ? 1u : (p - 1 < total ? (rv.bases[p - 1] == 10u) : 0u);
-            const uint32_t first = ((nl << 1) | prev_nl) & 0xFFFFu;
-#pragma unroll
-            for (int i = 15; i >= 0; --i) {
-                const uint32_t c = (w[i >> 2] >> (8 * (i & 3))) & 0xFFu;
-                const uint32_t line = line0 + (uint32_t)__popc(nl & ((1u << i) - 1u));
-                const uint32_t phase = line & rv.period_mask;
-                const bool term = ((nl | cr) >> i) & 1u;
-                const bool is_seq = phase == 1u && !term && p + i < total;
-                const uint32_t l = sm.lut[c];
-                if (is_seq && l == 0xFFu)
-                    bad = i;
-                if (((first >> i) & 1u) && p + i < total &&
-                    ((phase == 0u && c != rv.header_char) || (phase == 2u && c != '+')))
-                    malformed = i;
-                brk |= (is_seq ? 0u : 1u) << i;
-                code |= (l & 3u) << (2 * i);
-            }
-        }
-        __syncthreads(); // every thread has read the borrowed per-vector counts
-        if (v < NV) {
-            sm.codes[v] = code;
-            reinterpret_cast<uint16_t *>(sm.bits)[v] = (uint16_t)brk;
-            if (bad >= 0)
-                atomicMin(&rv.first_bad[0], (unsigned long long)(p + bad));
-            if (malformed >= 0)
-                atomicMin(&rv.first_bad[1], (unsigned long long)(p + malformed));
-        }
-        __syncthreads();
-    } else {
-
-    // ---- stage 1: bytes -> 2-bit codes in LDS ----------------------------------------------
-    for (int v = tid; v < NV; v += 256) {
-        const int64_t p = t0 + (int64_t)v * 16;
-        uint32_t w[4];
-        if (tc.aligned && p + 16 <= total) {
-            // streamed once: non-temporal so the read bytes do not displace index lines in L2
-            u32x4 x = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(rv.bases + p));
-            w[0] = x[0]; w[1] = x[1]; w[2] = x[2]; w[3] = x[3];
-        } else {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                uint32_t acc = 0;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    int64_t pp = p + i * 4 + j;
-                    uint32_t c = (pp < total) ? rv.bases[pp] : 0u;
-                    acc |= c << (8 * j);
-                }
-                w[i] = acc;
-            }
-        }
-        uint32_t code = 0;
-        int bad = -1;
-#pragma unroll
-        for (int i = 15; i >= 0; --i) {
-            uint32_t c = (w[i >> 2] >> (8 * (i & 3))) & 0xFFu;
-            uint32_t l = sm.lut[c];
-            if (l == 0xFFu && p + i < total)
-                bad = i;
-            code |= (l & 3u) << (2 * i);
-        }
-        sm.codes[v] = code;
-        if (bad >= 0)
-            atomicMin(rv.first_bad, (unsigned long long)(p + bad));
-    }
-    // ---- stage 2: read starts inside (t0, t0 + T + k - 2] ----------------------------------
-    if (MODE == MODE_GENERAL) {
-        for (int64_t r = rv.tile_first[tile] + tid; r <= rv.n_reads; r += 256) {
-            int64_t o = rv.offsets[r] - t0;
-            if (o > (int64_t)T + k - 2)
-                break;
-            if (o >= 1)
-                atomicOr(&sm.bits[o >> 5], 1u << (o & 31));
-        }
-    }
-    __syncthreads();
-    } // !RECORDS
-
-    // ---- stage 3: S consecutive windows per lane -------------------------------------------
-    const int q0 = tid * S;
-    const int64_t p0 = t0 + q0;
-    uint64_t lo, hi;
-    {
-        const int w = q0 >> 4;
-        const uint32_t c0 = sm.codes[w], c1 = sm.codes[w + 1], c2 = sm.codes[w + 2];
-        const int sh = (q0 & 15) * 2;
-        lo = ((uint64_t)c1 << 32) | c0;
-        hi = c2;
-        if (sh) {
-            lo = (lo >> sh) | (hi << (64 - sh));
-            hi >>= sh;
-        }
-    }
-    uint32_t valid = 0;
-    if (UNIFORM) {
-        uint64_t o;
-        (void)fastdiv((uint64_t)p0, rv.read_len, rv.read_len_magic, &o);
-#pragma unroll
-        for (int j = 0; j < S; ++j) {
-            uint64_t oj = o + j;
-            if (oj >= rv.read_len)
-                oj -= rv.read_len;
-            if (oj + k <= rv.read_len && p0 + j < total)
-                valid |= 1u << j;
-        }
-    } else {
-        const int sw = q0 >> 5, off = q0 & 31;
-        uint64_t B = ((uint64_t)sm.bits[sw + 1] << 32) | sm.bits[sw];
-        if (off)
-            B = (B >> off) | ((uint64_t)sm.bits[sw + 2] << (64 - off));
-        if (RECORDS) { // no break byte inside [p, p+k-1]
-            const uint64_t wmask = (1ull << k) - 1ull;
-#pragma unroll
-            for (int j = 0; j < S; ++j)
-                if (((B >> j) & wmask) == 0 && p0 + j + k <= total)
-                    valid |= 1u << j;
-        } else {       // no read start inside (p, p+k-1]
-#pragma unroll
-            for (int j = 0; j < S; ++j)
-                if (((B >> (j + 1)) & tc.bmask) == 0 && p0 + j + k <= total)
-                    valid |= 1u << j;
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < S; ++j)
-        q[j] = (j == 0 ? lo : ((lo >> (2 * j)) | (hi << (64 - 2 * j)))) & tc.kmask;
-    return valid;
-}
-
-// ------------------------------------------------------------------------------------------------
-// K1 (direct path): fused reads -> counts, every probe goes to HBM.  Used for small batches and for
-// indexes whose hash space cannot be cut into L2-sized partitions.
-// ------------------------------------------------------------------------------------------------
-template <int S, int MODE>
-__global__ void __launch_bounds__(256) k_map_reads(ReadsView rv, IndexView iv, int k, int max_freq,
-                                                   int also_rc, int64_t tile_begin, int64_t tile_end)
-{
-    __shared__ TileSmem<S> sm;
-    __shared__ NodeAgg agg;
-    sm.lut[threadIdx.x] = rv.lut[threadIdx.x];
-    agg_init(agg); // ordered before the first agg_add by the barriers inside tile_kmers
-    const TileConst tc = tile_const(rv, k);
-    for (int64_t tile = tile_begin + blockIdx.x; tile < tile_end; tile += gridDim.x) {
-        uint64_t q[S];
-        const uint32_t valid = tile_kmers<S, MODE>(rv, tc, tile, k, sm, q);
-        if (__builtin_amdgcn_ballot_w64(valid != 0)) {
-            probe_batch<S>(iv, agg, q, valid, max_freq);
-            if (also_rc) {
-#pragma unroll
-                for (int j = 0; j < S; ++j)
-                    q[j] = revcomp(q[j], k);
-                probe_batch<S>(iv, agg, q, valid, max_freq);
-            }
-        }
-    }
-    __syncthreads();
-    agg_flush(iv, agg);
-}
-
-// ------------------------------------------------------------------------------------------------
-// Partitioned path.  Random probes that miss L2 are capped at ~55 G requests/s on MI355X while
-// L2-resident probes run ~4.6x faster, so large batches are first grouped by hash range
-// (partition = h >> shift, each partition's bucket-table slice ~1 MiB, i.e. L2-resident) and then
-// probed partition by partition, each XCD working on its own partitions so that the slice stays in
-// that XCD's 4 MiB L2.  Per sub-batch, all streaming except the L2-local gathers:
-//   k_part_hist     reads -> k-mers per (partition, workgroup): every workgroup owns a fixed set
-//                   of tiles (grid-stride), so its histogram row is private — no global atomics
-//   k_part_scan1/2  exclusive scan over (partition, workgroup) -> a private, exactly sized output
-//                   range per workgroup inside every partition
-//   k_part_scatter  same tiles again: k-mers are counting-sorted by partition inside LDS so that
-//                   each partition's run leaves the workgroup as contiguous 8-byte stores at the
-//                   workgroup's private cursor (kept in LDS)
-//   k_part_probe    workgroup b takes chunks of the k-mers of XCD (b mod 8) — partitions are laid
-//                   out XCD-major, p mod 8 = XCD — in lock step with the other workgroups of that
-//                   XCD.  blockIdx mod 8 is where the dispatcher has been observed to place a
-//                   workgroup; it is used for L2 affinity only — every chunk is processed exactly
-//                   once whatever the placement.
-// ------------------------------------------------------------------------------------------------
-constexpr int KMM_MAX_PARTS = 1024;
-constexpr int KMM_N_XCD = 8;
-constexpr int KMM_CHUNK = 2048;    // k-mers per probe work item (256 lanes x 8)
-constexpr int KMM_PART_GRID = 2048; // workgroups of the hist / scatter kernels (fixed: rows of wg_hist)
-
-struct PartView {
-    int shift; // partition = hash >> shift
-    int P;     // number of partitions, <= KMM_MAX_PARTS
-    int PX;    // partition slots per XCD = ceil(P / 8); slot(p) = (p % 8) * PX + p / 8
-    uint32_t *wg_hist;  // [8*PX][KMM_PART_GRID] k-mers per (slot, workgroup); after scan1: exclusive
-                        //                       prefix over the workgroups of the slot
-    uint32_t *slot_tot; // [8*PX]     k-mers per slot
-    uint32_t *slot_off; // [8*PX + 1] exclusive prefix of slot_tot (XCD x owns [x*PX, (x+1)*PX))
-    uint64_t *kmers;    // grouped k-mers of the sub-batch
-};
-
-__device__ __forceinline__ uint32_t slot_of(const IndexView &iv, const PartView &pv, uint64_t q)
-{
-    const uint32_t p = (uint32_t)(fastmod(q, iv.modulo, iv.magic) >> pv.shift);
-    return (p & (KMM_N_XCD - 1)) * pv.PX + (p >> 3);
-}
-
-template <int S, int MODE>
-__global__ void __launch_bounds__(256) k_part_hist(ReadsView rv, IndexView iv, int k, int also_rc,
-                                                   PartView pv, int64_t tile_begin, int64_t tile_end)
-{
-    __shared__ TileSmem<S> sm;
-    __shared__ uint32_t s_hist[KMM_MAX_PARTS + KMM_N_XCD];
-    const int n_slots = KMM_N_XCD * pv.PX;
-    sm.lut[threadIdx.x] = rv.lut[threadIdx.x];
-    for (int i = threadIdx.x; i < n_slots; i += 256)
-        s_hist[i] = 0;
-    const TileConst tc = tile_const(rv, k);
-    for (int64_t tile = tile_begin + blockIdx.x; tile < tile_end; tile += gridDim.x) {
-        uint64_t q[S];
-        const uint32_t valid = tile_kmers<S, MODE>(rv, tc, tile, k, sm, q);
-#pragma unroll
-        for (int j = 0; j < S; ++j)
-            if ((valid >> j) & 1u) {
-                atomicAdd(&s_hist[slot_of(iv, pv, q[j])], 1u);
-                if (also_rc)
-                    atomicAdd(&s_hist[slot_of(iv, pv, revcomp(q[j], k))], 1u);
-            }
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < n_slots; i += 256)
-        pv.wg_hist[(size_t)i * KMM_PART_GRID + blockIdx.x] = s_hist[i];
-}
-
-// One workgroup per slot: exclusive scan of the slot's KMM_PART_GRID per-workgroup counts, in place.
-__global__ void __launch_bounds__(256) k_part_scan1(PartView pv)
-{
-    __shared__ uint32_t s_wave[4];
-    constexpr int PER = KMM_PART_GRID / 256;
-    uint32_t *row = pv.wg_hist + (size_t)blockIdx.x * KMM_PART_GRID;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    uint32_t v[PER], sum = 0;
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-        v[i] = row[tid * PER + i];
-        sum += v[i];
-    }
-    uint32_t inc = sum;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t o = __shfl_up(inc, d);
-        if (lane >= d)
-            inc += o;
-    }
-    if (lane == 63)
-        s_wave[wave] = inc;
-    __syncthreads();
-    uint32_t base = 0;
-    for (int w = 0; w < wave; ++w)
-        base += s_wave[w];
-    uint32_t run = base + inc - sum;
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-        row[tid * PER + i] = run;
-        run += v[i];
-    }
-    if (tid == 255)
-        pv.slot_tot[blockIdx.x] = run;
-}
-
-// One workgroup of 1024 threads: exclusive scan of the (<= 1032) slot totals.
-__global__ void __launch_bounds__(1024) k_part_scan2(PartView pv)
-{
-    __shared__ uint32_t s_a[2048];
-    const int n_slots = KMM_N_XCD * pv.PX;
-    const int t = threadIdx.x;
-    const uint32_t c0 = t < n_slots ? pv.slot_tot[t] : 0u;
-    const uint32_t c1 = t + 1024 < n_slots ? pv.slot_tot[t + 1024] : 0u;
-    s_a[t] = c0;
-    s_a[t + 1024] = c1;
-    __syncthreads();
-    for (int d = 1; d < 2048; d <<= 1) { // Hillis-Steele inclusive scan over 2048 slots
-        uint32_t v0 = t >= d ? s_a[t - d] : 0u;
-        uint32_t v1 = s_a[t + 1024 - d];
-        __syncthreads();
-        s_a[t] += v0;
-        s_a[t + 1024] += v1;
-        __syncthreads();
-    }
-    if (t < n_slots)
-        pv.slot_off[t] = s_a[t] - c0;
-    if (t + 1024 < n_slots)
-        pv.slot_off[t + 1024] = s_a[t + 1024] - c1;
-    if (t == 0)
-        pv.slot_off[n_slots] = s_a[2047];
-}
-
-// Exclusive scan of s_cnt[0..n) into s_loc[0..n) (n <= 1280) by one 256-thread workgroup; returns
-// the total.
-__device__ __forceinline__ uint32_t block_excl_scan(const uint32_t *s_cnt, uint32_t *s_loc, int n,
-                                                    uint32_t *s_wave)
-{
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    constexpr int PER = 5; // 256 x 5 = 1280 >= KMM_MAX_PARTS + 8
-    uint32_t v[PER], sum = 0;
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-        const int p = tid * PER + i;
-        v[i] = p < n ? s_cnt[p] : 0u;
-        sum += v[i];
-    }
-    uint32_t inc = sum;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t o = __shfl_up(inc, d);
-        if (lane >= d)
-            inc += o;
-    }
-    __syncthreads(); // s_wave may still be read by the previous call
-    if (lane == 63)
-        s_wave[wave] = inc;
-    __syncthreads();
-    uint32_t base = 0;
-    for (int w = 0; w < wave; ++w)
-        base += s_wave[w];
-    const uint32_t total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
-    uint32_t run = base + inc - sum;
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-        const int p = tid * PER + i;
-        if (p < n)
-            s_loc[p] = run;
-        run += v[i];
-    }
-    __syncthreads();
-    return total;
-}
-
-template <int S, int MODE>
-__global__ void __launch_bounds__(256) k_part_scatter(ReadsView rv, IndexView iv, int k, int also_rc,
-                                                      PartView pv, int64_t tile_begin,
-                                                      int64_t tile_end)
-{
-    constexpr int T = 256 * S;
-    constexpr int NS = KMM_MAX_PARTS + KMM_N_XCD;
-    __shared__ TileSmem<S> sm;
-    __shared__ uint32_t s_cur[NS]; // this workgroup's next free slot per partition (private range)
-    __shared__ uint32_t s_cnt[NS]; // k-mers of this tile per partition
-    __shared__ uint32_t s_loc[NS]; // where the partition's run starts in s_km
-    __shared__ uint32_t s_wave[4];
-    __shared__ uint64_t s_km[T];
-    __shared__ uint16_t s_pd[T];
-    const int tid = threadIdx.x;
-    const int n_slots = KMM_N_XCD * pv.PX;
-    sm.lut[tid] = rv.lut[tid];
-    for (int i = tid; i < n_slots; i += 256)
-        s_cur[i] = pv.slot_off[i] + pv.wg_hist[(size_t)i * KMM_PART_GRID + blockIdx.x];
-    const TileConst tc = tile_const(rv, k);
-    for (int64_t tile = tile_begin + blockIdx.x; tile < tile_end; tile += gridDim.x) {
-        uint64_t q[S];
-        const uint32_t valid = tile_kmers<S, MODE>(rv, tc, tile, k, sm, q);
-        for (int round = 0; round < (also_rc ? 2 : 1); ++round) {
-            if (round == 1) {
-#pragma unroll
-                for (int j = 0; j < S; ++j)
-                    q[j] = revcomp(q[j], k);
-            }
-            for (int i = tid; i < n_slots; i += 256)
-                s_cnt[i] = 0;
-            __syncthreads(); // also: the previous round's readers of s_km / s_pd / s_loc are done
-            uint16_t pid[S], rk[S];
-#pragma unroll
-            for (int j = 0; j < S; ++j) {
-                pid[j] = 0;
-                rk[j] = 0;
-                if ((valid >> j) & 1u) {
-                    pid[j] = (uint16_t)slot_of(iv, pv, q[j]);
-                    rk[j] = (uint16_t)atomicAdd(&s_cnt[pid[j]], 1u);
-                }
-            }
-            __syncthreads();
-            const uint32_t n_tile = block_excl_scan(s_cnt, s_loc, n_slots, s_wave);
-#pragma unroll
-            for (int j = 0; j < S; ++j)
-                if ((valid >> j) & 1u) {
-                    const uint32_t pos = s_loc[pid[j]] + rk[j];
-                    s_km[pos] = q[j];
-                    s_pd[pos] = pid[j];
-                }
-            __syncthreads();
-            for (uint32_t i = tid; i < n_tile; i += 256) {
-                const uint32_t sl = s_pd[i];
-                pv.kmers[s_cur[sl] + (i - s_loc[sl])] = s_km[i];
-            }
-            __syncthreads();
-            for (int i = tid; i < n_slots; i += 256)
-                s_cur[i] += s_cnt[i];
-        }
-    }
-}
-
-template <int U>
-__global__ void __launch_bounds__(256) k_part_probe(IndexView iv, PartView pv, int max_freq)
-{
-    static_assert(256 * U == KMM_CHUNK, "chunk = one k-mer per lane per unroll slot");
-    __shared__ NodeAgg agg;
-    agg_init(agg);
-    __syncthreads();
-    const int tid = threadIdx.x;
-    const int x = blockIdx.x & (KMM_N_XCD - 1); // expected XCD of this workgroup (speed only)
-    const uint32_t j = blockIdx.x >> 3, nj = gridDim.x >> 3;
-    const uint32_t begin_x = pv.slot_off[x * pv.PX], end_x = pv.slot_off[(x + 1) * pv.PX];
-    const uint32_t n_chunks = (end_x - begin_x + KMM_CHUNK - 1) / KMM_CHUNK;
-    for (uint32_t c = j; c < n_chunks; c += nj) {
-        const uint32_t begin = begin_x + c * KMM_CHUNK;
-        uint64_t q[U];
-        uint32_t valid = 0;
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const uint32_t i = begin + u * 256 + tid;
-            q[u] = 0;
-            if (i < end_x) {
-                q[u] = __builtin_nontemporal_load(&pv.kmers[i]);
-                valid |= 1u << u;
-            }
-        }
-        probe_batch<U>(iv, agg, q, valid, max_freq);
-    }
-    __syncthreads();
-    agg_flush(iv, agg);
-}
-
-// ------------------------------------------------------------------------------------------------
-// Records mode pre-pass: newline census of a raw FASTQ / two-line FASTA chunk (tile = 1024 bytes,
-// super-tile = 1024 tiles), so that every tile knows the line number of its first byte, and the
-// position where the last complete record ends.
-// ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_rec_count(const uint8_t *__restrict__ raw, int64_t n,
-                                                   int64_t n_tiles, uint32_t *__restrict__ tile_cnt)
-{
-    const int lane = threadIdx.x & 63;
-    const int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); // one wavefront per tile
-    if (tile >= n_tiles)
-        return;
-    const int64_t p = tile * 1024 + lane * 16;
-    uint32_t c = 0;
-    if ((((uintptr_t)raw) & 15u) == 0 && p + 16 <= n) {
-        u32x4 x = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(raw + p));
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            c += (uint32_t)__popc(bytes_equal(x[i], 10u));
-    } else {
-        for (int i = 0; i < 16; ++i)
-            if (p + i < n && raw[p + i] == 10u)
-                ++c;
-    }
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1)
-        c += __shfl_xor(c, d);
-    if (lane == 0)
-        tile_cnt[tile] = c;
-}
-
-// Inclusive Hillis-Steele scan of s_a[0..1024) by a 1024-thread workgroup.
-__device__ __forceinline__ void block_scan_1024(uint32_t *s_a)
-{
-    const int t = threadIdx.x;
-    for (int d = 1; d < 1024; d <<= 1) {
-        const uint32_t v = t >= d ? s_a[t - d] : 0u;
-        __syncthreads();
-        s_a[t] += v;
-        __syncthreads();
-    }
-}
-
-// One workgroup per super-tile: counts -> exclusive prefix inside the super-tile (in place) + total.
-__global__ void __launch_bounds__(1024) k_rec_scan1(uint32_t *tile_cnt, uint32_t *super_tot)
-{
-    __shared__ uint32_t s_a[1024];
-    const int t = threadIdx.x;
-    const size_t idx = (size_t)blockIdx.x * 1024 + t;
-    const uint32_t c = tile_cnt[idx];
-    s_a[t] = c;
-    __syncthreads();
-    block_scan_1024(s_a);
-    tile_cnt[idx] = s_a[t] - c;
-    if (t == 1023)
-        super_tot[blockIdx.x] = s_a[t];
-}
-
-// One workgroup: exclusive prefix over the super-tiles, then the byte position just after the last
-// newline that completes a record (records have `period` lines).  out = {consumed, n_records, n_lines}.
-__global__ void __launch_bounds__(1024) k_rec_scan2(const uint8_t *__restrict__ raw, int64_t n,
-                                                    int n_super, const uint32_t *__restrict__ tile_pre,
-                                                    uint32_t *super_tot, uint32_t period, int64_t *out)
-{
-    __shared__ uint32_t s_a[1024];
-    __shared__ uint32_t s_super, s_rem, s_super_cnt;
-    __shared__ int64_t s_tile;
-    const int t = threadIdx.x;
-    const uint32_t c = t < n_super ? super_tot[t] : 0u;
-    s_a[t] = c;
-    __syncthreads();
-    block_scan_1024(s_a);
-    const uint32_t excl = s_a[t] - c;
-    const uint32_t total = s_a[1023];
-    __syncthreads();
-    if (t < n_super)
-        super_tot[t] = excl;
-    const uint32_t target = total - total % period;
-    if (target == 0) { // same for every thread
-        if (t == 0) {
-            out[0] = 0;
-            out[1] = 0;
-            out[2] = total;
-        }
-        return;
-    }
-    if (t < n_super && excl < target && target <= excl + c) {
-        s_super = (uint32_t)t;
-        s_rem = target - excl;
-        s_super_cnt = c;
-    }
-    __syncthreads();
-    const uint32_t sup = s_super, rem = s_rem;
-    const uint32_t pre = tile_pre[(size_t)sup * 1024 + t];
-    const uint32_t nxt = t < 1023 ? tile_pre[(size_t)sup * 1024 + t + 1] : s_super_cnt;
-    if (pre < rem && rem <= nxt)
-        s_tile = (int64_t)sup * 1024 + t;
-    __syncthreads();
-    const int64_t tile = s_tile;
-    const uint32_t r = rem - tile_pre[tile];
-    const int64_t pos = tile * 1024 + t;
-    const uint32_t is_nl = (pos < n && raw[pos] == 10u) ? 1u : 0u;
-    s_a[t] = is_nl;
-    __syncthreads();
-    block_scan_1024(s_a);
-    if (is_nl && s_a[t] == r)
-        out[0] = pos + 1;
-    if (t == 0) {
-        out[1] = target / period;
-        out[2] = total;
-    }
-}
-
-// General path helper: for every tile, the first read index r in [0, n_reads+1] whose start lies
-// strictly after the tile's first position (upper bound over the n_reads+1 offsets).
-__global__ void k_tile_first(const int64_t *__restrict__ offs, int64_t n_reads, int64_t n_tiles,
-                             int T, int64_t *__restrict__ out)
-{
-    int64_t tile = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (tile >= n_tiles)
-        return;
-    const int64_t t0 = tile * T;
-    int64_t lo = 0, hi = n_reads + 1;
-    while (lo < hi) {
-        int64_t mid = (lo + hi) >> 1;
-        if (offs[mid] <= t0)
-            lo = mid + 1;
-        else
-            hi = mid;
-    }
-    out[tile] = lo;
-}
-
-__global__ void k_iota_offsets(int64_t *out, int64_t n_reads, int64_t read_len)
-{
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i <= n_reads)
-        out[i] = i * read_len;
-}
-
-// ------------------------------------------------------------------------------------------------
-// Operator façade kernels (not on the fused path).
-// ------------------------------------------------------------------------------------------------
-// get_kmer_hashes_from_chunk_sequence (util.py:71-75): one lane per base position.
-__global__ void k_extract_kmers(const uint8_t *__restrict__ bases, const int64_t *__restrict__ offs,
-                                const int64_t *__restrict__ kmer_offs, int64_t n_reads, int k,
-                                const uint8_t *__restrict__ lut, uint64_t *__restrict__ out,
-                                unsigned long long *first_bad)
-{
-    const int64_t total = offs[n_reads];
-    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total;
-         p += (int64_t)gridDim.x * blockDim.x) {
-        if (lut[bases[p]] == 0xFFu)
-            atomicMin(first_bad, (unsigned long long)p);
-        // read containing p: last r with offs[r] <= p
-        int64_t lo = 0, hi = n_reads + 1;
-        while (lo < hi) {
-            int64_t mid = (lo + hi) >> 1;
-            if (offs[mid] <= p)
-                lo = mid + 1;
-            else
-                hi = mid;
-        }
-        const int64_t r = lo - 1;
-        if (p + k > offs[r + 1])
-            continue;
-        uint64_t w = 0;
-        for (int j = 0; j < k; ++j)
-            w |= (uint64_t)(lut[bases[p + j]] & 3u) << (2 * j);
-        out[kmer_offs[r] + (p - offs[r])] = w;
-    }
-}
-
-// in_graph_index (mapper.pyx:112-127): first match wins, no frequency filter.
-__global__ void k_in_index(const uint64_t *__restrict__ kmers, int64_t n, IndexView iv,
-                           uint8_t *__restrict__ out)
-{
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-         i += (int64_t)gridDim.x * blockDim.x) {
-        const uint64_t q = kmers[i];
-        const uint4 b = iv.buckets[fastmod(q, iv.modulo, iv.magic)];
-        const uint32_t kind = b.w & 3u;
-        uint8_t hit = 0;
-        if (kind == 1u) {
-            hit = (((uint64_t)b.x | ((uint64_t)b.y << 32)) == q) ? 1 : 0;
-        } else if (kind == 2u) {
-            for (uint32_t j = 0; j < b.y; ++j) {
-                uint4 e = iv.entries[(uint64_t)b.x + j];
-                if (((uint64_t)e.x | ((uint64_t)e.y << 32)) == q) {
-                    hit = 1;
-                    break;
-                }
-            }
-        }
-        out[i] = hit;
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Index repack (on the GPU, at load).  Also the validation the reference does not do.
-// err bit 0: bucket outside [0, n_entries); bit 1: node outside [0, max_node_id].
-// ------------------------------------------------------------------------------------------------
-__global__ void k_pack_buckets(const int32_t *__restrict__ h2i, const int32_t *__restrict__ nk,
-                               const uint64_t *__restrict__ kmers, const int32_t *__restrict__ nodes,
-                               const uint16_t *__restrict__ freqs, uint64_t modulo,
-                               int64_t n_entries, int64_t max_node_id, uint4 *__restrict__ buckets,
-                               uint32_t *err)
-{
-    for (uint64_t h = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; h < modulo;
-         h += (uint64_t)gridDim.x * blockDim.x) {
-        const int32_t c = nk[h], s = h2i[h];
-        uint4 b = make_uint4(0u, 0u, 0u, 0u);
-        if (c > 0) { // c <= 0: `for j in range(n_local_hits)` runs zero times (mapper.pyx:58)
-            if (s < 0 || (int64_t)s + c > n_entries) {
-                atomicOr(err, 1u);
-            } else if (c == 1) {
-                const uint64_t km = kmers[s];
-                int32_t nd = nodes[s];
-                if (nd < 0 || (int64_t)nd > max_node_id)
-                    nd = 0; // reported by k_pack_entries
-                b = make_uint4((uint32_t)km, (uint32_t)(km >> 32), (uint32_t)nd,
-                               ((uint32_t)freqs[s] << 16) | 1u);
-            } else {
-                b = make_uint4((uint32_t)s, (uint32_t)c, 0u, 2u);
-            }
-        }
-        buckets[h] = b;
-    }
-}
-
-__global__ void k_pack_entries(const uint64_t *__restrict__ kmers, const int32_t *__restrict__ nodes,
-                               const uint16_t *__restrict__ freqs, int64_t n, int64_t max_node_id,
-                               uint4 *__restrict__ entries, uint32_t *err)
-{
-    for (int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; l < n;
-         l += (int64_t)gridDim.x * blockDim.x) {
-        uint64_t km = kmers[l];
-        int32_t nd = nodes[l];
-        if (nd < 0 || (int64_t)nd > max_node_id) {
-            atomicOr(err, 2u);
-            nd = 0;
-        }
-        entries[l] = make_uint4((uint32_t)km, (uint32_t)(km >> 32), (uint32_t)nd, (uint32_t)freqs[l]);
-    }
-}
-
-// One bit per bucket: set iff the bucket holds at least one entry.
-__global__ void k_build_occ(const uint4 *__restrict__ buckets, uint64_t modulo, uint32_t *__restrict__ occ)
-{
-    const uint64_t n_words = (modulo + 31) / 32;
-    for (uint64_t wd = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; wd < n_words;
-         wd += (uint64_t)gridDim.x * blockDim.x) {
-        uint32_t bits = 0;
-        for (int i = 0; i < 32; ++i) {
-            const uint64_t h = wd * 32 + i;
-            if (h < modulo && (buckets[h].w & 3u))
-                bits |= 1u << i;
-        }
-        occ[wd] = bits;
-    }
-}
+#include "kmm_probe.hpp"
+#include "kmm_tile.hpp"
+#include "kmm_kernels.hpp"
+#include "kmm_partition.hpp"
+#include "kmm_records.hpp"
 
 // ------------------------------------------------------------------------------------------------
 // host side

@@ -1,0 +1,217 @@
+// kmm_kernels.hpp — part of libkmm (MI355X / gfx950); included by kmm.hip inside its anonymous namespace.
+// Direct-path kernels (k_map_reads, k_map_kmers), operator facades, index repack.
+#pragma once
+
+// ------------------------------------------------------------------------------------------------
+// K1 (direct path): fused reads -> counts, every probe goes to HBM.  Used for small batches and for
+// indexes whose hash space cannot be cut into L2-sized partitions.
+// ------------------------------------------------------------------------------------------------
+template <int S, int MODE>
+__global__ void __launch_bounds__(256) k_map_reads(ReadsView rv, IndexView iv, int k, int max_freq,
+                                                   int also_rc, int64_t tile_begin, int64_t tile_end)
+{
+    __shared__ TileSmem<S> sm;
+    __shared__ NodeAgg agg;
+    sm.lut[threadIdx.x] = rv.lut[threadIdx.x];
+    agg_init(agg); // ordered before the first agg_add by the barriers inside tile_kmers
+    const TileConst tc = tile_const(rv, k);
+    for (int64_t tile = tile_begin + blockIdx.x; tile < tile_end; tile += gridDim.x) {
+        uint64_t q[S];
+        const uint32_t valid = tile_kmers<S, MODE>(rv, tc, tile, k, sm, q);
+        if (__builtin_amdgcn_ballot_w64(valid != 0)) {
+            probe_batch<S>(iv, agg, q, valid, max_freq);
+            if (also_rc) {
+#pragma unroll
+                for (int j = 0; j < S; ++j)
+                    q[j] = revcomp(q[j], k);
+                probe_batch<S>(iv, agg, q, valid, max_freq);
+            }
+        }
+    }
+    __syncthreads();
+    agg_flush(iv, agg);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2: operator-level lookup, uint64 k-mers already in HBM (drop-in for map_kmers_to_graph_index).
+// ------------------------------------------------------------------------------------------------
+template <int U>
+__global__ void __launch_bounds__(256) k_map_kmers(const uint64_t *__restrict__ kmers, int64_t n,
+                                                   IndexView iv, int max_freq, int also_rc, int k)
+{
+    __shared__ NodeAgg agg;
+    agg_init(agg);
+    __syncthreads();
+    const int64_t span = (int64_t)256 * U;
+    for (int64_t base = (int64_t)blockIdx.x * span; base < n; base += (int64_t)gridDim.x * span) {
+        uint64_t q[U];
+        uint32_t valid = 0;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            int64_t i = base + (int64_t)u * 256 + threadIdx.x;
+            q[u] = 0;
+            if (i < n) {
+                q[u] = kmers[i];
+                valid |= 1u << u;
+            }
+        }
+        probe_batch<U>(iv, agg, q, valid, max_freq);
+        if (also_rc) {
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                q[u] = revcomp(q[u], k);
+            probe_batch<U>(iv, agg, q, valid, max_freq);
+        }
+    }
+    __syncthreads();
+    agg_flush(iv, agg);
+}
+
+// General path helper: for every tile, the first read index r in [0, n_reads+1] whose start lies
+// strictly after the tile's first position (upper bound over the n_reads+1 offsets).
+__global__ void k_tile_first(const int64_t *__restrict__ offs, int64_t n_reads, int64_t n_tiles,
+                             int T, int64_t *__restrict__ out)
+{
+    int64_t tile = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tile >= n_tiles)
+        return;
+    const int64_t t0 = tile * T;
+    int64_t lo = 0, hi = n_reads + 1;
+    while (lo < hi) {
+        int64_t mid = (lo + hi) >> 1;
+        if (offs[mid] <= t0)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    out[tile] = lo;
+}
+
+__global__ void k_iota_offsets(int64_t *out, int64_t n_reads, int64_t read_len)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i <= n_reads)
+        out[i] = i * read_len;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Operator façade kernels (not on the fused path).
+// ------------------------------------------------------------------------------------------------
+// get_kmer_hashes_from_chunk_sequence (util.py:71-75): one lane per base position.
+__global__ void k_extract_kmers(const uint8_t *__restrict__ bases, const int64_t *__restrict__ offs,
+                                const int64_t *__restrict__ kmer_offs, int64_t n_reads, int k,
+                                const uint8_t *__restrict__ lut, uint64_t *__restrict__ out,
+                                unsigned long long *first_bad)
+{
+    const int64_t total = offs[n_reads];
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total;
+         p += (int64_t)gridDim.x * blockDim.x) {
+        if (lut[bases[p]] == 0xFFu)
+            atomicMin(first_bad, (unsigned long long)p);
+        // read containing p: last r with offs[r] <= p
+        int64_t lo = 0, hi = n_reads + 1;
+        while (lo < hi) {
+            int64_t mid = (lo + hi) >> 1;
+            if (offs[mid] <= p)
+                lo = mid + 1;
+            else
+                hi = mid;
+        }
+        const int64_t r = lo - 1;
+        if (p + k > offs[r + 1])
+            continue;
+        uint64_t w = 0;
+        for (int j = 0; j < k; ++j)
+            w |= (uint64_t)(lut[bases[p + j]] & 3u) << (2 * j);
+        out[kmer_offs[r] + (p - offs[r])] = w;
+    }
+}
+
+// in_graph_index (mapper.pyx:112-127): first match wins, no frequency filter.
+__global__ void k_in_index(const uint64_t *__restrict__ kmers, int64_t n, IndexView iv,
+                           uint8_t *__restrict__ out)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const uint64_t q = kmers[i];
+        const uint4 b = iv.buckets[fastmod(q, iv.modulo, iv.magic)];
+        const uint32_t kind = b.w & 3u;
+        uint8_t hit = 0;
+        if (kind == 1u) {
+            hit = (((uint64_t)b.x | ((uint64_t)b.y << 32)) == q) ? 1 : 0;
+        } else if (kind == 2u) {
+            for (uint32_t j = 0; j < b.y; ++j) {
+                uint4 e = iv.entries[(uint64_t)b.x + j];
+                if (((uint64_t)e.x | ((uint64_t)e.y << 32)) == q) {
+                    hit = 1;
+                    break;
+                }
+            }
+        }
+        out[i] = hit;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Index repack (on the GPU, at load).  Also the validation the reference does not do.
+// err bit 0: bucket outside [0, n_entries); bit 1: node outside [0, max_node_id].
+// ------------------------------------------------------------------------------------------------
+__global__ void k_pack_buckets(const int32_t *__restrict__ h2i, const int32_t *__restrict__ nk,
+                               const uint64_t *__restrict__ kmers, const int32_t *__restrict__ nodes,
+                               const uint16_t *__restrict__ freqs, uint64_t modulo,
+                               int64_t n_entries, int64_t max_node_id, uint4 *__restrict__ buckets,
+                               uint32_t *err)
+{
+    for (uint64_t h = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; h < modulo;
+         h += (uint64_t)gridDim.x * blockDim.x) {
+        const int32_t c = nk[h], s = h2i[h];
+        uint4 b = make_uint4(0u, 0u, 0u, 0u);
+        if (c > 0) { // c <= 0: `for j in range(n_local_hits)` runs zero times (mapper.pyx:58)
+            if (s < 0 || (int64_t)s + c > n_entries) {
+                atomicOr(err, 1u);
+            } else if (c == 1) {
+                const uint64_t km = kmers[s];
+                int32_t nd = nodes[s];
+                if (nd < 0 || (int64_t)nd > max_node_id)
+                    nd = 0; // reported by k_pack_entries
+                b = make_uint4((uint32_t)km, (uint32_t)(km >> 32), (uint32_t)nd,
+                               ((uint32_t)freqs[s] << 16) | 1u);
+            } else {
+                b = make_uint4((uint32_t)s, (uint32_t)c, 0u, 2u);
+            }
+        }
+        buckets[h] = b;
+    }
+}
+
+__global__ void k_pack_entries(const uint64_t *__restrict__ kmers, const int32_t *__restrict__ nodes,
+                               const uint16_t *__restrict__ freqs, int64_t n, int64_t max_node_id,
+                               uint4 *__restrict__ entries, uint32_t *err)
+{
+    for (int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; l < n;
+         l += (int64_t)gridDim.x * blockDim.x) {
+        uint64_t km = kmers[l];
+        int32_t nd = nodes[l];
+        if (nd < 0 || (int64_t)nd > max_node_id) {
+            atomicOr(err, 2u);
+            nd = 0;
+        }
+        entries[l] = make_uint4((uint32_t)km, (uint32_t)(km >> 32), (uint32_t)nd, (uint32_t)freqs[l]);
+    }
+}
+
+// One bit per bucket: set iff the bucket holds at least one entry.
+__global__ void k_build_occ(const uint4 *__restrict__ buckets, uint64_t modulo, uint32_t *__restrict__ occ)
+{
+    const uint64_t n_words = (modulo + 31) / 32;
+    for (uint64_t wd = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; wd < n_words;
+         wd += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t bits = 0;
+        for (int i = 0; i < 32; ++i) {
+            const uint64_t h = wd * 32 + i;
+            if (h < modulo && (buckets[h].w & 3u))
+                bits |= 1u << i;
+        }
+        occ[wd] = bits;
+    }
+}

@@ -1,0 +1,204 @@
+// kmm_probe.hpp — part of libkmm (MI355X / gfx950); included by kmm.hip inside its anonymous namespace.
+// HBM layout of the index, exact modulo, reverse complement, LDS node-count aggregation, bucket probe.
+#pragma once
+
+// ------------------------------------------------------------------------------------------------
+// device-side data layout (ours; the .npz surface is unchanged)
+//   bucket h : uint4, 16 B — ONE gather resolves an empty or single-entry bucket:
+//        w & 3 == 0  empty
+//        w & 3 == 1  single entry stored inline: {x,y} = k-mer, z = node, w >> 16 = frequency
+//        w & 3 == 2  two or more entries: x = start, y = count into `entries`
+//   entry  l : uint4 {kmer_lo, kmer_hi, node, freq}, 16 B, in the index's own order (grouped by hash)
+// The MI355X random-access ceiling is ~55 G L2-missing requests/s whatever their width (8 or 16 B,
+// profiles/r01/gather_bench_mi355x.txt), so the layout minimises REQUESTS per k-mer, not bytes.
+// ------------------------------------------------------------------------------------------------
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+struct IndexView {
+    const uint4 *buckets;
+    const uint4 *entries;
+    const uint32_t *occ; // optional L2-resident occupancy bitmap (bit h = bucket h non-empty), or null
+    uint32_t *counts;
+    uint64_t modulo;
+    uint64_t magic; // floor(2^64 / modulo) (all ones for modulo == 1)
+};
+
+struct ReadsView {
+    const uint8_t *bases;
+    int64_t total;             // number of base bytes
+    const int64_t *offsets;    // n_reads + 1 (general path)
+    int64_t n_reads;
+    const int64_t *tile_first; // per tile: first r with offsets[r] > tile start (general path)
+    uint64_t read_len;         // uniform path
+    uint64_t read_len_magic;   // floor(2^64 / read_len)
+    const uint8_t *lut;        // 256 bytes in HBM
+    unsigned long long *first_bad; // [0] min position of a non-nucleotide byte, [1] of a malformed
+                                   //     record line (both init ~0)
+    // records mode (raw FASTQ / two-line FASTA bytes): newlines before every tile
+    const uint32_t *tile_nl;   // per tile: newlines before the tile inside its super-tile (1024 tiles)
+    const uint32_t *super_nl;  // per super-tile: newlines before it
+    uint32_t period_mask;      // lines per record - 1 (3 for FASTQ, 1 for two-line FASTA)
+    uint32_t header_char;      // '@' or '>'
+};
+
+enum { MODE_GENERAL = 0, MODE_UNIFORM = 1, MODE_RECORDS = 2 };
+
+// Exact x % m for any m >= 1 with one 64x64->hi multiply: q = hi64(x * floor(2^64/m)) is either
+// floor(x/m) or one less (x * (2^64/m - magic) / 2^64 < 1), so a single conditional subtract
+// restores the remainder.  The reference computes kmers[i] % modulo with a hardware divide
+// (mapper.pyx:54); results are identical for every x.
+__device__ __forceinline__ uint64_t fastmod(uint64_t x, uint64_t m, uint64_t magic)
+{
+    uint64_t q = __umul64hi(x, magic);
+    uint64_t r = x - q * m;
+    return r >= m ? r - m : r;
+}
+
+__device__ __forceinline__ uint64_t fastdiv(uint64_t x, uint64_t m, uint64_t magic, uint64_t *rem)
+{
+    uint64_t q = __umul64hi(x, magic);
+    uint64_t r = x - q * m;
+    if (r >= m) {
+        r -= m;
+        q += 1;
+    }
+    *rem = r;
+    return q;
+}
+
+// Reverse complement under A,C,G,T = 0,1,2,3, first base in the lowest bits: complement every
+// 2-bit group (NOT), reverse the groups, realign (the `-r` operation).
+__device__ __forceinline__ uint64_t revcomp(uint64_t x, int k)
+{
+    x = ~x;
+    x = ((x >> 2) & 0x3333333333333333ull) | ((x & 0x3333333333333333ull) << 2);
+    x = ((x >> 4) & 0x0F0F0F0F0F0F0F0Full) | ((x & 0x0F0F0F0F0F0F0F0Full) << 4);
+    x = ((x >> 8) & 0x00FF00FF00FF00FFull) | ((x & 0x00FF00FF00FF00FFull) << 8);
+    x = ((x >> 16) & 0x0000FFFF0000FFFFull) | ((x & 0x0000FFFF0000FFFFull) << 16);
+    x = (x >> 32) | (x << 32);
+    return x >> (64 - 2 * k);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Node-count accumulation (mapper.pyx:68: node_counts[nodes[l]] += 1).
+// Real graph indexes map many k-mers to few nodes, so hits are first aggregated in a small
+// direct-mapped table in LDS that lives as long as the workgroup: a hit claims the slot of its
+// node (ds_cmpst) and bumps the slot's counter (ds_add); a hit whose slot belongs to another node
+// falls through to one global atomicAdd.  The table is flushed with one global atomicAdd per used
+// slot when the workgroup retires.  uint32 wrap-around is preserved (sums of sums mod 2^32).
+// ------------------------------------------------------------------------------------------------
+constexpr int AGG_LOG_SLOTS = 11;
+constexpr int AGG_SLOTS = 1 << AGG_LOG_SLOTS;
+constexpr uint32_t AGG_EMPTY = 0xFFFFFFFFu; // node ids are < 2^31
+
+struct NodeAgg {
+    uint32_t key[AGG_SLOTS];
+    uint32_t val[AGG_SLOTS];
+};
+
+__device__ __forceinline__ void agg_init(NodeAgg &agg)
+{
+    for (int i = threadIdx.x; i < AGG_SLOTS; i += blockDim.x) {
+        agg.key[i] = AGG_EMPTY;
+        agg.val[i] = 0;
+    }
+}
+
+__device__ __forceinline__ void agg_add(const IndexView &iv, NodeAgg &agg, uint32_t node)
+{
+    const uint32_t slot = (node * 2654435761u) >> (32 - AGG_LOG_SLOTS);
+    const uint32_t prev = atomicCAS(&agg.key[slot], AGG_EMPTY, node);
+    if (prev == AGG_EMPTY || prev == node)
+        atomicAdd(&agg.val[slot], 1u);
+    else
+        atomicAdd(&iv.counts[node], 1u);
+}
+
+// Call after a __syncthreads() that follows the workgroup's last agg_add.
+__device__ __forceinline__ void agg_flush(const IndexView &iv, NodeAgg &agg)
+{
+    for (int i = threadIdx.x; i < AGG_SLOTS; i += blockDim.x) {
+        const uint32_t v = agg.val[i];
+        if (v)
+            atomicAdd(&iv.counts[agg.key[i]], v);
+    }
+}
+
+// mapper.pyx:60-68 for one entry.
+__device__ __forceinline__ void count_if_match(const IndexView &iv, NodeAgg &agg, uint4 e, uint64_t q,
+                                               int max_freq)
+{
+    uint64_t ek = (uint64_t)e.x | ((uint64_t)e.y << 32);
+    if (ek == q && (int)e.w <= max_freq)
+        agg_add(iv, agg, e.z);
+}
+
+// The probe of mapper.pyx:53-69 for U k-mers per lane.  All U bucket gathers are in flight before
+// any is consumed; empty and single-entry buckets (the common cases) finish there.  Buckets with
+// two or more entries (hash collisions, k-mers present under several nodes) then load their first
+// two entries together and walk the rest.
+template <int U, bool FILTER>
+__device__ __forceinline__ void probe_batch_impl(const IndexView &iv, NodeAgg &agg,
+                                                 const uint64_t (&q)[U], uint32_t valid, int max_freq)
+{
+    uint64_t h[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+        h[u] = fastmod(q[u], iv.modulo, iv.magic);
+    if (FILTER) {
+        // Small indexes: one bit per bucket fits the XCD's L2 (4 MiB), and an L2 hit is ~4.6x cheaper
+        // than the HBM request it saves for every k-mer whose bucket is empty.
+        uint32_t w[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            w[u] = ((valid >> u) & 1u) ? iv.occ[h[u] >> 5] : 0u;
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (!((w[u] >> (h[u] & 31u)) & 1u))
+                valid &= ~(1u << u);
+    }
+    uint4 b[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        b[u] = make_uint4(0u, 0u, 0u, 0u);
+        if ((valid >> u) & 1u) {
+            if (FILTER) { // streamed once: keep the bitmap, not these lines, in L2
+                u32x4 x = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(&iv.buckets[h[u]]));
+                b[u] = make_uint4(x[0], x[1], x[2], x[3]);
+            } else {
+                b[u] = iv.buckets[h[u]];
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const uint32_t kind = b[u].w & 3u;
+        if (kind == 1u) {
+            uint64_t ek = (uint64_t)b[u].x | ((uint64_t)b[u].y << 32);
+            if (ek == q[u] && (int)(b[u].w >> 16) <= max_freq)
+                agg_add(iv, agg, b[u].z);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        if ((b[u].w & 3u) == 2u) {
+            const uint32_t st = b[u].x, cn = b[u].y; // cn >= 2 by construction
+            const uint4 e0 = iv.entries[st];
+            const uint4 e1 = iv.entries[(uint64_t)st + 1];
+            count_if_match(iv, agg, e0, q[u], max_freq);
+            count_if_match(iv, agg, e1, q[u], max_freq);
+            for (uint32_t j = 2; j < cn; ++j)
+                count_if_match(iv, agg, iv.entries[(uint64_t)st + j], q[u], max_freq);
+        }
+    }
+}
+
+template <int U>
+__device__ __forceinline__ void probe_batch(const IndexView &iv, NodeAgg &agg, const uint64_t (&q)[U],
+                                            uint32_t valid, int max_freq)
+{
+    if (iv.occ) // wave-uniform
+        probe_batch_impl<U, true>(iv, agg, q, valid, max_freq);
+    else
+        probe_batch_impl<U, false>(iv, agg, q, valid, max_freq);
+}

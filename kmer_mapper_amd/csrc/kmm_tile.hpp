@@ -1,0 +1,241 @@
+// kmm_tile.hpp — part of libkmm (MI355X / gfx950); included by kmm.hip inside its anonymous namespace.
+// Tile front end: read bytes (flat, uniform-length or raw FASTA/FASTQ records) -> packed k-mers per lane.
+#pragma once
+
+// ------------------------------------------------------------------------------------------------
+// Tile front end shared by every kernel that starts from read bytes.  A workgroup (4 wavefronts)
+// owns tiles of T = 256*S consecutive base positions of the chunk's flat byte stream:
+//   1. 16-byte coalesced loads of the T + 48 bytes the tile's windows can touch; each byte goes
+//      through the 256-entry LDS lookup table and 16 codes are packed into one 32-bit LDS word;
+//   2. read starts that fall inside the tile are marked in an LDS bitset (general path) so that
+//      no window spans two reads (bionumpy's ragged windowing, util.py:72);
+//   3. each lane takes S consecutive positions: three LDS words give it S+31 bases in a 128-bit
+//      register window, and successive k-mers are 2-bit funnel shifts of that window
+//      (first base in the lowest bits).
+// Returns the lane's S k-mers and the bitmask of those that are real windows.
+// ------------------------------------------------------------------------------------------------
+template <int S>
+struct TileSmem {
+    static constexpr int T = 256 * S;
+    static constexpr int NV = T / 16 + 3; // 16-base words staged per tile (T + 48 positions)
+    static constexpr int NB = T / 32 + 3; // 32-position words of the read-start bitset
+    uint8_t lut[256];
+    uint32_t codes[NV + 1];
+    uint32_t bits[NB + 1];
+};
+
+struct TileConst {
+    uint64_t kmask; // low 2k bits
+    uint64_t bmask; // read starts in (p, p+k-1] kill the window at p
+    bool aligned;   // bases pointer is 16-byte aligned
+};
+
+__device__ __forceinline__ TileConst tile_const(const ReadsView &rv, int k)
+{
+    TileConst c;
+    c.kmask = (1ull << (2 * k)) - 1ull; // k <= 31
+    c.bmask = (1ull << (k - 1)) - 1ull;
+    c.aligned = (((uintptr_t)rv.bases) & 15u) == 0;
+    return c;
+}
+
+// SWAR: 0x80 in every byte of x that equals the byte value c (exact, no cross-byte carries).
+__device__ __forceinline__ uint32_t bytes_equal(uint32_t x, uint32_t c)
+{
+    const uint32_t y = x ^ (c * 0x01010101u);
+    return ~(((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y | 0x7F7F7F7Fu);
+}
+
+// 0x80-per-byte flags of four bytes -> 4-bit mask (bit i = byte i).
+__device__ __forceinline__ uint32_t flags_to_bits(uint32_t f)
+{
+    return ((f >> 7) & 1u) | ((f >> 14) & 2u) | ((f >> 21) & 4u) | ((f >> 28) & 8u);
+}
+
+template <int S, int MODE>
+__device__ __forceinline__ uint32_t tile_kmers(const ReadsView &rv, const TileConst &tc, int64_t tile,
+                                               int k, TileSmem<S> &sm, uint64_t (&q)[S])
+{
+    constexpr bool UNIFORM = MODE == MODE_UNIFORM;
+    constexpr bool RECORDS = MODE == MODE_RECORDS;
+    constexpr int T = TileSmem<S>::T;
+    constexpr int NV = TileSmem<S>::NV;
+    constexpr int NB = TileSmem<S>::NB;
+    static_assert(NV <= 256, "one staged 16-byte vector per thread");
+    const int tid = threadIdx.x;
+    const int64_t total = rv.total;
+    const int64_t t0 = tile * T;
+    if (MODE == MODE_GENERAL)
+        for (int i = tid; i < NB + 1; i += 256)
+            sm.bits[i] = 0;
+    __syncthreads(); // LUT visible; bitset cleared; previous tile's LDS readers are done
+
+    if (RECORDS) {
+        // ---- records mode, stage 1: raw file bytes.  A byte is a base iff it lies on the sequence
+        // line of its record (line index mod period == 1) and is not a line terminator; every other
+        // byte is a "break" that no window may contain, so k-mers never leave their read.
+        uint32_t w[4] = {0u, 0u, 0u, 0u};
+        uint32_t nl = 0, cr = 0; // 16-bit masks: byte i is '\n' / '\r'
+        const int v = tid;
+        const int64_t p = t0 + (int64_t)v * 16;
+        if (v < NV) {
+            if (tc.aligned && p + 16 <= total) {
+                u32x4 x = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(rv.bases + p));
+                w[0] = x[0]; w[1] = x[1]; w[2] = x[2]; w[3] = x[3];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    uint32_t acc = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        int64_t pp = p + i * 4 + j;
+                        uint32_t c = (pp < total) ? rv.bases[pp] : 0u;
+                        acc |= c << (8 * j);
+                    }
+                    w[i] = acc;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                nl |= flags_to_bits(bytes_equal(w[i], 10u)) << (4 * i);
+                cr |= flags_to_bits(bytes_equal(w[i], 13u)) << (4 * i);
+            }
+            sm.codes[v] = (uint32_t)__popc(nl); // borrowed as the per-vector newline count
+        }
+        __syncthreads();
+        uint32_t brk = 0, code = 0;
+        int bad = -1, malformed = -1;
+        if (v < NV) {
+            uint32_t line0 = rv.super_nl[tile >> 10] + rv.tile_nl[tile]; // newlines before the tile
+            for (int i = 0; i < v; ++i)
+                line0 += sm.codes[i];
+            // first byte of a line: preceded by '\n' (or the very first byte of the chunk)
+            const uint32_t prev_nl = (p == 0) ? 1u : (p - 1 < total ? (rv.bases[p - 1] == 10u) : 0u);
+            const uint32_t first = ((nl << 1) | prev_nl) & 0xFFFFu;
+#pragma unroll
+            for (int i = 15; i >= 0; --i) {
+                const uint32_t c = (w[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+                const uint32_t line = line0 + (uint32_t)__popc(nl & ((1u << i) - 1u));
+                const uint32_t phase = line & rv.period_mask;
+                const bool term = ((nl | cr) >> i) & 1u;
+                const bool is_seq = phase == 1u && !term && p + i < total;
+                const uint32_t l = sm.lut[c];
+                if (is_seq && l == 0xFFu)
+                    bad = i;
+                if (((first >> i) & 1u) && p + i < total &&
+                    ((phase == 0u && c != rv.header_char) || (phase == 2u && c != '+')))
+                    malformed = i;
+                brk |= (is_seq ? 0u : 1u) << i;
+                code |= (l & 3u) << (2 * i);
+            }
+        }
+        __syncthreads(); // every thread has read the borrowed per-vector counts
+        if (v < NV) {
+            sm.codes[v] = code;
+            reinterpret_cast<uint16_t *>(sm.bits)[v] = (uint16_t)brk;
+            if (bad >= 0)
+                atomicMin(&rv.first_bad[0], (unsigned long long)(p + bad));
+            if (malformed >= 0)
+                atomicMin(&rv.first_bad[1], (unsigned long long)(p + malformed));
+        }
+        __syncthreads();
+    } else {
+
+    // ---- stage 1: bytes -> 2-bit codes in LDS ----------------------------------------------
+    for (int v = tid; v < NV; v += 256) {
+        const int64_t p = t0 + (int64_t)v * 16;
+        uint32_t w[4];
+        if (tc.aligned && p + 16 <= total) {
+            // streamed once: non-temporal so the read bytes do not displace index lines in L2
+            u32x4 x = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(rv.bases + p));
+            w[0] = x[0]; w[1] = x[1]; w[2] = x[2]; w[3] = x[3];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                uint32_t acc = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    int64_t pp = p + i * 4 + j;
+                    uint32_t c = (pp < total) ? rv.bases[pp] : 0u;
+                    acc |= c << (8 * j);
+                }
+                w[i] = acc;
+            }
+        }
+        uint32_t code = 0;
+        int bad = -1;
+#pragma unroll
+        for (int i = 15; i >= 0; --i) {
+            uint32_t c = (w[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+            uint32_t l = sm.lut[c];
+            if (l == 0xFFu && p + i < total)
+                bad = i;
+            code |= (l & 3u) << (2 * i);
+        }
+        sm.codes[v] = code;
+        if (bad >= 0)
+            atomicMin(rv.first_bad, (unsigned long long)(p + bad));
+    }
+    // ---- stage 2: read starts inside (t0, t0 + T + k - 2] ----------------------------------
+    if (MODE == MODE_GENERAL) {
+        for (int64_t r = rv.tile_first[tile] + tid; r <= rv.n_reads; r += 256) {
+            int64_t o = rv.offsets[r] - t0;
+            if (o > (int64_t)T + k - 2)
+                break;
+            if (o >= 1)
+                atomicOr(&sm.bits[o >> 5], 1u << (o & 31));
+        }
+    }
+    __syncthreads();
+    } // !RECORDS
+
+    // ---- stage 3: S consecutive windows per lane -------------------------------------------
+    const int q0 = tid * S;
+    const int64_t p0 = t0 + q0;
+    uint64_t lo, hi;
+    {
+        const int w = q0 >> 4;
+        const uint32_t c0 = sm.codes[w], c1 = sm.codes[w + 1], c2 = sm.codes[w + 2];
+        const int sh = (q0 & 15) * 2;
+        lo = ((uint64_t)c1 << 32) | c0;
+        hi = c2;
+        if (sh) {
+            lo = (lo >> sh) | (hi << (64 - sh));
+            hi >>= sh;
+        }
+    }
+    uint32_t valid = 0;
+    if (UNIFORM) {
+        uint64_t o;
+        (void)fastdiv((uint64_t)p0, rv.read_len, rv.read_len_magic, &o);
+#pragma unroll
+        for (int j = 0; j < S; ++j) {
+            uint64_t oj = o + j;
+            if (oj >= rv.read_len)
+                oj -= rv.read_len;
+            if (oj + k <= rv.read_len && p0 + j < total)
+                valid |= 1u << j;
+        }
+    } else {
+        const int sw = q0 >> 5, off = q0 & 31;
+        uint64_t B = ((uint64_t)sm.bits[sw + 1] << 32) | sm.bits[sw];
+        if (off)
+            B = (B >> off) | ((uint64_t)sm.bits[sw + 2] << (64 - off));
+        if (RECORDS) { // no break byte inside [p, p+k-1]
+            const uint64_t wmask = (1ull << k) - 1ull;
+#pragma unroll
+            for (int j = 0; j < S; ++j)
+                if (((B >> j) & wmask) == 0 && p0 + j + k <= total)
+                    valid |= 1u << j;
+        } else {       // no read start inside (p, p+k-1]
+#pragma unroll
+            for (int j = 0; j < S; ++j)
+                if (((B >> (j + 1)) & tc.bmask) == 0 && p0 + j + k <= total)
+                    valid |= 1u << j;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < S; ++j)
+        q[j] = (j == 0 ? lo : ((lo >> (2 * j)) | (hi << (64 - 2 * j)))) & tc.kmask;
+    return valid;
+}

@@ -44,7 +44,7 @@ def test_product_package_never_imports_the_oracle():
     pkg = os.path.join(ROOT, "kmer_mapper_amd")
     for dirpath, _, files in os.walk(pkg):
         for f in files:
-            if f.endswith((".py", ".hip", ".h", ".cpp")):
+            if f.endswith((".py", ".hip", ".h", ".hpp", ".cpp")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in text.replace("no CPU oracle", ""), (f, "mentions oracle")
 
