@@ -53,8 +53,9 @@ int kmm_device_count(int *n_devices);
  * mapper.pyx:22-29 and the cucounter table construction at gpu_counter.py:13-16.
  * Arrays are the attributes of graph_kmer_index.KmerIndex after convert_to_int32()
  * (util.py:60-62): hashes_to_index int32[modulo], n_kmers int32[modulo], kmers uint64[n_entries],
- * nodes int32[n_entries], frequencies uint16[n_entries].  They are copied to HBM and repacked
- * (interleaved {start,count} bucket records; 16-byte {kmer,node,freq} entries).  Unlike the
+ * nodes int32[n_entries], frequencies uint16[n_entries].  They are copied to HBM and repacked on the
+ * GPU (16-byte bucket records with the single entry of a bucket stored inline, 16-byte {kmer,node,freq}
+ * entries, and for small indexes an L2-resident occupancy bitmap).  Unlike the
  * reference (no bounds checks, mapper.pyx:17) the arrays are validated: every non-empty bucket
  * must lie inside [0, n_entries) and every node inside [0, max_node_id], else KMM_ERR_INDEX.
  */

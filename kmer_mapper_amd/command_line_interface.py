@@ -55,6 +55,22 @@ def _get_kmer_index_from_args(args):
     return kmer_index
 
 
+def map_cpu(args, kmer_index, chunk_sequence):
+    """Per-chunk mapper with the reference's name and return value (command_line_interface.py:32-56):
+    a fresh uint32 node-count vector for ONE chunk.  `chunk_sequence` is a ReadBatch (the reference
+    passes a shared-memory name of the chunk; there is no process pool here).  N->A (:41), k-mer
+    extraction (:42) and lookup (:51, default frequency filter 1000) all happen in the fused kernel."""
+    from .mapper import _device_index
+    from .util import as_read_batch
+    k = args["kmer_size"] if isinstance(args, dict) else args.kmer_size
+    batch = as_read_batch(chunk_sequence)
+    max_node_id = kmer_index.max_node_id() if hasattr(kmer_index, "max_node_id") else int(np.max(kmer_index._nodes))
+    dev = _device_index(kmer_index, max_node_id)
+    dev.reset()
+    dev.map_reads(batch.bases, batch.offsets, k)
+    return dev.get_node_counts()
+
+
 def map_gpu(index, chunks, k, hash_map_size=0, map_reverse_complements=False,
             max_index_lookup_frequency=1000, device=0, rank=0, world_size=1):
     """command_line_interface.py:59-79 on the HIP engine: chunks -> fused kmm_map_reads calls."""

@@ -572,3 +572,14 @@ def test_map_records_device_buffer_large(kmm, syn, oracle):
         used, n_rec = dev.map_records(d_raw, fmt=_lib.FORMAT_FASTQ)
         assert (used, n_rec) == (raw.shape[0], n)
         assert np.array_equal(dev.get_node_counts(), expect)
+
+
+def test_map_cpu_facade_returns_fresh_vector_per_chunk(kmm, syn, oracle):
+    from kmer_mapper_amd.command_line_interface import map_cpu
+    from kmer_mapper_amd.util import ReadBatch
+    index, genome = syn.make_index(3000, seed=161)
+    bases, offs = syn.make_reads(genome, 500, 100, seed=162)
+    expect, _ = oracle.map_reads(index, index.max_node_id(), bases, offs, 31)
+    for _ in range(2):      # no accumulation between calls (mapper.pyx:37)
+        got = map_cpu({"kmer_size": 31}, index, ReadBatch(bases, offs))
+        assert got.dtype == np.uint32 and np.array_equal(got, expect)
