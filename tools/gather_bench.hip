@@ -19,6 +19,29 @@ __device__ __forceinline__ uint64_t mix(uint64_t x)
     return x ^ (x >> 31);
 }
 
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// same as k_gather<uint4> but with non-temporal loads
+template <int U>
+__global__ void __launch_bounds__(256) k_gather_nt(const uint4 *__restrict__ tab, uint64_t n_elems, int iters,
+                                                   uint64_t *sink)
+{
+    uint64_t tid = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    uint64_t acc = 0;
+    for (int it = 0; it < iters; ++it) {
+        u32x4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            uint64_t r = mix(tid * 1315423911ull + (uint64_t)it * U + u);
+            uint64_t idx = __umul64hi(r, n_elems);
+            v[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(&tab[idx]));
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc += v[u][0];
+    }
+    if (acc == 0x1234567887654321ull) *sink = acc;
+}
+
 template <typename T, int U>
 __global__ void __launch_bounds__(256) k_gather(const T *__restrict__ tab, uint64_t n_elems, int iters,
                                                 uint64_t *sink)
@@ -86,6 +109,17 @@ int main(int argc, char **argv)
         double d = run_gather<uint4, 8>(tab, s, grid, 8);
         printf("%10zu %12.1f %12.1f %12.1f %12.1f\n", s >> 20, a, b, c, d);
         fflush(stdout);
+    }
+    printf("# 16-byte gathers with non-temporal loads, U=4\n");
+    for (size_t s : {(size_t)320 << 20, (size_t)3200 << 20}) {
+        uint64_t *sink; CK(hipMalloc(&sink, 8));
+        hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+        hipLaunchKernelGGL((k_gather_nt<4>), dim3(grid), dim3(256), 0, 0, (const uint4 *)tab, s / 16, 2, sink);
+        CK(hipEventRecord(a));
+        hipLaunchKernelGGL((k_gather_nt<4>), dim3(grid), dim3(256), 0, 0, (const uint4 *)tab, s / 16, 16, sink);
+        CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+        float ms; CK(hipEventElapsedTime(&ms, a, b));
+        printf("%10zu %12.1f\n", s >> 20, (double)grid * 256 * 16 * 4 / (ms * 1e-3) / 1e9);
     }
     printf("# random uint32 atomicAdd (no return), G atomics/s; active = %% of lanes issuing\n");
     printf("%10s %12s %12s %12s\n", "table_MiB", "act100", "act20", "act5");
