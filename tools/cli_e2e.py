@@ -33,6 +33,7 @@ def main():
     fq = os.path.join(out_dir, "reads.fq")
     write_fastq_fast(fq, bases, n_reads, 150)
     size = os.path.getsize(fq)
+    run_argument_parser(["map", "-i", idx_path, "-f", fq, "-o", os.path.join(out_dir, "warm"), "-c", "50000000"])
     for chunk in (2_500_000, 10_000_000, 100_000_000):
         t0 = time.perf_counter()
         run_argument_parser(["map", "-i", idx_path, "-f", fq, "-o", os.path.join(out_dir, "out"),
@@ -42,5 +43,28 @@ def main():
               % (chunk, dt, size / dt / 1e6, n_reads / dt / 1e6, n_reads * 120 / dt / 1e6), flush=True)
 
 
+def gz_case(out_dir, idx_path, n_reads=1_000_000):
+    import gzip
+    import shutil
+    fq = os.path.join(out_dir, "reads.fq")
+    small = os.path.join(out_dir, "small.fq")
+    with open(fq, "rb") as f, open(small, "wb") as g:
+        g.write(f.read(307 * n_reads))
+    gz = small + ".gz"
+    t0 = time.perf_counter()
+    with open(small, "rb") as f, gzip.open(gz, "wb", compresslevel=1) as g:
+        shutil.copyfileobj(f, g, 1 << 24)
+    print("gzip -1 of %d MB took %.1f s" % (os.path.getsize(small) >> 20, time.perf_counter() - t0), flush=True)
+    for extra in ([], ["--host-parser"]):
+        t0 = time.perf_counter()
+        run_argument_parser(["map", "-i", idx_path, "-f", gz, "-o", os.path.join(out_dir, "outgz"),
+                             "-c", "10000000"] + extra)
+        dt = time.perf_counter() - t0
+        print("E2E gz %s: %.2f s, %.1f MB/s of inflated FASTQ, %.2f M reads/s"
+              % (extra or "gpu-parser", dt, os.path.getsize(small) / dt / 1e6, n_reads / dt / 1e6), flush=True)
+
+
 if __name__ == "__main__":
     main()
+    d = sys.argv[2] if len(sys.argv) > 2 else "/tmp/kmm_e2e"
+    gz_case(d, os.path.join(d, "index.npz"))
