@@ -117,3 +117,18 @@ def test_cli_flags_match_reference(monkeypatch):
     assert seen["gpu"] is True and seen["map_reverse_complements"] is True and seen["index_bundle"] == "bundle"
     with pytest.raises(SystemExit):
         cli.run_argument_parser([])
+
+
+def test_header_is_plain_c_and_demo_client_links(tmp_path):
+    """include/kmm.h must be consumable from C (no C++ / torch types), and a C client must link."""
+    import subprocess
+    inc = os.path.join(ROOT, "include")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-fsyntax-only", "-x", "c",
+                           os.path.join(inc, "kmm.h")])
+    _lib.build()
+    exe = str(tmp_path / "kmm_demo")
+    libdir = os.path.dirname(_lib.SO_PATH)
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-I" + inc, os.path.join(ROOT, "tools", "kmm_demo.c"),
+                           "-o", exe, "-L" + libdir, "-l:libkmm.so", "-Wl,-rpath," + libdir,
+                           "-Wl,-rpath,/opt/rocm/lib"])
+    assert os.path.exists(exe)
