@@ -60,6 +60,9 @@ def main():
     ap.add_argument("--grid-per-cu", type=int, default=None)
     ap.add_argument("--no-filter", action="store_true", help="disable the L2 occupancy-bitmap prefilter")
     ap.add_argument("--general-path", action="store_true", help="use kmm_map_reads with an offsets array")
+    ap.add_argument("--operator", action="store_true",
+                    help="time the operator path instead: k-mers extracted once (kmm_extract_kmers) into HBM, "
+                         "each step = kmm_map_kmers over them (drop-in for map_kmers_to_graph_index)")
     ap.add_argument("--cpu-sample-reads", type=int, default=5_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl",
@@ -117,11 +120,26 @@ def main():
     del g_ascii
     torch.cuda.synchronize()
     kmers_per_step = R * max(L - k + 1, 0)
+    kmer_batches = None
+    if args.operator:
+        from kmer_mapper_amd.engine import extract_kmers
+        o = torch.arange(R + 1, dtype=torch.int64, device=dev_t) * L
+        kmer_batches = []
+        for b in batches:
+            km = torch.empty(kmers_per_step, dtype=torch.int64, device=dev_t)     # uint64 bit patterns
+            torch.cuda.synchronize()
+            t_e = time.perf_counter()
+            extract_kmers(b, o, k, device=local_rank, out=km)
+            log("kmm_extract_kmers: %.1f ms for %d k-mers" % ((time.perf_counter() - t_e) * 1e3, kmers_per_step))
+            kmer_batches.append(km)
+        del o
     log("setup done in %.1fs; %d reads/batch/GPU, %d k-mers/step/GPU" % (time.time() - t_setup, R, kmers_per_step))
 
     def step(i):
         b = batches[i & 1]
-        if offs is not None:
+        if kmer_batches is not None:
+            dev.map_kmers(kmer_batches[i & 1], args.max_freq)
+        elif offs is not None:
             dev.map_reads(b, offs, k, args.max_freq)
         else:
             dev.map_reads_uniform(b, R, L, k, args.max_freq)
@@ -208,9 +226,10 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": "configs[1]: %d synthetic %d bp reads per batch per GPU, k=%d, %d-k-mer index "
-                            "(modulo %d, %d entries), reads resident in HBM, fused kmm_map_reads%s"
+                            "(modulo %d, %d entries), reads resident in HBM, %s"
                             % (R, L, k, args.index_kmers, index._modulo, len(index._kmers),
-                               "" if args.general_path else "_uniform"),
+                               "operator kmm_map_kmers on pre-extracted k-mers" if args.operator else
+                               "fused kmm_map_reads" + ("" if args.general_path else "_uniform")),
                 "kmers_per_step_per_gpu": kmers_per_step,
                 "hit_rate": round(hits / max(total_kmers, 1), 4),
                 "nodes": "skewed(mod 1000)" if args.skewed else "uniform",

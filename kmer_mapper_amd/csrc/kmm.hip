@@ -55,9 +55,9 @@ int fail(int code, const char *fmt, ...)
 
 #include "kmm_probe.hpp"
 #include "kmm_tile.hpp"
+#include "kmm_records.hpp"
 #include "kmm_kernels.hpp"
 #include "kmm_partition.hpp"
-#include "kmm_records.hpp"
 
 // ------------------------------------------------------------------------------------------------
 // host side
@@ -910,37 +910,32 @@ int kmm_extract_kmers(int device, const uint8_t *bases, const int64_t *read_offs
         return fail(KMM_ERR_HIP, "no HIP device available: libkmm has no CPU fallback");
     }
     HIPCHK(hipSetDevice(device));
-    // host copy of the offsets for the prefix sums of per-read k-mer counts
-    std::vector<int64_t> offs((size_t)n_reads + 1);
-    if (is_device_ptr(read_offsets))
-        HIPCHK(hipMemcpy(offs.data(), read_offsets, offs.size() * 8, hipMemcpyDeviceToHost));
-    else
-        memcpy(offs.data(), read_offsets, offs.size() * 8);
-    if (offs[0] != 0)
-        return fail(KMM_ERR_INVALID_ARG, "read_offsets[0] must be 0");
-    std::vector<int64_t> koffs((size_t)n_reads + 1);
-    koffs[0] = 0;
-    for (int64_t r = 0; r < n_reads; ++r) {
-        int64_t len = offs[r + 1] - offs[r];
-        if (len < 0)
-            return fail(KMM_ERR_INVALID_ARG, "read_offsets not non-decreasing at read %lld", (long long)r);
-        koffs[r + 1] = koffs[r] + (len >= k ? len - k + 1 : 0);
+    const bool offs_dev = is_device_ptr(read_offsets);
+    int64_t ends[2];
+    if (offs_dev) {
+        HIPCHK(hipMemcpy(&ends[0], read_offsets, 8, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(&ends[1], read_offsets + n_reads, 8, hipMemcpyDeviceToHost));
+    } else {
+        ends[0] = read_offsets[0];
+        ends[1] = read_offsets[n_reads];
+        for (int64_t r = 0; r < n_reads; ++r)
+            if (read_offsets[r + 1] < read_offsets[r])
+                return fail(KMM_ERR_INVALID_ARG, "read_offsets not non-decreasing at read %lld", (long long)r);
     }
-    if (koffs[n_reads] != n_out)
-        return fail(KMM_ERR_INVALID_ARG, "n_out=%lld but the reads hold %lld k-mers", (long long)n_out,
-                    (long long)koffs[n_reads]);
-    const int64_t total = offs[n_reads];
-    if (total == 0 || n_out == 0)
-        return KMM_OK;
-    if (!bases || !out)
+    if (ends[0] != 0)
+        return fail(KMM_ERR_INVALID_ARG, "read_offsets[0] must be 0");
+    const int64_t total = ends[1];
+    if (total < 0)
+        return fail(KMM_ERR_INVALID_ARG, "read_offsets[n_reads] negative");
+    if (total == 0)
+        return n_out == 0 ? KMM_OK : fail(KMM_ERR_INVALID_ARG, "n_out != 0 but the reads are empty");
+    if (!bases || (n_out > 0 && !out))
         return fail(KMM_ERR_INVALID_ARG, "bases / out is NULL");
 
-    DevBuf d_bases, d_offs, d_koffs, d_lut, d_out, d_bad;
+    DevBuf d_bases, d_offs, d_lut, d_out, d_bad, d_tf, d_cnt, d_sup;
     int rc = KMM_OK;
     hipError_t e = hipSuccess;
-    const uint8_t *p_bases = bases;
-    uint64_t *p_out = out;
-    const bool bases_dev = is_device_ptr(bases), out_dev = is_device_ptr(out);
+    const bool out_dev = n_out == 0 || is_device_ptr(out);
     uint8_t lutbuf[256];
     if (lut) {
         if (is_device_ptr(lut))
@@ -950,45 +945,95 @@ int kmm_extract_kmers(int device, const uint8_t *bases, const int64_t *read_offs
     } else {
         default_lut(lutbuf);
     }
-    unsigned long long bad = NO_BAD;
+    unsigned long long bad[2] = {NO_BAD, NO_BAD};
+    int64_t produced = 0;
+    const int64_t n_tiles = (total + TILE_T - 1) / TILE_T;
+    const int64_t sub_tiles = (int64_t)1 << 20; // 1024 super-tiles of 1024 tiles per round
     do {
         if (e != hipSuccess) break;
-        if (!bases_dev) {
+        ReadsView rv;
+        memset(&rv, 0, sizeof rv);
+        rv.total = total;
+        rv.n_reads = n_reads;
+        if (is_device_ptr(bases)) {
+            rv.bases = bases;
+        } else {
             if ((rc = ensure(d_bases, (size_t)total))) break;
             if ((e = hipMemcpy(d_bases.p, bases, (size_t)total, hipMemcpyHostToDevice))) break;
-            p_bases = (const uint8_t *)d_bases.p;
+            rv.bases = (const uint8_t *)d_bases.p;
         }
+        if (offs_dev) {
+            rv.offsets = read_offsets;
+        } else {
+            if ((rc = ensure(d_offs, (size_t)(n_reads + 1) * 8))) break;
+            if ((e = hipMemcpy(d_offs.p, read_offsets, (size_t)(n_reads + 1) * 8, hipMemcpyHostToDevice))) break;
+            rv.offsets = (const int64_t *)d_offs.p;
+        }
+        uint64_t *p_out = out;
         if (!out_dev) {
             if ((rc = ensure(d_out, (size_t)n_out * 8))) break;
             p_out = (uint64_t *)d_out.p;
         }
-        if ((rc = ensure(d_offs, offs.size() * 8))) break;
-        if ((rc = ensure(d_koffs, koffs.size() * 8))) break;
+        const int64_t max_tiles = n_tiles < sub_tiles ? n_tiles : sub_tiles;
+        const int max_super = (int)((max_tiles + 1023) / 1024);
         if ((rc = ensure(d_lut, 256))) break;
-        if ((rc = ensure(d_bad, 8))) break;
-        if ((e = hipMemcpy(d_offs.p, offs.data(), offs.size() * 8, hipMemcpyHostToDevice))) break;
-        if ((e = hipMemcpy(d_koffs.p, koffs.data(), koffs.size() * 8, hipMemcpyHostToDevice))) break;
+        if ((rc = ensure(d_bad, 16))) break;
+        if ((rc = ensure(d_tf, (size_t)n_tiles * 8))) break;
+        if ((rc = ensure(d_cnt, (size_t)max_super * 1024 * 4))) break;
+        if ((rc = ensure(d_sup, (size_t)max_super * 4 + 16))) break;
         if ((e = hipMemcpy(d_lut.p, lutbuf, 256, hipMemcpyHostToDevice))) break;
-        if ((e = hipMemcpy(d_bad.p, &bad, 8, hipMemcpyHostToDevice))) break;
-        int64_t blocks = (total + 255) / 256;
-        if (blocks > 65536) blocks = 65536;
-        hipLaunchKernelGGL(k_extract_kmers, dim3((unsigned)blocks), dim3(256), 0, 0, p_bases,
-                           (const int64_t *)d_offs.p, (const int64_t *)d_koffs.p, n_reads, k,
-                           (const uint8_t *)d_lut.p, p_out, (unsigned long long *)d_bad.p);
+        if ((e = hipMemcpy(d_bad.p, bad, 16, hipMemcpyHostToDevice))) break;
+        rv.lut = (const uint8_t *)d_lut.p;
+        rv.first_bad = (unsigned long long *)d_bad.p;
+        rv.tile_first = (const int64_t *)d_tf.p;
+        hipLaunchKernelGGL(k_tile_first, dim3((unsigned)((n_tiles + 255) / 256)), dim3(256), 0, 0, rv.offsets,
+                           n_reads, n_tiles, TILE_T, (int64_t *)d_tf.p);
+        uint32_t *tile_cnt = (uint32_t *)d_cnt.p;
+        uint32_t *super_tot = (uint32_t *)d_sup.p;
+        uint32_t *d_total = super_tot + max_super;
+        for (int64_t t0 = 0; t0 < n_tiles && rc == KMM_OK; t0 += sub_tiles) {
+            const int64_t t1 = t0 + sub_tiles < n_tiles ? t0 + sub_tiles : n_tiles;
+            const int n_super = (int)((t1 - t0 + 1023) / 1024);
+            int64_t g = t1 - t0;
+            if (g > 65536) g = 65536;
+            if ((e = hipMemsetAsync(tile_cnt, 0, (size_t)n_super * 1024 * 4, 0))) break;
+            hipLaunchKernelGGL((k_extract_count<TILE_S, MODE_GENERAL>), dim3((unsigned)g), dim3(256), 0, 0, rv,
+                               k, t0, t1, tile_cnt);
+            hipLaunchKernelGGL(k_rec_scan1, dim3(n_super), dim3(1024), 0, 0, tile_cnt, super_tot);
+            hipLaunchKernelGGL(k_super_scan, dim3(1), dim3(1024), 0, 0, super_tot, n_super, d_total);
+            uint32_t sub_total = 0;
+            if ((e = hipGetLastError())) break;
+            if ((e = hipMemcpy(&sub_total, d_total, 4, hipMemcpyDeviceToHost))) break;
+            if (produced + (int64_t)sub_total > n_out) { // never write past the caller's buffer
+                rc = fail(KMM_ERR_INVALID_ARG, "n_out=%lld but the reads hold more k-mers", (long long)n_out);
+                break;
+            }
+            if (sub_total)
+                hipLaunchKernelGGL((k_extract_write<TILE_S, MODE_GENERAL>), dim3((unsigned)g), dim3(256), 0, 0,
+                                   rv, k, t0, t1, tile_cnt, super_tot, p_out + produced);
+            produced += sub_total;
+        }
+        if (rc != KMM_OK || e != hipSuccess) break;
         if ((e = hipGetLastError())) break;
         if ((e = hipDeviceSynchronize())) break;
-        if ((e = hipMemcpy(&bad, d_bad.p, 8, hipMemcpyDeviceToHost))) break;
-        if (!out_dev)
+        if ((e = hipMemcpy(bad, d_bad.p, 16, hipMemcpyDeviceToHost))) break;
+        if (produced != n_out) {
+            rc = fail(KMM_ERR_INVALID_ARG, "n_out=%lld but the reads hold %lld k-mers", (long long)n_out,
+                      (long long)produced);
+            break;
+        }
+        if (!out_dev && n_out)
             if ((e = hipMemcpy(out, d_out.p, (size_t)n_out * 8, hipMemcpyDeviceToHost))) break;
     } while (0);
-    release(d_bases); release(d_offs); release(d_koffs); release(d_lut); release(d_out); release(d_bad);
+    release(d_bases); release(d_offs); release(d_lut); release(d_out); release(d_bad); release(d_tf);
+    release(d_cnt); release(d_sup);
     if (rc != KMM_OK)
         return rc;
     if (e != hipSuccess)
         return fail(KMM_ERR_HIP, "kmm_extract_kmers: %s", hipGetErrorString(e));
-    if (bad != NO_BAD)
+    if (bad[0] != NO_BAD)
         return fail(KMM_ERR_INVALID_BASE, "read byte at offset %llu is not a nucleotide under the "
-                    "lookup table (the reference's DNA encoder raises here)", bad);
+                    "lookup table (the reference's DNA encoder raises here)", bad[0]);
     return KMM_OK;
 }
 

@@ -97,33 +97,83 @@ __global__ void k_iota_offsets(int64_t *out, int64_t n_reads, int64_t read_len)
 // ------------------------------------------------------------------------------------------------
 // Operator façade kernels (not on the fused path).
 // ------------------------------------------------------------------------------------------------
-// get_kmer_hashes_from_chunk_sequence (util.py:71-75): one lane per base position.
-__global__ void k_extract_kmers(const uint8_t *__restrict__ bases, const int64_t *__restrict__ offs,
-                                const int64_t *__restrict__ kmer_offs, int64_t n_reads, int k,
-                                const uint8_t *__restrict__ lut, uint64_t *__restrict__ out,
-                                unsigned long long *first_bad)
+// get_kmer_hashes_from_chunk_sequence (util.py:71-75) as an operator: the k-mers of all reads,
+// flattened in (read, offset) order, i.e. in increasing base position.  The output slot of a window is
+// therefore the number of valid windows before it: pass 1 counts the valid windows per tile, a
+// two-level scan turns the counts into tile bases, pass 2 regenerates the k-mers (cheaper than storing
+// them) and writes each lane's run of up to S k-mers contiguously.
+template <int S, int MODE>
+__global__ void __launch_bounds__(256) k_extract_count(ReadsView rv, int k, int64_t tile_begin,
+                                                       int64_t tile_end, uint32_t *__restrict__ tile_cnt)
 {
-    const int64_t total = offs[n_reads];
-    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total;
-         p += (int64_t)gridDim.x * blockDim.x) {
-        if (lut[bases[p]] == 0xFFu)
-            atomicMin(first_bad, (unsigned long long)p);
-        // read containing p: last r with offs[r] <= p
-        int64_t lo = 0, hi = n_reads + 1;
-        while (lo < hi) {
-            int64_t mid = (lo + hi) >> 1;
-            if (offs[mid] <= p)
-                lo = mid + 1;
-            else
-                hi = mid;
+    __shared__ TileSmem<S> sm;
+    __shared__ uint32_t s_wave[4];
+    sm.lut[threadIdx.x] = rv.lut[threadIdx.x];
+    const TileConst tc = tile_const(rv, k);
+    for (int64_t tile = tile_begin + blockIdx.x; tile < tile_end; tile += gridDim.x) {
+        uint64_t q[S];
+        uint32_t c = (uint32_t)__popc(tile_kmers<S, MODE>(rv, tc, tile, k, sm, q));
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1)
+            c += __shfl_xor(c, d);
+        if ((threadIdx.x & 63) == 0)
+            s_wave[threadIdx.x >> 6] = c;
+        __syncthreads();
+        if (threadIdx.x == 0)
+            tile_cnt[tile - tile_begin] = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    }
+}
+
+// Exclusive scan of the (<= 1024) super-tile totals, in place; total -> *total_out.
+__global__ void __launch_bounds__(1024) k_super_scan(uint32_t *super_tot, int n_super, uint32_t *total_out)
+{
+    __shared__ uint32_t s_a[1024];
+    const int t = threadIdx.x;
+    const uint32_t c = t < n_super ? super_tot[t] : 0u;
+    s_a[t] = c;
+    __syncthreads();
+    block_scan_1024(s_a);
+    if (t < n_super)
+        super_tot[t] = s_a[t] - c;
+    if (t == 1023)
+        *total_out = s_a[t];
+}
+
+template <int S, int MODE>
+__global__ void __launch_bounds__(256) k_extract_write(ReadsView rv, int k, int64_t tile_begin,
+                                                       int64_t tile_end, const uint32_t *__restrict__ tile_pre,
+                                                       const uint32_t *__restrict__ super_pre,
+                                                       uint64_t *__restrict__ out)
+{
+    __shared__ TileSmem<S> sm;
+    __shared__ uint32_t s_wave[4];
+    sm.lut[threadIdx.x] = rv.lut[threadIdx.x];
+    const TileConst tc = tile_const(rv, k);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int64_t tile = tile_begin + blockIdx.x; tile < tile_end; tile += gridDim.x) {
+        uint64_t q[S];
+        const uint32_t valid = tile_kmers<S, MODE>(rv, tc, tile, k, sm, q);
+        const uint32_t c = (uint32_t)__popc(valid);
+        uint32_t inc = c;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = __shfl_up(inc, d);
+            if (lane >= d)
+                inc += o;
         }
-        const int64_t r = lo - 1;
-        if (p + k > offs[r + 1])
-            continue;
-        uint64_t w = 0;
-        for (int j = 0; j < k; ++j)
-            w |= (uint64_t)(lut[bases[p + j]] & 3u) << (2 * j);
-        out[kmer_offs[r] + (p - offs[r])] = w;
+        if (lane == 63)
+            s_wave[wave] = inc;
+        __syncthreads();
+        uint32_t base = inc - c;
+        for (int w = 0; w < wave; ++w)
+            base += s_wave[w];
+        const int64_t lt = tile - tile_begin;
+        uint64_t slot = (uint64_t)super_pre[lt >> 10] + tile_pre[lt] + base;
+#pragma unroll
+        for (int j = 0; j < S; ++j)
+            if ((valid >> j) & 1u)
+                out[slot++] = q[j];
+        __syncthreads(); // s_wave is rewritten by the next tile
     }
 }
 

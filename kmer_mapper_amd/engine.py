@@ -197,15 +197,19 @@ class DeviceIndex:
         return v.value
 
 
-def extract_kmers(bases, read_offsets, k, lut=None, device=0):
-    """Operator form of util.py:71-75 on the GPU: flat uint64 k-mers in (read, offset) order."""
+def extract_kmers(bases, read_offsets, k, lut=None, device=0, out=None):
+    """Operator form of util.py:71-75 on the GPU: flat uint64 k-mers in (read, offset) order.
+    bases / read_offsets may be numpy arrays or torch tensors (host or device).  With `out` (a
+    uint64 numpy array or an int64/uint64 torch tensor of the right length, host or device) the k-mers
+    are written there; otherwise a numpy array is returned."""
     b = _Arg(bases, np.uint8, "bases")
-    offs = np.ascontiguousarray(np.asarray(read_offsets, dtype=np.int64))
+    o = _Arg(read_offsets if _is_torch_tensor(read_offsets)
+             else np.ascontiguousarray(np.asarray(read_offsets, dtype=np.int64)), np.int64, "read_offsets")
     t = _Arg(lut, np.uint8, "lut")
-    lens = np.diff(offs)
-    n_out = int(np.maximum(lens - int(k) + 1, 0).sum())
-    out = np.empty(n_out, dtype=np.uint64)
-    _lib.check(_lib.lib().kmm_extract_kmers(int(device), b.ptr, offs.ctypes.data_as(_P),
-                                            offs.size - 1, int(k), t.ptr,
-                                            out.ctypes.data_as(_P), n_out))
+    if out is None:
+        offs = o.keep.cpu().numpy() if _is_torch_tensor(o.keep) else o.keep
+        n_out = int(np.maximum(np.diff(offs) - int(k) + 1, 0).sum())
+        out = np.empty(n_out, dtype=np.uint64)
+    dst = _Arg(out, np.uint64, "out")
+    _lib.check(_lib.lib().kmm_extract_kmers(int(device), b.ptr, o.ptr, o.n - 1, int(k), t.ptr, dst.ptr, dst.n))
     return out

@@ -583,3 +583,21 @@ def test_map_cpu_facade_returns_fresh_vector_per_chunk(kmm, syn, oracle):
     for _ in range(2):      # no accumulation between calls (mapper.pyx:37)
         got = map_cpu({"kmer_size": 31}, index, ReadBatch(bases, offs))
         assert got.dtype == np.uint32 and np.array_equal(got, expect)
+
+
+def test_extract_operator_large_ragged_and_device_io(kmm, syn, oracle):
+    import torch
+    index, genome = syn.make_index(20000, seed=171)
+    bases, offs = syn.make_ragged_reads(genome, 60000, 0, 260, seed=172)
+    expect = oracle.extract(bases, offs, 31)
+    got = kmm.extract_kmers(bases, offs, 31)
+    assert np.array_equal(got, expect)
+    d_out = torch.empty(expect.shape[0], dtype=torch.int64, device="cuda")
+    d_b, d_o = torch.from_numpy(bases).cuda(), torch.from_numpy(offs).cuda()
+    torch.cuda.synchronize()
+    kmm.extract_kmers(d_b, d_o, 31, out=d_out)
+    assert np.array_equal(d_out.cpu().numpy().view(np.uint64), expect)
+    with pytest.raises(ValueError):                 # wrong n_out never writes past the buffer
+        kmm.extract_kmers(bases, offs, 31, out=np.empty(expect.shape[0] - 1, dtype=np.uint64))
+    for kk in (1, 13):
+        assert np.array_equal(kmm.extract_kmers(bases, offs, kk), oracle.extract(bases, offs, kk))
