@@ -157,6 +157,11 @@ int kmm_in_index(kmm_index_t *idx, const uint64_t *kmers, int64_t n, uint8_t *ou
 #define KMM_KERNEL_PART_PROBE 4   /* partitioned path: L2-local probe + count                 */
 #define KMM_N_KERNELS 5
 int kmm_set_timing(kmm_index_t *idx, int enabled);
+/* Work done by the map calls of this handle since creation (or the last call with reset != 0):
+ * k-mer lookups performed (windows, doubled with also_revcomp) and count increments (index hits that
+ * passed the frequency filter) — the numbers the reference logs per chunk
+ * (command_line_interface.py:53, util.py:74).  Synchronises like kmm_get_node_counts. */
+int kmm_get_stats(kmm_index_t *idx, int reset, uint64_t *n_lookups, uint64_t *n_hits);
 int kmm_get_timing(kmm_index_t *idx, int kernel_id, double *kernel_ms, int64_t *n_launches);
 
 /*

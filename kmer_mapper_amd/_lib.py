@@ -50,6 +50,7 @@ SIGNATURES = {
     "kmm_extract_kmers": (_c.c_int, [_c.c_int, _P, _P, _c.c_int64, _c.c_int, _P, _P, _c.c_int64]),
     "kmm_in_index": (_c.c_int, [_P, _P, _c.c_int64, _P]),
     "kmm_set_timing": (_c.c_int, [_P, _c.c_int]),
+    "kmm_get_stats": (_c.c_int, [_P, _c.c_int, _P, _P]),
     "kmm_get_timing": (_c.c_int, [_P, _c.c_int, _P, _P]),
     "kmm_set_param": (_c.c_int, [_P, _c.c_char_p, _c.c_int64]),
     "kmm_get_param": (_c.c_int, [_P, _c.c_char_p, _P]),

@@ -136,13 +136,15 @@ def map_gpu_raw(index, path, chunk_size, fmt, k, map_reverse_complements=False,
             chunker.consumed(used)
             i += 1
         node_counts = dev.get_node_counts()
+        n_lookups, n_hits = dev.get_stats()
     finally:
         chunker.close()
         dev.close()
     dt = time.perf_counter() - t_start
     logging.info("Time spent only on hashing and counting hashes: %.5f" % dt)
-    logging.info("Mapped %d reads from %d bytes (%.1f MB/s, GPU record parser)"
-                 % (n_reads, n_bytes, n_bytes / max(dt, 1e-9) / 1e6))
+    logging.info("Mapped %d reads from %d bytes (%.1f MB/s, GPU record parser): %d k-mer lookups "
+                 "(%.1f M/s), %d index hits" % (n_reads, n_bytes, n_bytes / max(dt, 1e-9) / 1e6, n_lookups,
+                                                  n_lookups / max(dt, 1e-9) / 1e6, n_hits))
     return node_counts
 
 

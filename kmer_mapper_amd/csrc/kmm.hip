@@ -152,6 +152,7 @@ struct kmm_index {
     uint32_t *own_counts_buf = nullptr;
     uint8_t *lut_default = nullptr;
     unsigned long long *first_bad = nullptr;
+    unsigned long long *stats = nullptr;
     uint64_t modulo = 0, magic = 0;
     int64_t n_entries = 0, max_node_id = 0;
     Stage stage[2];
@@ -180,6 +181,7 @@ IndexView view_of(const kmm_index *ix)
     v.entries = ix->entries;
     v.occ = ix->use_occ ? ix->occ : nullptr;
     v.counts = ix->counts;
+    v.stats = ix->stats;
     v.modulo = ix->modulo;
     v.magic = ix->magic;
     return v;
@@ -470,6 +472,8 @@ void kmm_index_destroy(kmm_index_t *ix)
         (void)hipFree(ix->lut_default);
     if (ix->first_bad)
         (void)hipFree(ix->first_bad);
+    if (ix->stats)
+        (void)hipFree(ix->stats);
     if (ix->copy_stream)
         (void)hipStreamDestroy(ix->copy_stream);
     if (ix->stream)
@@ -499,6 +503,8 @@ static int index_create_impl(kmm_index *ix, const int32_t *h2i, const int32_t *n
     HIPCHK(hipMemsetAsync(ix->counts, 0, sizeof(uint32_t) * (size_t)(ix->max_node_id + 1), ix->stream));
     HIPCHK(hipMalloc(&ix->lut_default, 256));
     HIPCHK(hipMalloc(&ix->first_bad, 2 * sizeof(unsigned long long)));
+    HIPCHK(hipMalloc(&ix->stats, 2 * sizeof(unsigned long long)));
+    HIPCHK(hipMemset(ix->stats, 0, 2 * sizeof(unsigned long long)));
     uint8_t lut[256];
     default_lut(lut);
     HIPCHK(hipMemcpy(ix->lut_default, lut, 256, hipMemcpyHostToDevice));
@@ -1034,6 +1040,23 @@ int kmm_extract_kmers(int device, const uint8_t *bases, const int64_t *read_offs
     if (bad[0] != NO_BAD)
         return fail(KMM_ERR_INVALID_BASE, "read byte at offset %llu is not a nucleotide under the "
                     "lookup table (the reference's DNA encoder raises here)", bad[0]);
+    return KMM_OK;
+}
+
+int kmm_get_stats(kmm_index_t *ix, int reset, uint64_t *n_lookups, uint64_t *n_hits)
+{
+    if (!ix)
+        return fail(KMM_ERR_INVALID_ARG, "idx is NULL");
+    HIPCHK(hipSetDevice(ix->device));
+    KMMCHK(drain(ix));
+    unsigned long long st[2] = {0, 0};
+    HIPCHK(hipMemcpy(st, ix->stats, sizeof st, hipMemcpyDeviceToHost));
+    if (n_lookups)
+        *n_lookups = st[0];
+    if (n_hits)
+        *n_hits = st[1];
+    if (reset)
+        HIPCHK(hipMemset(ix->stats, 0, sizeof st));
     return KMM_OK;
 }
 

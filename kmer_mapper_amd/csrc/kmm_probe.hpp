@@ -19,6 +19,7 @@ struct IndexView {
     const uint4 *entries;
     const uint32_t *occ; // optional L2-resident occupancy bitmap (bit h = bucket h non-empty), or null
     uint32_t *counts;
+    unsigned long long *stats; // [0] k-mer lookups performed, [1] count increments (hits)
     uint64_t modulo;
     uint64_t magic; // floor(2^64 / modulo) (all ones for modulo == 1)
 };
@@ -94,6 +95,7 @@ constexpr uint32_t AGG_EMPTY = 0xFFFFFFFFu; // node ids are < 2^31
 struct NodeAgg {
     uint32_t key[AGG_SLOTS];
     uint32_t val[AGG_SLOTS];
+    uint32_t lookups, hits; // statistics of this workgroup (kmm_get_stats)
 };
 
 __device__ __forceinline__ void agg_init(NodeAgg &agg)
@@ -102,11 +104,16 @@ __device__ __forceinline__ void agg_init(NodeAgg &agg)
         agg.key[i] = AGG_EMPTY;
         agg.val[i] = 0;
     }
+    if (threadIdx.x == 0) {
+        agg.lookups = 0;
+        agg.hits = 0;
+    }
 }
 
 __device__ __forceinline__ void agg_add(const IndexView &iv, NodeAgg &agg, uint32_t node)
 {
     const uint32_t slot = (node * 2654435761u) >> (32 - AGG_LOG_SLOTS);
+    atomicAdd(&agg.hits, 1u);
     const uint32_t prev = atomicCAS(&agg.key[slot], AGG_EMPTY, node);
     if (prev == AGG_EMPTY || prev == node)
         atomicAdd(&agg.val[slot], 1u);
@@ -121,6 +128,10 @@ __device__ __forceinline__ void agg_flush(const IndexView &iv, NodeAgg &agg)
         const uint32_t v = agg.val[i];
         if (v)
             atomicAdd(&iv.counts[agg.key[i]], v);
+    }
+    if (threadIdx.x == 0) {
+        atomicAdd(&iv.stats[0], (unsigned long long)agg.lookups);
+        atomicAdd(&iv.stats[1], (unsigned long long)agg.hits);
     }
 }
 
@@ -141,6 +152,14 @@ template <int U, bool FILTER>
 __device__ __forceinline__ void probe_batch_impl(const IndexView &iv, NodeAgg &agg,
                                                  const uint64_t (&q)[U], uint32_t valid, int max_freq)
 {
+    {
+        uint32_t n = (uint32_t)__popc(valid);
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1)
+            n += __shfl_xor(n, d);
+        if ((threadIdx.x & 63) == 0)
+            atomicAdd(&agg.lookups, n);
+    }
     uint64_t h[U];
 #pragma unroll
     for (int u = 0; u < U; ++u)

@@ -187,6 +187,12 @@ class DeviceIndex:
         _lib.check(_lib.lib().kmm_get_timing(self._h, int(kernel_id), ctypes.byref(ms), ctypes.byref(n)))
         return ms.value, n.value
 
+    def get_stats(self, reset=False):
+        """(k-mer lookups performed, count increments) since creation / the last reset."""
+        a, b = ctypes.c_uint64(0), ctypes.c_uint64(0)
+        _lib.check(_lib.lib().kmm_get_stats(self._h, int(bool(reset)), ctypes.byref(a), ctypes.byref(b)))
+        return a.value, b.value
+
     def set_param(self, name, value):
         """Tuning knobs of include/kmm.h: "path" (0 auto, 1 direct, 2 partitioned), "part_shift"."""
         _lib.check(_lib.lib().kmm_set_param(self._h, name.encode(), int(value)))

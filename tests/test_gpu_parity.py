@@ -601,3 +601,22 @@ def test_extract_operator_large_ragged_and_device_io(kmm, syn, oracle):
         kmm.extract_kmers(bases, offs, 31, out=np.empty(expect.shape[0] - 1, dtype=np.uint64))
     for kk in (1, 13):
         assert np.array_equal(kmm.extract_kmers(bases, offs, kk), oracle.extract(bases, offs, kk))
+
+
+def test_stats_count_lookups_and_hits(kmm, syn, oracle):
+    index, genome = syn.make_index(3000, seed=181)
+    mx = index.max_node_id()
+    bases, offs = syn.make_ragged_reads(genome, 2000, 0, 200, seed=182)
+    expect, n = oracle.map_reads(index, mx, bases, offs, 31)
+    with kmm.DeviceIndex.from_index(index, mx) as dev:
+        dev.map_reads(bases, offs, 31)
+        assert dev.get_stats() == (n, int(expect.sum()))
+        dev.map_reads(bases, offs, 31, also_revcomp=True)
+        e2, _ = oracle.map_reads(index, mx, bases, offs, 31, also_revcomp=True)
+        assert dev.get_stats(reset=True) == (3 * n, int(expect.sum()) + int(e2.sum()))
+        assert dev.get_stats() == (0, 0)
+        km = oracle.extract(bases, offs, 31)
+        dev.set_param("path", 2)
+        dev.map_reads(bases, offs, 31)
+        dev.map_kmers(km)
+        assert dev.get_stats() == (2 * n, 2 * int(expect.sum()))
