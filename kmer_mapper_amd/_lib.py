@@ -9,7 +9,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_HERE)
-SO_PATH = os.path.join(_HERE, "libkmm.so")
+SO_PATH = os.environ.get("KMM_LIB_PATH") or os.path.join(_HERE, "libkmm.so")   # override: A/B builds
 SRC = os.path.join(_HERE, "csrc", "kmm.hip")
 INCLUDE = os.path.join(ROOT, "include")
 
@@ -102,6 +102,8 @@ def lib():
         _share_hip_runtime_with_torch()
         L = ctypes.CDLL(SO_PATH)
         for name, (res, args) in SIGNATURES.items():
+            if os.environ.get("KMM_LIB_PATH") and not hasattr(L, name):
+                continue           # A/B runs against an older build may lack newer entry points
             fn = getattr(L, name)  # AttributeError if the symbol is not exported
             fn.restype = res
             fn.argtypes = args

@@ -12,6 +12,7 @@ __global__ void __launch_bounds__(256) k_map_reads(ReadsView rv, IndexView iv, i
 {
     __shared__ TileSmem<S> sm;
     __shared__ NodeAgg agg;
+    LaneStats st;
     sm.lut[threadIdx.x] = rv.lut[threadIdx.x];
     agg_init(agg); // ordered before the first agg_add by the barriers inside tile_kmers
     const TileConst tc = tile_const(rv, k);
@@ -19,17 +20,18 @@ __global__ void __launch_bounds__(256) k_map_reads(ReadsView rv, IndexView iv, i
         uint64_t q[S];
         const uint32_t valid = tile_kmers<S, MODE>(rv, tc, tile, k, sm, q);
         if (__builtin_amdgcn_ballot_w64(valid != 0)) {
-            probe_batch<S>(iv, agg, q, valid, max_freq);
+            probe_batch<S>(iv, agg, st, q, valid, max_freq);
             if (also_rc) {
 #pragma unroll
                 for (int j = 0; j < S; ++j)
                     q[j] = revcomp(q[j], k);
-                probe_batch<S>(iv, agg, q, valid, max_freq);
+                probe_batch<S>(iv, agg, st, q, valid, max_freq);
             }
         }
     }
     __syncthreads();
     agg_flush(iv, agg);
+    stats_flush(iv, st);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -40,6 +42,7 @@ __global__ void __launch_bounds__(256) k_map_kmers(const uint64_t *__restrict__ 
                                                    IndexView iv, int max_freq, int also_rc, int k)
 {
     __shared__ NodeAgg agg;
+    LaneStats st;
     agg_init(agg);
     __syncthreads();
     const int64_t span = (int64_t)256 * U;
@@ -55,16 +58,17 @@ __global__ void __launch_bounds__(256) k_map_kmers(const uint64_t *__restrict__ 
                 valid |= 1u << u;
             }
         }
-        probe_batch<U>(iv, agg, q, valid, max_freq);
+        probe_batch<U>(iv, agg, st, q, valid, max_freq);
         if (also_rc) {
 #pragma unroll
             for (int u = 0; u < U; ++u)
                 q[u] = revcomp(q[u], k);
-            probe_batch<U>(iv, agg, q, valid, max_freq);
+            probe_batch<U>(iv, agg, st, q, valid, max_freq);
         }
     }
     __syncthreads();
     agg_flush(iv, agg);
+    stats_flush(iv, st);
 }
 
 // General path helper: for every tile, the first read index r in [0, n_reads+1] whose start lies

@@ -242,6 +242,7 @@ __global__ void __launch_bounds__(256) k_part_probe(IndexView iv, PartView pv, i
 {
     static_assert(256 * U == KMM_CHUNK, "chunk = one k-mer per lane per unroll slot");
     __shared__ NodeAgg agg;
+    LaneStats st;
     agg_init(agg);
     __syncthreads();
     const int tid = threadIdx.x;
@@ -262,8 +263,9 @@ __global__ void __launch_bounds__(256) k_part_probe(IndexView iv, PartView pv, i
                 valid |= 1u << u;
             }
         }
-        probe_batch<U>(iv, agg, q, valid, max_freq);
+        probe_batch<U>(iv, agg, st, q, valid, max_freq);
     }
     __syncthreads();
     agg_flush(iv, agg);
+    stats_flush(iv, st);
 }

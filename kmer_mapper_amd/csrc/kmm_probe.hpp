@@ -95,7 +95,6 @@ constexpr uint32_t AGG_EMPTY = 0xFFFFFFFFu; // node ids are < 2^31
 struct NodeAgg {
     uint32_t key[AGG_SLOTS];
     uint32_t val[AGG_SLOTS];
-    uint32_t lookups, hits; // statistics of this workgroup (kmm_get_stats)
 };
 
 __device__ __forceinline__ void agg_init(NodeAgg &agg)
@@ -104,16 +103,12 @@ __device__ __forceinline__ void agg_init(NodeAgg &agg)
         agg.key[i] = AGG_EMPTY;
         agg.val[i] = 0;
     }
-    if (threadIdx.x == 0) {
-        agg.lookups = 0;
-        agg.hits = 0;
-    }
 }
 
-__device__ __forceinline__ void agg_add(const IndexView &iv, NodeAgg &agg, uint32_t node)
+__device__ __forceinline__ void agg_add(const IndexView &iv, NodeAgg &agg, uint32_t node, uint32_t &hits)
 {
+    ++hits;
     const uint32_t slot = (node * 2654435761u) >> (32 - AGG_LOG_SLOTS);
-    atomicAdd(&agg.hits, 1u);
     const uint32_t prev = atomicCAS(&agg.key[slot], AGG_EMPTY, node);
     if (prev == AGG_EMPTY || prev == node)
         atomicAdd(&agg.val[slot], 1u);
@@ -129,19 +124,35 @@ __device__ __forceinline__ void agg_flush(const IndexView &iv, NodeAgg &agg)
         if (v)
             atomicAdd(&iv.counts[agg.key[i]], v);
     }
-    if (threadIdx.x == 0) {
-        atomicAdd(&iv.stats[0], (unsigned long long)agg.lookups);
-        atomicAdd(&iv.stats[1], (unsigned long long)agg.hits);
+}
+
+// Per-lane work counters (kmm_get_stats), kept in registers for the lifetime of the workgroup and
+// reduced once per wavefront when it retires.
+struct LaneStats {
+    uint32_t lookups = 0, hits = 0;
+};
+
+__device__ __forceinline__ void stats_flush(const IndexView &iv, const LaneStats &st)
+{
+    uint32_t a = st.lookups, b = st.hits;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        a += __shfl_xor(a, d);
+        b += __shfl_xor(b, d);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&iv.stats[0], (unsigned long long)a);
+        atomicAdd(&iv.stats[1], (unsigned long long)b);
     }
 }
 
 // mapper.pyx:60-68 for one entry.
 __device__ __forceinline__ void count_if_match(const IndexView &iv, NodeAgg &agg, uint4 e, uint64_t q,
-                                               int max_freq)
+                                               int max_freq, uint32_t &hits)
 {
     uint64_t ek = (uint64_t)e.x | ((uint64_t)e.y << 32);
     if (ek == q && (int)e.w <= max_freq)
-        agg_add(iv, agg, e.z);
+        agg_add(iv, agg, e.z, hits);
 }
 
 // The probe of mapper.pyx:53-69 for U k-mers per lane.  All U bucket gathers are in flight before
@@ -149,17 +160,11 @@ __device__ __forceinline__ void count_if_match(const IndexView &iv, NodeAgg &agg
 // two or more entries (hash collisions, k-mers present under several nodes) then load their first
 // two entries together and walk the rest.
 template <int U, bool FILTER>
-__device__ __forceinline__ void probe_batch_impl(const IndexView &iv, NodeAgg &agg,
+__device__ __forceinline__ void probe_batch_impl(const IndexView &iv, NodeAgg &agg, LaneStats &ls,
                                                  const uint64_t (&q)[U], uint32_t valid, int max_freq)
 {
-    {
-        uint32_t n = (uint32_t)__popc(valid);
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1)
-            n += __shfl_xor(n, d);
-        if ((threadIdx.x & 63) == 0)
-            atomicAdd(&agg.lookups, n);
-    }
+    uint32_t &hits = ls.hits;
+    ls.lookups += (uint32_t)__popc(valid);
     uint64_t h[U];
 #pragma unroll
     for (int u = 0; u < U; ++u)
@@ -195,7 +200,7 @@ __device__ __forceinline__ void probe_batch_impl(const IndexView &iv, NodeAgg &a
         if (kind == 1u) {
             uint64_t ek = (uint64_t)b[u].x | ((uint64_t)b[u].y << 32);
             if (ek == q[u] && (int)(b[u].w >> 16) <= max_freq)
-                agg_add(iv, agg, b[u].z);
+                agg_add(iv, agg, b[u].z, hits);
         }
     }
 #pragma unroll
@@ -204,20 +209,20 @@ __device__ __forceinline__ void probe_batch_impl(const IndexView &iv, NodeAgg &a
             const uint32_t st = b[u].x, cn = b[u].y; // cn >= 2 by construction
             const uint4 e0 = iv.entries[st];
             const uint4 e1 = iv.entries[(uint64_t)st + 1];
-            count_if_match(iv, agg, e0, q[u], max_freq);
-            count_if_match(iv, agg, e1, q[u], max_freq);
+            count_if_match(iv, agg, e0, q[u], max_freq, hits);
+            count_if_match(iv, agg, e1, q[u], max_freq, hits);
             for (uint32_t j = 2; j < cn; ++j)
-                count_if_match(iv, agg, iv.entries[(uint64_t)st + j], q[u], max_freq);
+                count_if_match(iv, agg, iv.entries[(uint64_t)st + j], q[u], max_freq, hits);
         }
     }
 }
 
 template <int U>
-__device__ __forceinline__ void probe_batch(const IndexView &iv, NodeAgg &agg, const uint64_t (&q)[U],
-                                            uint32_t valid, int max_freq)
+__device__ __forceinline__ void probe_batch(const IndexView &iv, NodeAgg &agg, LaneStats &st,
+                                            const uint64_t (&q)[U], uint32_t valid, int max_freq)
 {
     if (iv.occ) // wave-uniform
-        probe_batch_impl<U, true>(iv, agg, q, valid, max_freq);
+        probe_batch_impl<U, true>(iv, agg, st, q, valid, max_freq);
     else
-        probe_batch_impl<U, false>(iv, agg, q, valid, max_freq);
+        probe_batch_impl<U, false>(iv, agg, st, q, valid, max_freq);
 }
