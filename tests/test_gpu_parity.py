@@ -620,3 +620,36 @@ def test_stats_count_lookups_and_hits(kmm, syn, oracle):
         dev.map_reads(bases, offs, 31)
         dev.map_kmers(km)
         assert dev.get_stats() == (2 * n, 2 * int(expect.sum()))
+
+
+def test_beyond_4gib_batch_int64_positions(kmm, syn, oracle):
+    """A single call over 4.8e9 read bytes (> 2^32): the 1.6e9-byte batch repeated three times must give
+    exactly three times its counts on the uniform, general and partitioned (sub-batched) paths."""
+    import torch
+    index, genome = syn.make_index(100000, seed=191)
+    mx = index.max_node_id()
+    g_ascii = torch.from_numpy(syn.ACGT[genome]).cuda()
+    R, L = 10_700_000, 150                        # 1.605e9 bytes per copy, 4.815e9 in total
+    one = syn.make_reads_torch(g_ascii, R, L, seed=192)
+    big = one.repeat(3)
+    assert big.numel() > 2 ** 32
+    torch.cuda.synchronize()
+    with kmm.DeviceIndex.from_index(index, mx) as dev:
+        dev.map_reads_uniform(one, R, L, 31)
+        base = dev.get_node_counts().astype(np.uint64)
+        sample = one[:20000 * L].cpu().numpy()
+        dev.reset(); dev.map_reads_uniform(one[:20000 * L], 20000, L, 31)
+        expect, _ = oracle.map_reads(index, mx, sample, np.arange(20001, dtype=np.int64) * L, 31, n_threads=4)
+        assert np.array_equal(dev.get_node_counts(), expect)
+        for path, general in ((1, False), (1, True), (2, False)):
+            dev.reset()
+            dev.set_param("path", path)
+            if general:
+                offs = torch.arange(3 * R + 1, dtype=torch.int64, device="cuda") * L
+                torch.cuda.synchronize()
+                dev.map_reads(big, offs, 31)
+            else:
+                dev.map_reads_uniform(big, 3 * R, L, 31)
+            got = dev.get_node_counts().astype(np.uint64)
+            assert np.array_equal(got, 3 * base), (path, general)
+        assert dev.get_stats()[0] >= 3 * 3 * R * 120
