@@ -29,9 +29,9 @@ __global__ void __launch_bounds__(256) k_map_reads(ReadsView rv, IndexView iv, i
             }
         }
     }
+    stats_reduce(agg, st);
     __syncthreads();
     agg_flush(iv, agg);
-    stats_flush(iv, st);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -66,9 +66,9 @@ __global__ void __launch_bounds__(256) k_map_kmers(const uint64_t *__restrict__ 
             probe_batch<U>(iv, agg, st, q, valid, max_freq);
         }
     }
+    stats_reduce(agg, st);
     __syncthreads();
     agg_flush(iv, agg);
-    stats_flush(iv, st);
 }
 
 // General path helper: for every tile, the first read index r in [0, n_reads+1] whose start lies

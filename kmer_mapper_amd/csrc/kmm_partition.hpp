@@ -265,7 +265,7 @@ __global__ void __launch_bounds__(256) k_part_probe(IndexView iv, PartView pv, i
         }
         probe_batch<U>(iv, agg, st, q, valid, max_freq);
     }
+    stats_reduce(agg, st);
     __syncthreads();
     agg_flush(iv, agg);
-    stats_flush(iv, st);
 }

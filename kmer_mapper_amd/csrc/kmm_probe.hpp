@@ -88,6 +88,8 @@ __device__ __forceinline__ uint64_t revcomp(uint64_t x, int k)
 // falls through to one global atomicAdd.  The table is flushed with one global atomicAdd per used
 // slot when the workgroup retires.  uint32 wrap-around is preserved (sums of sums mod 2^32).
 // ------------------------------------------------------------------------------------------------
+constexpr int KMM_STAT_SHARDS = 256;
+constexpr int KMM_STAT_STRIDE = 16; // unsigned long longs = 128 bytes between shards
 constexpr int AGG_LOG_SLOTS = 11;
 constexpr int AGG_SLOTS = 1 << AGG_LOG_SLOTS;
 constexpr uint32_t AGG_EMPTY = 0xFFFFFFFFu; // node ids are < 2^31
@@ -95,6 +97,7 @@ constexpr uint32_t AGG_EMPTY = 0xFFFFFFFFu; // node ids are < 2^31
 struct NodeAgg {
     uint32_t key[AGG_SLOTS];
     uint32_t val[AGG_SLOTS];
+    uint32_t st[2]; // workgroup totals of LaneStats, see stats_reduce
 };
 
 __device__ __forceinline__ void agg_init(NodeAgg &agg)
@@ -103,6 +106,8 @@ __device__ __forceinline__ void agg_init(NodeAgg &agg)
         agg.key[i] = AGG_EMPTY;
         agg.val[i] = 0;
     }
+    if (threadIdx.x < 2)
+        agg.st[threadIdx.x] = 0;
 }
 
 __device__ __forceinline__ void agg_add(const IndexView &iv, NodeAgg &agg, uint32_t node, uint32_t &hits)
@@ -124,15 +129,22 @@ __device__ __forceinline__ void agg_flush(const IndexView &iv, NodeAgg &agg)
         if (v)
             atomicAdd(&iv.counts[agg.key[i]], v);
     }
+    if (threadIdx.x == 0) {
+        unsigned long long *shard = iv.stats + (size_t)(blockIdx.x % KMM_STAT_SHARDS) * KMM_STAT_STRIDE;
+        atomicAdd(&shard[0], (unsigned long long)agg.st[0]);
+        atomicAdd(&shard[1], (unsigned long long)agg.st[1]);
+    }
 }
 
-// Per-lane work counters (kmm_get_stats), kept in registers for the lifetime of the workgroup and
-// reduced once per wavefront when it retires.
+// Per-lane work counters (kmm_get_stats), kept in registers for the lifetime of the workgroup.
+// stats_reduce (before the workgroup's final barrier) folds them into LDS; agg_flush's thread 0 then
+// issues ONE pair of global atomics per workgroup, on a shard chosen by the workgroup id: thousands of
+// workgroups retiring together on a single counter would serialise on that address.
 struct LaneStats {
     uint32_t lookups = 0, hits = 0;
 };
 
-__device__ __forceinline__ void stats_flush(const IndexView &iv, const LaneStats &st)
+__device__ __forceinline__ void stats_reduce(NodeAgg &agg, const LaneStats &st)
 {
     uint32_t a = st.lookups, b = st.hits;
 #pragma unroll
@@ -141,8 +153,8 @@ __device__ __forceinline__ void stats_flush(const IndexView &iv, const LaneStats
         b += __shfl_xor(b, d);
     }
     if ((threadIdx.x & 63) == 0) {
-        atomicAdd(&iv.stats[0], (unsigned long long)a);
-        atomicAdd(&iv.stats[1], (unsigned long long)b);
+        atomicAdd(&agg.st[0], a);
+        atomicAdd(&agg.st[1], b);
     }
 }
 
