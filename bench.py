@@ -53,6 +53,7 @@ def main():
     ap.add_argument("--reads", type=int, default=10_000_000, help="reads per batch per GPU")
     ap.add_argument("--index-kmers", type=int, default=10_000_000)
     ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--modulo", type=int, default=None, help="hash-table size (default: smallest prime >= 2N)")
     ap.add_argument("-k", "--kmer-size", type=int, default=31)
     ap.add_argument("--skewed", action="store_true", help="node = i mod 1000 (atomic contention)")
     ap.add_argument("--path", type=int, default=0, help="0 auto, 1 direct fused kernel, 2 radix-partitioned")
@@ -97,7 +98,7 @@ def main():
 
     k, L, R = args.kmer_size, args.read_len, args.reads
     t_setup = time.time()
-    index, genome = syn.make_index(args.index_kmers, k=k, seed=1, skewed=args.skewed)
+    index, genome = syn.make_index(args.index_kmers, k=k, seed=1, skewed=args.skewed, modulo=args.modulo)
     mx = index.max_node_id()
     log("index: %d entries, modulo %d, max_node_id %d (%.1fs)"
         % (len(index._kmers), index._modulo, mx, time.time() - t_setup))
