@@ -65,10 +65,10 @@ __device__ __forceinline__ uint32_t tile_kmers(const ReadsView &rv, const TileCo
     const int tid = threadIdx.x;
     const int64_t total = rv.total;
     const int64_t t0 = tile * T;
-    if (MODE == MODE_GENERAL)
+    __syncthreads(); // LUT visible; every wave has finished reading the previous tile's LDS words
+    if (MODE == MODE_GENERAL) // cleared only now: a fast wave must not wipe bits a slow one still reads
         for (int i = tid; i < NB + 1; i += 256)
             sm.bits[i] = 0;
-    __syncthreads(); // LUT visible; bitset cleared; previous tile's LDS readers are done
 
     if (RECORDS) {
         // ---- records mode, stage 1: raw file bytes.  A byte is a base iff it lies on the sequence
@@ -178,6 +178,7 @@ __device__ __forceinline__ uint32_t tile_kmers(const ReadsView &rv, const TileCo
     }
     // ---- stage 2: read starts inside (t0, t0 + T + k - 2] ----------------------------------
     if (MODE == MODE_GENERAL) {
+        __syncthreads(); // bitset cleared before any bit is set
         for (int64_t r = rv.tile_first[tile] + tid; r <= rv.n_reads; r += 256) {
             int64_t o = rv.offsets[r] - t0;
             if (o > (int64_t)T + k - 2)
