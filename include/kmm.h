@@ -12,8 +12,10 @@
  *     ABI; kmm_last_error() returns a thread-local human-readable message for the last failure.
  *   - Input pointers are BORROWED for the duration of the call.  Every data pointer may be a
  *     host pointer or a device (HBM) pointer on the handle's device; the library detects which
- *     (hipPointerGetAttributes).  Host inputs are staged to HBM by the call; device inputs are
- *     used in place.
+ *     (hipPointerGetAttributes).  Host inputs are staged to HBM by the call (the host buffer is free
+ *     again when the call returns); device inputs are used in place by kernels that run after the
+ *     call returns: they must already be complete (produced on another stream -> synchronise that
+ *     stream first) and must stay valid and unmodified until the next synchronising call.
  *   - One handle = one device + one HIP stream + one uint32 node-count vector in HBM.
  *     map calls are asynchronous on the handle's stream and ACCUMULATE into the count vector
  *     (the reference sums per-chunk vectors, command_line_interface.py:124-130);
