@@ -14,6 +14,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -327,7 +328,9 @@ int resolve_lut(kmm_index *ix, Stage &s, const uint8_t *lut, const uint8_t **dev
 }
 
 constexpr size_t KMM_STAT_BYTES = (size_t)KMM_STAT_SHARDS * KMM_STAT_STRIDE * 8;
-constexpr size_t KMM_OCC_MAX_BYTES = (size_t)3 << 20; // 25 M buckets
+// Measured (profiles/r01/partitioned_path_ablation.md): the bitmap wins by 23 % at 2.5 MB, 16 % at 3.75 MB,
+// 8 % at 5 MB, 4 % at 10 MB and loses 9 % at 25 MB (it no longer fits the 4 MiB L2 of an XCD).
+constexpr size_t KMM_OCC_MAX_BYTES = (size_t)8 << 20; // 67 M buckets
 constexpr int TILE_S = 4;
 constexpr int TILE_T = 256 * TILE_S;
 
@@ -576,7 +579,10 @@ static int index_create_impl(kmm_index *ix, const int32_t *h2i, const int32_t *n
                     (long long)ix->max_node_id);
     // occupancy bitmap for indexes whose bitmap stays resident in one XCD's 4 MiB L2
     const size_t occ_bytes = (size_t)((M + 31) / 32) * 4;
-    if (occ_bytes <= KMM_OCC_MAX_BYTES) {
+    size_t occ_max = KMM_OCC_MAX_BYTES;
+    if (const char *env = getenv("KMM_OCC_MAX_BYTES")) // experiments: threshold of the bitmap prefilter
+        occ_max = (size_t)strtoull(env, nullptr, 10);
+    if (occ_bytes <= occ_max) {
         HIPCHK(hipMalloc(&ix->occ, occ_bytes));
         hipLaunchKernelGGL(k_build_occ, dim3(grid_for(ix, (int64_t)((M / 32 + 256) / 256), 16)), dim3(256),
                            0, ix->stream, ix->buckets, M, ix->occ);
