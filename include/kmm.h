@@ -146,6 +146,20 @@ int kmm_extract_kmers(int device, const uint8_t *bases, const int64_t *read_offs
 int kmm_in_index(kmm_index_t *idx, const uint64_t *kmers, int64_t n, uint8_t *out);
 
 /*
+ * kmm_build_index — builds the Kmer Index arrays on the GPU from flat (k-mer, node) pairs: replaces
+ * graph_kmer_index's KmerIndex.from_flat_kmers(flat_kmers, modulo) (reference call site
+ * tests/test_mapping.py:36-38; gpu_counter.py:16 builds its table from the same pairs).  Entries are
+ * ordered by kmer % modulo, ties by original position (a stable sort, reproducible bit for bit);
+ * hashes_to_index[h] = first entry of bucket h (0 for empty buckets),
+ * frequencies[l] = number of entries holding the same k-mer as entry l, clipped to 65535.
+ * Outputs: hashes_to_index int32[modulo], n_kmers int32[modulo], kmers_out uint64[n], nodes_out int32[n],
+ * frequencies_out uint16[n]; every pointer may be host or device memory.  n, modulo < 2^31.
+ */
+int kmm_build_index(int device, const uint64_t *kmers, const int32_t *nodes, int64_t n, uint64_t modulo,
+                    int32_t *hashes_to_index, int32_t *n_kmers, uint64_t *kmers_out, int32_t *nodes_out,
+                    uint16_t *frequencies_out);
+
+/*
  * Measurement hooks (the reference only logs perf_counter deltas,
  * command_line_interface.py:67-78).  With timing on, every launch of a hot-path kernel is
  * bracketed by HIP events on the handle's stream; kmm_get_timing drains the stream and returns,

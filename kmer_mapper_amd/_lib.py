@@ -48,6 +48,7 @@ SIGNATURES = {
                                          _c.c_int, _P]),
     "kmm_map_records": (_c.c_int, [_P, _P, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _P, _P, _P]),
     "kmm_extract_kmers": (_c.c_int, [_c.c_int, _P, _P, _c.c_int64, _c.c_int, _P, _P, _c.c_int64]),
+    "kmm_build_index": (_c.c_int, [_c.c_int, _P, _P, _c.c_int64, _c.c_uint64, _P, _P, _P, _P, _P]),
     "kmm_in_index": (_c.c_int, [_P, _P, _c.c_int64, _P]),
     "kmm_set_timing": (_c.c_int, [_P, _c.c_int]),
     "kmm_get_stats": (_c.c_int, [_P, _c.c_int, _P, _P]),

@@ -59,6 +59,7 @@ int fail(int code, const char *fmt, ...)
 #include "kmm_records.hpp"
 #include "kmm_kernels.hpp"
 #include "kmm_partition.hpp"
+#include "kmm_build.hpp"
 
 // ------------------------------------------------------------------------------------------------
 // host side
@@ -1063,6 +1064,129 @@ int kmm_extract_kmers(int device, const uint8_t *bases, const int64_t *read_offs
     if (bad[0] != NO_BAD)
         return fail(KMM_ERR_INVALID_BASE, "read byte at offset %llu is not a nucleotide under the "
                     "lookup table (the reference's DNA encoder raises here)", bad[0]);
+    return KMM_OK;
+}
+
+// Exclusive scan of n uint32 values on the device (in -> out), any n < 2^42: 1024-wide block scans,
+// recursing on the block totals.  `levels` provides the scratch (one DevBuf pair per level).
+static int scan_exclusive(const uint32_t *in, uint32_t *out, uint64_t n, std::vector<DevBuf> &scratch,
+                          size_t level)
+{
+    const uint64_t n_blocks = (n + 1023) / 1024;
+    if (scratch.size() < 2 * (level + 1))
+        scratch.resize(2 * (level + 1));
+    DevBuf &sums = scratch[2 * level], &pre = scratch[2 * level + 1];
+    KMMCHK(ensure(sums, (size_t)n_blocks * 4));
+    hipLaunchKernelGGL(k_scan_blocks, dim3((unsigned)n_blocks), dim3(1024), 0, 0, in, out, (uint32_t *)sums.p, n);
+    HIPCHK(hipGetLastError());
+    if (n_blocks == 1)
+        return KMM_OK;
+    KMMCHK(ensure(pre, (size_t)n_blocks * 4));
+    KMMCHK(scan_exclusive((const uint32_t *)sums.p, (uint32_t *)pre.p, n_blocks, scratch, level + 1));
+    uint64_t g = (n + 255) / 256;
+    if (g > 65536)
+        g = 65536;
+    hipLaunchKernelGGL(k_scan_add, dim3((unsigned)g), dim3(256), 0, 0, out, (const uint32_t *)pre.p, n);
+    HIPCHK(hipGetLastError());
+    return KMM_OK;
+}
+
+int kmm_build_index(int device, const uint64_t *kmers, const int32_t *nodes, int64_t n, uint64_t modulo,
+                    int32_t *hashes_to_index, int32_t *n_kmers, uint64_t *kmers_out, int32_t *nodes_out,
+                    uint16_t *frequencies_out)
+{
+    if (n < 0 || modulo < 1)
+        return fail(KMM_ERR_INVALID_ARG, "n negative or modulo < 1");
+    if (n > 0x7FFFFFFFll || modulo > 0x7FFFFFFFull)
+        return fail(KMM_ERR_INVALID_ARG, "n / modulo exceed the int32 arrays of the index format");
+    if (!hashes_to_index || !n_kmers || (n > 0 && (!kmers || !nodes || !kmers_out || !nodes_out || !frequencies_out)))
+        return fail(KMM_ERR_INVALID_ARG, "NULL argument");
+    int ndev = 0;
+    hipError_t e0 = hipGetDeviceCount(&ndev);
+    if (e0 != hipSuccess || ndev < 1) {
+        (void)hipGetLastError();
+        return fail(KMM_ERR_HIP, "no HIP device available: libkmm has no CPU fallback");
+    }
+    HIPCHK(hipSetDevice(device));
+    const uint64_t M = modulo;
+    const uint64_t magic = magic_for(M);
+    DevBuf d_km, d_nd, d_nk, d_h2i, d_cur, d_src, d_ko, d_no, d_fo;
+    std::vector<DevBuf> scratch;
+    int rc = KMM_OK;
+    hipError_t e = hipSuccess;
+    auto up = [&](DevBuf &b, const void *src, size_t bytes, const void **dev) -> bool {
+        if (bytes == 0 || is_device_ptr(src)) {
+            *dev = src;
+            return true;
+        }
+        if ((rc = ensure(b, bytes)))
+            return false;
+        if ((e = hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice)))
+            return false;
+        *dev = b.p;
+        return true;
+    };
+    auto down = [&](void *dst, const void *dev, size_t bytes) -> bool {
+        if (bytes == 0 || dst == dev)
+            return true;
+        e = hipMemcpy(dst, dev, bytes, is_device_ptr(dst) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost);
+        return e == hipSuccess;
+    };
+    do {
+        const void *p_km = nullptr, *p_nd = nullptr;
+        if (!up(d_km, kmers, (size_t)n * 8, &p_km)) break;
+        if (!up(d_nd, nodes, (size_t)n * 4, &p_nd)) break;
+        // outputs: work in place when the caller's arrays are already on the device
+        uint32_t *w_nk = is_device_ptr(n_kmers) ? (uint32_t *)n_kmers : nullptr;
+        uint32_t *w_h2i = is_device_ptr(hashes_to_index) ? (uint32_t *)hashes_to_index : nullptr;
+        if (!w_nk) { if ((rc = ensure(d_nk, (size_t)M * 4))) break; w_nk = (uint32_t *)d_nk.p; }
+        if (!w_h2i) { if ((rc = ensure(d_h2i, (size_t)M * 4))) break; w_h2i = (uint32_t *)d_h2i.p; }
+        if ((rc = ensure(d_cur, (size_t)M * 4))) break;
+        if ((e = hipMemsetAsync(w_nk, 0, (size_t)M * 4, 0))) break;
+        if ((e = hipMemsetAsync(d_cur.p, 0, (size_t)M * 4, 0))) break;
+        int64_t g = (n + 255) / 256;
+        if (g > 65536) g = 65536;
+        if (g < 1) g = 1;
+        if (n > 0)
+            hipLaunchKernelGGL(k_bi_hist, dim3((unsigned)g), dim3(256), 0, 0, (const uint64_t *)p_km, n, M, magic, w_nk);
+        if ((rc = scan_exclusive(w_nk, w_h2i, M, scratch, 0))) break;
+        if (n > 0) {
+            uint64_t *w_ko = is_device_ptr(kmers_out) ? kmers_out : nullptr;
+            int32_t *w_no = is_device_ptr(nodes_out) ? nodes_out : nullptr;
+            uint16_t *w_fo = is_device_ptr(frequencies_out) ? frequencies_out : nullptr;
+            if (!w_ko) { if ((rc = ensure(d_ko, (size_t)n * 8))) break; w_ko = (uint64_t *)d_ko.p; }
+            if (!w_no) { if ((rc = ensure(d_no, (size_t)n * 4))) break; w_no = (int32_t *)d_no.p; }
+            if (!w_fo) { if ((rc = ensure(d_fo, (size_t)n * 2))) break; w_fo = (uint16_t *)d_fo.p; }
+            if ((rc = ensure(d_src, (size_t)n * 4))) break;
+            hipLaunchKernelGGL(k_bi_scatter, dim3((unsigned)g), dim3(256), 0, 0, (const uint64_t *)p_km, n, M, magic,
+                               w_h2i, (uint32_t *)d_cur.p, (uint32_t *)d_src.p);
+            hipLaunchKernelGGL(k_bi_place, dim3((unsigned)g), dim3(256), 0, 0, (const uint64_t *)p_km,
+                               (const int32_t *)p_nd, n, M, magic, w_h2i, w_nk, (const uint32_t *)d_src.p, w_ko,
+                               w_no, w_fo);
+            if ((e = hipGetLastError())) break;
+            if ((e = hipDeviceSynchronize())) break;
+            if (!down(kmers_out, w_ko, (size_t)n * 8)) break;
+            if (!down(nodes_out, w_no, (size_t)n * 4)) break;
+            if (!down(frequencies_out, w_fo, (size_t)n * 2)) break;
+        }
+        {   // the format leaves hashes_to_index = 0 for empty buckets (upstream fills only the used ones)
+            uint64_t gm = (M + 255) / 256;
+            if (gm > 65536) gm = 65536;
+            hipLaunchKernelGGL(k_bi_zero_empty, dim3((unsigned)gm), dim3(256), 0, 0, w_h2i, w_nk, M);
+        }
+        if ((e = hipGetLastError())) break;
+        if ((e = hipDeviceSynchronize())) break;
+        if (!down(n_kmers, w_nk, (size_t)M * 4)) break;
+        if (!down(hashes_to_index, w_h2i, (size_t)M * 4)) break;
+    } while (0);
+    release(d_km); release(d_nd); release(d_nk); release(d_h2i); release(d_cur); release(d_src);
+    release(d_ko); release(d_no); release(d_fo);
+    for (DevBuf &b : scratch)
+        release(b);
+    if (rc != KMM_OK)
+        return rc;
+    if (e != hipSuccess)
+        return fail(KMM_ERR_HIP, "kmm_build_index: %s", hipGetErrorString(e));
     return KMM_OK;
 }
 

@@ -219,3 +219,25 @@ def extract_kmers(bases, read_offsets, k, lut=None, device=0, out=None):
     dst = _Arg(out, np.uint64, "out")
     _lib.check(_lib.lib().kmm_extract_kmers(int(device), b.ptr, o.ptr, o.n - 1, int(k), t.ptr, dst.ptr, dst.n))
     return out
+
+
+def build_index(kmers, nodes, modulo, device=0):
+    """GPU counterpart of graph_kmer_index's KmerIndex.from_flat_kmers (tests/test_mapping.py:36-38):
+    returns (hashes_to_index int32[M], n_kmers int32[M], kmers uint64[n], nodes int32[n],
+    frequencies uint16[n]) — bit-identical to the stable-sort numpy construction."""
+    km = np.ascontiguousarray(np.asarray(kmers, dtype=np.uint64))
+    nd_in = np.asarray(nodes)
+    if nd_in.size and (nd_in.min() < 0 or nd_in.max() > 2 ** 31 - 1):
+        raise ValueError("node ids must fit int32")
+    nd = np.ascontiguousarray(nd_in, dtype=np.int32)
+    if km.shape != nd.shape or km.ndim != 1:
+        raise ValueError("kmers and nodes must be 1-D arrays of the same length")
+    M, n = int(modulo), km.shape[0]
+    h2i = np.empty(M, dtype=np.int32)
+    nk = np.empty(M, dtype=np.int32)
+    ko = np.empty(n, dtype=np.uint64)
+    no = np.empty(n, dtype=np.int32)
+    fo = np.empty(n, dtype=np.uint16)
+    p = lambda a: a.ctypes.data_as(_P)
+    _lib.check(_lib.lib().kmm_build_index(int(device), p(km), p(nd), n, M, p(h2i), p(nk), p(ko), p(no), p(fo)))
+    return h2i, nk, ko, no, fo

@@ -60,6 +60,13 @@ class KmerIndex:
 
     # -- construction (tests/test_mapping.py:36-38: FlatKmers -> from_flat_kmers(modulo)) --------
     @classmethod
+    def from_flat_kmers_gpu(cls, kmers, nodes, modulo, device=0):
+        """Same index, built by the hand-written counting sort on the GPU (kmm_build_index)."""
+        from .engine import build_index
+        h2i, nk, ko, no, fo = build_index(kmers, nodes, modulo, device=device)
+        return cls(h2i, nk, no, ko, int(modulo), fo)
+
+    @classmethod
     def from_flat_kmers(cls, kmers, nodes, modulo, ref_offsets=None):
         kmers = np.asarray(kmers, dtype=np.uint64)
         nodes = np.asarray(nodes)

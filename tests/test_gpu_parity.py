@@ -653,3 +653,21 @@ def test_beyond_4gib_batch_int64_positions(kmm, syn, oracle):
             got = dev.get_node_counts().astype(np.uint64)
             assert np.array_equal(got, 3 * base), (path, general)
         assert dev.get_stats()[0] >= 3 * 3 * R * 120
+
+
+@pytest.mark.parametrize("n,modulo", [(0, 5), (1, 1), (1000, 7), (5000, 10007), (300000, 600011), (2000, 2 ** 20)])
+def test_gpu_index_builder_equals_numpy_builder(kmm, n, modulo):
+    """kmm_build_index == KmerIndex.from_flat_kmers (stable sort by hash), array for array."""
+    from kmer_mapper_amd.kmer_index import KmerIndex
+    rng = np.random.default_rng(n + modulo)
+    kmers = rng.integers(0, 2 ** 62, size=n, dtype=np.uint64)
+    if n > 10:
+        kmers[rng.integers(0, n, size=n // 5)] = kmers[rng.integers(0, n, size=n // 5)]   # duplicates
+        kmers[: min(n, 1500)] = kmers[0] if n == 5000 else kmers[: min(n, 1500)]           # one long run
+    nodes = rng.integers(0, 2 ** 31 - 1, size=n)
+    a = KmerIndex.from_flat_kmers(kmers, nodes, modulo)
+    b = KmerIndex.from_flat_kmers_gpu(kmers, nodes, modulo)
+    for attr in ("_hashes_to_index", "_n_kmers", "_kmers", "_nodes", "_frequencies"):
+        x, y = getattr(a, attr), getattr(b, attr)
+        assert x.dtype == y.dtype and np.array_equal(x, y), attr
+    assert b._modulo == modulo
