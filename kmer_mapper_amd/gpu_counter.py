@@ -35,8 +35,8 @@ class GpuCounter:
         n = len(self.kmers)
         if not modulo:
             modulo = _next_prime(max(2 * n, 3))
-        index = KmerIndex.from_flat_kmers(np.asarray(self.kmers, dtype=np.uint64),
-                                          np.asarray(self.nodes), int(modulo))
+        index = KmerIndex.from_flat_kmers_gpu(np.asarray(self.kmers, dtype=np.uint64),
+                                              np.asarray(self.nodes), int(modulo), device=device)
         self._max_node = int(np.max(self.nodes)) if n else 0
         self.counter = DeviceIndex.from_index(index, self._max_node, device=device)
 
