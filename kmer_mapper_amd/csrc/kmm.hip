@@ -1067,14 +1067,16 @@ int kmm_extract_kmers(int device, const uint8_t *bases, const int64_t *read_offs
     return KMM_OK;
 }
 
-// Exclusive scan of n uint32 values on the device (in -> out), any n < 2^42: 1024-wide block scans,
-// recursing on the block totals.  `levels` provides the scratch (one DevBuf pair per level).
+// Exclusive scan of n uint32 values on the device (in -> out): 1024-wide block scans, recursing on the
+// block totals (n < 2^31 needs at most 4 levels).  `scratch` holds one DevBuf pair per level and is sized
+// by the caller ONCE — it must not reallocate while outer levels hold references into it.
+constexpr size_t SCAN_MAX_LEVELS = 8;
 static int scan_exclusive(const uint32_t *in, uint32_t *out, uint64_t n, std::vector<DevBuf> &scratch,
                           size_t level)
 {
     const uint64_t n_blocks = (n + 1023) / 1024;
-    if (scratch.size() < 2 * (level + 1))
-        scratch.resize(2 * (level + 1));
+    if (level >= SCAN_MAX_LEVELS || scratch.size() < 2 * SCAN_MAX_LEVELS)
+        return fail(KMM_ERR_INVALID_ARG, "scan_exclusive: level %zu out of range", level);
     DevBuf &sums = scratch[2 * level], &pre = scratch[2 * level + 1];
     KMMCHK(ensure(sums, (size_t)n_blocks * 4));
     hipLaunchKernelGGL(k_scan_blocks, dim3((unsigned)n_blocks), dim3(1024), 0, 0, in, out, (uint32_t *)sums.p, n);
@@ -1111,7 +1113,7 @@ int kmm_build_index(int device, const uint64_t *kmers, const int32_t *nodes, int
     const uint64_t M = modulo;
     const uint64_t magic = magic_for(M);
     DevBuf d_km, d_nd, d_nk, d_h2i, d_cur, d_src, d_ko, d_no, d_fo;
-    std::vector<DevBuf> scratch;
+    std::vector<DevBuf> scratch(2 * SCAN_MAX_LEVELS);
     int rc = KMM_OK;
     hipError_t e = hipSuccess;
     auto up = [&](DevBuf &b, const void *src, size_t bytes, const void **dev) -> bool {

@@ -655,7 +655,8 @@ def test_beyond_4gib_batch_int64_positions(kmm, syn, oracle):
         assert dev.get_stats()[0] >= 3 * 3 * R * 120
 
 
-@pytest.mark.parametrize("n,modulo", [(0, 5), (1, 1), (1000, 7), (5000, 10007), (300000, 600011), (2000, 2 ** 20)])
+@pytest.mark.parametrize("n,modulo", [(0, 5), (1, 1), (1000, 7), (5000, 10007), (300000, 600011), (2000, 2 ** 20),
+                                      (40000, 5_000_011), (3_000_000, 6_000_011)])   # 3-level scans
 def test_gpu_index_builder_equals_numpy_builder(kmm, n, modulo):
     """kmm_build_index == KmerIndex.from_flat_kmers (stable sort by hash), array for array."""
     from kmer_mapper_amd.kmer_index import KmerIndex
