@@ -53,6 +53,7 @@ def main():
     ap.add_argument("--reads", type=int, default=10_000_000, help="reads per batch per GPU")
     ap.add_argument("--index-kmers", type=int, default=10_000_000)
     ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--numpy-builder", action="store_true", help="build the synthetic index with numpy instead of kmm_build_index")
     ap.add_argument("--modulo", type=int, default=None, help="hash-table size (default: smallest prime >= 2N)")
     ap.add_argument("-k", "--kmer-size", type=int, default=31)
     ap.add_argument("--skewed", action="store_true", help="node = i mod 1000 (atomic contention)")
@@ -99,7 +100,7 @@ def main():
     k, L, R = args.kmer_size, args.read_len, args.reads
     t_setup = time.time()
     index, genome = syn.make_index(args.index_kmers, k=k, seed=1, skewed=args.skewed, modulo=args.modulo,
-                                   gpu_builder=True)   # untimed setup; arrays identical to the numpy builder
+                                   gpu_builder=not args.numpy_builder)   # untimed setup; identical arrays
     mx = index.max_node_id()
     log("index: %d entries, modulo %d, max_node_id %d (%.1fs)"
         % (len(index._kmers), index._modulo, mx, time.time() - t_setup))
