@@ -60,6 +60,8 @@ def main():
     ap.add_argument("--path", type=int, default=0, help="0 auto, 1 direct fused kernel, 2 radix-partitioned")
     ap.add_argument("--part-shift", type=int, default=None)
     ap.add_argument("--grid-per-cu", type=int, default=None)
+    ap.add_argument("--static-schedule", action="store_true", help="disable the dynamic tile queue")
+    ap.add_argument("--dyn-chunk", type=int, default=None)
     ap.add_argument("--no-filter", action="store_true", help="disable the L2 occupancy-bitmap prefilter")
     ap.add_argument("--general-path", action="store_true", help="use kmm_map_reads with an offsets array")
     ap.add_argument("--operator", action="store_true",
@@ -108,6 +110,10 @@ def main():
     dev.set_param("path", args.path)
     if args.no_filter:
         dev.set_param("occupancy_filter", 0)
+    if args.dyn_chunk is not None:
+        dev.set_param("dyn_chunk", args.dyn_chunk)
+    if args.static_schedule:
+        dev.set_param("dynamic_schedule", 0)
     if args.grid_per_cu is not None:
         dev.set_param("grid_per_cu", args.grid_per_cu)
     if args.part_shift is not None:

@@ -155,6 +155,9 @@ struct kmm_index {
     uint8_t *lut_default = nullptr;
     unsigned long long *first_bad = nullptr;
     unsigned long long *stats = nullptr;
+    unsigned long long *queue = nullptr; // tile counter of the dynamic schedule
+    bool dynamic_schedule = true;
+    int dyn_chunk = 16;                  // tiles per grab
     uint64_t modulo = 0, magic = 0;
     int64_t n_entries = 0, max_node_id = 0;
     Stage stage[2];
@@ -379,8 +382,15 @@ int launch_map_reads(kmm_index *ix, const ReadsView &rv, int k, int max_freq, in
     if (!use_partitioned(ix, rv.total)) {
         ScopedTimer tm;
         KMMCHK(tm.begin(ix, KMM_KERNEL_MAP_READS));
-        hipLaunchKernelGGL((k_map_reads<TILE_S, MODE>), dim3(grid_for_tiles(ix, n_tiles)), dim3(256),
-                           0, ix->stream, rv, iv, k, max_freq, also_rc, (int64_t)0, n_tiles);
+        // large launches: persistent workgroups + dynamic tile queue; small ones: static schedule
+        const int64_t slots = (int64_t)ix->n_cu * 8;
+        const bool dynamic = ix->dynamic_schedule && n_tiles >= slots * 4 * ix->dyn_chunk;
+        if (dynamic)
+            HIPCHK(hipMemsetAsync(ix->queue, 0, sizeof(unsigned long long), ix->stream));
+        hipLaunchKernelGGL((k_map_reads<TILE_S, MODE>),
+                           dim3(dynamic ? (unsigned)slots : (unsigned)grid_for_tiles(ix, n_tiles)), dim3(256),
+                           0, ix->stream, rv, iv, k, max_freq, also_rc, (int64_t)0, n_tiles,
+                           dynamic ? ix->queue : nullptr, ix->dyn_chunk);
         HIPCHK(hipGetLastError());
         return tm.end();
     }
@@ -495,6 +505,8 @@ void kmm_index_destroy(kmm_index_t *ix)
         (void)hipFree(ix->first_bad);
     if (ix->stats)
         (void)hipFree(ix->stats);
+    if (ix->queue)
+        (void)hipFree(ix->queue);
     if (ix->copy_stream)
         (void)hipStreamDestroy(ix->copy_stream);
     if (ix->stream)
@@ -524,6 +536,7 @@ static int index_create_impl(kmm_index *ix, const int32_t *h2i, const int32_t *n
     HIPCHK(hipMemsetAsync(ix->counts, 0, sizeof(uint32_t) * (size_t)(ix->max_node_id + 1), ix->stream));
     HIPCHK(hipMalloc(&ix->lut_default, 256));
     HIPCHK(hipMalloc(&ix->first_bad, 2 * sizeof(unsigned long long)));
+    HIPCHK(hipMalloc(&ix->queue, sizeof(unsigned long long)));
     HIPCHK(hipMalloc(&ix->stats, KMM_STAT_BYTES));
     HIPCHK(hipMemset(ix->stats, 0, KMM_STAT_BYTES));
     uint8_t lut[256];
@@ -1266,6 +1279,12 @@ int kmm_set_param(kmm_index_t *ix, const char *name, int64_t value)
         if (value < 1 || value > 1024)
             return fail(KMM_ERR_INVALID_ARG, "grid_per_cu outside [1, 1024]");
         ix->grid_per_cu = (int)value;
+    } else if (!strcmp(name, "dynamic_schedule")) {
+        ix->dynamic_schedule = value != 0;
+    } else if (!strcmp(name, "dyn_chunk")) {
+        if (value < 1 || value > 4096)
+            return fail(KMM_ERR_INVALID_ARG, "dyn_chunk outside [1, 4096]");
+        ix->dyn_chunk = (int)value;
     } else if (!strcmp(name, "occupancy_filter")) {
         ix->use_occ = value != 0;
 
@@ -1285,6 +1304,8 @@ int kmm_get_param(kmm_index_t *ix, const char *name, int64_t *value)
         *value = ix->part_shift;
     else if (!strcmp(name, "grid_per_cu"))
         *value = ix->grid_per_cu;
+    else if (!strcmp(name, "dynamic_schedule"))
+        *value = ix->dynamic_schedule ? 1 : 0;
     else if (!strcmp(name, "occupancy_filter"))
         *value = (ix->use_occ && ix->occ) ? 1 : 0;
     else if (!strcmp(name, "n_partitions"))

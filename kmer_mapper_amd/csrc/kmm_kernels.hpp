@@ -6,27 +6,55 @@
 // K1 (direct path): fused reads -> counts, every probe goes to HBM.  Used for small batches and for
 // indexes whose hash space cannot be cut into L2-sized partitions.
 // ------------------------------------------------------------------------------------------------
+
+template <int S, int MODE>
+__device__ __forceinline__ void map_one_tile(const ReadsView &rv, const IndexView &iv, const TileConst &tc,
+                                             int64_t tile, int k, int max_freq, int also_rc, TileSmem<S> &sm,
+                                             NodeAgg &agg, LaneStats &st)
+{
+    uint64_t q[S];
+    const uint32_t valid = tile_kmers<S, MODE>(rv, tc, tile, k, sm, q);
+    if (__builtin_amdgcn_ballot_w64(valid != 0)) {
+        probe_batch<S>(iv, agg, st, q, valid, max_freq);
+        if (also_rc) {
+#pragma unroll
+            for (int j = 0; j < S; ++j)
+                q[j] = revcomp(q[j], k);
+            probe_batch<S>(iv, agg, st, q, valid, max_freq);
+        }
+    }
+}
+
+// `queue` == null: static grid-stride schedule.  Otherwise the workgroups are persistent (one per CU
+// slot) and pull chunks of `chunk` consecutive tiles from a device-side counter, so that the last
+// round of a large launch does not leave CU slots idle while a few workgroups finish their fixed share.
 template <int S, int MODE>
 __global__ void __launch_bounds__(256) k_map_reads(ReadsView rv, IndexView iv, int k, int max_freq,
-                                                   int also_rc, int64_t tile_begin, int64_t tile_end)
+                                                   int also_rc, int64_t tile_begin, int64_t tile_end,
+                                                   unsigned long long *queue, int chunk)
 {
     __shared__ TileSmem<S> sm;
     __shared__ NodeAgg agg;
+    __shared__ unsigned long long s_next;
     LaneStats st;
     sm.lut[threadIdx.x] = rv.lut[threadIdx.x];
     agg_init(agg); // ordered before the first agg_add by the barriers inside tile_kmers
     const TileConst tc = tile_const(rv, k);
-    for (int64_t tile = tile_begin + blockIdx.x; tile < tile_end; tile += gridDim.x) {
-        uint64_t q[S];
-        const uint32_t valid = tile_kmers<S, MODE>(rv, tc, tile, k, sm, q);
-        if (__builtin_amdgcn_ballot_w64(valid != 0)) {
-            probe_batch<S>(iv, agg, st, q, valid, max_freq);
-            if (also_rc) {
-#pragma unroll
-                for (int j = 0; j < S; ++j)
-                    q[j] = revcomp(q[j], k);
-                probe_batch<S>(iv, agg, st, q, valid, max_freq);
-            }
+    if (!queue) {
+        for (int64_t tile = tile_begin + blockIdx.x; tile < tile_end; tile += gridDim.x)
+            map_one_tile<S, MODE>(rv, iv, tc, tile, k, max_freq, also_rc, sm, agg, st);
+    } else {
+        for (;;) {
+            if (threadIdx.x == 0)
+                s_next = atomicAdd(queue, (unsigned long long)chunk);
+            __syncthreads();
+            const int64_t first = tile_begin + (int64_t)s_next;
+            __syncthreads(); // s_next may be rewritten only after everyone has read it
+            if (first >= tile_end)
+                break;
+            const int64_t last = first + chunk < tile_end ? first + chunk : tile_end;
+            for (int64_t tile = first; tile < last; ++tile)
+                map_one_tile<S, MODE>(rv, iv, tc, tile, k, max_freq, also_rc, sm, agg, st);
         }
     }
     stats_reduce(agg, st);
