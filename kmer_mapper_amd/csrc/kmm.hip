@@ -150,6 +150,7 @@ struct kmm_index {
     uint4 *entries = nullptr;
     uint32_t *occ = nullptr;           // occupancy bitmap, only for indexes small enough (see occ_max_bytes)
     bool use_occ = true;
+    bool wide = false;                 // 32-byte buckets (chosen when the index is too large for the bitmap)
     uint32_t *counts = nullptr;
     uint32_t *own_counts_buf = nullptr;
     uint8_t *lut_default = nullptr;
@@ -185,6 +186,7 @@ IndexView view_of(const kmm_index *ix)
     v.buckets = ix->buckets;
     v.entries = ix->entries;
     v.occ = ix->use_occ ? ix->occ : nullptr;
+    v.wide = ix->wide ? 1 : 0;
     v.counts = ix->counts;
     v.stats = ix->stats;
     v.modulo = ix->modulo;
@@ -349,7 +351,7 @@ bool use_partitioned(const kmm_index *ix, int64_t total_positions)
     (void)total_positions;
     // r01 measurements (profiles/r01/partitioned_path_ablation.md): the direct kernel is faster on
     // every configuration tried, so "auto" (0) means direct; the partitioned path is opt-in.
-    if (ix->path != 2)
+    if (ix->path != 2 || ix->wide)
         return false;
     const uint64_t per = 1ull << ix->part_shift;
     return (ix->modulo + per - 1) / per <= (uint64_t)KMM_MAX_PARTS;
@@ -387,10 +389,17 @@ int launch_map_reads(kmm_index *ix, const ReadsView &rv, int k, int max_freq, in
         const bool dynamic = ix->dynamic_schedule && n_tiles >= slots * 4 * ix->dyn_chunk;
         if (dynamic)
             HIPCHK(hipMemsetAsync(ix->queue, 0, sizeof(unsigned long long), ix->stream));
-        hipLaunchKernelGGL((k_map_reads<TILE_S, MODE>),
-                           dim3(dynamic ? (unsigned)slots : (unsigned)grid_for_tiles(ix, n_tiles)), dim3(256),
-                           0, ix->stream, rv, iv, k, max_freq, also_rc, (int64_t)0, n_tiles,
-                           dynamic ? ix->queue : nullptr, ix->dyn_chunk);
+        const dim3 grid(dynamic ? (unsigned)slots : (unsigned)grid_for_tiles(ix, n_tiles));
+        unsigned long long *queue = dynamic ? ix->queue : nullptr;
+        if (iv.occ)
+            hipLaunchKernelGGL((k_map_reads<TILE_S, MODE, PROBE_BITMAP>), grid, dim3(256), 0, ix->stream, rv, iv, k,
+                               max_freq, also_rc, (int64_t)0, n_tiles, queue, ix->dyn_chunk);
+        else if (iv.wide)
+            hipLaunchKernelGGL((k_map_reads<TILE_S, MODE, PROBE_WIDE>), grid, dim3(256), 0, ix->stream, rv, iv, k,
+                               max_freq, also_rc, (int64_t)0, n_tiles, queue, ix->dyn_chunk);
+        else
+            hipLaunchKernelGGL((k_map_reads<TILE_S, MODE, PROBE_NARROW>), grid, dim3(256), 0, ix->stream, rv, iv, k,
+                               max_freq, also_rc, (int64_t)0, n_tiles, queue, ix->dyn_chunk);
         HIPCHK(hipGetLastError());
         return tm.end();
     }
@@ -529,7 +538,16 @@ static int index_create_impl(kmm_index *ix, const int32_t *h2i, const int32_t *n
     for (Stage &s : ix->stage)
         HIPCHK(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
 
-    HIPCHK(hipMalloc(&ix->buckets, sizeof(uint4) * (size_t)M));
+    // layout: small indexes get 16-byte buckets + the L2 occupancy bitmap, larger ones 32-byte buckets
+    size_t occ_max = KMM_OCC_MAX_BYTES;
+    if (const char *env = getenv("KMM_OCC_MAX_BYTES")) // experiments: threshold of the bitmap prefilter
+        occ_max = (size_t)strtoull(env, nullptr, 10);
+    const size_t occ_bytes = (size_t)((M + 31) / 32) * 4;
+    const bool with_occ = occ_bytes <= occ_max;
+    ix->wide = !with_occ;
+    if (const char *env = getenv("KMM_WIDE_BUCKETS")) // experiments: force the bucket layout
+        ix->wide = !with_occ && atoi(env) != 0;
+    HIPCHK(hipMalloc(&ix->buckets, sizeof(uint4) * (size_t)M * (ix->wide ? 2 : 1)));
     HIPCHK(hipMalloc(&ix->entries, sizeof(uint4) * (size_t)(N > 0 ? N : 1)));
     HIPCHK(hipMalloc(&ix->own_counts_buf, sizeof(uint32_t) * (size_t)(ix->max_node_id + 1)));
     ix->counts = ix->own_counts_buf;
@@ -568,9 +586,14 @@ static int index_create_impl(kmm_index *ix, const int32_t *h2i, const int32_t *n
     }
     uint32_t err = 0;
     if (rc == KMM_OK) {
-        hipLaunchKernelGGL(k_pack_buckets, dim3(grid_for(ix, (int64_t)((M + 255) / 256), 16)),
-                           dim3(256), 0, ix->stream, p_h2i, p_nk, p_km, p_nd, p_fr, M, N,
-                           ix->max_node_id, ix->buckets, (uint32_t *)d_err.p);
+        if (ix->wide)
+            hipLaunchKernelGGL(k_pack_buckets_wide, dim3(grid_for(ix, (int64_t)((M + 255) / 256), 16)),
+                               dim3(256), 0, ix->stream, p_h2i, p_nk, p_km, p_nd, p_fr, M, N,
+                               ix->max_node_id, ix->buckets, (uint32_t *)d_err.p);
+        else
+            hipLaunchKernelGGL(k_pack_buckets, dim3(grid_for(ix, (int64_t)((M + 255) / 256), 16)),
+                               dim3(256), 0, ix->stream, p_h2i, p_nk, p_km, p_nd, p_fr, M, N,
+                               ix->max_node_id, ix->buckets, (uint32_t *)d_err.p);
         if (N > 0)
             hipLaunchKernelGGL(k_pack_entries, dim3(grid_for(ix, (N + 255) / 256, 16)), dim3(256),
                                0, ix->stream, p_km, p_nd, p_fr, N, ix->max_node_id, ix->entries,
@@ -591,12 +614,8 @@ static int index_create_impl(kmm_index *ix, const int32_t *h2i, const int32_t *n
     if (err & 2u)
         return fail(KMM_ERR_INDEX, "index inconsistent: a node id lies outside [0, max_node_id=%lld]",
                     (long long)ix->max_node_id);
-    // occupancy bitmap for indexes whose bitmap stays resident in one XCD's 4 MiB L2
-    const size_t occ_bytes = (size_t)((M + 31) / 32) * 4;
-    size_t occ_max = KMM_OCC_MAX_BYTES;
-    if (const char *env = getenv("KMM_OCC_MAX_BYTES")) // experiments: threshold of the bitmap prefilter
-        occ_max = (size_t)strtoull(env, nullptr, 10);
-    if (occ_bytes <= occ_max) {
+    // occupancy bitmap (narrow layout only)
+    if (with_occ) {
         HIPCHK(hipMalloc(&ix->occ, occ_bytes));
         hipLaunchKernelGGL(k_build_occ, dim3(grid_for(ix, (int64_t)((M / 32 + 256) / 256), 16)), dim3(256),
                            0, ix->stream, ix->buckets, M, ix->occ);
@@ -728,9 +747,19 @@ int kmm_map_kmers(kmm_index_t *ix, const uint64_t *kmers, int64_t n, int max_fre
     constexpr int U = 8;
     ScopedTimer tm;
     KMMCHK(tm.begin(ix, KMM_KERNEL_MAP_KMERS));
-    hipLaunchKernelGGL((k_map_kmers<U>), dim3(grid_for(ix, (n + 256 * U - 1) / (256 * U), 64)),
-                       dim3(256), 0, ix->stream, d_kmers, n, view_of(ix), max_freq,
-                       also_revcomp ? 1 : 0, k);
+    {
+        const IndexView iv = view_of(ix);
+        const dim3 grid(grid_for(ix, (n + 256 * U - 1) / (256 * U), 64));
+        if (iv.occ)
+            hipLaunchKernelGGL((k_map_kmers<U, PROBE_BITMAP>), grid, dim3(256), 0, ix->stream, d_kmers, n, iv,
+                               max_freq, also_revcomp ? 1 : 0, k);
+        else if (iv.wide)
+            hipLaunchKernelGGL((k_map_kmers<U, PROBE_WIDE>), grid, dim3(256), 0, ix->stream, d_kmers, n, iv,
+                               max_freq, also_revcomp ? 1 : 0, k);
+        else
+            hipLaunchKernelGGL((k_map_kmers<U, PROBE_NARROW>), grid, dim3(256), 0, ix->stream, d_kmers, n, iv,
+                               max_freq, also_revcomp ? 1 : 0, k);
+    }
     HIPCHK(hipGetLastError());
     KMMCHK(tm.end());
     return stage_release(ix, s, staged);
@@ -1308,6 +1337,8 @@ int kmm_get_param(kmm_index_t *ix, const char *name, int64_t *value)
         *value = ix->dynamic_schedule ? 1 : 0;
     else if (!strcmp(name, "occupancy_filter"))
         *value = (ix->use_occ && ix->occ) ? 1 : 0;
+    else if (!strcmp(name, "wide_buckets"))
+        *value = ix->wide ? 1 : 0;
     else if (!strcmp(name, "n_partitions"))
         *value = part_count(ix);
     else if (!strcmp(name, "partitioned_available"))

@@ -7,7 +7,7 @@
 // indexes whose hash space cannot be cut into L2-sized partitions.
 // ------------------------------------------------------------------------------------------------
 
-template <int S, int MODE>
+template <int S, int MODE, int PROBE>
 __device__ __forceinline__ void map_one_tile(const ReadsView &rv, const IndexView &iv, const TileConst &tc,
                                              int64_t tile, int k, int max_freq, int also_rc, TileSmem<S> &sm,
                                              NodeAgg &agg, LaneStats &st)
@@ -15,12 +15,12 @@ __device__ __forceinline__ void map_one_tile(const ReadsView &rv, const IndexVie
     uint64_t q[S];
     const uint32_t valid = tile_kmers<S, MODE>(rv, tc, tile, k, sm, q);
     if (__builtin_amdgcn_ballot_w64(valid != 0)) {
-        probe_batch<S>(iv, agg, st, q, valid, max_freq);
+        probe_batch<S, PROBE>(iv, agg, st, q, valid, max_freq);
         if (also_rc) {
 #pragma unroll
             for (int j = 0; j < S; ++j)
                 q[j] = revcomp(q[j], k);
-            probe_batch<S>(iv, agg, st, q, valid, max_freq);
+            probe_batch<S, PROBE>(iv, agg, st, q, valid, max_freq);
         }
     }
 }
@@ -28,7 +28,7 @@ __device__ __forceinline__ void map_one_tile(const ReadsView &rv, const IndexVie
 // `queue` == null: static grid-stride schedule.  Otherwise the workgroups are persistent (one per CU
 // slot) and pull chunks of `chunk` consecutive tiles from a device-side counter, so that the last
 // round of a large launch does not leave CU slots idle while a few workgroups finish their fixed share.
-template <int S, int MODE>
+template <int S, int MODE, int PROBE>
 __global__ void __launch_bounds__(256) k_map_reads(ReadsView rv, IndexView iv, int k, int max_freq,
                                                    int also_rc, int64_t tile_begin, int64_t tile_end,
                                                    unsigned long long *queue, int chunk)
@@ -42,7 +42,7 @@ __global__ void __launch_bounds__(256) k_map_reads(ReadsView rv, IndexView iv, i
     const TileConst tc = tile_const(rv, k);
     if (!queue) {
         for (int64_t tile = tile_begin + blockIdx.x; tile < tile_end; tile += gridDim.x)
-            map_one_tile<S, MODE>(rv, iv, tc, tile, k, max_freq, also_rc, sm, agg, st);
+            map_one_tile<S, MODE, PROBE>(rv, iv, tc, tile, k, max_freq, also_rc, sm, agg, st);
     } else {
         for (;;) {
             if (threadIdx.x == 0)
@@ -54,7 +54,7 @@ __global__ void __launch_bounds__(256) k_map_reads(ReadsView rv, IndexView iv, i
                 break;
             const int64_t last = first + chunk < tile_end ? first + chunk : tile_end;
             for (int64_t tile = first; tile < last; ++tile)
-                map_one_tile<S, MODE>(rv, iv, tc, tile, k, max_freq, also_rc, sm, agg, st);
+                map_one_tile<S, MODE, PROBE>(rv, iv, tc, tile, k, max_freq, also_rc, sm, agg, st);
         }
     }
     stats_reduce(agg, st);
@@ -65,7 +65,7 @@ __global__ void __launch_bounds__(256) k_map_reads(ReadsView rv, IndexView iv, i
 // ------------------------------------------------------------------------------------------------
 // K2: operator-level lookup, uint64 k-mers already in HBM (drop-in for map_kmers_to_graph_index).
 // ------------------------------------------------------------------------------------------------
-template <int U>
+template <int U, int PROBE>
 __global__ void __launch_bounds__(256) k_map_kmers(const uint64_t *__restrict__ kmers, int64_t n,
                                                    IndexView iv, int max_freq, int also_rc, int k)
 {
@@ -86,12 +86,12 @@ __global__ void __launch_bounds__(256) k_map_kmers(const uint64_t *__restrict__ 
                 valid |= 1u << u;
             }
         }
-        probe_batch<U>(iv, agg, st, q, valid, max_freq);
+        probe_batch<U, PROBE>(iv, agg, st, q, valid, max_freq);
         if (also_rc) {
 #pragma unroll
             for (int u = 0; u < U; ++u)
                 q[u] = revcomp(q[u], k);
-            probe_batch<U>(iv, agg, st, q, valid, max_freq);
+            probe_batch<U, PROBE>(iv, agg, st, q, valid, max_freq);
         }
     }
     stats_reduce(agg, st);
@@ -216,7 +216,29 @@ __global__ void k_in_index(const uint64_t *__restrict__ kmers, int64_t n, IndexV
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (int64_t)gridDim.x * blockDim.x) {
         const uint64_t q = kmers[i];
-        const uint4 b = iv.buckets[fastmod(q, iv.modulo, iv.magic)];
+        const uint64_t hq = fastmod(q, iv.modulo, iv.magic);
+        if (iv.wide) {
+            const uint4 a = iv.buckets[2 * hq];
+            const uint32_t kd = a.w & 3u;
+            uint8_t hw = 0;
+            if (kd == 1u || kd == 2u)
+                hw = (((uint64_t)a.x | ((uint64_t)a.y << 32)) == q) ? 1 : 0;
+            if (kd == 2u && !hw) {
+                const uint4 b2 = iv.buckets[2 * hq + 1];
+                hw = (((uint64_t)b2.x | ((uint64_t)b2.y << 32)) == q) ? 1 : 0;
+            } else if (kd == 3u) {
+                for (uint32_t j = 0; j < a.y; ++j) {
+                    uint4 e = iv.entries[(uint64_t)a.x + j];
+                    if (((uint64_t)e.x | ((uint64_t)e.y << 32)) == q) {
+                        hw = 1;
+                        break;
+                    }
+                }
+            }
+            out[i] = hw;
+            continue;
+        }
+        const uint4 b = iv.buckets[hq];
         const uint32_t kind = b.w & 3u;
         uint8_t hit = 0;
         if (kind == 1u) {
@@ -263,6 +285,41 @@ __global__ void k_pack_buckets(const int32_t *__restrict__ h2i, const int32_t *_
             }
         }
         buckets[h] = b;
+    }
+}
+
+// Wide layout: 32-byte bucket = halves A (2h) and B (2h+1), up to two entries inline.
+__global__ void k_pack_buckets_wide(const int32_t *__restrict__ h2i, const int32_t *__restrict__ nk,
+                                    const uint64_t *__restrict__ kmers, const int32_t *__restrict__ nodes,
+                                    const uint16_t *__restrict__ freqs, uint64_t modulo, int64_t n_entries,
+                                    int64_t max_node_id, uint4 *__restrict__ buckets, uint32_t *err)
+{
+    for (uint64_t h = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; h < modulo;
+         h += (uint64_t)gridDim.x * blockDim.x) {
+        const int32_t c = nk[h], s = h2i[h];
+        uint4 a = make_uint4(0u, 0u, 0u, 0u), b = make_uint4(0u, 0u, 0u, 0u);
+        if (c > 0) {
+            if (s < 0 || (int64_t)s + c > n_entries) {
+                atomicOr(err, 1u);
+            } else if (c <= 2) {
+                for (int j = 0; j < c; ++j) {
+                    const uint64_t km = kmers[s + j];
+                    int32_t nd = nodes[s + j];
+                    if (nd < 0 || (int64_t)nd > max_node_id)
+                        nd = 0; // reported by k_pack_entries
+                    const uint4 e = make_uint4((uint32_t)km, (uint32_t)(km >> 32), (uint32_t)nd,
+                                               ((uint32_t)freqs[s + j] << 16) | (uint32_t)c);
+                    if (j == 0)
+                        a = e;
+                    else
+                        b = e;
+                }
+            } else {
+                a = make_uint4((uint32_t)s, (uint32_t)c, 0u, 3u);
+            }
+        }
+        buckets[2 * h] = a;
+        buckets[2 * h + 1] = b;
     }
 }
 

@@ -263,7 +263,7 @@ __global__ void __launch_bounds__(256) k_part_probe(IndexView iv, PartView pv, i
                 valid |= 1u << u;
             }
         }
-        probe_batch<U>(iv, agg, st, q, valid, max_freq);
+        probe_batch<U, PROBE_NARROW>(iv, agg, st, q, valid, max_freq);
     }
     stats_reduce(agg, st);
     __syncthreads();

@@ -8,6 +8,9 @@
 //        w & 3 == 0  empty
 //        w & 3 == 1  single entry stored inline: {x,y} = k-mer, z = node, w >> 16 = frequency
 //        w & 3 == 2  two or more entries: x = start, y = count into `entries`
+//   wide variant (indexes too large for the L2 bitmap): bucket h = two uint4 halves A = buckets[2h],
+//        B = buckets[2h+1] inside one 64-byte fabric request; A.w & 3 == 1 one entry in A, == 2 two entries
+//        in A and B (B is then an L2 hit), == 3 three or more: A.x = start, A.y = count into `entries`
 //   entry  l : uint4 {kmer_lo, kmer_hi, node, freq}, 16 B, in the index's own order (grouped by hash)
 // The MI355X random-access ceiling is ~55 G L2-missing requests/s whatever their width (8 or 16 B,
 // profiles/r01/gather_bench_mi355x.txt), so the layout minimises REQUESTS per k-mer, not bytes.
@@ -18,6 +21,7 @@ struct IndexView {
     const uint4 *buckets;
     const uint4 *entries;
     const uint32_t *occ; // optional L2-resident occupancy bitmap (bit h = bucket h non-empty), or null
+    int wide;            // 1: 32-byte buckets with two inline entries (never together with occ)
     uint32_t *counts;
     unsigned long long *stats; // [0] k-mer lookups performed, [1] count increments (hits)
     uint64_t modulo;
@@ -229,12 +233,72 @@ __device__ __forceinline__ void probe_batch_impl(const IndexView &iv, NodeAgg &a
     }
 }
 
+// Same probe on the wide (32-byte) bucket layout: one L2-missing gather (A) resolves empty and single
+// buckets, two-entry buckets add an L2 hit (B), only >= 3 entries (2.9 % of probes at load factor 0.5) walk
+// `entries`.
 template <int U>
+__device__ __forceinline__ void probe_batch_wide(const IndexView &iv, NodeAgg &agg, LaneStats &ls,
+                                                 const uint64_t (&q)[U], uint32_t valid, int max_freq)
+{
+    uint32_t &hits = ls.hits;
+    ls.lookups += (uint32_t)__popc(valid);
+    uint64_t h[U];
+    uint4 a[U], b[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        h[u] = fastmod(q[u], iv.modulo, iv.magic);
+        a[u] = make_uint4(0u, 0u, 0u, 0u);
+        if ((valid >> u) & 1u)
+            a[u] = iv.buckets[2 * h[u]];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        b[u] = make_uint4(0u, 0u, 0u, 0u);
+        if ((a[u].w & 3u) == 2u)
+            b[u] = iv.buckets[2 * h[u] + 1];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const uint32_t kind = a[u].w & 3u;
+        if (kind == 1u || kind == 2u) {
+            const uint64_t ek = (uint64_t)a[u].x | ((uint64_t)a[u].y << 32);
+            if (ek == q[u] && (int)(a[u].w >> 16) <= max_freq)
+                agg_add(iv, agg, a[u].z, hits);
+        }
+        if (kind == 2u) {
+            const uint64_t ek = (uint64_t)b[u].x | ((uint64_t)b[u].y << 32);
+            if (ek == q[u] && (int)(b[u].w >> 16) <= max_freq)
+                agg_add(iv, agg, b[u].z, hits);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        if ((a[u].w & 3u) == 3u) {
+            const uint32_t st = a[u].x, cn = a[u].y; // cn >= 3 by construction
+            const uint4 e0 = iv.entries[st];
+            const uint4 e1 = iv.entries[(uint64_t)st + 1];
+            const uint4 e2 = iv.entries[(uint64_t)st + 2];
+            count_if_match(iv, agg, e0, q[u], max_freq, hits);
+            count_if_match(iv, agg, e1, q[u], max_freq, hits);
+            count_if_match(iv, agg, e2, q[u], max_freq, hits);
+            for (uint32_t j = 3; j < cn; ++j)
+                count_if_match(iv, agg, iv.entries[(uint64_t)st + j], q[u], max_freq, hits);
+        }
+    }
+}
+
+// Probe flavours are separate kernel instantiations (not run-time branches) so that each keeps its own
+// register budget: the bitmap flavour runs at 8 waves/SIMD, the wide one needs ~84 VGPRs.
+enum { PROBE_NARROW = 0, PROBE_BITMAP = 1, PROBE_WIDE = 2 };
+
+template <int U, int PROBE>
 __device__ __forceinline__ void probe_batch(const IndexView &iv, NodeAgg &agg, LaneStats &st,
                                             const uint64_t (&q)[U], uint32_t valid, int max_freq)
 {
-    if (iv.occ) // wave-uniform
+    if (PROBE == PROBE_BITMAP)
         probe_batch_impl<U, true>(iv, agg, st, q, valid, max_freq);
+    else if (PROBE == PROBE_WIDE)
+        probe_batch_wide<U>(iv, agg, st, q, valid, max_freq);
     else
         probe_batch_impl<U, false>(iv, agg, st, q, valid, max_freq);
 }
