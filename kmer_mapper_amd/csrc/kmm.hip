@@ -334,9 +334,10 @@ int resolve_lut(kmm_index *ix, Stage &s, const uint8_t *lut, const uint8_t **dev
 }
 
 constexpr size_t KMM_STAT_BYTES = (size_t)KMM_STAT_SHARDS * KMM_STAT_STRIDE * 8;
-// Measured (profiles/r01/partitioned_path_ablation.md): the bitmap wins by 23 % at 2.5 MB, 16 % at 3.75 MB,
-// 8 % at 5 MB, 4 % at 10 MB and loses 9 % at 25 MB (it no longer fits the 4 MiB L2 of an XCD).
-constexpr size_t KMM_OCC_MAX_BYTES = (size_t)8 << 20; // 67 M buckets
+// Layout choice by index size (profiles/r01/partitioned_path_ablation.md, ms per 1.2e9 k-mers, same box):
+//   16-byte buckets + L2 bitmap vs 32-byte buckets without: 10 M entries 20.2 / 24.4, 15 M 21.4 / 26.3,
+//   20 M 23.6 / 27.9, 40 M (10 MB bitmap) 28.7 / 30.3, 100 M (25 MB bitmap) 34.0 / 31.7.
+constexpr size_t KMM_OCC_MAX_BYTES = (size_t)12 << 20; // 100 M buckets
 constexpr int TILE_S = 4;
 constexpr int TILE_T = 256 * TILE_S;
 
