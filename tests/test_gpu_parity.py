@@ -672,3 +672,36 @@ def test_gpu_index_builder_equals_numpy_builder(kmm, n, modulo):
         x, y = getattr(a, attr), getattr(b, attr)
         assert x.dtype == y.dtype and np.array_equal(x, y), attr
     assert b._modulo == modulo
+
+
+def test_wide_bucket_layout_parity(kmm, syn, oracle, monkeypatch):
+    """Indexes beyond the bitmap threshold use 32-byte buckets with two inline entries; force that
+    layout on small indexes (KMM_OCC_MAX_BYTES=0) and run the main scenarios against the oracle."""
+    from kmer_mapper_amd import _lib
+    from kmer_mapper_amd.kmer_index import KmerIndex
+    from kmer_mapper_amd.util import ReadBatch
+    monkeypatch.setenv("KMM_OCC_MAX_BYTES", "0")
+    for modulo in (None, 257, 1):           # default load factor, long buckets, a single bucket
+        index, genome = syn.make_index(3000, seed=201, modulo=modulo)
+        mx = index.max_node_id()
+        bases, offs = syn.make_ragged_reads(genome, 1500, 0, 220, seed=202)
+        km = oracle.extract(bases, offs, 31)
+        with kmm.DeviceIndex.from_index(index, mx) as dev:
+            assert dev.get_param("wide_buckets") == 1 and dev.get_param("occupancy_filter") == 0
+            for mf, rc in ((1000, False), (2, False), (65535, True)):
+                expect, _ = oracle.map_reads(index, mx, bases, offs, 31, max_index_lookup_frequency=mf,
+                                             also_revcomp=rc)
+                dev.reset(); dev.map_reads(bases, offs, 31, mf, also_revcomp=rc)
+                assert np.array_equal(dev.get_node_counts(), expect)
+                dev.reset(); dev.map_kmers(km, mf, also_revcomp=rc, k=31)
+                assert np.array_equal(dev.get_node_counts(), expect)
+            assert np.array_equal(dev.in_index(km), oracle.in_index(index, km))
+            raw = _fastq_bytes(ReadBatch(bases, offs))
+            dev.reset(); dev.map_records(raw, fmt=_lib.FORMAT_FASTQ)
+            assert np.array_equal(dev.get_node_counts(), oracle.map_reads(index, mx, bases, offs, 31)[0])
+    # the reference's known answers on this layout too
+    for v in reference_vectors()["lookup"]:
+        idx = index_from_vector(v)
+        with kmm.DeviceIndex.from_index(idx, v["max_node_id"]) as dev:
+            dev.map_kmers(np.array(v["query"], dtype=np.uint64), v["max_index_lookup_frequency"])
+            assert dev.get_node_counts().tolist() == v["expected_node_counts"]
