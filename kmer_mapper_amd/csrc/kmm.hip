@@ -750,16 +750,22 @@ int kmm_map_kmers(kmm_index_t *ix, const uint64_t *kmers, int64_t n, int max_fre
     KMMCHK(tm.begin(ix, KMM_KERNEL_MAP_KMERS));
     {
         const IndexView iv = view_of(ix);
-        const dim3 grid(grid_for(ix, (n + 256 * U - 1) / (256 * U), 64));
+        const int64_t n_spans = (n + 256 * U - 1) / (256 * U);
+        const int64_t slots = (int64_t)ix->n_cu * 8;
+        const bool dynamic = ix->dynamic_schedule && n_spans >= slots * 4 * ix->dyn_chunk;
+        if (dynamic)
+            HIPCHK(hipMemsetAsync(ix->queue, 0, sizeof(unsigned long long), ix->stream));
+        const dim3 grid(dynamic ? (unsigned)slots : (unsigned)grid_for_tiles(ix, n_spans));
+        unsigned long long *queue = dynamic ? ix->queue : nullptr;
         if (iv.occ)
             hipLaunchKernelGGL((k_map_kmers<U, PROBE_BITMAP>), grid, dim3(256), 0, ix->stream, d_kmers, n, iv,
-                               max_freq, also_revcomp ? 1 : 0, k);
+                               max_freq, also_revcomp ? 1 : 0, k, queue, ix->dyn_chunk);
         else if (iv.wide)
             hipLaunchKernelGGL((k_map_kmers<U, PROBE_WIDE>), grid, dim3(256), 0, ix->stream, d_kmers, n, iv,
-                               max_freq, also_revcomp ? 1 : 0, k);
+                               max_freq, also_revcomp ? 1 : 0, k, queue, ix->dyn_chunk);
         else
             hipLaunchKernelGGL((k_map_kmers<U, PROBE_NARROW>), grid, dim3(256), 0, ix->stream, d_kmers, n, iv,
-                               max_freq, also_revcomp ? 1 : 0, k);
+                               max_freq, also_revcomp ? 1 : 0, k, queue, ix->dyn_chunk);
     }
     HIPCHK(hipGetLastError());
     KMMCHK(tm.end());

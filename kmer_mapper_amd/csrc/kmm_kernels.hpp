@@ -66,32 +66,57 @@ __global__ void __launch_bounds__(256) k_map_reads(ReadsView rv, IndexView iv, i
 // K2: operator-level lookup, uint64 k-mers already in HBM (drop-in for map_kmers_to_graph_index).
 // ------------------------------------------------------------------------------------------------
 template <int U, int PROBE>
+__device__ __forceinline__ void map_kmer_span(const uint64_t *__restrict__ kmers, int64_t n, int64_t base,
+                                              const IndexView &iv, int max_freq, int also_rc, int k,
+                                              NodeAgg &agg, LaneStats &st)
+{
+    uint64_t q[U];
+    uint32_t valid = 0;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        int64_t i = base + (int64_t)u * 256 + threadIdx.x;
+        q[u] = 0;
+        if (i < n) {
+            q[u] = __builtin_nontemporal_load(&kmers[i]);
+            valid |= 1u << u;
+        }
+    }
+    probe_batch<U, PROBE>(iv, agg, st, q, valid, max_freq);
+    if (also_rc) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            q[u] = revcomp(q[u], k);
+        probe_batch<U, PROBE>(iv, agg, st, q, valid, max_freq);
+    }
+}
+
+// `queue` as in k_map_reads: null = static grid-stride over spans of 256*U k-mers, otherwise persistent
+// workgroups pulling `chunk` consecutive spans per grab.
+template <int U, int PROBE>
 __global__ void __launch_bounds__(256) k_map_kmers(const uint64_t *__restrict__ kmers, int64_t n,
-                                                   IndexView iv, int max_freq, int also_rc, int k)
+                                                   IndexView iv, int max_freq, int also_rc, int k,
+                                                   unsigned long long *queue, int chunk)
 {
     __shared__ NodeAgg agg;
+    __shared__ unsigned long long s_next;
     LaneStats st;
     agg_init(agg);
     __syncthreads();
     const int64_t span = (int64_t)256 * U;
-    for (int64_t base = (int64_t)blockIdx.x * span; base < n; base += (int64_t)gridDim.x * span) {
-        uint64_t q[U];
-        uint32_t valid = 0;
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            int64_t i = base + (int64_t)u * 256 + threadIdx.x;
-            q[u] = 0;
-            if (i < n) {
-                q[u] = kmers[i];
-                valid |= 1u << u;
-            }
-        }
-        probe_batch<U, PROBE>(iv, agg, st, q, valid, max_freq);
-        if (also_rc) {
-#pragma unroll
-            for (int u = 0; u < U; ++u)
-                q[u] = revcomp(q[u], k);
-            probe_batch<U, PROBE>(iv, agg, st, q, valid, max_freq);
+    if (!queue) {
+        for (int64_t base = (int64_t)blockIdx.x * span; base < n; base += (int64_t)gridDim.x * span)
+            map_kmer_span<U, PROBE>(kmers, n, base, iv, max_freq, also_rc, k, agg, st);
+    } else {
+        for (;;) {
+            if (threadIdx.x == 0)
+                s_next = atomicAdd(queue, (unsigned long long)chunk);
+            __syncthreads();
+            const int64_t first = (int64_t)s_next * span;
+            __syncthreads();
+            if (first >= n)
+                break;
+            for (int c = 0; c < chunk && first + c * span < n; ++c)
+                map_kmer_span<U, PROBE>(kmers, n, first + c * span, iv, max_freq, also_rc, k, agg, st);
         }
     }
     stats_reduce(agg, st);
