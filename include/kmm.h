@@ -60,6 +60,8 @@ int kmm_device_count(int *n_devices);
  * entries, and for small indexes an L2-resident occupancy bitmap).  Unlike the
  * reference (no bounds checks, mapper.pyx:17) the arrays are validated: every non-empty bucket
  * must lie inside [0, n_entries) and every node inside [0, max_node_id], else KMM_ERR_INDEX.
+ * Environment knobs for experiments, read here: KMM_OCC_MAX_BYTES (largest occupancy bitmap that is still
+ * built; 0 forces the wide 32-byte bucket layout), KMM_WIDE_BUCKETS=0 (16-byte buckets without bitmap).
  */
 int kmm_index_create(const int32_t *hashes_to_index, const int32_t *n_kmers, uint64_t modulo,
                      const uint64_t *kmers, const int32_t *nodes, const uint16_t *frequencies,
