@@ -8,8 +8,6 @@ offsets, exactly what kmm_map_reads takes.  Parsing is vectorised numpy over the
 scan, header/sequence line masks); no per-read Python loop.
 """
 import gzip
-import io
-import os
 import queue
 import threading
 

@@ -6,7 +6,6 @@ import os
 import sys
 import time
 
-import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from kmer_mapper_amd import synthetic as syn          # noqa: E402
