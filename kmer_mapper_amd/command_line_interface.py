@@ -169,6 +169,9 @@ def map_bnp(args):
     max_freq = args.max_hits_per_kmer if getattr(args, "apply_max_hits_per_kmer", False) else 1000
 
     device = local_rank if world > 1 else getattr(args, "device", 0)
+    backend = os.environ.get("KMM_DIST_BACKEND", "nccl")      # "gloo": rehearsal of the N>1 flow on one GPU
+    if world > 1 and backend == "gloo":
+        device = local_rank % max(_lib.device_count(), 1)
     revcomp = bool(getattr(args, "map_reverse_complements", False))
     fmt, gpu_parsable = sniff_format(args.reads)
     if gpu_parsable and not getattr(args, "host_parser", False):
@@ -186,8 +189,8 @@ def map_bnp(args):
         from .distributed import reduce_node_counts
         if not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            dist.init_process_group("nccl" if torch.cuda.is_available() else "gloo")
-        t = torch.from_numpy(node_counts.view(np.int32))
+            dist.init_process_group(backend if torch.cuda.is_available() else "gloo")
+        t = torch.from_numpy(node_counts.view(np.int32).copy())
         if dist.get_backend() == "nccl":
             t = t.cuda(local_rank)
         reduce_node_counts(t, dst=0)

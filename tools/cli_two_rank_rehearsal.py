@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Rehearsal of the multi-rank CLI flow on a 1-GPU box: run under
+   KMM_DIST_BACKEND=gloo python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 tools/cli_two_rank_rehearsal.py
+Chunk i goes to rank i mod 2, counts are summed with one reduce; rank 0 compares with the oracle."""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from kmer_mapper_amd import reads_io, synthetic as syn                      # noqa: E402
+from kmer_mapper_amd.command_line_interface import run_argument_parser      # noqa: E402
+from kmer_mapper_amd.util import ReadBatch                                  # noqa: E402
+
+
+def main():
+    rank = int(os.environ.get("RANK", "0"))
+    d = "/tmp/kmm_rehearsal"
+    os.makedirs(d, exist_ok=True)
+    index, genome = syn.make_index(20000, seed=5)
+    bases, offs = syn.make_ragged_reads(genome, 30000, 20, 220, seed=6)
+    idx_path, fq = os.path.join(d, "index.npz"), os.path.join(d, "reads.fq")
+    if rank == 0:
+        index.to_file(idx_path)
+        reads_io.write_fastq(fq, ReadBatch(bases, offs))
+    import torch.distributed as dist
+    dist.init_process_group(os.environ.get("KMM_DIST_BACKEND", "gloo"))
+    dist.barrier()
+    out = os.path.join(d, "out")
+    run_argument_parser(["map", "-i", idx_path, "-f", fq, "-o", out, "-c", "300000"])
+    dist.barrier()
+    if rank == 0:
+        from oracle import oracle
+        expect, _ = oracle.map_reads(index, index.max_node_id(), bases, offs, 31, n_threads=4)
+        got = np.load(out + ".npy")
+        print("two-rank CLI rehearsal:", "BIT-EXACT" if np.array_equal(got, expect) else "MISMATCH", flush=True)
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
