@@ -91,7 +91,10 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.dist_backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev_t)
+            try:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev_t)
+            except TypeError:               # older torch without the device_id keyword
+                dist.init_process_group("nccl", rank=rank, world_size=world)
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
