@@ -40,6 +40,15 @@ def main():
         rc = oracle.map_kmers(index, mx, oracle.revcomp(km, k), out=oracle.map_kmers(index, mx, km))
         out[name + "_counts_revcomp"] = rc
         out[name + "_in_index"] = oracle.in_index(index, km)
+    # the ragged reads once more as a raw FASTQ chunk (CRLF on every third record, '@' / '+' leading
+    # quality strings) for the GPU record parser; expected counts = ragged_counts
+    rec = []
+    for i in range(len(o2) - 1):
+        seq = b2[o2[i]:o2[i + 1]].tobytes()
+        eol = b"\r\n" if i % 3 == 0 else b"\n"
+        qual = (b"@+I" * len(seq))[:len(seq)]
+        rec.append(b"@r%d" % i + eol + seq + eol + b"+" + eol + qual + eol)
+    out["ragged_fastq"] = np.frombuffer(b"".join(rec), dtype=np.uint8)
     path = os.path.join(ROOT, "tests", "golden", "golden_small.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes")

@@ -705,3 +705,13 @@ def test_wide_bucket_layout_parity(kmm, syn, oracle, monkeypatch):
         with kmm.DeviceIndex.from_index(idx, v["max_node_id"]) as dev:
             dev.map_kmers(np.array(v["query"], dtype=np.uint64), v["max_index_lookup_frequency"])
             assert dev.get_node_counts().tolist() == v["expected_node_counts"]
+
+
+def test_golden_fastq_chunk_through_record_parser(kmm):
+    from kmer_mapper_amd import _lib
+    d, index, mx, k = golden_small()
+    raw = d["ragged_fastq"]
+    with kmm.DeviceIndex.from_index(index, mx) as dev:
+        used, n_rec = dev.map_records(raw, fmt=_lib.FORMAT_FASTQ, k=k)
+        assert used == raw.shape[0] and n_rec == len(d["ragged_offsets"]) - 1
+        assert np.array_equal(dev.get_node_counts(), d["ragged_counts"])
