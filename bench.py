@@ -64,6 +64,9 @@ def main():
     ap.add_argument("--dyn-chunk", type=int, default=None)
     ap.add_argument("--no-filter", action="store_true", help="disable the L2 occupancy-bitmap prefilter")
     ap.add_argument("--general-path", action="store_true", help="use kmm_map_reads with an offsets array")
+    ap.add_argument("--records", action="store_true",
+                    help="time kmm_map_records instead: each batch is a raw FASTQ chunk in HBM (<= 2^30 bytes), "
+                         "records are parsed on the GPU")
     ap.add_argument("--operator", action="store_true",
                     help="time the operator path instead: k-mers extracted once (kmm_extract_kmers) into HBM, "
                          "each step = kmm_map_kmers over them (drop-in for map_kmers_to_graph_index)")
@@ -132,6 +135,21 @@ def main():
     del g_ascii
     torch.cuda.synchronize()
     kmers_per_step = R * max(L - k + 1, 0)
+    fastq_batches = None
+    if args.records:
+        from kmer_mapper_amd import _lib as kmm_lib
+        rec_len = 4 + L + 3 + L + 1                                   # "@rd\n" seq "\n+\n" qual "\n"
+        assert R * rec_len <= 2 ** 30, "--records needs --reads <= %d" % (2 ** 30 // rec_len)
+        fastq_batches = []
+        for b in batches:
+            rec = torch.empty((R, rec_len), dtype=torch.uint8, device=dev_t)
+            rec[:, 0:4] = torch.tensor(list(b"@rd\n"), dtype=torch.uint8, device=dev_t)
+            rec[:, 4:4 + L] = b.view(R, L)
+            rec[:, 4 + L:4 + L + 3] = torch.tensor(list(b"\n+\n"), dtype=torch.uint8, device=dev_t)
+            rec[:, 4 + L + 3:4 + L + 3 + L] = ord("F")
+            rec[:, -1] = 10
+            fastq_batches.append(rec.reshape(-1))
+        torch.cuda.synchronize()
     kmer_batches = None
     if args.operator:
         from kmer_mapper_amd.engine import extract_kmers
@@ -149,7 +167,11 @@ def main():
 
     def step(i):
         b = batches[i & 1]
-        if kmer_batches is not None:
+        if fastq_batches is not None:
+            used, n_rec = dev.map_records(fastq_batches[i & 1], fmt=kmm_lib.FORMAT_FASTQ, k=k,
+                                          max_index_lookup_frequency=args.max_freq)
+            assert n_rec == R
+        elif kmer_batches is not None:
             dev.map_kmers(kmer_batches[i & 1], args.max_freq)
         elif offs is not None:
             dev.map_reads(b, offs, k, args.max_freq)
@@ -240,6 +262,7 @@ def main():
                 "workload": "configs[1]: %d synthetic %d bp reads per batch per GPU, k=%d, %d-k-mer index "
                             "(modulo %d, %d entries), reads resident in HBM, %s"
                             % (R, L, k, args.index_kmers, index._modulo, len(index._kmers),
+                               "kmm_map_records on raw FASTQ chunks" if args.records else
                                "operator kmm_map_kmers on pre-extracted k-mers" if args.operator else
                                "fused kmm_map_reads" + ("" if args.general_path else "_uniform")),
                 "kmers_per_step_per_gpu": kmers_per_step,

@@ -168,7 +168,7 @@ struct kmm_index {
     int path = 0;        // 0 auto, 1 direct, 2 partitioned
     int grid_per_cu = 64; // upper bound on workgroups per CU of the grid-stride fused kernel
     int part_shift = 16; // 2^16 buckets x 16 B = 1 MiB bucket-table slice per partition
-    DevBuf part_meta;    // hist, part_off, cursor, xcd_cum, xcd_queue
+    DevBuf part_meta;    // wg_hist, slot_tot, slot_off (PartView)
     DevBuf part_kmers;
     // timing
     bool timing = false;
