@@ -97,7 +97,9 @@ int kmm_map_kmers(kmm_index_t *idx, const uint64_t *kmers, int64_t n,
  * (command_line_interface.py:41 N->A, :42 get_kmer_hashes_from_chunk_sequence = util.py:71-75,
  * :51 map_kmers_to_graph_index) without materialising the k-mer array.
  * bases: the chunk's flat ASCII read bytes; read_offsets: int64[n_reads+1], read r is
- * bases[read_offsets[r] : read_offsets[r+1]] (read_offsets[0] must be 0).  Every window of k
+ * bases[read_offsets[r] : read_offsets[r+1]] (read_offsets[0] must be 0; the offsets must be
+ * non-decreasing, which is checked on the GPU and reported by the next synchronising call as
+ * KMM_ERR_INVALID_ARG).  Every window of k
  * bases inside one read is packed first-base-lowest, 2 bits/base through `lut`
  * (uint8[256]: 0..3 = code, 0xFF = not a nucleotide; NULL = A,C,G,T->0,1,2,3 case-insensitive
  * with N->A) and looked up as in kmm_map_kmers.  A byte with lut 0xFF makes the NEXT

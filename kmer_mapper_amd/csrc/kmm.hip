@@ -231,11 +231,14 @@ int drain(kmm_index *ix)
 {
     HIPCHK(hipStreamSynchronize(ix->copy_stream));
     HIPCHK(hipStreamSynchronize(ix->stream));
-    unsigned long long bad[2] = {NO_BAD, NO_BAD};
+    unsigned long long bad[3] = {NO_BAD, NO_BAD, NO_BAD};
     HIPCHK(hipMemcpy(bad, ix->first_bad, sizeof bad, hipMemcpyDeviceToHost));
-    if (bad[0] != NO_BAD || bad[1] != NO_BAD) {
-        unsigned long long reset[2] = {NO_BAD, NO_BAD};
+    if (bad[0] != NO_BAD || bad[1] != NO_BAD || bad[2] != NO_BAD) {
+        unsigned long long reset[3] = {NO_BAD, NO_BAD, NO_BAD};
         HIPCHK(hipMemcpy(ix->first_bad, reset, sizeof reset, hipMemcpyHostToDevice));
+        if (bad[2] != NO_BAD)
+            return fail(KMM_ERR_INVALID_ARG, "read_offsets of a mapped chunk is not non-decreasing at read %llu",
+                        bad[2]);
         if (bad[1] != NO_BAD)
             return fail(KMM_ERR_MALFORMED,
                         "record structure violated at byte offset %llu of a mapped chunk (a record line "
@@ -554,14 +557,14 @@ static int index_create_impl(kmm_index *ix, const int32_t *h2i, const int32_t *n
     ix->counts = ix->own_counts_buf;
     HIPCHK(hipMemsetAsync(ix->counts, 0, sizeof(uint32_t) * (size_t)(ix->max_node_id + 1), ix->stream));
     HIPCHK(hipMalloc(&ix->lut_default, 256));
-    HIPCHK(hipMalloc(&ix->first_bad, 2 * sizeof(unsigned long long)));
+    HIPCHK(hipMalloc(&ix->first_bad, 3 * sizeof(unsigned long long)));
     HIPCHK(hipMalloc(&ix->queue, sizeof(unsigned long long)));
     HIPCHK(hipMalloc(&ix->stats, KMM_STAT_BYTES));
     HIPCHK(hipMemset(ix->stats, 0, KMM_STAT_BYTES));
     uint8_t lut[256];
     default_lut(lut);
     HIPCHK(hipMemcpy(ix->lut_default, lut, 256, hipMemcpyHostToDevice));
-    unsigned long long nb[2] = {NO_BAD, NO_BAD};
+    unsigned long long nb[3] = {NO_BAD, NO_BAD, NO_BAD};
     HIPCHK(hipMemcpy(ix->first_bad, nb, sizeof nb, hipMemcpyHostToDevice));
 
     // raw arrays -> HBM (temporary), repack + validate on the GPU
@@ -795,11 +798,6 @@ static int map_reads_common(kmm_index_t *ix, const uint8_t *bases, const int64_t
             return fail(KMM_ERR_INVALID_ARG, "read_offsets[0] must be 0 (got %lld)", (long long)ends[0]);
         if (ends[1] < 0)
             return fail(KMM_ERR_INVALID_ARG, "read_offsets[n_reads] negative");
-        if (!offs_on_device)
-            for (int64_t r = 0; r < n_reads; ++r)
-                if (read_offsets[r + 1] < read_offsets[r])
-                    return fail(KMM_ERR_INVALID_ARG, "read_offsets not non-decreasing at read %lld",
-                                (long long)r);
         total = ends[1];
     }
     if (total == 0)
@@ -841,6 +839,9 @@ static int map_reads_common(kmm_index_t *ix, const uint8_t *bases, const int64_t
         KMMCHK(stage_copies_done(ix));
         hipLaunchKernelGGL(k_tile_first, dim3((unsigned)((n_tiles + 255) / 256)), dim3(256), 0,
                            ix->stream, rv.offsets, n_reads, n_tiles, TILE_T, (int64_t *)s.tile_first.p);
+        if (!uniform)
+            hipLaunchKernelGGL(k_check_offsets, dim3(grid_for(ix, (n_reads + 255) / 256, 8)), dim3(256), 0,
+                               ix->stream, rv.offsets, n_reads, ix->first_bad);
         HIPCHK(hipGetLastError());
         KMMCHK(launch_map_reads<MODE_GENERAL>(ix, rv, k, max_freq, also_revcomp ? 1 : 0));
     }

@@ -144,6 +144,15 @@ __global__ void k_tile_first(const int64_t *__restrict__ offs, int64_t n_reads, 
     out[tile] = lo;
 }
 
+// read_offsets must be non-decreasing; checked here (off the host's critical path) and reported at the
+// next synchronising call.  A violation cannot make the map kernels touch memory out of bounds.
+__global__ void k_check_offsets(const int64_t *__restrict__ offs, int64_t n_reads, unsigned long long *first_bad)
+{
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_reads; r += (int64_t)gridDim.x * blockDim.x)
+        if (offs[r + 1] < offs[r])
+            atomicMin(&first_bad[2], (unsigned long long)r);
+}
+
 __global__ void k_iota_offsets(int64_t *out, int64_t n_reads, int64_t read_len)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -715,3 +715,15 @@ def test_golden_fastq_chunk_through_record_parser(kmm):
         used, n_rec = dev.map_records(raw, fmt=_lib.FORMAT_FASTQ, k=k)
         assert used == raw.shape[0] and n_rec == len(d["ragged_offsets"]) - 1
         assert np.array_equal(dev.get_node_counts(), d["ragged_counts"])
+
+
+def test_non_monotone_offsets_are_reported_at_sync(kmm, syn):
+    index, genome = syn.make_index(200, k=5, seed=211, plant=False)
+    bases = syn.ACGT[genome[:300]]
+    with kmm.DeviceIndex.from_index(index) as dev:
+        dev.map_reads(bases, np.array([0, 100, 50, 300], dtype=np.int64), 5)
+        with pytest.raises(ValueError, match="not non-decreasing at read 1"):
+            dev.get_node_counts()
+        dev.reset()
+        dev.map_reads(bases, np.array([0, 100, 200, 300], dtype=np.int64), 5)
+        dev.get_node_counts()
