@@ -727,3 +727,29 @@ def test_non_monotone_offsets_are_reported_at_sync(kmm, syn):
         dev.reset()
         dev.map_reads(bases, np.array([0, 100, 200, 300], dtype=np.int64), 5)
         dev.get_node_counts()
+
+
+def test_handles_do_not_leak_device_memory(kmm, syn):
+    """Create / use / destroy many handles (all paths, staging growth): free HBM returns to its level."""
+    import torch
+    index, genome = syn.make_index(50000, seed=221)
+    bases, offs = syn.make_ragged_reads(genome, 20000, 0, 200, seed=222)
+    km = np.arange(100000, dtype=np.uint64)
+
+    def cycle(n):
+        for i in range(n):
+            with kmm.DeviceIndex.from_index(index) as dev:
+                dev.set_param("path", 1 + (i & 1))
+                dev.map_reads(bases, offs, 31)
+                dev.map_kmers(km)
+                dev.in_index(km[:1000])
+                dev.get_node_counts()
+            kmm.extract_kmers(bases[:50000], np.array([0, 50000], dtype=np.int64), 31)
+
+    cycle(3)                                  # warm up allocator pools
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    cycle(40)
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 64 << 20, "leaked %.1f MiB of HBM" % ((free0 - free1) / 2 ** 20)
