@@ -236,6 +236,7 @@ def main():
         b_alg = B_ALG[dom]
         achieved = kmers_per_launch * b_alg / avg_kernel_s / 1e9
         traffic = None
+        sector = None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath):
             try:
@@ -243,6 +244,17 @@ def main():
                 if (tj.get("reads") == R and tj.get("index_kmers") == args.index_kmers
                         and tj.get("kernel") == dom and not args.skewed):
                     traffic = tj.get("hbm_bytes_per_launch")
+                    if "l2_miss_read_requests_per_kmer" in tj:
+                        # request-granular view: the probe is bound by the NUMBER of
+                        # requests — ~55 G/s for L2-missing reads, ~254 G/s for L2 hits, and the two add
+                        miss, hit = tj["l2_miss_read_requests_per_kmer"], tj["l2_hits_per_kmer"]
+                        sector = {
+                            "l2_miss_read_requests_per_kmer": round(miss, 3),
+                            "l2_hits_per_kmer": round(hit, 3),
+                            "miss_ceiling_Greq_per_s": 55.0, "hit_ceiling_Greq_per_s": 254.0,
+                            "model_ms_per_launch": round(kmers_per_launch * (miss / 55e9 + hit / 254e9) * 1e3, 2),
+                            "hbm_bytes_per_kmer": round(traffic / kmers_per_launch, 1),
+                        }
             except Exception:
                 traffic = None
         result = {
@@ -287,6 +299,7 @@ def main():
                 "avg_kernel_ms": round(avg_kernel_s * 1e3, 3),
                 "launches": launches,
                 "kernel_gkmers_per_s": round(kmers_per_launch / avg_kernel_s / 1e9, 2),
+                "request_model": sector,
             },
         }
 

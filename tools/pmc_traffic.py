@@ -33,6 +33,8 @@ def main():
     ap.add_argument("--reads", type=int, required=True)
     ap.add_argument("--index-kmers", type=int, required=True)
     ap.add_argument("--stream-bytes", type=float, default=0.0)
+    ap.add_argument("--tcc", default=None, help="optional pass with TCC_EA0_RDREQ_sum TCC_HIT_sum TCC_EA0_WRREQ_sum")
+    ap.add_argument("--kmers-per-launch", type=float, default=None)
     ap.add_argument("--out", required=True)
     a = ap.parse_args()
     fetch, nf = mean_counter(a.fetch, a.kernel, "FETCH_SIZE")
@@ -46,6 +48,17 @@ def main():
         "note": "FETCH_SIZE*1024 + half of the coalesced read stream again (gfx950 tallies 128-B stream "
                 "requests at 64 B) + WRITE_SIZE*1024; separate --pmc passes",
     }
+    if a.tcc:
+        rd, _ = mean_counter(a.tcc, a.kernel, "TCC_EA0_RDREQ_sum")
+        hit, _ = mean_counter(a.tcc, a.kernel, "TCC_HIT_sum")
+        wr, _ = mean_counter(a.tcc, a.kernel, "TCC_EA0_WRREQ_sum")
+        out["TCC_EA0_RDREQ_per_launch"] = rd
+        out["TCC_HIT_per_launch"] = hit
+        out["TCC_EA0_WRREQ_per_launch"] = wr
+        if a.kmers_per_launch:
+            out["l2_miss_read_requests_per_kmer"] = rd / a.kmers_per_launch
+            out["l2_hits_per_kmer"] = hit / a.kmers_per_launch
+            out["atomic_write_requests_per_kmer"] = wr / a.kmers_per_launch
     json.dump(out, open(a.out, "w"), indent=1)
     print(json.dumps(out))
 
