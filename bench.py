@@ -254,6 +254,7 @@ def main():
                             "miss_ceiling_Greq_per_s": 55.0, "hit_ceiling_Greq_per_s": 254.0,
                             "model_ms_per_launch": round(kmers_per_launch * (miss / 55e9 + hit / 254e9) * 1e3, 2),
                             "hbm_bytes_per_kmer": round(traffic / kmers_per_launch, 1),
+                            "measured_hbm_GB_per_s": round(traffic / avg_kernel_s / 1e9, 1),
                         }
             except Exception:
                 traffic = None
