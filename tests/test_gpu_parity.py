@@ -753,3 +753,18 @@ def test_handles_do_not_leak_device_memory(kmm, syn):
     torch.cuda.synchronize()
     free1, _ = torch.cuda.mem_get_info()
     assert free0 - free1 < 64 << 20, "leaked %.1f MiB of HBM" % ((free0 - free1) / 2 ** 20)
+
+
+def test_cli_tiny_chunk_size_grows_until_a_record_fits(kmm, syn, oracle, tmp_path):
+    """`-c 64` is smaller than one FASTQ record: the raw chunker must grow instead of looping forever."""
+    from kmer_mapper_amd import reads_io
+    from kmer_mapper_amd.command_line_interface import run_argument_parser
+    from kmer_mapper_amd.util import ReadBatch
+    index, genome = syn.make_index(2000, seed=231)
+    bases, offs = syn.make_ragged_reads(genome, 300, 100, 400, seed=232)
+    idx_path, fq, out = str(tmp_path / "i.npz"), str(tmp_path / "r.fq"), str(tmp_path / "o")
+    index.to_file(idx_path)
+    reads_io.write_fastq(fq, ReadBatch(bases, offs))
+    run_argument_parser(["map", "-i", idx_path, "-f", fq, "-o", out, "-c", "64"])
+    expect, _ = oracle.map_reads(index, index.max_node_id(), bases, offs, 31)
+    assert np.array_equal(np.load(out + ".npy"), expect)
