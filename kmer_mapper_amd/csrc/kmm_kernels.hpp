@@ -314,6 +314,10 @@ __global__ void k_pack_buckets(const int32_t *__restrict__ h2i, const int32_t *_
                     nd = 0; // reported by k_pack_entries
                 b = make_uint4((uint32_t)km, (uint32_t)(km >> 32), (uint32_t)nd,
                                ((uint32_t)freqs[s] << 16) | 1u);
+            } else if (c <= 3) {
+                const uint32_t f0 = kmer_fp16(kmers[s]), f1 = kmer_fp16(kmers[s + 1]);
+                const uint32_t f2 = c > 2 ? kmer_fp16(kmers[s + 2]) : 0u;
+                b = make_uint4((uint32_t)s, (uint32_t)c, f0 | (f1 << 16), (f2 << 16) | 4u | 2u);
             } else {
                 b = make_uint4((uint32_t)s, (uint32_t)c, 0u, 2u);
             }

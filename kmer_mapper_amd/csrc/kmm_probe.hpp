@@ -7,7 +7,8 @@
 //   bucket h : uint4, 16 B — ONE gather resolves an empty or single-entry bucket:
 //        w & 3 == 0  empty
 //        w & 3 == 1  single entry stored inline: {x,y} = k-mer, z = node, w >> 16 = frequency
-//        w & 3 == 2  two or more entries: x = start, y = count into `entries`
+//        w & 3 == 2  two or more entries: x = start, y = count into `entries`; if w & 4, the bucket has at
+//                    most three entries and z[15:0], z[31:16], w[31:16] hold their 16-bit fingerprints
 //   wide variant (indexes too large for the L2 bitmap): bucket h = two uint4 halves A = buckets[2h],
 //        B = buckets[2h+1] inside one 64-byte fabric request; A.w & 3 == 1 one entry in A, == 2 two entries
 //        in A and B (B is then an L2 hit), == 3 three or more: A.x = start, A.y = count into `entries`
@@ -82,6 +83,15 @@ __device__ __forceinline__ uint64_t revcomp(uint64_t x, int k)
     x = ((x >> 16) & 0x0000FFFF0000FFFFull) | ((x & 0x0000FFFF0000FFFFull) << 16);
     x = (x >> 32) | (x << 32);
     return x >> (64 - 2 * k);
+}
+
+// 16-bit fingerprint of a k-mer, independent of its bucket (all k-mers of a bucket agree mod `modulo`).
+// Multi-entry buckets of the 16-byte layout keep the fingerprints of their (up to three) entries in the
+// bucket record, so a k-mer that matches none of them — nearly every k-mer that is not in the index —
+// never touches `entries`.
+__device__ __forceinline__ uint32_t kmer_fp16(uint64_t q)
+{
+    return (uint32_t)((q * 0x9E3779B97F4A7C15ull) >> 48);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -223,6 +233,13 @@ __device__ __forceinline__ void probe_batch_impl(const IndexView &iv, NodeAgg &a
     for (int u = 0; u < U; ++u) {
         if ((b[u].w & 3u) == 2u) {
             const uint32_t st = b[u].x, cn = b[u].y; // cn >= 2 by construction
+            if (b[u].w & 4u) { // fingerprints present: skip the walk unless one of them matches
+                const uint32_t f = kmer_fp16(q[u]);
+                const bool may = f == (b[u].z & 0xFFFFu) || f == (b[u].z >> 16) ||
+                                 (cn > 2u && f == (b[u].w >> 16));
+                if (!may)
+                    continue;
+            }
             const uint4 e0 = iv.entries[st];
             const uint4 e1 = iv.entries[(uint64_t)st + 1];
             count_if_match(iv, agg, e0, q[u], max_freq, hits);
