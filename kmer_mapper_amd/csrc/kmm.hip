@@ -150,6 +150,7 @@ struct kmm_index {
     uint4 *entries = nullptr;
     uint32_t *occ = nullptr;           // occupancy bitmap, only for indexes small enough (see occ_max_bytes)
     bool use_occ = true;
+    int occ_shift = 0;                 // log2(bitmap bits per bucket)
     bool wide = false;                 // 32-byte buckets (chosen when the index is too large for the bitmap)
     uint32_t *counts = nullptr;
     uint32_t *own_counts_buf = nullptr;
@@ -186,6 +187,7 @@ IndexView view_of(const kmm_index *ix)
     v.buckets = ix->buckets;
     v.entries = ix->entries;
     v.occ = ix->use_occ ? ix->occ : nullptr;
+    v.occ_shift = ix->occ_shift;
     v.wide = ix->wide ? 1 : 0;
     v.counts = ix->counts;
     v.stats = ix->stats;
@@ -340,7 +342,8 @@ constexpr size_t KMM_STAT_BYTES = (size_t)KMM_STAT_SHARDS * KMM_STAT_STRIDE * 8;
 // Layout choice by index size (profiles/r01/partitioned_path_ablation.md, ms per 1.2e9 k-mers, same box):
 //   16-byte buckets + L2 bitmap vs 32-byte buckets without: 10 M entries 20.2 / 24.4, 15 M 21.4 / 26.3,
 //   20 M 23.6 / 27.9, 40 M (10 MB bitmap) 28.7 / 30.3, 100 M (25 MB bitmap) 34.0 / 31.7.
-constexpr size_t KMM_OCC_MAX_BYTES = (size_t)12 << 20; // 100 M buckets
+constexpr size_t KMM_OCC_MAX_BYTES = (size_t)12 << 20;  // 100 M buckets at one bit per bucket
+constexpr size_t KMM_OCC_SWEET_BYTES = (size_t)5 << 20; // bitmap size that still lives in the 4 MiB L2s + MALL
 constexpr int TILE_S = 4;
 constexpr int TILE_T = 256 * TILE_S;
 
@@ -546,8 +549,20 @@ static int index_create_impl(kmm_index *ix, const int32_t *h2i, const int32_t *n
     size_t occ_max = KMM_OCC_MAX_BYTES;
     if (const char *env = getenv("KMM_OCC_MAX_BYTES")) // experiments: threshold of the bitmap prefilter
         occ_max = (size_t)strtoull(env, nullptr, 10);
-    const size_t occ_bytes = (size_t)((M + 31) / 32) * 4;
+    // bits per bucket: as many (1, 2, 4 or 8) as keep the bitmap within KMM_OCC_SWEET_BYTES — an entry sets
+    // the bit chosen by its k-mer's fingerprint, so every doubling halves the false-positive passes of
+    // single-entry buckets (10 M-k-mer index: 1 bit 19.7 ms, 2 bits 18.1 ms, 4 bits (10 MB) 21.5 ms per step)
+    // (2.5 M: 4 bits/2.5 MB 14.5 ms, 8 bits/5 MB 15.3 ms; 5 M: 2 bits 16.1, 4 bits/5 MB 16.3, 8 bits/10 MB 20.6;
+    //  15 M: 1 bit/3.75 MB 20.4, 2 bits/7.5 MB 21.3): the second bit is worth up to 5 MiB, further bits 3 MiB
+    int occ_shift = 0;
+    while (occ_shift < 3 &&
+           ((M << (occ_shift + 1)) + 7) / 8 <= (occ_shift == 0 ? KMM_OCC_SWEET_BYTES : KMM_OCC_SWEET_BYTES * 3 / 5))
+        occ_shift++;
+    if (const char *env = getenv("KMM_OCC_SHIFT")) // experiments: force 2^shift bitmap bits per bucket
+        occ_shift = atoi(env) < 0 ? 0 : (atoi(env) > 3 ? 3 : atoi(env));
+    const size_t occ_bytes = (size_t)(((M << occ_shift) + 31) / 32) * 4;
     const bool with_occ = occ_bytes <= occ_max;
+    ix->occ_shift = occ_shift;
     ix->wide = !with_occ;
     if (const char *env = getenv("KMM_WIDE_BUCKETS")) // experiments: force the bucket layout
         ix->wide = !with_occ && atoi(env) != 0;
@@ -603,6 +618,16 @@ static int index_create_impl(kmm_index *ix, const int32_t *h2i, const int32_t *n
                                0, ix->stream, p_km, p_nd, p_fr, N, ix->max_node_id, ix->entries,
                                (uint32_t *)d_err.p);
         hipError_t e = hipGetLastError();
+        // occupancy bitmap (16-byte layout only), built from the raw k-mers while they are still here
+        if (e == hipSuccess && with_occ) {
+            e = hipMalloc(&ix->occ, occ_bytes);
+            if (e == hipSuccess) e = hipMemsetAsync(ix->occ, 0, occ_bytes, ix->stream);
+            if (e == hipSuccess && N > 0) {
+                hipLaunchKernelGGL(k_build_occ, dim3(grid_for(ix, (N + 255) / 256, 16)), dim3(256), 0, ix->stream,
+                                   p_km, N, M, ix->magic, ix->occ_shift, ix->occ);
+                e = hipGetLastError();
+            }
+        }
         if (e == hipSuccess) e = hipStreamSynchronize(ix->stream);
         if (e == hipSuccess) e = hipMemcpy(&err, d_err.p, 4, hipMemcpyDeviceToHost);
         if (e != hipSuccess)
@@ -618,14 +643,6 @@ static int index_create_impl(kmm_index *ix, const int32_t *h2i, const int32_t *n
     if (err & 2u)
         return fail(KMM_ERR_INDEX, "index inconsistent: a node id lies outside [0, max_node_id=%lld]",
                     (long long)ix->max_node_id);
-    // occupancy bitmap (narrow layout only)
-    if (with_occ) {
-        HIPCHK(hipMalloc(&ix->occ, occ_bytes));
-        hipLaunchKernelGGL(k_build_occ, dim3(grid_for(ix, (int64_t)((M / 32 + 256) / 256), 16)), dim3(256),
-                           0, ix->stream, ix->buckets, M, ix->occ);
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipStreamSynchronize(ix->stream));
-    }
     // default partition granularity: 1 MiB bucket-table slices, coarser if that needs > 1024 parts
     ix->part_shift = 16;
     while (((M + (1ull << ix->part_shift) - 1) >> ix->part_shift) > (uint64_t)KMM_MAX_PARTS &&
@@ -1345,6 +1362,8 @@ int kmm_get_param(kmm_index_t *ix, const char *name, int64_t *value)
         *value = ix->dynamic_schedule ? 1 : 0;
     else if (!strcmp(name, "occupancy_filter"))
         *value = (ix->use_occ && ix->occ) ? 1 : 0;
+    else if (!strcmp(name, "occupancy_bits_per_bucket"))
+        *value = (ix->use_occ && ix->occ) ? (1 << ix->occ_shift) : 0;
     else if (!strcmp(name, "wide_buckets"))
         *value = ix->wide ? 1 : 0;
     else if (!strcmp(name, "n_partitions"))

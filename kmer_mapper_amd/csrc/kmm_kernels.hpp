@@ -377,18 +377,15 @@ __global__ void k_pack_entries(const uint64_t *__restrict__ kmers, const int32_t
     }
 }
 
-// One bit per bucket: set iff the bucket holds at least one entry.
-__global__ void k_build_occ(const uint4 *__restrict__ buckets, uint64_t modulo, uint32_t *__restrict__ occ)
+// Occupancy bitmap with 2^shift bits per bucket: every index entry sets bit (h << shift) | (fingerprint of
+// its k-mer & (2^shift - 1)).  The bitmap must be zeroed first.
+__global__ void k_build_occ(const uint64_t *__restrict__ kmers, int64_t n, uint64_t modulo, uint64_t magic,
+                            int shift, uint32_t *__restrict__ occ)
 {
-    const uint64_t n_words = (modulo + 31) / 32;
-    for (uint64_t wd = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; wd < n_words;
-         wd += (uint64_t)gridDim.x * blockDim.x) {
-        uint32_t bits = 0;
-        for (int i = 0; i < 32; ++i) {
-            const uint64_t h = wd * 32 + i;
-            if (h < modulo && (buckets[h].w & 3u))
-                bits |= 1u << i;
-        }
-        occ[wd] = bits;
+    const uint32_t sub = (1u << shift) - 1u;
+    for (int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; l < n; l += (int64_t)gridDim.x * blockDim.x) {
+        const uint64_t km = kmers[l];
+        const uint64_t bit = (fastmod(km, modulo, magic) << shift) | (kmer_fp16(km) & sub);
+        atomicOr(&occ[bit >> 5], 1u << (bit & 31u));
     }
 }

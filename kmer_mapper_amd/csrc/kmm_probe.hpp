@@ -22,6 +22,7 @@ struct IndexView {
     const uint4 *buckets;
     const uint4 *entries;
     const uint32_t *occ; // optional L2-resident occupancy bitmap (bit h = bucket h non-empty), or null
+    int occ_shift;       // log2(bits per bucket) of the bitmap: bit index = (h << occ_shift) | low fingerprint bits
     int wide;            // 1: 32-byte buckets with two inline entries (never together with occ)
     uint32_t *counts;
     unsigned long long *stats; // [0] k-mer lookups performed, [1] count increments (hits)
@@ -198,13 +199,20 @@ __device__ __forceinline__ void probe_batch_impl(const IndexView &iv, NodeAgg &a
     if (FILTER) {
         // Small indexes: one bit per bucket fits the XCD's L2 (4 MiB), and an L2 hit is ~4.6x cheaper
         // than the HBM request it saves for every k-mer whose bucket is empty.
+        // With 2^occ_shift bits per bucket, an entry sets the bit selected by the low bits of its k-mer's
+        // fingerprint: a k-mer that is not in the index then passes a single-entry bucket only half (or a
+        // quarter) of the time.
+        uint64_t bit[U];
         uint32_t w[U];
+        const uint32_t sub = (1u << iv.occ_shift) - 1u;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            bit[u] = (h[u] << iv.occ_shift) | (kmer_fp16(q[u]) & sub);
+            w[u] = ((valid >> u) & 1u) ? iv.occ[bit[u] >> 5] : 0u;
+        }
 #pragma unroll
         for (int u = 0; u < U; ++u)
-            w[u] = ((valid >> u) & 1u) ? iv.occ[h[u] >> 5] : 0u;
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-            if (!((w[u] >> (h[u] & 31u)) & 1u))
+            if (!((w[u] >> (bit[u] & 31u)) & 1u))
                 valid &= ~(1u << u);
     }
     uint4 b[U];
