@@ -342,7 +342,8 @@ constexpr size_t KMM_STAT_BYTES = (size_t)KMM_STAT_SHARDS * KMM_STAT_STRIDE * 8;
 // Layout choice by index size (profiles/r01/partitioned_path_ablation.md, ms per 1.2e9 k-mers, same box):
 //   16-byte buckets + L2 bitmap vs 32-byte buckets without: 10 M entries 20.2 / 24.4, 15 M 21.4 / 26.3,
 //   20 M 23.6 / 27.9, 40 M (10 MB bitmap) 28.7 / 30.3, 100 M (25 MB bitmap) 34.0 / 31.7.
-constexpr size_t KMM_OCC_MAX_BYTES = (size_t)12 << 20;  // 100 M buckets at one bit per bucket
+// (with fingerprints: 55 M entries 28.1 bitmap / 30.9 wide, 70 M 29.2 / 31.2, 100 M 30.6 / 31.7, 200 M 32.4 / 27.9)
+constexpr size_t KMM_OCC_MAX_BYTES = (size_t)20 << 20;  // 168 M buckets at one bit per bucket
 constexpr size_t KMM_OCC_SWEET_BYTES = (size_t)5 << 20; // bitmap size that still lives in the 4 MiB L2s + MALL
 constexpr int TILE_S = 4;
 constexpr int TILE_T = 256 * TILE_S;
