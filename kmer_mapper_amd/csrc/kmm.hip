@@ -460,7 +460,7 @@ int check_k(int k)
 // ================================================================================================
 extern "C" {
 
-const char *kmm_version(void) { return "kmm 0.2.0 (gfx950)"; }
+const char *kmm_version(void) { return "kmm 0.3.0 (gfx950)"; }
 
 const char *kmm_last_error(void) { return g_err.c_str(); }
 
