@@ -285,6 +285,7 @@ def main():
                 "n_partitions": dev.get_param("n_partitions"),
                 "occupancy_filter": bool(dev.get_param("occupancy_filter")),
                 "occupancy_bits_per_bucket": dev.get_param("occupancy_bits_per_bucket"),
+                "bloom_filter_bytes": dev.get_param("bloom_filter_bytes"),
                 "final_reduce_ms": round(reduce_s * 1e3, 3) if world > 1 else 0.0,
                 "parallelism": "reads sharded by batch over %d GPU(s), index replicated, one RCCL sum" % world,
                 "kernel_ms_per_step": {n: round(t[0] / args.steps, 3) for n, t in timing.items() if t[1]},

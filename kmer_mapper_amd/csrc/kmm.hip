@@ -151,6 +151,7 @@ struct kmm_index {
     uint32_t *occ = nullptr;           // occupancy bitmap, only for indexes small enough (see occ_max_bytes)
     bool use_occ = true;
     int occ_shift = 0;                 // log2(bitmap bits per bucket)
+    uint32_t bloom_words = 0;          // != 0: occ is a word-blocked Bloom filter
     bool wide = false;                 // 32-byte buckets (chosen when the index is too large for the bitmap)
     uint32_t *counts = nullptr;
     uint32_t *own_counts_buf = nullptr;
@@ -188,6 +189,7 @@ IndexView view_of(const kmm_index *ix)
     v.entries = ix->entries;
     v.occ = ix->use_occ ? ix->occ : nullptr;
     v.occ_shift = ix->occ_shift;
+    v.bloom_words = ix->bloom_words;
     v.wide = ix->wide ? 1 : 0;
     v.counts = ix->counts;
     v.stats = ix->stats;
@@ -344,6 +346,8 @@ constexpr size_t KMM_STAT_BYTES = (size_t)KMM_STAT_SHARDS * KMM_STAT_STRIDE * 8;
 //   20 M 23.6 / 27.9, 40 M (10 MB bitmap) 28.7 / 30.3, 100 M (25 MB bitmap) 34.0 / 31.7.
 // (with fingerprints: 55 M entries 28.1 bitmap / 30.9 wide, 70 M 29.2 / 31.2, 100 M 30.6 / 31.7, 200 M 32.4 / 27.9)
 constexpr size_t KMM_OCC_MAX_BYTES = (size_t)20 << 20;  // 168 M buckets at one bit per bucket
+constexpr size_t KMM_BLOOM_MAX_BYTES = (size_t)4 << 20;  // Bloom filter size cap (L2 of one XCD)
+constexpr int64_t KMM_BLOOM_MAX_ENTRIES = 20000000;     // beyond: fewer than ~2.5 bits per key, no better than the bitmap
 constexpr size_t KMM_OCC_SWEET_BYTES = (size_t)5 << 20; // bitmap size that still lives in the 4 MiB L2s + MALL
 constexpr int TILE_S = 4;
 constexpr int TILE_T = 256 * TILE_S;
@@ -561,8 +565,27 @@ static int index_create_impl(kmm_index *ix, const int32_t *h2i, const int32_t *n
         occ_shift++;
     if (const char *env = getenv("KMM_OCC_SHIFT")) // experiments: force 2^shift bitmap bits per bucket
         occ_shift = atoi(env) < 0 ? 0 : (atoi(env) > 3 ? 3 : atoi(env));
-    const size_t occ_bytes = (size_t)(((M << occ_shift) + 31) / 32) * 4;
-    const bool with_occ = occ_bytes <= occ_max;
+    size_t occ_bytes = (size_t)(((M << occ_shift) + 31) / 32) * 4;
+    const bool with_occ = (size_t)((M + 31) / 32) * 4 <= occ_max || occ_bytes <= occ_max;
+    // Up to ~13 M entries a word-blocked Bloom filter (two bits per key inside one 32-bit word, chosen by a
+    // hash of the k-mer alone) of at most 4 MiB beats the per-bucket bitmap: 10 M entries, ms per step:
+    // bitmap 2 bits/bucket (5 MB) 18.0; Bloom 2.5 MB 19.6, 4 MB 16.7, 5 MB 17.0, 6.5 MB 18.1.  13 M: Bloom 4 MiB 18.3,
+    // bitmap 19.5; 16 M: Bloom 6 MiB 19.9, bitmap 20.5; 20 M and 30 M: equal.
+    int64_t bloom_max_entries = KMM_BLOOM_MAX_ENTRIES;
+    if (const char *env = getenv("KMM_BLOOM_MAX_ENTRIES")) // experiments
+        bloom_max_entries = strtoll(env, nullptr, 10);
+    if (with_occ && N <= bloom_max_entries) {
+        size_t bb = (size_t)N * 2;             // 16 bits per key is plenty
+        const size_t cap = N <= 13000000 ? KMM_BLOOM_MAX_BYTES : KMM_BLOOM_MAX_BYTES * 3 / 2; // 13-20 M: 6 MiB
+        if (bb > cap) bb = cap;
+        if (bb < 64) bb = 64;
+        if (const char *env = getenv("KMM_BLOOM_BYTES")) // experiments: filter size; 0 = per-bucket bitmap
+            bb = (size_t)strtoull(env, nullptr, 10);
+        if (bb >= 4) {
+            ix->bloom_words = (uint32_t)(bb / 4);
+            occ_bytes = (size_t)ix->bloom_words * 4;
+        }
+    }
     ix->occ_shift = occ_shift;
     ix->wide = !with_occ;
     if (const char *env = getenv("KMM_WIDE_BUCKETS")) // experiments: force the bucket layout
@@ -624,8 +647,12 @@ static int index_create_impl(kmm_index *ix, const int32_t *h2i, const int32_t *n
             e = hipMalloc(&ix->occ, occ_bytes);
             if (e == hipSuccess) e = hipMemsetAsync(ix->occ, 0, occ_bytes, ix->stream);
             if (e == hipSuccess && N > 0) {
-                hipLaunchKernelGGL(k_build_occ, dim3(grid_for(ix, (N + 255) / 256, 16)), dim3(256), 0, ix->stream,
-                                   p_km, N, M, ix->magic, ix->occ_shift, ix->occ);
+                if (ix->bloom_words)
+                    hipLaunchKernelGGL(k_build_bloom, dim3(grid_for(ix, (N + 255) / 256, 16)), dim3(256), 0,
+                                       ix->stream, p_km, N, ix->bloom_words, ix->occ);
+                else
+                    hipLaunchKernelGGL(k_build_occ, dim3(grid_for(ix, (N + 255) / 256, 16)), dim3(256), 0, ix->stream,
+                                       p_km, N, M, ix->magic, ix->occ_shift, ix->occ);
                 e = hipGetLastError();
             }
         }
@@ -1363,8 +1390,10 @@ int kmm_get_param(kmm_index_t *ix, const char *name, int64_t *value)
         *value = ix->dynamic_schedule ? 1 : 0;
     else if (!strcmp(name, "occupancy_filter"))
         *value = (ix->use_occ && ix->occ) ? 1 : 0;
+    else if (!strcmp(name, "bloom_filter_bytes"))
+        *value = (ix->use_occ && ix->occ) ? (int64_t)ix->bloom_words * 4 : 0;
     else if (!strcmp(name, "occupancy_bits_per_bucket"))
-        *value = (ix->use_occ && ix->occ) ? (1 << ix->occ_shift) : 0;
+        *value = (ix->use_occ && ix->occ && !ix->bloom_words) ? (1 << ix->occ_shift) : 0;
     else if (!strcmp(name, "wide_buckets"))
         *value = ix->wide ? 1 : 0;
     else if (!strcmp(name, "n_partitions"))

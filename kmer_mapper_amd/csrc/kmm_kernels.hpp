@@ -377,6 +377,17 @@ __global__ void k_pack_entries(const uint64_t *__restrict__ kmers, const int32_t
     }
 }
 
+// Word-blocked Bloom filter over the index k-mers: two bits inside one 32-bit word per key.
+__global__ void k_build_bloom(const uint64_t *__restrict__ kmers, int64_t n, uint32_t n_words,
+                              uint32_t *__restrict__ occ)
+{
+    for (int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; l < n; l += (int64_t)gridDim.x * blockDim.x) {
+        const uint64_t hs = kmers[l] * 0x9E3779B97F4A7C15ull;
+        const uint32_t wi = (uint32_t)(((hs >> 32) * (uint64_t)n_words) >> 32);
+        atomicOr(&occ[wi], (1u << ((hs >> 7) & 31u)) | (1u << ((hs >> 12) & 31u)));
+    }
+}
+
 // Occupancy bitmap with 2^shift bits per bucket: every index entry sets bit (h << shift) | (fingerprint of
 // its k-mer & (2^shift - 1)).  The bitmap must be zeroed first.
 __global__ void k_build_occ(const uint64_t *__restrict__ kmers, int64_t n, uint64_t modulo, uint64_t magic,

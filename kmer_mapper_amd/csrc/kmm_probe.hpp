@@ -23,6 +23,8 @@ struct IndexView {
     const uint4 *entries;
     const uint32_t *occ; // optional L2-resident occupancy bitmap (bit h = bucket h non-empty), or null
     int occ_shift;       // log2(bits per bucket) of the bitmap: bit index = (h << occ_shift) | low fingerprint bits
+    uint32_t bloom_words; // != 0: `occ` is a word-blocked Bloom filter of that many 32-bit words (two bits per key
+                          // inside one word chosen by a hash of the k-mer) instead of the per-bucket bitmap
     int wide;            // 1: 32-byte buckets with two inline entries (never together with occ)
     uint32_t *counts;
     unsigned long long *stats; // [0] k-mer lookups performed, [1] count increments (hits)
@@ -202,6 +204,20 @@ __device__ __forceinline__ void probe_batch_impl(const IndexView &iv, NodeAgg &a
         // With 2^occ_shift bits per bucket, an entry sets the bit selected by the low bits of its k-mer's
         // fingerprint: a k-mer that is not in the index then passes a single-entry bucket only half (or a
         // quarter) of the time.
+        if (iv.bloom_words) {
+            uint32_t w[U], need[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint64_t hs = q[u] * 0x9E3779B97F4A7C15ull;
+                const uint32_t wi = (uint32_t)(((hs >> 32) * (uint64_t)iv.bloom_words) >> 32);
+                need[u] = (1u << ((hs >> 7) & 31u)) | (1u << ((hs >> 12) & 31u));
+                w[u] = ((valid >> u) & 1u) ? iv.occ[wi] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if ((w[u] & need[u]) != need[u])
+                    valid &= ~(1u << u);
+        } else {
         uint64_t bit[U];
         uint32_t w[U];
         const uint32_t sub = (1u << iv.occ_shift) - 1u;
@@ -214,6 +230,7 @@ __device__ __forceinline__ void probe_batch_impl(const IndexView &iv, NodeAgg &a
         for (int u = 0; u < U; ++u)
             if (!((w[u] >> (bit[u] & 31u)) & 1u))
                 valid &= ~(1u << u);
+        }
     }
     uint4 b[U];
 #pragma unroll
