@@ -57,11 +57,13 @@ int kmm_device_count(int *n_devices);
  * (util.py:60-62): hashes_to_index int32[modulo], n_kmers int32[modulo], kmers uint64[n_entries],
  * nodes int32[n_entries], frequencies uint16[n_entries].  They are copied to HBM and repacked on the
  * GPU (16-byte bucket records with the single entry of a bucket stored inline, 16-byte {kmer,node,freq}
- * entries, and for small indexes an L2-resident occupancy bitmap).  Unlike the
+ * entries, and for small and medium indexes an L2-resident Bloom filter / occupancy bitmap that rejects
+ * most absent k-mers without an HBM access; large indexes get 32-byte buckets).  Unlike the
  * reference (no bounds checks, mapper.pyx:17) the arrays are validated: every non-empty bucket
  * must lie inside [0, n_entries) and every node inside [0, max_node_id], else KMM_ERR_INDEX.
  * Environment knobs for experiments, read here: KMM_OCC_MAX_BYTES (largest occupancy bitmap that is still
- * built; 0 forces the wide 32-byte bucket layout), KMM_WIDE_BUCKETS=0 (16-byte buckets without bitmap).
+ * built; 0 forces the wide 32-byte bucket layout), KMM_WIDE_BUCKETS=0 (16-byte buckets without filter),
+ * KMM_BLOOM_BYTES (Bloom filter size; 0 = per-bucket bitmap), KMM_BLOOM_MAX_ENTRIES, KMM_OCC_SHIFT.
  */
 int kmm_index_create(const int32_t *hashes_to_index, const int32_t *n_kmers, uint64_t modulo,
                      const uint64_t *kmers, const int32_t *nodes, const uint16_t *frequencies,
