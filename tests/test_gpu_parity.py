@@ -768,3 +768,35 @@ def test_cli_tiny_chunk_size_grows_until_a_record_fits(kmm, syn, oracle, tmp_pat
     run_argument_parser(["map", "-i", idx_path, "-f", fq, "-o", out, "-c", "64"])
     expect, _ = oracle.map_reads(index, index.max_node_id(), bases, offs, 31)
     assert np.array_equal(np.load(out + ".npy"), expect)
+
+
+@pytest.mark.parametrize("env", [
+    {"KMM_BLOOM_BYTES": "0", "KMM_OCC_SHIFT": "0"},        # per-bucket bitmap, 1 bit
+    {"KMM_BLOOM_BYTES": "0", "KMM_OCC_SHIFT": "1"},        # fingerprint-keyed, 2 bits
+    {"KMM_BLOOM_BYTES": "0", "KMM_OCC_SHIFT": "3"},        # 8 bits
+    {"KMM_BLOOM_BYTES": "4"},                               # a one-word Bloom filter: saturated, passes everything
+    {"KMM_BLOOM_BYTES": "256"},                             # heavily loaded Bloom filter
+    {"KMM_BLOOM_BYTES": "1048576"},                         # sparse Bloom filter
+])
+def test_prefilter_variants_never_drop_a_hit(kmm, syn, oracle, monkeypatch, env):
+    """Whatever the filter flavour and its false-positive rate, results stay bit-exact: a filter may only
+    reject k-mers that are not in the index."""
+    for key, val in env.items():
+        monkeypatch.setenv(key, val)
+    index, genome = syn.make_index(6000, seed=241)
+    mx = index.max_node_id()
+    bases, offs = syn.make_ragged_reads(genome, 3000, 0, 200, seed=242)
+    expect, _ = oracle.map_reads(index, mx, bases, offs, 31)
+    expect_rc, _ = oracle.map_reads(index, mx, bases, offs, 31, also_revcomp=True, max_index_lookup_frequency=2)
+    with kmm.DeviceIndex.from_index(index, mx) as dev:
+        assert dev.get_param("occupancy_filter") == 1
+        if "KMM_BLOOM_BYTES" in env and env["KMM_BLOOM_BYTES"] != "0":
+            assert dev.get_param("bloom_filter_bytes") == int(env["KMM_BLOOM_BYTES"])
+        else:
+            assert dev.get_param("occupancy_bits_per_bucket") == 1 << int(env["KMM_OCC_SHIFT"])
+        dev.map_reads(bases, offs, 31)
+        assert np.array_equal(dev.get_node_counts(), expect)
+        dev.reset(); dev.map_reads(bases, offs, 31, 2, also_revcomp=True)
+        assert np.array_equal(dev.get_node_counts(), expect_rc)
+        dev.reset(); dev.set_param("occupancy_filter", 0); dev.map_reads(bases, offs, 31)
+        assert np.array_equal(dev.get_node_counts(), expect)
