@@ -403,7 +403,10 @@ int launch_map_reads(kmm_index *ix, const ReadsView &rv, int k, int max_freq, in
             HIPCHK(hipMemsetAsync(ix->queue, 0, sizeof(unsigned long long), ix->stream));
         const dim3 grid(dynamic ? (unsigned)slots : (unsigned)grid_for_tiles(ix, n_tiles));
         unsigned long long *queue = dynamic ? ix->queue : nullptr;
-        if (iv.occ)
+        if (iv.occ && iv.wide)
+            hipLaunchKernelGGL((k_map_reads<TILE_S, MODE, PROBE_WIDE_FILTER>), grid, dim3(256), 0, ix->stream, rv,
+                               iv, k, max_freq, also_rc, (int64_t)0, n_tiles, queue, ix->dyn_chunk);
+        else if (iv.occ)
             hipLaunchKernelGGL((k_map_reads<TILE_S, MODE, PROBE_BITMAP>), grid, dim3(256), 0, ix->stream, rv, iv, k,
                                max_freq, also_rc, (int64_t)0, n_tiles, queue, ix->dyn_chunk);
         else if (iv.wide)
@@ -588,8 +591,8 @@ static int index_create_impl(kmm_index *ix, const int32_t *h2i, const int32_t *n
     }
     ix->occ_shift = occ_shift;
     ix->wide = !with_occ;
-    if (const char *env = getenv("KMM_WIDE_BUCKETS")) // experiments: force the bucket layout
-        ix->wide = !with_occ && atoi(env) != 0;
+    if (const char *env = getenv("KMM_WIDE_BUCKETS")) // experiments: force the bucket layout (0 / 1)
+        ix->wide = atoi(env) != 0;
     HIPCHK(hipMalloc(&ix->buckets, sizeof(uint4) * (size_t)M * (ix->wide ? 2 : 1)));
     HIPCHK(hipMalloc(&ix->entries, sizeof(uint4) * (size_t)(N > 0 ? N : 1)));
     HIPCHK(hipMalloc(&ix->own_counts_buf, sizeof(uint32_t) * (size_t)(ix->max_node_id + 1)));
@@ -805,7 +808,10 @@ int kmm_map_kmers(kmm_index_t *ix, const uint64_t *kmers, int64_t n, int max_fre
             HIPCHK(hipMemsetAsync(ix->queue, 0, sizeof(unsigned long long), ix->stream));
         const dim3 grid(dynamic ? (unsigned)slots : (unsigned)grid_for_tiles(ix, n_spans));
         unsigned long long *queue = dynamic ? ix->queue : nullptr;
-        if (iv.occ)
+        if (iv.occ && iv.wide)
+            hipLaunchKernelGGL((k_map_kmers<U, PROBE_WIDE_FILTER>), grid, dim3(256), 0, ix->stream, d_kmers, n, iv,
+                               max_freq, also_revcomp ? 1 : 0, k, queue, ix->dyn_chunk);
+        else if (iv.occ)
             hipLaunchKernelGGL((k_map_kmers<U, PROBE_BITMAP>), grid, dim3(256), 0, ix->stream, d_kmers, n, iv,
                                max_freq, also_revcomp ? 1 : 0, k, queue, ix->dyn_chunk);
         else if (iv.wide)

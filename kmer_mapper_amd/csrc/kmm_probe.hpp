@@ -184,6 +184,47 @@ __device__ __forceinline__ void count_if_match(const IndexView &iv, NodeAgg &agg
         agg_add(iv, agg, e.z, hits);
 }
 
+// Pre-filter stage shared by the probe flavours: clears the `valid` bit of every k-mer the L2/Infinity-Cache
+// resident filter proves absent from the index (Bloom filter keyed by the k-mer, or per-bucket bitmap keyed
+// by bucket and fingerprint bits).  One 4-byte access per k-mer, all U in flight together.
+template <int U>
+__device__ __forceinline__ uint32_t filter_stage(const IndexView &iv, const uint64_t (&q)[U],
+                                                 const uint64_t (&h)[U], uint32_t valid)
+{
+    if (iv.bloom_words) {
+        // Word-blocked Bloom filter: the hash of the k-mer picks one 32-bit word and two bits inside it.
+        uint32_t w[U], need[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint64_t hs = q[u] * 0x9E3779B97F4A7C15ull;
+            const uint32_t wi = (uint32_t)(((hs >> 32) * (uint64_t)iv.bloom_words) >> 32);
+            need[u] = (1u << ((hs >> 7) & 31u)) | (1u << ((hs >> 12) & 31u));
+            w[u] = ((valid >> u) & 1u) ? iv.occ[wi] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if ((w[u] & need[u]) != need[u])
+                valid &= ~(1u << u);
+    } else {
+        // Per-bucket bitmap with 2^occ_shift bits per bucket: an entry sets the bit selected by the low
+        // bits of its k-mer's fingerprint, so a k-mer that is not in the index passes a single-entry bucket
+        // only 1 / 2^occ_shift of the time.
+        uint64_t bit[U];
+        uint32_t w[U];
+        const uint32_t sub = (1u << iv.occ_shift) - 1u;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            bit[u] = (h[u] << iv.occ_shift) | (kmer_fp16(q[u]) & sub);
+            w[u] = ((valid >> u) & 1u) ? iv.occ[bit[u] >> 5] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (!((w[u] >> (bit[u] & 31u)) & 1u))
+                valid &= ~(1u << u);
+    }
+    return valid;
+}
+
 // The probe of mapper.pyx:53-69 for U k-mers per lane.  All U bucket gathers are in flight before
 // any is consumed; empty and single-entry buckets (the common cases) finish there.  Buckets with
 // two or more entries (hash collisions, k-mers present under several nodes) then load their first
@@ -198,40 +239,8 @@ __device__ __forceinline__ void probe_batch_impl(const IndexView &iv, NodeAgg &a
 #pragma unroll
     for (int u = 0; u < U; ++u)
         h[u] = fastmod(q[u], iv.modulo, iv.magic);
-    if (FILTER) {
-        // Small indexes: one bit per bucket fits the XCD's L2 (4 MiB), and an L2 hit is ~4.6x cheaper
-        // than the HBM request it saves for every k-mer whose bucket is empty.
-        // With 2^occ_shift bits per bucket, an entry sets the bit selected by the low bits of its k-mer's
-        // fingerprint: a k-mer that is not in the index then passes a single-entry bucket only half (or a
-        // quarter) of the time.
-        if (iv.bloom_words) {
-            uint32_t w[U], need[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const uint64_t hs = q[u] * 0x9E3779B97F4A7C15ull;
-                const uint32_t wi = (uint32_t)(((hs >> 32) * (uint64_t)iv.bloom_words) >> 32);
-                need[u] = (1u << ((hs >> 7) & 31u)) | (1u << ((hs >> 12) & 31u));
-                w[u] = ((valid >> u) & 1u) ? iv.occ[wi] : 0u;
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u)
-                if ((w[u] & need[u]) != need[u])
-                    valid &= ~(1u << u);
-        } else {
-        uint64_t bit[U];
-        uint32_t w[U];
-        const uint32_t sub = (1u << iv.occ_shift) - 1u;
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            bit[u] = (h[u] << iv.occ_shift) | (kmer_fp16(q[u]) & sub);
-            w[u] = ((valid >> u) & 1u) ? iv.occ[bit[u] >> 5] : 0u;
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-            if (!((w[u] >> (bit[u] & 31u)) & 1u))
-                valid &= ~(1u << u);
-        }
-    }
+    if (FILTER)
+        valid = filter_stage<U>(iv, q, h, valid);
     uint4 b[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -278,17 +287,21 @@ __device__ __forceinline__ void probe_batch_impl(const IndexView &iv, NodeAgg &a
 // Same probe on the wide (32-byte) bucket layout: one L2-missing gather (A) resolves empty and single
 // buckets, two-entry buckets add an L2 hit (B), only >= 3 entries (2.9 % of probes at load factor 0.5) walk
 // `entries`.
-template <int U>
+template <int U, bool FILTER>
 __device__ __forceinline__ void probe_batch_wide(const IndexView &iv, NodeAgg &agg, LaneStats &ls,
                                                  const uint64_t (&q)[U], uint32_t valid, int max_freq)
 {
     uint32_t &hits = ls.hits;
     ls.lookups += (uint32_t)__popc(valid);
     uint64_t h[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+        h[u] = fastmod(q[u], iv.modulo, iv.magic);
+    if (FILTER)
+        valid = filter_stage<U>(iv, q, h, valid);
     uint4 a[U], b[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-        h[u] = fastmod(q[u], iv.modulo, iv.magic);
         a[u] = make_uint4(0u, 0u, 0u, 0u);
         if ((valid >> u) & 1u)
             a[u] = iv.buckets[2 * h[u]];
@@ -331,7 +344,7 @@ __device__ __forceinline__ void probe_batch_wide(const IndexView &iv, NodeAgg &a
 
 // Probe flavours are separate kernel instantiations (not run-time branches) so that each keeps its own
 // register budget: the bitmap flavour runs at 8 waves/SIMD, the wide one needs ~84 VGPRs.
-enum { PROBE_NARROW = 0, PROBE_BITMAP = 1, PROBE_WIDE = 2 };
+enum { PROBE_NARROW = 0, PROBE_BITMAP = 1, PROBE_WIDE = 2, PROBE_WIDE_FILTER = 3 };
 
 template <int U, int PROBE>
 __device__ __forceinline__ void probe_batch(const IndexView &iv, NodeAgg &agg, LaneStats &st,
@@ -340,7 +353,9 @@ __device__ __forceinline__ void probe_batch(const IndexView &iv, NodeAgg &agg, L
     if (PROBE == PROBE_BITMAP)
         probe_batch_impl<U, true>(iv, agg, st, q, valid, max_freq);
     else if (PROBE == PROBE_WIDE)
-        probe_batch_wide<U>(iv, agg, st, q, valid, max_freq);
+        probe_batch_wide<U, false>(iv, agg, st, q, valid, max_freq);
+    else if (PROBE == PROBE_WIDE_FILTER)
+        probe_batch_wide<U, true>(iv, agg, st, q, valid, max_freq);
     else
         probe_batch_impl<U, false>(iv, agg, st, q, valid, max_freq);
 }
