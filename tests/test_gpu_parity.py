@@ -777,6 +777,8 @@ def test_cli_tiny_chunk_size_grows_until_a_record_fits(kmm, syn, oracle, tmp_pat
     {"KMM_BLOOM_BYTES": "4"},                               # a one-word Bloom filter: saturated, passes everything
     {"KMM_BLOOM_BYTES": "256"},                             # heavily loaded Bloom filter
     {"KMM_BLOOM_BYTES": "1048576"},                         # sparse Bloom filter
+    {"KMM_WIDE_BUCKETS": "1", "KMM_BLOOM_BYTES": "4096"},   # wide buckets behind a Bloom filter
+    {"KMM_WIDE_BUCKETS": "1", "KMM_BLOOM_BYTES": "0", "KMM_OCC_SHIFT": "1"},   # wide buckets behind the bitmap
 ])
 def test_prefilter_variants_never_drop_a_hit(kmm, syn, oracle, monkeypatch, env):
     """Whatever the filter flavour and its false-positive rate, results stay bit-exact: a filter may only
@@ -790,6 +792,7 @@ def test_prefilter_variants_never_drop_a_hit(kmm, syn, oracle, monkeypatch, env)
     expect_rc, _ = oracle.map_reads(index, mx, bases, offs, 31, also_revcomp=True, max_index_lookup_frequency=2)
     with kmm.DeviceIndex.from_index(index, mx) as dev:
         assert dev.get_param("occupancy_filter") == 1
+        assert dev.get_param("wide_buckets") == int(env.get("KMM_WIDE_BUCKETS", "0"))
         if "KMM_BLOOM_BYTES" in env and env["KMM_BLOOM_BYTES"] != "0":
             assert dev.get_param("bloom_filter_bytes") == int(env["KMM_BLOOM_BYTES"])
         else:
