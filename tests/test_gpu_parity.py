@@ -803,3 +803,20 @@ def test_prefilter_variants_never_drop_a_hit(kmm, syn, oracle, monkeypatch, env)
         assert np.array_equal(dev.get_node_counts(), expect_rc)
         dev.reset(); dev.set_param("occupancy_filter", 0); dev.map_reads(bases, offs, 31)
         assert np.array_equal(dev.get_node_counts(), expect)
+
+
+def test_empty_index(kmm, oracle):
+    """An index without entries: every lookup misses, on all layouts."""
+    import types
+    M = 1009
+    index = types.SimpleNamespace(_hashes_to_index=np.zeros(M, np.int32), _n_kmers=np.zeros(M, np.int32),
+                                  _nodes=np.zeros(0, np.int32), _kmers=np.zeros(0, np.uint64),
+                                  _frequencies=np.zeros(0, np.uint16), _modulo=M)
+    b = batch(["ACGTACGTACGTAACCGGTT", "TTTTTTTTTTTT"])
+    km = np.arange(1000, dtype=np.uint64)
+    with kmm.DeviceIndex.from_index(index, 5) as dev:
+        dev.map_reads(b.bases, b.offsets, 5)
+        dev.map_kmers(km)
+        assert dev.get_node_counts().tolist() == [0] * 6
+        assert dev.in_index(km).sum() == 0
+        assert dev.get_stats() == (16 + 8 + 1000, 0)
