@@ -108,7 +108,7 @@ def main():
     k, L, R = args.kmer_size, args.read_len, args.reads
     t_setup = time.time()
     index, genome = syn.make_index(args.index_kmers, k=k, seed=1, skewed=args.skewed, modulo=args.modulo,
-                                   gpu_builder=not args.numpy_builder)   # untimed setup; identical arrays
+                                   gpu_builder=not args.numpy_builder, device=local_rank)   # untimed setup; identical arrays
     mx = index.max_node_id()
     log("index: %d entries, modulo %d, max_node_id %d (%.1fs)"
         % (len(index._kmers), index._modulo, mx, time.time() - t_setup))

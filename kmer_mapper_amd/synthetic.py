@@ -44,7 +44,7 @@ def pack_kmers_at(codes, positions, k):
     return out
 
 
-def make_index(n_kmers, k=31, seed=1, skewed=False, plant=True, modulo=None, gpu_builder=False):
+def make_index(n_kmers, k=31, seed=1, skewed=False, plant=True, modulo=None, gpu_builder=False, device=0):
     """Returns (KmerIndex, genome codes).  gpu_builder: build the index arrays with kmm_build_index
     (bit-identical to the numpy construction, much faster for 1e8 entries)."""
     N = int(n_kmers)
@@ -67,8 +67,10 @@ def make_index(n_kmers, k=31, seed=1, skewed=False, plant=True, modulo=None, gpu
         nodes = np.concatenate([nodes, dup_n, hot_n])
     if modulo is None:
         modulo = next_prime(2 * N)
-    build = KmerIndex.from_flat_kmers_gpu if gpu_builder else KmerIndex.from_flat_kmers
-    index = build(kmers, nodes.astype(np.int64), modulo)
+    if gpu_builder:
+        index = KmerIndex.from_flat_kmers_gpu(kmers, nodes.astype(np.int64), modulo, device=device)
+    else:
+        index = KmerIndex.from_flat_kmers(kmers, nodes.astype(np.int64), modulo)
     return index, genome
 
 
