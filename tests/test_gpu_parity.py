@@ -820,3 +820,24 @@ def test_empty_index(kmm, oracle):
         assert dev.get_node_counts().tolist() == [0] * 6
         assert dev.in_index(km).sum() == 0
         assert dev.get_stats() == (16 + 8 + 1000, 0)
+
+
+def test_index_arrays_may_live_in_hbm(kmm, syn, oracle):
+    """kmm_index_create accepts device pointers for the five index arrays (used in place, no staging)."""
+    import torch
+    index, genome = syn.make_index(5000, seed=251)
+    mx = index.max_node_id()
+    bases, offs = syn.make_reads(genome, 2000, 100, seed=252)
+    expect, _ = oracle.map_reads(index, mx, bases, offs, 31)
+    dev_arrays = [torch.from_numpy(a).cuda() for a in
+                  (index._hashes_to_index, index._n_kmers)]
+    km = torch.from_numpy(index._kmers.view(np.int64)).cuda()          # uint64 bit patterns
+    nd = torch.from_numpy(index._nodes).cuda()
+    fr = torch.from_numpy(index._frequencies.view(np.int16)).cuda().view(torch.uint16) \
+        if hasattr(torch, "uint16") else None
+    if fr is None:
+        pytest.skip("torch without uint16")
+    torch.cuda.synchronize()
+    with kmm.DeviceIndex(dev_arrays[0], dev_arrays[1], index._modulo, km, nd, fr, mx) as dev:
+        dev.map_reads(bases, offs, 31)
+        assert np.array_equal(dev.get_node_counts(), expect)
