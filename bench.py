@@ -6,8 +6,9 @@
 
 One "step" = one pass of the hot path (kmm_map_reads_uniform: encode -> rolling 31-mer pack ->
 modulo -> bucket gather -> compare/filter -> atomic node counts) over one batch of synthetic reads
-that is already resident in HBM.  Workload at N=1: BASELINE configs[1] — 10 M synthetic 150 bp
-reads, k=31, 10 M-k-mer index.  With N ranks every rank maps its own 10 M-read batch per step
+that is already resident in HBM.  Workload at N=1 (default, --config 2): BASELINE configs[2] — 100 M
+synthetic 150 bp reads as batches of 10 M, k=31, 100 M-k-mer index (the headline config; --config 1 =
+configs[1], the 10 M-k-mer index).  With N ranks every rank maps its own 10 M-read batch per step
 (reads shard by chunk: weak scaling) against a replicated index and the per-rank uint32 count
 vectors are summed once with RCCL at the end of the job, inside the timed region.
 
@@ -50,8 +51,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", type=int, default=2, choices=(1, 2),
+                    help="BASELINE.json configs[]: 2 = 100 M-k-mer index (headline, default), 1 = 10 M-k-mer index; "
+                         "both map 10 M-read batches, so 10 steps = 100 M reads")
     ap.add_argument("--reads", type=int, default=10_000_000, help="reads per batch per GPU")
-    ap.add_argument("--index-kmers", type=int, default=10_000_000)
+    ap.add_argument("--index-kmers", type=int, default=None, help="overrides --config's index size")
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--numpy-builder", action="store_true", help="build the synthetic index with numpy instead of kmm_build_index")
     ap.add_argument("--modulo", type=int, default=None, help="hash-table size (default: smallest prime >= 2N)")
@@ -70,7 +74,9 @@ def main():
     ap.add_argument("--operator", action="store_true",
                     help="time the operator path instead: k-mers extracted once (kmm_extract_kmers) into HBM, "
                          "each step = kmm_map_kmers over them (drop-in for map_kmers_to_graph_index)")
-    ap.add_argument("--cpu-sample-reads", type=int, default=5_000_000)
+    ap.add_argument("--cpu-sample-reads", type=int, default=10_000_000,
+                    help="CPU baseline sample: a prefix of batch 0 (BASELINE.md section 3: 10 M-read prefix)")
+    ap.add_argument("--no-h2d-leg", action="store_true", help="skip the PCIe-inclusive measurement (value_incl_h2d)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl",
                     help="nccl (= RCCL, the real multi-GPU path) or gloo (rehearsal on a 1-GPU box: all "
@@ -78,6 +84,8 @@ def main():
     ap.add_argument("--max-freq", type=int, default=1000,
                     help="max_index_lookup_frequency (-1 filters every hit: timing ablation without atomics)")
     args = ap.parse_args()
+    if args.index_kmers is None:
+        args.index_kmers = {1: 10_000_000, 2: 100_000_000}[args.config]
 
     import torch
     import torch.distributed as dist
@@ -238,14 +246,17 @@ def main():
         traffic = None
         sector = None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and not args.skewed:
             try:
-                tj = json.load(open(tpath))
-                if (tj.get("reads") == R and tj.get("index_kmers") == args.index_kmers
-                        and tj.get("kernel") == dom and not args.skewed):
+                tj_all = json.load(open(tpath))
+                entries = tj_all.get("entries", [tj_all]) if isinstance(tj_all, dict) else tj_all
+                for tj in entries:      # one committed PMC pass per (kernel, batch size, index size)
+                    if (tj.get("reads") != R or tj.get("index_kmers") != args.index_kmers
+                            or tj.get("kernel") != dom):
+                        continue
                     traffic = tj.get("hbm_bytes_per_launch")
                     if "l2_miss_read_requests_per_kmer" in tj:
-                        # request-granular view: the probe is bound by the NUMBER of
+                        # request-granular view: random probes are bound by the NUMBER of
                         # requests — ~55 G/s for L2-missing reads, ~254 G/s for L2 hits, and the two add
                         miss, hit = tj["l2_miss_read_requests_per_kmer"], tj["l2_hits_per_kmer"]
                         sector = {
@@ -256,8 +267,15 @@ def main():
                             "hbm_bytes_per_kmer": round(traffic / kmers_per_launch, 1),
                             "measured_hbm_GB_per_s": round(traffic / avg_kernel_s / 1e9, 1),
                         }
+                    break
             except Exception:
                 traffic = None
+        if args.index_kmers == 100_000_000 and R == 10_000_000:
+            cfg_label = "configs[2] (100 M reads as batches of 10 M, 100 M-k-mer index)"
+        elif args.index_kmers == 10_000_000 and R == 10_000_000:
+            cfg_label = "configs[1] (10 M reads per batch, 10 M-k-mer index)"
+        else:
+            cfg_label = "custom"
         result = {
             "metric": "M k-mers mapped/sec (whole node), k=%d %dbp reads" % (k, L),
             "value": round(value, 1),
@@ -272,9 +290,9 @@ def main():
             "dtype": "u64",
             "data": "synthetic",
             "config": {
-                "workload": "configs[1]: %d synthetic %d bp reads per batch per GPU, k=%d, %d-k-mer index "
+                "workload": "%s: %d steps x %d synthetic %d bp reads per batch per GPU, k=%d, %d-k-mer index "
                             "(modulo %d, %d entries), reads resident in HBM, %s"
-                            % (R, L, k, args.index_kmers, index._modulo, len(index._kmers),
+                            % (cfg_label, args.steps, R, L, k, args.index_kmers, index._modulo, len(index._kmers),
                                "kmm_map_records on raw FASTQ chunks" if args.records else
                                "operator kmm_map_kmers on pre-extracted k-mers" if args.operator else
                                "fused kmm_map_reads" + ("" if args.general_path else "_uniform")),
@@ -306,13 +324,34 @@ def main():
             },
         }
 
+    # ---- PCIe-inclusive rate: the same steps with the reads in pinned host memory, staged by every call ----
+    if rank == 0 and world == 1 and not args.no_h2d_leg and not (args.records or args.operator or args.general_path):
+        host_batches = [b.cpu().pin_memory() for b in batches]
+        n_h = min(args.steps, 4)
+        dev.map_reads_uniform(host_batches[0], R, L, k, args.max_freq)      # warm the staging buffers
+        dev.synchronize()
+        th0 = time.perf_counter()
+        for i in range(n_h):
+            dev.map_reads_uniform(host_batches[i & 1], R, L, k, args.max_freq)
+        dev.synchronize()
+        th = time.perf_counter() - th0
+        result["value_incl_h2d"] = round(kmers_per_step * n_h / th / 1e6, 1)
+        result["config"]["h2d_leg"] = ("%d steps with the batch in pinned host memory, copied to HBM by every call "
+                                       "(double-buffered staging on a copy stream): %.1f GB/s of read bytes over PCIe"
+                                       % (n_h, R * L * n_h / th / 1e9))
+        del host_batches
+
     # ---- CPU baseline + parity on a bounded sample (rank 0, N=1 only) ---------------------------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle        # checker / reported baseline only
         n_s = min(args.cpu_sample_reads, R)
         sample = batches[0][: n_s * L].cpu().numpy()
         s_offs = np.arange(n_s + 1, dtype=np.int64) * L
-        n_threads = min(16, os.cpu_count() or 1)          # reference CLI default -t 16
+        try:
+            avail = len(os.sched_getaffinity(0))
+        except AttributeError:
+            avail = os.cpu_count() or 1
+        n_threads = min(16, avail)                         # reference CLI default -t 16
         oracle.map_reads(index, mx, sample[: 20000 * L], s_offs[:20001], k, n_threads=n_threads)  # warm
         tc0 = time.perf_counter()
         expect, n_k = oracle.map_reads(index, mx, sample, s_offs, k, n_threads=n_threads)
@@ -332,6 +371,18 @@ def main():
                       "oracle_map_reads, gcc -O3, %d pthreads, private count vectors summed"
                       % (n_s, n_k, tc, n_threads),
         }
+        # BASELINE.md section 3 also promises "all physical cores": every core this process may run on,
+        # capped so that the private count vectors (4 B x nodes per thread) stay within 32 GB
+        n_all = min(avail, max(1, int(32e9 // (4 * (mx + 1)))))
+        if n_all > n_threads:
+            ta0 = time.perf_counter()
+            expect_all, _ = oracle.map_reads(index, mx, sample, s_offs, k, n_threads=n_all)
+            ta = time.perf_counter() - ta0
+            result["cpu_baseline"]["all_cores"] = {"value": round(n_k / ta / 1e6, 2), "cores": n_all,
+                                                   "wall_s": round(ta, 1)}
+            parity = parity and bool(np.array_equal(expect_all, expect))
+        result["cpu_baseline"]["available_cores"] = avail
+        result["speedup_vs_cpu_16_threads"] = round(result["value"] / max(result["cpu_baseline"]["value"], 1e-9), 1)
         result["parity_vs_oracle_on_sample"] = parity
         if not parity:
             log("PARITY FAILURE: GPU counts differ from the oracle on the CPU sample")
