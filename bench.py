@@ -28,16 +28,17 @@ sys.path.insert(0, ROOT)
 # algorithmic bytes per k-mer of the fused path at alpha=0.5, p=0.18, d=1:
 # 150/120 read bytes + 8 bucket record + 8*(alpha + p*d) entry k-mers + 14*p*d (freq, node, count RMW)
 B_ALG_PER_KMER = 1.25 + 8.0 + 8.0 * (0.5 + 0.18) + 14.0 * 0.18      # = 17.21
-# per kernel (DESIGN.md "Measurement"): the fused kernel does all of it; on the partitioned path the
-# probe reads an 8-byte k-mer instead of 1.25 read bytes (SURVEY's 24.0 B operator figure), the
-# scatter reads 1.25 B and writes 8 B per k-mer, the histogram only reads.
+# The direct kernels do all of it in one launch.  The radix path does the same work as a
+# pipeline of streaming kernels; its roofline line prices the WHOLE pipeline against the same 17.21 B / k-mer
+# (sum of the kernels' average durations), and lists every kernel with the bytes it streams by design:
+# pass 1 reads 1.25 B and writes 8 B per k-mer, pass 2 reads 8 and writes 8, pass 3 reads 8 (+ the index
+# slices, once per batch), the directory scan and the flush are per-block / per-entry, not per k-mer.
 B_ALG = {
     "k_map_reads": B_ALG_PER_KMER,
     "k_map_kmers": B_ALG_PER_KMER - 1.25 + 8.0,
-    "k_part_probe": B_ALG_PER_KMER - 1.25 + 8.0,
-    "k_part_scatter": 1.25 + 8.0,
-    "k_part_hist": 1.25,
 }
+RX_STREAM_BYTES = {"k_rx_p1": 1.25 + 8.0, "k_rx_p2": 16.0, "k_rx_p3": 8.0}
+RX_KERNELS = ("k_rx_p1", "k_rx_scan", "k_rx_p2", "k_rx_p3")
 HBM_PEAK_GBPS = 8000.0                                               # MI355X_MICROARCH.md
 
 
@@ -61,7 +62,7 @@ def main():
     ap.add_argument("--modulo", type=int, default=None, help="hash-table size (default: smallest prime >= 2N)")
     ap.add_argument("-k", "--kmer-size", type=int, default=31)
     ap.add_argument("--skewed", action="store_true", help="node = i mod 1000 (atomic contention)")
-    ap.add_argument("--path", type=int, default=0, help="0 auto, 1 direct fused kernel, 2 radix-partitioned")
+    ap.add_argument("--path", type=int, default=0, help="0 auto (by batch size), 1 direct fused kernel, 2 radix path")
     ap.add_argument("--part-shift", type=int, default=None)
     ap.add_argument("--grid-per-cu", type=int, default=None)
     ap.add_argument("--static-schedule", action="store_true", help="disable the dynamic tile queue")
@@ -236,12 +237,30 @@ def main():
     result = None
     if rank == 0:
         value = total_kmers / elapsed / 1e6
-        # dominant kernel = the hot-path kernel with the largest summed HIP-event time
+        # dominant kernel = the hot-path kernel with the largest summed HIP-event time; the radix path is a
+        # pipeline of streaming kernels (one launch each per step) and is priced as a whole
         dom = max(timing, key=lambda n: timing[n][0])
-        kernel_ms, launches = timing[dom]
-        avg_kernel_s = kernel_ms / 1e3 / max(launches, 1)
-        kmers_per_launch = kmers_per_step * args.steps / max(launches, 1)
-        b_alg = B_ALG[dom]
+        per_kernel = None
+        if dom.startswith("k_rx"):
+            used = [n for n in RX_KERNELS if timing[n][1]]
+            launches = max(timing[n][1] for n in used)
+            avg_kernel_s = sum(timing[n][0] / max(timing[n][1], 1) for n in used) / 1e3
+            kmers_per_launch = kmers_per_step * args.steps / max(launches, 1)
+            per_kernel = {}
+            for n in used:
+                t_s = timing[n][0] / max(timing[n][1], 1) / 1e3
+                per_kernel[n] = {"avg_ms": round(t_s * 1e3, 3)}
+                if n in RX_STREAM_BYTES:
+                    gbps = kmers_per_launch * RX_STREAM_BYTES[n] / t_s / 1e9
+                    per_kernel[n].update(stream_bytes_per_kmer=RX_STREAM_BYTES[n], stream_GB_per_s=round(gbps, 1),
+                                         frac_of_hbm_peak=round(gbps / HBM_PEAK_GBPS, 4))
+            dom = "+".join(used)
+            b_alg = B_ALG_PER_KMER if not args.operator else B_ALG["k_map_kmers"]
+        else:
+            kernel_ms, launches = timing[dom]
+            avg_kernel_s = kernel_ms / 1e3 / max(launches, 1)
+            kmers_per_launch = kmers_per_step * args.steps / max(launches, 1)
+            b_alg = B_ALG[dom]
         achieved = kmers_per_launch * b_alg / avg_kernel_s / 1e9
         traffic = None
         sector = None
@@ -299,8 +318,10 @@ def main():
                 "kmers_per_step_per_gpu": kmers_per_step,
                 "hit_rate": round(hits / max(total_kmers, 1), 4),
                 "nodes": "skewed(mod 1000)" if args.skewed else "uniform",
-                "path": {0: "auto", 1: "direct", 2: "partitioned"}[args.path],
-                "n_partitions": dev.get_param("n_partitions"),
+                "path": {0: "auto", 1: "direct", 2: "radix"}[args.path],
+                "path_taken": "radix" if per_kernel else "direct",
+                "radix_fine_partitions": dev.get_param("n_partitions"),
+                "radix_coarse_partitions": dev.get_param("n_coarse_partitions"),
                 "occupancy_filter": bool(dev.get_param("occupancy_filter")),
                 "occupancy_bits_per_bucket": dev.get_param("occupancy_bits_per_bucket"),
                 "bloom_filter_bytes": dev.get_param("bloom_filter_bytes"),
@@ -321,6 +342,7 @@ def main():
                 "launches": launches,
                 "kernel_gkmers_per_s": round(kmers_per_launch / avg_kernel_s / 1e9, 2),
                 "request_model": sector,
+                "per_kernel": per_kernel,
             },
         }
 

@@ -21,6 +21,12 @@
  *     (the reference sums per-chunk vectors, command_line_interface.py:124-130);
  *     kmm_get_node_counts / kmm_synchronize are the synchronisation points.  Calls on one
  *     handle must be serialised by the caller; different handles are independent.
+ *   - Errors found by the kernels of a map call (a byte that is not a nucleotide, a malformed record,
+ *     decreasing read offsets) are reported by the next synchronising call and then STAY on the handle:
+ *     the chunk's valid windows are already counted by then (the reference raises before counting anything
+ *     of that chunk), so every later synchronising call fails with the same code until kmm_reset_counts
+ *     clears the counts and the error together.  A caller-owned buffer (kmm_bind_counts) must be zeroed by
+ *     the caller as well.
  *   - Counts are uint32 and wrap modulo 2^32 exactly like the reference (mapper.pyx:37,68).
  */
 #ifndef KMM_H
@@ -174,10 +180,12 @@ int kmm_build_index(int device, const uint64_t *kmers, const int32_t *nodes, int
  */
 #define KMM_KERNEL_MAP_READS 0    /* fused direct kernel (reads -> counts)                    */
 #define KMM_KERNEL_MAP_KMERS 1    /* operator kernel (uint64 k-mers -> counts)                */
-#define KMM_KERNEL_PART_HIST 2    /* partitioned path: reads -> per-partition histogram       */
-#define KMM_KERNEL_PART_SCATTER 3 /* partitioned path: reads -> k-mers grouped by hash range  */
-#define KMM_KERNEL_PART_PROBE 4   /* partitioned path: L2-local probe + count                 */
-#define KMM_N_KERNELS 5
+#define KMM_KERNEL_RX_P1 2        /* radix path, pass 1: reads -> blocks sorted by coarse hash range   */
+#define KMM_KERNEL_RX_SCAN 3      /* radix path: directory column scan between pass 1 and pass 2       */
+#define KMM_KERNEL_RX_P2 4        /* radix path, pass 2: items sorted by fine hash range               */
+#define KMM_KERNEL_RX_P3 5        /* radix path, pass 3: probe of LDS-resident index slices + counting */
+#define KMM_KERNEL_RX_FLUSH 6     /* radix path: per-entry hit counts -> node counts                   */
+#define KMM_N_KERNELS 7
 int kmm_set_timing(kmm_index_t *idx, int enabled);
 /* Work done by the map calls of this handle since creation (or the last call with reset != 0):
  * k-mer lookups performed (windows, doubled with also_revcomp) and count increments (index hits that
@@ -187,9 +195,25 @@ int kmm_get_stats(kmm_index_t *idx, int reset, uint64_t *n_lookups, uint64_t *n_
 int kmm_get_timing(kmm_index_t *idx, int kernel_id, double *kernel_ms, int64_t *n_launches);
 
 /*
+ * kmm_get_kmer_counts — per-k-mer counting mode: replaces the table lookup of GpuCounter.get_node_counts
+ * (gpu_counter.py:29-34, `counter[index_kmers]`) and the CounterKmerIndex branch of the CLI
+ * (command_line_interface.py:46-49,133-138): out[l] = number of mapped k-mers that matched index entry l
+ * (entry order of the arrays given to kmm_index_create; the frequency filter of every map call applied) since
+ * the mode was switched on or the last kmm_reset_counts.  Needs kmm_set_param(idx, "count_kmers", 1) BEFORE the
+ * map calls; the node counts are still maintained (they are the segmented sum of these counts over
+ * nodes[l], which is how the reference's GPU counter derives them, gpu_counter.py:37).  out: uint32[n_entries],
+ * host or device.  Synchronises.
+ */
+int kmm_get_kmer_counts(kmm_index_t *idx, uint32_t *out);
+
+/*
  * Tuning knobs, for experiments and benchmarks (defaults are chosen at index creation):
- *   "path"        0 = auto, 1 = direct fused kernel, 2 = radix-partitioned (L2-local) path
- *   "part_shift"  log2 of the number of hash buckets per partition (partitioned path)
+ *   "path"             0 = auto (by batch size), 1 = direct fused kernel (one HBM gather per k-mer),
+ *                      2 = radix path (two partition passes by hash range + probe of LDS-resident index
+ *                      slices)
+ *   "part_shift"       log2 of the number of hash buckets per fine partition of the radix path (2..12)
+ *   "radix_min_units"  auto: smallest batch (positions / k-mers) that takes the radix path
+ *   "count_kmers"      1 = per-k-mer counting mode (see kmm_get_kmer_counts)
  * Unknown names return KMM_ERR_INVALID_ARG.
  */
 int kmm_set_param(kmm_index_t *idx, const char *name, int64_t value);

@@ -23,8 +23,9 @@ KMM_ERR_MALFORMED = -6
 FORMAT_FASTA2, FORMAT_FASTQ = 2, 4
 
 # kernel ids of kmm_get_timing (include/kmm.h)
-KERNEL_MAP_READS, KERNEL_MAP_KMERS, KERNEL_PART_HIST, KERNEL_PART_SCATTER, KERNEL_PART_PROBE = range(5)
-KERNEL_NAMES = ("k_map_reads", "k_map_kmers", "k_part_hist", "k_part_scatter", "k_part_probe")
+(KERNEL_MAP_READS, KERNEL_MAP_KMERS, KERNEL_RX_P1, KERNEL_RX_SCAN, KERNEL_RX_P2, KERNEL_RX_P3,
+ KERNEL_RX_FLUSH) = range(7)
+KERNEL_NAMES = ("k_map_reads", "k_map_kmers", "k_rx_p1", "k_rx_scan", "k_rx_p2", "k_rx_p3", "k_rx_flush")
 
 _c = ctypes
 _P = ctypes.c_void_p
@@ -42,6 +43,7 @@ SIGNATURES = {
     "kmm_counts_device_ptr": (_c.c_int, [_P, _P]),
     "kmm_get_node_counts": (_c.c_int, [_P, _P]),
     "kmm_synchronize": (_c.c_int, [_P]),
+    "kmm_get_kmer_counts": (_c.c_int, [_P, _P]),
     "kmm_map_kmers": (_c.c_int, [_P, _P, _c.c_int64, _c.c_int, _c.c_int, _c.c_int]),
     "kmm_map_reads": (_c.c_int, [_P, _P, _P, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _P]),
     "kmm_map_reads_uniform": (_c.c_int, [_P, _P, _c.c_int64, _c.c_int64, _c.c_int, _c.c_int,

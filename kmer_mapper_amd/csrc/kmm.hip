@@ -58,7 +58,7 @@ int fail(int code, const char *fmt, ...)
 #include "kmm_tile.hpp"
 #include "kmm_records.hpp"
 #include "kmm_kernels.hpp"
-#include "kmm_partition.hpp"
+#include "kmm_radix.hpp"
 #include "kmm_build.hpp"
 
 // ------------------------------------------------------------------------------------------------
@@ -166,12 +166,24 @@ struct kmm_index {
     Stage stage[2];
     int cur = 0;
     int n_cu = 256;
-    // path selection / partitioned path state
-    int path = 0;        // 0 auto, 1 direct, 2 partitioned
+    // path selection / radix path state (kmm_radix.hpp)
+    int path = 0;         // 0 auto, 1 direct, 2 radix
     int grid_per_cu = 64; // upper bound on workgroups per CU of the grid-stride fused kernel
-    int part_shift = 16; // 2^16 buckets x 16 B = 1 MiB bucket-table slice per partition
-    DevBuf part_meta;    // wg_hist, slot_tot, slot_off (PartView)
-    DevBuf part_kmers;
+    bool rx_ok = false;   // the index fits the radix path's fan-out (<= 256 x 256 fine partitions)
+    int rx_w = 12, rx_f2 = 0; // log2 buckets per fine partition, log2 fine partitions per coarse one
+    uint32_t rx_PF = 1, rx_F1 = 1, rx_F2 = 1;
+    int64_t rx_min_units = 0; // auto: batches of at least this many positions / k-mers take the radix path
+    uint64_t rx_S = 0;        // entries in bucket order
+    uint32_t *rx_pstart = nullptr;
+    uint64_t *rx_pkeys = nullptr;
+    uint16_t *rx_pfreq = nullptr;
+    uint32_t *rx_pnodes = nullptr, *rx_porig = nullptr, *rx_ecnt = nullptr, *rx_ecnt_acc = nullptr;
+    bool ecnt_dirty = false;  // rx_ecnt holds hits that are not in `counts` yet
+    DevBuf rx_buf1, rx_buf2, rx_meta;
+    // deferred device-side error, sticky until kmm_reset_counts
+    int sticky_rc = KMM_OK;
+    std::string sticky_msg;
+    uint64_t map_calls = 0;   // sequence number of map calls on this handle (error reports name the call)
     // timing
     bool timing = false;
     std::vector<TimedEvent> ev_used;
@@ -230,27 +242,43 @@ struct ScopedTimer {
     }
 };
 
-// Drain the streams and surface deferred device-side errors (invalid bases).
+int rx_flush(kmm_index *ix);
+
+// Drain the streams and surface deferred device-side errors (invalid bases, malformed records, bad offsets).
+// The reference raises before any count of the offending chunk is added (bionumpy's encoder, util.py:72); here
+// the chunk's valid windows have already been counted when the error is seen, so the error stays on the handle:
+// every later synchronising call fails with the same code until kmm_reset_counts clears counts and error together.
 int drain(kmm_index *ix)
 {
+    KMMCHK(rx_flush(ix));
     HIPCHK(hipStreamSynchronize(ix->copy_stream));
     HIPCHK(hipStreamSynchronize(ix->stream));
+    if (ix->sticky_rc != KMM_OK)
+        return fail(ix->sticky_rc, "%s", ix->sticky_msg.c_str());
     unsigned long long bad[3] = {NO_BAD, NO_BAD, NO_BAD};
     HIPCHK(hipMemcpy(bad, ix->first_bad, sizeof bad, hipMemcpyDeviceToHost));
     if (bad[0] != NO_BAD || bad[1] != NO_BAD || bad[2] != NO_BAD) {
         unsigned long long reset[3] = {NO_BAD, NO_BAD, NO_BAD};
         HIPCHK(hipMemcpy(ix->first_bad, reset, sizeof reset, hipMemcpyHostToDevice));
+        char where[160];
+        snprintf(where, sizeof where, " [one of the map calls since the last synchronising call; the latest was call "
+                 "#%llu on this handle; counts are invalid until kmm_reset_counts]", (unsigned long long)ix->map_calls);
+        int rc;
         if (bad[2] != NO_BAD)
-            return fail(KMM_ERR_INVALID_ARG, "read_offsets of a mapped chunk is not non-decreasing at read %llu",
-                        bad[2]);
-        if (bad[1] != NO_BAD)
-            return fail(KMM_ERR_MALFORMED,
-                        "record structure violated at byte offset %llu of a mapped chunk (a record line "
-                        "does not start with '@' / '+' / '>'): multi-line FASTA/FASTQ is not supported by "
-                        "the GPU reader", bad[1]);
-        return fail(KMM_ERR_INVALID_BASE,
-                    "read byte at offset %llu of a mapped chunk is not a nucleotide under the "
-                    "lookup table (the reference's DNA encoder raises here)", bad[0]);
+            rc = fail(KMM_ERR_INVALID_ARG, "read_offsets of a mapped chunk is not non-decreasing at read %llu%s",
+                      bad[2], where);
+        else if (bad[1] != NO_BAD)
+            rc = fail(KMM_ERR_MALFORMED,
+                      "record structure violated at byte offset %llu of a mapped chunk (a record line "
+                      "does not start with '@' / '+' / '>'): multi-line FASTA/FASTQ is not supported by "
+                      "the GPU reader%s", bad[1], where);
+        else
+            rc = fail(KMM_ERR_INVALID_BASE,
+                      "read byte at offset %llu of a mapped chunk is not a nucleotide under the "
+                      "lookup table (the reference's DNA encoder raises here)%s", bad[0], where);
+        ix->sticky_rc = rc;
+        ix->sticky_msg = g_err;
+        return rc;
     }
     return KMM_OK;
 }
@@ -352,39 +380,119 @@ constexpr size_t KMM_OCC_SWEET_BYTES = (size_t)5 << 20; // bitmap size that stil
 constexpr int TILE_S = 4;
 constexpr int TILE_T = 256 * TILE_S;
 
-int part_count(const kmm_index *ix)
+// Fan-out of the radix path for 2^w buckets per fine partition: F1 coarse x F2 fine partitions.
+bool rx_configure(kmm_index *ix, int w)
 {
-    const uint64_t per = 1ull << ix->part_shift;
-    return (int)((ix->modulo + per - 1) / per);
-}
-
-bool use_partitioned(const kmm_index *ix, int64_t total_positions)
-{
-    (void)total_positions;
-    // r01 measurements (profiles/r01/partitioned_path_ablation.md): the direct kernel is faster on
-    // every configuration tried, so "auto" (0) means direct; the partitioned path is opt-in.
-    if (ix->path != 2 || ix->wide)
+    if (w < 2 || w > 12)
         return false;
-    const uint64_t per = 1ull << ix->part_shift;
-    return (ix->modulo + per - 1) / per <= (uint64_t)KMM_MAX_PARTS;
+    const uint64_t PF = (ix->modulo + (1ull << w) - 1) >> w;
+    if (PF > (uint64_t)RX_MAXF * RX_MAXF)
+        return false;
+    int lg = 0;
+    while ((1ull << lg) < PF)
+        ++lg;
+    const int f2 = (lg + 1) / 2;
+    const uint64_t F2 = 1ull << f2, F1 = (PF + F2 - 1) / F2;
+    if (F1 > (uint64_t)RX_MAXF || F2 > (uint64_t)RX_MAXF)
+        return false;
+    ix->rx_w = w;
+    ix->rx_f2 = f2;
+    ix->rx_PF = (uint32_t)PF;
+    ix->rx_F1 = (uint32_t)F1;
+    ix->rx_F2 = (uint32_t)F2;
+    return true;
 }
 
-int part_view(kmm_index *ix, size_t kmer_capacity, PartView *pv)
+bool use_radix(const kmm_index *ix, int64_t units)
 {
-    const int P = part_count(ix);
-    const int PX = (P + KMM_N_XCD - 1) / KMM_N_XCD;
-    const size_t n_slots = (size_t)KMM_N_XCD * PX;
-    const size_t words = n_slots * KMM_PART_GRID + n_slots + (n_slots + 1);
-    KMMCHK(ensure(ix->part_meta, words * 4));
-    KMMCHK(ensure(ix->part_kmers, kmer_capacity * 8));
-    uint32_t *w = (uint32_t *)ix->part_meta.p;
-    pv->shift = ix->part_shift;
-    pv->P = P;
-    pv->PX = PX;
-    pv->wg_hist = w; w += n_slots * KMM_PART_GRID;
-    pv->slot_tot = w; w += n_slots;
-    pv->slot_off = w;
-    pv->kmers = (uint64_t *)ix->part_kmers.p;
+    if (!ix->rx_ok || ix->path == 1)
+        return false;
+    return ix->path == 2 || ix->rx_ecnt_acc || units >= ix->rx_min_units;
+}
+
+size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// One sub-batch of the radix path: pass 1 (reads or k-mers -> blocks sorted by coarse partition), the
+// directory scan, pass 2 (items sorted by fine partition), pass 3 (LDS probe).  Hits land in rx_ecnt.
+template <int MODE>
+int launch_rx(kmm_index *ix, const ReadsView &rv, const uint64_t *kmers_in, int64_t n_in, int k, int max_freq,
+              int also_rc)
+{
+    const IndexView iv = view_of(ix);
+    const int64_t units = MODE == MODE_KMERS ? n_in : rv.total;
+    const int64_t n_src_total = (units + RX_B - 1) / RX_B;
+    const uint32_t X = also_rc ? 2u : 1u;
+    const int64_t max_src = (((int64_t)1 << 31) / RX_B) / X; // < 2^31 k-mers per sub-batch: 32-bit prefixes
+    const uint32_t F1 = ix->rx_F1, F2 = ix->rx_F2;
+    for (int64_t s0 = 0; s0 < n_src_total; s0 += max_src) {
+        const uint32_t n_src = (uint32_t)(n_src_total - s0 < max_src ? n_src_total - s0 : max_src);
+        const uint32_t NB = n_src * X;
+        const uint32_t chunks = (NB + RX_CH - 1) / RX_CH;
+        const size_t max_items = (size_t)NB + F1 + 1;
+        RxView rx;
+        memset(&rx, 0, sizeof rx);
+        rx.pstart = ix->rx_pstart; rx.pkeys = ix->rx_pkeys; rx.pfreq = ix->rx_pfreq; rx.ecnt = ix->rx_ecnt;
+        rx.w = ix->rx_w; rx.f2 = ix->rx_f2; rx.PF = ix->rx_PF; rx.F1 = F1; rx.F2 = F2;
+        rx.NB = NB; rx.max_items = (uint32_t)max_items;
+        size_t off = 0;
+        auto carve = [&](size_t bytes) { const size_t o = off; off += align256(bytes); return o; };
+        const size_t o_start1 = carve((size_t)NB * (F1 + 1) * 2), o_P1T = carve((size_t)F1 * (NB + 1) * 4),
+                     o_S1T = carve((size_t)F1 * NB * 2), o_csum = carve((size_t)chunks * F1 * 4),
+                     o_T1 = carve((size_t)F1 * 4), o_ib = carve((size_t)(F1 + 1) * 4), o_wb = carve((size_t)(F1 + 1) * 4),
+                     o_desc = carve(max_items * 8), o_start2 = carve(max_items * (F2 + 1) * 2), o_ctrl = carve(64),
+                     o_queue = carve(256);
+        KMMCHK(ensure(ix->rx_meta, off));
+        KMMCHK(ensure(ix->rx_buf1, (size_t)NB * RX_B * 8));
+        KMMCHK(ensure(ix->rx_buf2, max_items * RX_B * 8));
+        uint8_t *m = (uint8_t *)ix->rx_meta.p;
+        rx.start1 = (uint16_t *)(m + o_start1); rx.P1T = (uint32_t *)(m + o_P1T); rx.S1T = (uint16_t *)(m + o_S1T);
+        rx.csum = (uint32_t *)(m + o_csum); rx.T1 = (uint32_t *)(m + o_T1); rx.item_base = (uint32_t *)(m + o_ib);
+        rx.work_base = (uint32_t *)(m + o_wb); rx.item_desc = (uint2 *)(m + o_desc);
+        rx.start2 = (uint16_t *)(m + o_start2); rx.ctrl = (uint32_t *)(m + o_ctrl);
+        rx.queue = (unsigned long long *)(m + o_queue);
+        rx.buf1 = (uint64_t *)ix->rx_buf1.p;
+        rx.buf2 = (uint64_t *)ix->rx_buf2.p;
+        HIPCHK(hipMemsetAsync(m + o_ctrl, 0, align256(64) + 256, ix->stream));
+        ScopedTimer tm;
+        KMMCHK(tm.begin(ix, KMM_KERNEL_RX_P1));
+        const int64_t g1cap = (int64_t)ix->n_cu * 8;
+        const dim3 g1((unsigned)(n_src < g1cap ? n_src : g1cap));
+        hipLaunchKernelGGL((k_rx_p1<MODE>), g1, dim3(RX_NT), 0, ix->stream, rv,
+                           kmers_in ? kmers_in + s0 * RX_B : nullptr, n_in - s0 * RX_B, iv, rx, k, also_rc,
+                           s0 * RX_R * 2, n_src);
+        HIPCHK(hipGetLastError());
+        KMMCHK(tm.end());
+        KMMCHK(tm.begin(ix, KMM_KERNEL_RX_SCAN));
+        hipLaunchKernelGGL(k_rx_colsum, dim3(chunks), dim3(256), 0, ix->stream, rx);
+        hipLaunchKernelGGL(k_rx_mid, dim3(1), dim3(256), 0, ix->stream, rx, chunks);
+        hipLaunchKernelGGL(k_rx_colscan, dim3(chunks), dim3(256), 0, ix->stream, rx);
+        HIPCHK(hipGetLastError());
+        KMMCHK(tm.end());
+        KMMCHK(tm.begin(ix, KMM_KERNEL_RX_P2));
+        hipLaunchKernelGGL(k_rx_p2, dim3(ix->n_cu * 2), dim3(RX_NT), 0, ix->stream, iv, rx);
+        HIPCHK(hipGetLastError());
+        KMMCHK(tm.end());
+        KMMCHK(tm.begin(ix, KMM_KERNEL_RX_P3));
+        hipLaunchKernelGGL(k_rx_p3, dim3(ix->n_cu * 2), dim3(RX_NT), 0, ix->stream, iv, rx, max_freq);
+        HIPCHK(hipGetLastError());
+        KMMCHK(tm.end());
+        ix->ecnt_dirty = true;
+    }
+    return KMM_OK;
+}
+
+// Per-entry hits of the radix path -> node counts (mapper.pyx:68 summed per entry first).  Asynchronous.
+int rx_flush(kmm_index *ix)
+{
+    if (!ix->ecnt_dirty)
+        return KMM_OK;
+    ScopedTimer tm;
+    KMMCHK(tm.begin(ix, KMM_KERNEL_RX_FLUSH));
+    hipLaunchKernelGGL(k_rx_flush, dim3(ix->n_cu * 8), dim3(256), 0, ix->stream, view_of(ix), ix->rx_ecnt,
+                       ix->rx_pnodes, ix->rx_S, ix->rx_ecnt_acc);
+    HIPCHK(hipGetLastError());
+    KMMCHK(tm.end());
+    ix->ecnt_dirty = false;
     return KMM_OK;
 }
 
@@ -393,7 +501,7 @@ int launch_map_reads(kmm_index *ix, const ReadsView &rv, int k, int max_freq, in
 {
     const IndexView iv = view_of(ix);
     const int64_t n_tiles = (rv.total + TILE_T - 1) / TILE_T;
-    if (!use_partitioned(ix, rv.total)) {
+    if (!use_radix(ix, rv.total)) {
         ScopedTimer tm;
         KMMCHK(tm.begin(ix, KMM_KERNEL_MAP_READS));
         // large launches: persistent workgroups + dynamic tile queue; small ones: static schedule
@@ -418,38 +526,32 @@ int launch_map_reads(kmm_index *ix, const ReadsView &rv, int k, int max_freq, in
         HIPCHK(hipGetLastError());
         return tm.end();
     }
-    // partitioned path, in sub-batches whose grouped k-mers fit 32-bit slots
-    const int64_t sub_tiles = ((int64_t)1 << 29) / TILE_T; // 2^29 positions -> <= 2^30 k-mers with -r
-    const int64_t max_tiles = n_tiles < sub_tiles ? n_tiles : sub_tiles;
-    PartView pv;
-    KMMCHK(part_view(ix, (size_t)max_tiles * TILE_T * (also_rc ? 2 : 1), &pv));
-    for (int64_t t0 = 0; t0 < n_tiles; t0 += sub_tiles) {
-        const int64_t t1 = t0 + sub_tiles < n_tiles ? t0 + sub_tiles : n_tiles;
-        // every workgroup writes its (possibly all-zero) histogram row: the grid is always full
-        const int grid = KMM_PART_GRID;
-        const int n_slots = KMM_N_XCD * pv.PX;
-        ScopedTimer tm;
-        KMMCHK(tm.begin(ix, KMM_KERNEL_PART_HIST));
-        hipLaunchKernelGGL((k_part_hist<TILE_S, MODE>), dim3(grid), dim3(256), 0, ix->stream, rv, iv,
-                           k, also_rc, pv, t0, t1);
-        HIPCHK(hipGetLastError());
-        KMMCHK(tm.end());
-        hipLaunchKernelGGL(k_part_scan1, dim3(n_slots), dim3(256), 0, ix->stream, pv);
-        hipLaunchKernelGGL(k_part_scan2, dim3(1), dim3(1024), 0, ix->stream, pv);
-        HIPCHK(hipGetLastError());
-        KMMCHK(tm.begin(ix, KMM_KERNEL_PART_SCATTER));
-        hipLaunchKernelGGL((k_part_scatter<TILE_S, MODE>), dim3(grid), dim3(256), 0, ix->stream, rv,
-                           iv, k, also_rc, pv, t0, t1);
-        HIPCHK(hipGetLastError());
-        KMMCHK(tm.end());
-        KMMCHK(tm.begin(ix, KMM_KERNEL_PART_PROBE));
-        IndexView iv_nofilter = iv; // bucket gathers are L2 hits here: the bitmap would only add requests
-        iv_nofilter.occ = nullptr;
-        hipLaunchKernelGGL((k_part_probe<KMM_CHUNK / 256>), dim3(ix->n_cu * 8), dim3(256), 0,
-                           ix->stream, iv_nofilter, pv, max_freq);
-        HIPCHK(hipGetLastError());
-        KMMCHK(tm.end());
-    }
+    return launch_rx<MODE>(ix, rv, nullptr, 0, k, max_freq, also_rc);
+}
+
+// Exclusive scan of n uint32 values on the device (in -> out): 1024-wide block scans, recursing on the
+// block totals (n < 2^32 needs at most 4 levels).  All launches go to `stream`; ensure() may hipFree (device-wide sync).  `scratch` holds one DevBuf pair per level and is sized
+// by the caller ONCE — it must not reallocate while outer levels hold references into it.
+constexpr size_t SCAN_MAX_LEVELS = 8;
+int scan_exclusive(const uint32_t *in, uint32_t *out, uint64_t n, std::vector<DevBuf> &scratch,
+                   size_t level, hipStream_t stream)
+{
+    const uint64_t n_blocks = (n + 1023) / 1024;
+    if (level >= SCAN_MAX_LEVELS || scratch.size() < 2 * SCAN_MAX_LEVELS)
+        return fail(KMM_ERR_INVALID_ARG, "scan_exclusive: level %zu out of range", level);
+    DevBuf &sums = scratch[2 * level], &pre = scratch[2 * level + 1];
+    KMMCHK(ensure(sums, (size_t)n_blocks * 4));
+    hipLaunchKernelGGL(k_scan_blocks, dim3((unsigned)n_blocks), dim3(1024), 0, stream, in, out, (uint32_t *)sums.p, n);
+    HIPCHK(hipGetLastError());
+    if (n_blocks == 1)
+        return KMM_OK;
+    KMMCHK(ensure(pre, (size_t)n_blocks * 4));
+    KMMCHK(scan_exclusive((const uint32_t *)sums.p, (uint32_t *)pre.p, n_blocks, scratch, level + 1, stream));
+    uint64_t g = (n + 255) / 256;
+    if (g > 65536)
+        g = 65536;
+    hipLaunchKernelGGL(k_scan_add, dim3((unsigned)g), dim3(256), 0, stream, out, (const uint32_t *)pre.p, n);
+    HIPCHK(hipGetLastError());
     return KMM_OK;
 }
 
@@ -503,8 +605,13 @@ void kmm_index_destroy(kmm_index_t *ix)
         if (s.done)
             (void)hipEventDestroy(s.done);
     }
-    release(ix->part_meta);
-    release(ix->part_kmers);
+    release(ix->rx_meta);
+    release(ix->rx_buf1);
+    release(ix->rx_buf2);
+    for (void *q : {(void *)ix->rx_pstart, (void *)ix->rx_pkeys, (void *)ix->rx_pfreq, (void *)ix->rx_pnodes,
+                    (void *)ix->rx_porig, (void *)ix->rx_ecnt, (void *)ix->rx_ecnt_acc})
+        if (q)
+            (void)hipFree(q);
     for (auto &ev : ix->ev_used) {
         (void)hipEventDestroy(ev.start);
         (void)hipEventDestroy(ev.stop);
@@ -536,6 +643,68 @@ void kmm_index_destroy(kmm_index_t *ix)
     if (ix->stream)
         (void)hipStreamDestroy(ix->stream);
     delete ix;
+}
+
+// Radix-path view of the index (kmm_radix.hpp): entries regrouped in bucket order (whatever order the caller's
+// hashes_to_index uses) + the exclusive prefix of the bucket sizes, which serves as the bucket directory of any
+// 2^w-bucket slice.  Built from the raw arrays while they are still in HBM.
+static int rx_build(kmm_index *ix, const int32_t *h2i, const int32_t *nk, const uint64_t *kmers,
+                    const int32_t *nodes, const uint16_t *freqs)
+{
+    const uint64_t M = ix->modulo;
+    if (M + 1 > 0xFFFFFFFFull)
+        return KMM_OK; // no radix path; the direct path serves every batch
+    DevBuf sizes;
+    std::vector<DevBuf> scratch(2 * SCAN_MAX_LEVELS);
+    int rc = KMM_OK;
+    hipError_t e = hipSuccess;
+    do {
+        if ((rc = ensure(sizes, (size_t)(M + 1) * 4))) break;
+        if ((e = hipMalloc(&ix->rx_pstart, (size_t)(M + 1) * 4))) break;
+        hipLaunchKernelGGL(k_rx_bucket_sizes, dim3(grid_for(ix, (int64_t)((M + 256) / 256), 16)), dim3(256), 0,
+                           ix->stream, h2i, nk, M, ix->n_entries, (uint32_t *)sizes.p);
+        if ((rc = scan_exclusive((const uint32_t *)sizes.p, ix->rx_pstart, M + 1, scratch, 0, ix->stream))) break;
+        uint32_t total = 0;
+        if ((e = hipMemcpyAsync(&total, ix->rx_pstart + M, 4, hipMemcpyDeviceToHost, ix->stream))) break;
+        if ((e = hipStreamSynchronize(ix->stream))) break;
+        ix->rx_S = total; // < 2^32: a sum of validated bucket sizes may exceed n_entries only if buckets overlap
+        const size_t S = total ? total : 1;
+        if ((e = hipMalloc(&ix->rx_pkeys, S * 8))) break;
+        if ((e = hipMalloc(&ix->rx_pfreq, S * 2))) break;
+        if ((e = hipMalloc(&ix->rx_pnodes, S * 4))) break;
+        if ((e = hipMalloc(&ix->rx_porig, S * 4))) break;
+        if ((e = hipMalloc(&ix->rx_ecnt, S * 4))) break;
+        if ((e = hipMemsetAsync(ix->rx_ecnt, 0, S * 4, ix->stream))) break;
+        hipLaunchKernelGGL(k_rx_pack, dim3(grid_for(ix, (int64_t)((M + 255) / 256), 16)), dim3(256), 0, ix->stream, h2i,
+                           kmers, nodes, freqs, M, ix->max_node_id, ix->rx_pstart, ix->rx_pkeys, ix->rx_pfreq,
+                           ix->rx_pnodes, ix->rx_porig);
+        if ((e = hipGetLastError())) break;
+        if ((e = hipStreamSynchronize(ix->stream))) break;
+    } while (0);
+    release(sizes);
+    for (DevBuf &b : scratch)
+        release(b);
+    if (rc != KMM_OK)
+        return rc;
+    if (e != hipSuccess)
+        return fail(e == hipErrorOutOfMemory ? KMM_ERR_NOMEM : KMM_ERR_HIP, "radix index build: %s", hipGetErrorString(e));
+    // 2^w buckets per fine partition: as many as keep a slice's entries (load factor x 2^w) well inside the LDS key
+    // capacity; fewer when the table is dense.  The fan-out must fit 256 x 256 fine partitions.
+    int w = 12;
+    if (const char *env = getenv("KMM_RX_W")) // experiments / tests: force the slice width
+        w = atoi(env);
+    else
+        while (w > 4 && (double)ix->rx_S / (double)M * (double)(1u << w) * 1.3 + 64.0 > (double)RX_ECAP)
+            --w;
+    ix->rx_ok = rx_configure(ix, w);
+    // auto: the radix path streams the whole directory + key arrays once per batch (4 B x modulo + 14 B x entries),
+    // which pays off once the batch's own streams (~40 B per k-mer) dominate
+    ix->rx_min_units = (int64_t)((M * 4 + ix->rx_S * 14) / 8);
+    if (ix->rx_min_units < ((int64_t)1 << 22))
+        ix->rx_min_units = (int64_t)1 << 22;
+    if (const char *env = getenv("KMM_RX_MIN_UNITS"))
+        ix->rx_min_units = strtoll(env, nullptr, 10);
+    return KMM_OK;
 }
 
 static int index_create_impl(kmm_index *ix, const int32_t *h2i, const int32_t *nk,
@@ -664,6 +833,8 @@ static int index_create_impl(kmm_index *ix, const int32_t *h2i, const int32_t *n
         if (e != hipSuccess)
             rc = fail(KMM_ERR_HIP, "index repack: %s", hipGetErrorString(e));
     }
+    if (rc == KMM_OK && !err)
+        rc = rx_build(ix, p_h2i, p_nk, p_km, p_nd, p_fr);
     release(d_h2i); release(d_nk); release(d_km); release(d_nd); release(d_fr); release(d_err);
     if (rc != KMM_OK)
         return rc;
@@ -674,11 +845,6 @@ static int index_create_impl(kmm_index *ix, const int32_t *h2i, const int32_t *n
     if (err & 2u)
         return fail(KMM_ERR_INDEX, "index inconsistent: a node id lies outside [0, max_node_id=%lld]",
                     (long long)ix->max_node_id);
-    // default partition granularity: 1 MiB bucket-table slices, coarser if that needs > 1024 parts
-    ix->part_shift = 16;
-    while (((M + (1ull << ix->part_shift) - 1) >> ix->part_shift) > (uint64_t)KMM_MAX_PARTS &&
-           ix->part_shift < 18)
-        ix->part_shift++;
     return KMM_OK;
 }
 
@@ -732,6 +898,18 @@ int kmm_reset_counts(kmm_index_t *ix)
         return fail(KMM_ERR_INVALID_ARG, "idx is NULL");
     HIPCHK(hipSetDevice(ix->device));
     HIPCHK(hipMemsetAsync(ix->counts, 0, sizeof(uint32_t) * (size_t)(ix->max_node_id + 1), ix->stream));
+    if (ix->rx_ecnt && ix->ecnt_dirty)
+        HIPCHK(hipMemsetAsync(ix->rx_ecnt, 0, sizeof(uint32_t) * (size_t)(ix->rx_S ? ix->rx_S : 1), ix->stream));
+    if (ix->rx_ecnt_acc)
+        HIPCHK(hipMemsetAsync(ix->rx_ecnt_acc, 0, sizeof(uint32_t) * (size_t)(ix->rx_S ? ix->rx_S : 1), ix->stream));
+    ix->ecnt_dirty = false;
+    if (ix->sticky_rc != KMM_OK) { // the error of a mapped chunk goes away together with its partial counts
+        unsigned long long nb[3] = {NO_BAD, NO_BAD, NO_BAD};
+        HIPCHK(hipStreamSynchronize(ix->stream));
+        HIPCHK(hipMemcpy(ix->first_bad, nb, sizeof nb, hipMemcpyHostToDevice));
+        ix->sticky_rc = KMM_OK;
+        ix->sticky_msg.clear();
+    }
     return KMM_OK;
 }
 
@@ -740,6 +918,7 @@ int kmm_bind_counts(kmm_index_t *ix, uint32_t *device_counts)
     if (!ix)
         return fail(KMM_ERR_INVALID_ARG, "idx is NULL");
     HIPCHK(hipSetDevice(ix->device));
+    KMMCHK(rx_flush(ix)); // hits mapped so far belong to the buffer that was bound when they were mapped
     HIPCHK(hipStreamSynchronize(ix->stream));
     if (!device_counts) {
         ix->counts = ix->own_counts_buf;
@@ -778,6 +957,41 @@ int kmm_get_node_counts(kmm_index_t *ix, uint32_t *out)
     return KMM_OK;
 }
 
+int kmm_get_kmer_counts(kmm_index_t *ix, uint32_t *out)
+{
+    if (!ix || !out)
+        return fail(KMM_ERR_INVALID_ARG, "NULL argument");
+    if (!ix->rx_ecnt_acc)
+        return fail(KMM_ERR_INVALID_ARG, "per-k-mer counts are only kept in count_kmers mode "
+                    "(kmm_set_param(idx, \"count_kmers\", 1) before mapping)");
+    HIPCHK(hipSetDevice(ix->device));
+    KMMCHK(drain(ix));
+    const size_t n = (size_t)ix->n_entries;
+    if (n == 0)
+        return KMM_OK;
+    const bool out_dev = is_device_ptr(out);
+    DevBuf tmp;
+    uint32_t *d_out = out;
+    if (!out_dev) {
+        KMMCHK(ensure(tmp, n * 4));
+        d_out = (uint32_t *)tmp.p;
+    }
+    hipError_t e = hipMemsetAsync(d_out, 0, n * 4, ix->stream); // entries that no bucket references stay 0
+    if (e == hipSuccess && ix->rx_S) {
+        hipLaunchKernelGGL(k_rx_entry_counts, dim3(grid_for(ix, (int64_t)((ix->rx_S + 255) / 256), 16)), dim3(256), 0,
+                           ix->stream, ix->rx_ecnt_acc, ix->rx_porig, ix->rx_S, d_out);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess && !out_dev)
+        e = hipMemcpyAsync(out, d_out, n * 4, hipMemcpyDeviceToHost, ix->stream);
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(ix->stream);
+    release(tmp);
+    if (e != hipSuccess)
+        return fail(KMM_ERR_HIP, "kmm_get_kmer_counts: %s", hipGetErrorString(e));
+    return KMM_OK;
+}
+
 int kmm_map_kmers(kmm_index_t *ix, const uint64_t *kmers, int64_t n, int max_freq, int also_revcomp,
                   int k)
 {
@@ -796,6 +1010,14 @@ int kmm_map_kmers(kmm_index_t *ix, const uint64_t *kmers, int64_t n, int max_fre
     const uint64_t *d_kmers = nullptr;
     KMMCHK(stage_in<uint64_t>(ix, s.kmers, kmers, (size_t)n, &d_kmers, &staged));
     KMMCHK(stage_copies_done(ix));
+    ix->map_calls++;
+    if (use_radix(ix, n)) {
+        ReadsView rv;
+        memset(&rv, 0, sizeof rv);
+        rv.first_bad = ix->first_bad;
+        KMMCHK(launch_rx<MODE_KMERS>(ix, rv, d_kmers, n, k, max_freq, also_revcomp ? 1 : 0));
+        return stage_release(ix, s, staged);
+    }
     constexpr int U = 8;
     ScopedTimer tm;
     KMMCHK(tm.begin(ix, KMM_KERNEL_MAP_KMERS));
@@ -858,6 +1080,7 @@ static int map_reads_common(kmm_index_t *ix, const uint8_t *bases, const int64_t
 
     Stage &s = next_stage(ix);
     KMMCHK(stage_acquire(ix, s));
+    ix->map_calls++;
     bool staged = false;
     ReadsView rv;
     memset(&rv, 0, sizeof rv);
@@ -950,6 +1173,7 @@ int kmm_map_records(kmm_index_t *ix, const uint8_t *raw, int64_t n_bytes, int fo
     HIPCHK(hipSetDevice(ix->device));
     Stage &s = next_stage(ix);
     KMMCHK(stage_acquire(ix, s));
+    ix->map_calls++;
     bool staged = false;
     ReadsView rv;
     memset(&rv, 0, sizeof rv);
@@ -1168,32 +1392,6 @@ int kmm_extract_kmers(int device, const uint8_t *bases, const int64_t *read_offs
     return KMM_OK;
 }
 
-// Exclusive scan of n uint32 values on the device (in -> out): 1024-wide block scans, recursing on the
-// block totals (n < 2^31 needs at most 4 levels).  `scratch` holds one DevBuf pair per level and is sized
-// by the caller ONCE — it must not reallocate while outer levels hold references into it.
-constexpr size_t SCAN_MAX_LEVELS = 8;
-static int scan_exclusive(const uint32_t *in, uint32_t *out, uint64_t n, std::vector<DevBuf> &scratch,
-                          size_t level)
-{
-    const uint64_t n_blocks = (n + 1023) / 1024;
-    if (level >= SCAN_MAX_LEVELS || scratch.size() < 2 * SCAN_MAX_LEVELS)
-        return fail(KMM_ERR_INVALID_ARG, "scan_exclusive: level %zu out of range", level);
-    DevBuf &sums = scratch[2 * level], &pre = scratch[2 * level + 1];
-    KMMCHK(ensure(sums, (size_t)n_blocks * 4));
-    hipLaunchKernelGGL(k_scan_blocks, dim3((unsigned)n_blocks), dim3(1024), 0, 0, in, out, (uint32_t *)sums.p, n);
-    HIPCHK(hipGetLastError());
-    if (n_blocks == 1)
-        return KMM_OK;
-    KMMCHK(ensure(pre, (size_t)n_blocks * 4));
-    KMMCHK(scan_exclusive((const uint32_t *)sums.p, (uint32_t *)pre.p, n_blocks, scratch, level + 1));
-    uint64_t g = (n + 255) / 256;
-    if (g > 65536)
-        g = 65536;
-    hipLaunchKernelGGL(k_scan_add, dim3((unsigned)g), dim3(256), 0, 0, out, (const uint32_t *)pre.p, n);
-    HIPCHK(hipGetLastError());
-    return KMM_OK;
-}
-
 int kmm_build_index(int device, const uint64_t *kmers, const int32_t *nodes, int64_t n, uint64_t modulo,
                     int32_t *hashes_to_index, int32_t *n_kmers, uint64_t *kmers_out, int32_t *nodes_out,
                     uint16_t *frequencies_out)
@@ -1252,7 +1450,7 @@ int kmm_build_index(int device, const uint64_t *kmers, const int32_t *nodes, int
         if (g < 1) g = 1;
         if (n > 0)
             hipLaunchKernelGGL(k_bi_hist, dim3((unsigned)g), dim3(256), 0, 0, (const uint64_t *)p_km, n, M, magic, w_nk);
-        if ((rc = scan_exclusive(w_nk, w_h2i, M, scratch, 0))) break;
+        if ((rc = scan_exclusive(w_nk, w_h2i, M, scratch, 0, 0))) break;
         if (n > 0) {
             uint64_t *w_ko = is_device_ptr(kmers_out) ? kmers_out : nullptr;
             int32_t *w_no = is_device_ptr(nodes_out) ? nodes_out : nullptr;
@@ -1356,13 +1554,33 @@ int kmm_set_param(kmm_index_t *ix, const char *name, int64_t value)
     HIPCHK(hipStreamSynchronize(ix->stream)); // scratch layouts depend on the knobs
     if (!strcmp(name, "path")) {
         if (value < 0 || value > 2)
-            return fail(KMM_ERR_INVALID_ARG, "path must be 0 (auto), 1 (direct) or 2 (partitioned)");
+            return fail(KMM_ERR_INVALID_ARG, "path must be 0 (auto), 1 (direct) or 2 (radix)");
+        if (value == 2 && !ix->rx_ok)
+            return fail(KMM_ERR_INVALID_ARG, "the radix path is not available for this index (modulo %llu needs more "
+                        "than 256 x 256 fine partitions)", (unsigned long long)ix->modulo);
         ix->path = (int)value;
     } else if (!strcmp(name, "part_shift")) {
-        if (value < 4 || value > 30)
-            return fail(KMM_ERR_INVALID_ARG, "part_shift outside [4, 30]");
-        ix->part_shift = (int)value;
-        release(ix->part_meta); // re-laid out (and re-zeroed) on next use
+        if (!rx_configure(ix, (int)value))
+            return fail(KMM_ERR_INVALID_ARG, "part_shift %lld: needs 2 <= shift <= 12 and at most 256 x 256 fine "
+                        "partitions", (long long)value);
+        ix->rx_ok = ix->rx_pstart != nullptr;
+    } else if (!strcmp(name, "radix_min_units")) {
+        ix->rx_min_units = value;
+    } else if (!strcmp(name, "count_kmers")) {
+        // per-k-mer counting mode (GpuCounter semantics, gpu_counter.py:23-37): every batch takes the radix path
+        // and the per-entry hit counts are kept (kmm_get_kmer_counts) besides being summed into the node counts
+        if (value && !ix->rx_ok)
+            return fail(KMM_ERR_INVALID_ARG, "count_kmers needs the radix path, which is not available for this index");
+        KMMCHK(rx_flush(ix));
+        HIPCHK(hipStreamSynchronize(ix->stream));
+        if (value && !ix->rx_ecnt_acc) {
+            const size_t S = ix->rx_S ? ix->rx_S : 1;
+            HIPCHK(hipMalloc(&ix->rx_ecnt_acc, S * 4));
+            HIPCHK(hipMemset(ix->rx_ecnt_acc, 0, S * 4));
+        } else if (!value && ix->rx_ecnt_acc) {
+            HIPCHK(hipFree(ix->rx_ecnt_acc));
+            ix->rx_ecnt_acc = nullptr;
+        }
     } else if (!strcmp(name, "grid_per_cu")) {
         if (value < 1 || value > 1024)
             return fail(KMM_ERR_INVALID_ARG, "grid_per_cu outside [1, 1024]");
@@ -1389,7 +1607,15 @@ int kmm_get_param(kmm_index_t *ix, const char *name, int64_t *value)
     if (!strcmp(name, "path"))
         *value = ix->path;
     else if (!strcmp(name, "part_shift"))
-        *value = ix->part_shift;
+        *value = ix->rx_w;
+    else if (!strcmp(name, "radix_min_units"))
+        *value = ix->rx_min_units;
+    else if (!strcmp(name, "radix_available"))
+        *value = ix->rx_ok ? 1 : 0;
+    else if (!strcmp(name, "count_kmers"))
+        *value = ix->rx_ecnt_acc ? 1 : 0;
+    else if (!strcmp(name, "n_coarse_partitions"))
+        *value = ix->rx_ok ? ix->rx_F1 : 0;
     else if (!strcmp(name, "grid_per_cu"))
         *value = ix->grid_per_cu;
     else if (!strcmp(name, "dynamic_schedule"))
@@ -1403,9 +1629,7 @@ int kmm_get_param(kmm_index_t *ix, const char *name, int64_t *value)
     else if (!strcmp(name, "wide_buckets"))
         *value = ix->wide ? 1 : 0;
     else if (!strcmp(name, "n_partitions"))
-        *value = part_count(ix);
-    else if (!strcmp(name, "partitioned_available"))
-        *value = part_count(ix) <= KMM_MAX_PARTS ? 1 : 0;
+        *value = ix->rx_ok ? ix->rx_PF : 0;
     else
         return fail(KMM_ERR_INVALID_ARG, "unknown parameter '%s'", name);
     return KMM_OK;

@@ -127,25 +127,35 @@ __device__ __forceinline__ void agg_init(NodeAgg &agg)
         agg.st[threadIdx.x] = 0;
 }
 
-__device__ __forceinline__ void agg_add(const IndexView &iv, NodeAgg &agg, uint32_t node, uint32_t &hits)
+__device__ __forceinline__ void agg_add_n(const IndexView &iv, NodeAgg &agg, uint32_t node, uint32_t inc)
 {
-    ++hits;
     const uint32_t slot = (node * 2654435761u) >> (32 - AGG_LOG_SLOTS);
     const uint32_t prev = atomicCAS(&agg.key[slot], AGG_EMPTY, node);
     if (prev == AGG_EMPTY || prev == node)
-        atomicAdd(&agg.val[slot], 1u);
+        atomicAdd(&agg.val[slot], inc);
     else
-        atomicAdd(&iv.counts[node], 1u);
+        atomicAdd(&iv.counts[node], inc);
+}
+
+__device__ __forceinline__ void agg_add(const IndexView &iv, NodeAgg &agg, uint32_t node, uint32_t &hits)
+{
+    ++hits;
+    agg_add_n(iv, agg, node, 1u);
 }
 
 // Call after a __syncthreads() that follows the workgroup's last agg_add.
-__device__ __forceinline__ void agg_flush(const IndexView &iv, NodeAgg &agg)
+__device__ __forceinline__ void agg_flush_counts(const IndexView &iv, NodeAgg &agg)
 {
     for (int i = threadIdx.x; i < AGG_SLOTS; i += blockDim.x) {
         const uint32_t v = agg.val[i];
         if (v)
             atomicAdd(&iv.counts[agg.key[i]], v);
     }
+}
+
+__device__ __forceinline__ void agg_flush(const IndexView &iv, NodeAgg &agg)
+{
+    agg_flush_counts(iv, agg);
     if (threadIdx.x == 0) {
         unsigned long long *shard = iv.stats + (size_t)(blockIdx.x % KMM_STAT_SHARDS) * KMM_STAT_STRIDE;
         atomicAdd(&shard[0], (unsigned long long)agg.st[0]);

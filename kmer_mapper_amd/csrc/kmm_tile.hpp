@@ -52,9 +52,12 @@ __device__ __forceinline__ uint32_t flags_to_bits(uint32_t f)
     return ((f >> 7) & 1u) | ((f >> 14) & 2u) | ((f >> 21) & 4u) | ((f >> 28) & 8u);
 }
 
+// `tid` is the thread's index inside the 256-thread group that owns the tile: threadIdx.x for 256-thread
+// workgroups; wider workgroups (the radix path) run one tile per 256-thread quarter, every quarter with its
+// own TileSmem, and all of them pass through the same barriers.
 template <int S, int MODE>
 __device__ __forceinline__ uint32_t tile_kmers(const ReadsView &rv, const TileConst &tc, int64_t tile,
-                                               int k, TileSmem<S> &sm, uint64_t (&q)[S])
+                                               int k, TileSmem<S> &sm, uint64_t (&q)[S], const int tid)
 {
     constexpr bool UNIFORM = MODE == MODE_UNIFORM;
     constexpr bool RECORDS = MODE == MODE_RECORDS;
@@ -62,7 +65,6 @@ __device__ __forceinline__ uint32_t tile_kmers(const ReadsView &rv, const TileCo
     constexpr int NV = TileSmem<S>::NV;
     constexpr int NB = TileSmem<S>::NB;
     static_assert(NV <= 256, "one staged 16-byte vector per thread");
-    const int tid = threadIdx.x;
     const int64_t total = rv.total;
     const int64_t t0 = tile * T;
     __syncthreads(); // LUT visible; every wave has finished reading the previous tile's LDS words
@@ -106,7 +108,9 @@ __device__ __forceinline__ uint32_t tile_kmers(const ReadsView &rv, const TileCo
         uint32_t brk = 0, code = 0;
         int bad = -1, malformed = -1;
         if (v < NV) {
-            uint32_t line0 = rv.super_nl[tile >> 10] + rv.tile_nl[tile]; // newlines before the tile
+            // newlines before the tile (tiles past the end of the chunk — the radix path rounds the tile
+            // count up to whole blocks — hold no bytes and must not index the census arrays)
+            uint32_t line0 = t0 < total ? rv.super_nl[tile >> 10] + rv.tile_nl[tile] : 0u;
             for (int i = 0; i < v; ++i)
                 line0 += sm.codes[i];
             // first byte of a line: preceded by '\n' (or the very first byte of the chunk)
@@ -179,7 +183,7 @@ __device__ __forceinline__ uint32_t tile_kmers(const ReadsView &rv, const TileCo
     // ---- stage 2: read starts inside (t0, t0 + T + k - 2] ----------------------------------
     if (MODE == MODE_GENERAL) {
         __syncthreads(); // bitset cleared before any bit is set
-        for (int64_t r = rv.tile_first[tile] + tid; r <= rv.n_reads; r += 256) {
+        for (int64_t r = (t0 < total ? rv.tile_first[tile] : rv.n_reads + 1) + tid; r <= rv.n_reads; r += 256) {
             int64_t o = rv.offsets[r] - t0;
             if (o > (int64_t)T + k - 2)
                 break;
@@ -239,4 +243,11 @@ __device__ __forceinline__ uint32_t tile_kmers(const ReadsView &rv, const TileCo
     for (int j = 0; j < S; ++j)
         q[j] = (j == 0 ? lo : ((lo >> (2 * j)) | (hi << (64 - 2 * j)))) & tc.kmask;
     return valid;
+}
+
+template <int S, int MODE>
+__device__ __forceinline__ uint32_t tile_kmers(const ReadsView &rv, const TileConst &tc, int64_t tile,
+                                               int k, TileSmem<S> &sm, uint64_t (&q)[S])
+{
+    return tile_kmers<S, MODE>(rv, tc, tile, k, sm, q, (int)threadIdx.x);
 }

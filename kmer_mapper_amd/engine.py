@@ -122,6 +122,21 @@ class DeviceIndex:
         _lib.check(_lib.lib().kmm_get_node_counts(self._h, out.ctypes.data_as(_P)))
         return out
 
+    def count_kmers_mode(self, on=True):
+        """Per-k-mer counting mode (gpu_counter.py:23-37, command_line_interface.py:46-49): every batch takes the
+        radix path, hits are kept per index entry (get_kmer_counts) and summed into the node counts."""
+        self.set_param("count_kmers", int(bool(on)))
+
+    def get_kmer_counts(self, out=None):
+        """uint32[n_entries]: how many mapped k-mers matched each index entry, in the entry order given to the
+        constructor (needs count_kmers_mode() before mapping)."""
+        if out is None:
+            out = np.empty(self.n_entries, dtype=np.uint32)
+        dst = _Arg(out, np.uint32, "out") if not _is_torch_tensor(out) else None
+        ptr = dst.ptr if dst is not None else _P(out.data_ptr())
+        _lib.check(_lib.lib().kmm_get_kmer_counts(self._h, ptr))
+        return out
+
     # -- the hot path ----------------------------------------------------------------------------
     def map_kmers(self, kmers, max_index_lookup_frequency=1000, also_revcomp=False, k=31):
         a = _Arg(kmers, np.uint64, "kmers")
@@ -194,7 +209,8 @@ class DeviceIndex:
         return a.value, b.value
 
     def set_param(self, name, value):
-        """Tuning knobs of include/kmm.h: "path" (0 auto, 1 direct, 2 partitioned), "part_shift"."""
+        """Tuning knobs of include/kmm.h: "path" (0 auto, 1 direct, 2 radix), "part_shift", "radix_min_units",
+        "count_kmers"."""
         _lib.check(_lib.lib().kmm_set_param(self._h, name.encode(), int(value)))
 
     def get_param(self, name):

@@ -1,0 +1,190 @@
+"""GPU tests of the radix path (csrc/kmm_radix.hpp): bit-exact against the oracle and against the direct path,
+per-k-mer counting mode (GpuCounter semantics, reference kmer_mapper/gpu_counter.py:23-37), slices whose
+entries exceed the LDS capacity, sticky device-side errors."""
+import numpy as np
+import pytest
+
+from tests.helpers import batch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def kmm():
+    from kmer_mapper_amd import _lib
+    assert _lib.device_count() >= 1, "GPU tests need a HIP device"
+    import kmer_mapper_amd.engine as engine
+    return engine
+
+
+@pytest.fixture(scope="module")
+def syn():
+    from kmer_mapper_amd import synthetic
+    return synthetic
+
+
+@pytest.mark.parametrize("shift", [2, 4, 7, 12])
+@pytest.mark.parametrize("revcomp", [False, True])
+def test_radix_equals_oracle_at_every_slice_width(kmm, syn, oracle, shift, revcomp):
+    """Same reads, slice widths from 4 to 4096 buckets: one coarse partition up to hundreds, items that span
+    many blocks, fine partitions with and without entries."""
+    index, genome = syn.make_index(20000, seed=301)
+    mx = index.max_node_id()
+    bases, offs = syn.make_ragged_reads(genome, 30000, 0, 260, seed=302)
+    expect, n = oracle.map_reads(index, mx, bases, offs, 31, also_revcomp=revcomp, n_threads=4)
+    km = oracle.extract(bases, offs, 31)
+    with kmm.DeviceIndex.from_index(index, mx) as dev:
+        dev.set_param("part_shift", shift)
+        dev.set_param("path", 2)
+        assert dev.get_param("n_partitions") == -(-index._modulo // (1 << shift))
+        dev.map_reads(bases, offs, 31, also_revcomp=revcomp)
+        assert np.array_equal(dev.get_node_counts(), expect)
+        assert dev.get_stats(reset=True) == ((2 if revcomp else 1) * n, int(expect.sum()))
+        dev.reset()
+        dev.map_kmers(km, also_revcomp=revcomp, k=31)          # operator entry point through the same passes
+        assert np.array_equal(dev.get_node_counts(), expect)
+        dev.reset()
+        dev.map_reads(bases, offs, 31, max_index_lookup_frequency=1, also_revcomp=revcomp)
+        e1, _ = oracle.map_reads(index, mx, bases, offs, 31, max_index_lookup_frequency=1, also_revcomp=revcomp)
+        assert np.array_equal(dev.get_node_counts(), e1)
+
+
+def test_radix_counts_accumulate_across_calls_and_paths(kmm, syn, oracle):
+    """Counts of radix calls (kept per entry until the next synchronising call) and of direct calls add up."""
+    index, genome = syn.make_index(8000, seed=311)
+    mx = index.max_node_id()
+    parts = [syn.make_reads(genome, 5000, 150, seed=312 + i) for i in range(4)]
+    expect = sum(oracle.map_reads(index, mx, b, o, 31)[0].astype(np.uint64) for b, o in parts)
+    with kmm.DeviceIndex.from_index(index, mx) as dev:
+        for i, (b, o) in enumerate(parts):
+            dev.set_param("path", 1 + (i & 1))
+            dev.map_reads_uniform(b, 5000, 150, 31)
+        assert np.array_equal(dev.get_node_counts().astype(np.uint64), expect)
+        # a second round on top, reading the counts in between
+        for i, (b, o) in enumerate(parts):
+            dev.set_param("path", 2 - (i & 1))
+            dev.map_reads(b, o, 31)
+            dev.synchronize()
+        assert np.array_equal(dev.get_node_counts().astype(np.uint64), 2 * expect)
+
+
+def test_auto_path_picks_radix_for_large_batches_only(kmm, syn, oracle):
+    index, genome = syn.make_index(50000, seed=321)
+    mx = index.max_node_id()
+    bases, offs = syn.make_reads(genome, 40000, 150, seed=322)
+    expect, _ = oracle.map_reads(index, mx, bases, offs, 31, n_threads=4)
+    with kmm.DeviceIndex.from_index(index, mx) as dev:
+        assert dev.get_param("radix_available") == 1
+        dev.set_timing(True)
+        dev.map_reads_uniform(bases[:1000 * 150], 1000, 150, 31)     # 150 k positions: below the threshold
+        t = dev.get_timing()
+        assert t["k_map_reads"][1] == 1 and t["k_rx_p1"][1] == 0
+        dev.reset()
+        dev.set_param("radix_min_units", 1_000_000)
+        dev.map_reads_uniform(bases, 40000, 150, 31)                  # 6 M positions
+        t = dev.get_timing()
+        assert t["k_map_reads"][1] == 0 and t["k_rx_p1"][1] == 1 and t["k_rx_p3"][1] == 1
+        assert np.array_equal(dev.get_node_counts(), expect)
+
+
+def test_slice_with_more_entries_than_lds_capacity(kmm, oracle):
+    """One bucket with 6000 entries (same k-mer under 6000 nodes) and a fine partition whose entries exceed
+    the 4096 keys a slice keeps in LDS: those buckets are walked in HBM, results unchanged."""
+    rng = np.random.default_rng(331)
+    modulo = 8191
+    base = rng.integers(0, 1 << 62, size=3000, dtype=np.uint64)
+    heavy = np.uint64(123456789012345)
+    dense = (np.uint64(modulo) * np.arange(1, 3001, dtype=np.uint64) + np.uint64(77))   # 3000 k-mers, one bucket
+    kmers = np.concatenate([base, np.full(6000, heavy, dtype=np.uint64), dense])
+    nodes = np.concatenate([np.arange(3000), rng.integers(0, 5000, size=6000), rng.integers(0, 5000, size=3000)])
+    from kmer_mapper_amd.kmer_index import KmerIndex
+    index = KmerIndex.from_flat_kmers(kmers, nodes.astype(np.int64), modulo)
+    mx = int(nodes.max())
+    q = np.concatenate([base[:500], np.full(7, heavy, dtype=np.uint64), dense[::3],
+                        rng.integers(0, 1 << 62, size=2000, dtype=np.uint64)])
+    for mf in (1000, 65535):
+        expect = oracle.map_kmers(index, mx, q, mf)
+        with kmm.DeviceIndex.from_index(index, mx) as dev:
+            dev.set_param("path", 2)
+            dev.map_kmers(q, mf)
+            assert np.array_equal(dev.get_node_counts(), expect), mf
+            dev.reset()
+            dev.set_param("part_shift", 3)
+            dev.map_kmers(q, mf)
+            assert np.array_equal(dev.get_node_counts(), expect), mf
+    assert oracle.map_kmers(index, mx, q, 65535).sum() >= 7 * 6000
+
+
+def test_per_kmer_counting_mode(kmm, syn, oracle):
+    """GpuCounter semantics (reference gpu_counter.py:23-37): a count per index k-mer, node counts = their
+    segmented sum over `nodes` (np.bincount in the reference)."""
+    from kmer_mapper_amd.gpu_counter import GpuCounter
+    index, genome = syn.make_index(6000, seed=341, plant=True)
+    bases, offs = syn.make_reads(genome, 8000, 150, seed=342)
+    q = oracle.extract(bases, offs, 31)
+    kmers, nodes = index._kmers.copy(), index._nodes.astype(np.int64)
+    perm = np.random.default_rng(343).permutation(len(kmers))           # any entry order must work
+    kmers, nodes = kmers[perm], nodes[perm]
+    counter = GpuCounter.from_kmers_and_nodes(kmers, nodes, 31)
+    counter.initialize_cuda(12011)
+    half = len(q) // 2
+    counter.count(q[:half])
+    counter.count(q[half:])
+    uq, uc = np.unique(q, return_counts=True)
+    pos = np.searchsorted(uq, kmers)
+    pos[pos >= len(uq)] = 0
+    expect_k = np.where(uq[pos] == kmers, uc[pos], 0).astype(np.uint32)
+    got_k = counter.get_kmer_counts()
+    assert got_k.dtype == np.uint32 and np.array_equal(got_k, expect_k)
+    node_counts = counter.get_node_counts()
+    assert node_counts.dtype == np.float64
+    assert np.array_equal(node_counts, np.bincount(nodes, expect_k, minlength=len(node_counts)))
+    # with reverse complements (`-r`, command_line_interface.py:74): additive
+    counter.count(q[:1000], count_revcomps=True)
+    rc = oracle.revcomp(q[:1000], 31)
+    uq2, uc2 = np.unique(np.concatenate([q, q[:1000], rc]), return_counts=True)
+    pos = np.searchsorted(uq2, kmers)
+    pos[pos >= len(uq2)] = 0
+    assert np.array_equal(counter.get_kmer_counts(), np.where(uq2[pos] == kmers, uc2[pos], 0).astype(np.uint32))
+
+
+def test_device_errors_are_sticky_until_reset(kmm, syn):
+    """a chunk with an invalid base has already been counted when the error is reported, so the error
+    stays on the handle until reset() clears counts and error together."""
+    index, genome = syn.make_index(100, k=5, seed=351, plant=False)
+    bad = batch(["ACGTACGT", "ACGTXCGT"])
+    ok = batch(["ACGTACGT"])
+    for path in (1, 2):
+        with kmm.DeviceIndex.from_index(index) as dev:
+            dev.set_param("path", path)
+            dev.map_reads(bad.bases, bad.offsets, 5)
+            with pytest.raises(ValueError, match="offset 12"):
+                dev.synchronize()
+            dev.map_reads(ok.bases, ok.offsets, 5)
+            with pytest.raises(ValueError, match="offset 12"):       # still there: counts are polluted
+                dev.get_node_counts()
+            dev.reset()
+            dev.map_reads(ok.bases, ok.offsets, 5)
+            dev.get_node_counts()
+
+
+def test_radix_records_mode_and_long_reads(kmm, syn, oracle):
+    """Raw FASTQ bytes through pass 1 (records front end), including a chunk whose tile count is a multiple of
+    the block size and one that is not."""
+    from kmer_mapper_amd import _lib
+    from kmer_mapper_amd.util import ReadBatch
+    index, genome = syn.make_index(4000, seed=361)
+    mx = index.max_node_id()
+    for n_reads in (50, 3000, 20011):
+        bases, offs = syn.make_ragged_reads(genome, n_reads, 0, 200, seed=362 + n_reads)
+        expect, _ = oracle.map_reads(index, mx, bases, offs, 31)
+        lines = []
+        for r in range(n_reads):
+            s = bases[offs[r]:offs[r + 1]].tobytes()
+            lines.append(b"@r%d\n" % r + s + b"\n+\n" + b"I" * len(s) + b"\n")
+        raw = np.frombuffer(b"".join(lines), dtype=np.uint8)
+        with kmm.DeviceIndex.from_index(index, mx) as dev:
+            dev.set_param("path", 2)
+            used, n_rec = dev.map_records(raw, fmt=_lib.FORMAT_FASTQ)
+            assert used == raw.shape[0] and n_rec == n_reads
+            assert np.array_equal(dev.get_node_counts(), expect)
