@@ -439,7 +439,8 @@ int launch_rx(kmm_index *ix, const ReadsView &rv, const uint64_t *kmers_in, int6
         const size_t o_start1 = carve((size_t)NB * (F1 + 1) * 2), o_P1T = carve((size_t)F1 * (NB + 1) * 4),
                      o_S1T = carve((size_t)F1 * NB * 2), o_csum = carve((size_t)chunks * F1 * 4),
                      o_T1 = carve((size_t)F1 * 4), o_ib = carve((size_t)(F1 + 1) * 4), o_wb = carve((size_t)(F1 + 1) * 4),
-                     o_desc = carve(max_items * 8), o_start2 = carve(max_items * (F2 + 1) * 2), o_ctrl = carve(64),
+                     o_desc = carve(max_items * 8), o_start2 = carve(max_items * (F2 + 1) * 2), o_start2T = carve(max_items * (F2 + 1) * 2 + 256),
+                     o_ctrl = carve(64),
                      o_queue = carve(256);
         KMMCHK(ensure(ix->rx_meta, off));
         KMMCHK(ensure(ix->rx_buf1, (size_t)NB * RX_B * 8));
@@ -448,7 +449,8 @@ int launch_rx(kmm_index *ix, const ReadsView &rv, const uint64_t *kmers_in, int6
         rx.start1 = (uint16_t *)(m + o_start1); rx.P1T = (uint32_t *)(m + o_P1T); rx.S1T = (uint16_t *)(m + o_S1T);
         rx.csum = (uint32_t *)(m + o_csum); rx.T1 = (uint32_t *)(m + o_T1); rx.item_base = (uint32_t *)(m + o_ib);
         rx.work_base = (uint32_t *)(m + o_wb); rx.item_desc = (uint2 *)(m + o_desc);
-        rx.start2 = (uint16_t *)(m + o_start2); rx.ctrl = (uint32_t *)(m + o_ctrl);
+        rx.start2 = (uint16_t *)(m + o_start2); rx.start2T = (uint16_t *)(m + o_start2T);
+        rx.ctrl = (uint32_t *)(m + o_ctrl);
         rx.queue = (unsigned long long *)(m + o_queue);
         rx.buf1 = (uint64_t *)ix->rx_buf1.p;
         rx.buf2 = (uint64_t *)ix->rx_buf2.p;
@@ -470,6 +472,10 @@ int launch_rx(kmm_index *ix, const ReadsView &rv, const uint64_t *kmers_in, int6
         KMMCHK(tm.end());
         KMMCHK(tm.begin(ix, KMM_KERNEL_RX_P2));
         hipLaunchKernelGGL(k_rx_p2, dim3(ix->n_cu * 2), dim3(RX_NT), 0, ix->stream, iv, rx);
+        HIPCHK(hipGetLastError());
+        KMMCHK(tm.end());
+        KMMCHK(tm.begin(ix, KMM_KERNEL_RX_SCAN));
+        hipLaunchKernelGGL(k_rx_tr2, dim3((unsigned)((max_items + 63) / 64)), dim3(256), 0, ix->stream, rx);
         HIPCHK(hipGetLastError());
         KMMCHK(tm.end());
         KMMCHK(tm.begin(ix, KMM_KERNEL_RX_P3));

@@ -39,10 +39,12 @@ constexpr int RX_R = 4;               // rounds of two 1024-position tiles per p
 constexpr int RX_B = 2 * 1024 * RX_R; // 8192: positions per pass-1 block = k-mer capacity of a block area / item
 constexpr int RX_KPT = RX_B / RX_NT;  // 16 k-mers per thread
 constexpr int RX_MAXF = 256;          // largest fan-out of one pass
-constexpr int RX_CH = 1024;           // blocks per chunk of the directory scan
+constexpr int RX_CH = 512;            // blocks per chunk of the directory scan
 constexpr int RX_IC = 1024;           // pass-2 items per pass-3 work item
 constexpr int RX_LPR = 32;            // lanes that copy one run
 constexpr int RX_NG = RX_NT / RX_LPR; // run copiers per workgroup
+constexpr int RX_SUBCAP = 1024;       // sub-runs (<= RX_LPR k-mers each) listed in LDS per window
+constexpr int RX_U = 8;               // sub-runs in flight per copier
 constexpr int RX_WMAX = 4096;         // buckets per fine partition (LDS directory)
 constexpr int RX_ECAP = 4096;         // entries of a fine partition kept in LDS (keys + counters)
 enum { MODE_KMERS = 3 };              // pass-1 source: a uint64 k-mer array instead of read bytes
@@ -69,6 +71,7 @@ struct RxView {
     uint32_t *work_base;   // [F1 + 1]
     uint2 *item_desc;      // [max_items] {first block, coarse partition}
     uint16_t *start2;      // [max_items][F2 + 1]
+    uint16_t *start2T;     // [F2 + 1][max_items] (transposed for pass 3: one fine partition's run starts are contiguous)
     uint32_t *ctrl;        // [0] items, [1] pass-3 work items
     unsigned long long *queue; // [0] pass-2 item queue, [16] pass-3 work queue
 };
@@ -116,17 +119,24 @@ __device__ __forceinline__ void rx_sort_emit(const uint64_t (&q)[RX_KPT], uint32
                                              uint64_t *__restrict__ out, uint16_t *__restrict__ dir_row)
 {
     const int tid = threadIdx.x;
-    if (tid < F)
+    if (tid <= F)
         s_cnt[tid] = 0;
     __syncthreads();
-    uint32_t cr[RX_KPT]; // key << 16 | rank inside the key's run
+    // rank inside the key's run: one returning LDS atomic per k-mer, all of a thread's atomics issued before the
+    // first result is consumed (k-mers that are not real count into the spare slot F)
+    uint32_t cr[RX_KPT]; // key << 16 | rank
 #pragma unroll
-    for (int i = 0; i < RX_KPT; ++i) {
-        cr[i] = 0;
-        if ((valid >> i) & 1u) {
-            const uint32_t c = key(q[i]);
-            cr[i] = (c << 16) | atomicAdd(&s_cnt[c], 1u);
-        }
+    for (int h = 0; h < RX_KPT; h += 8) { // eight atomics in flight at a time (register budget)
+        uint32_t ck[8], rk[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            ck[i] = ((valid >> (h + i)) & 1u) ? key(q[h + i]) : (uint32_t)F;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            rk[i] = atomicAdd(&s_cnt[ck[i]], 1u);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            cr[h + i] = (ck[i] << 16) | rk[i];
     }
     __syncthreads();
     const uint32_t total = rx_scan256(s_cnt, s_base, F, s_wave);
@@ -154,6 +164,51 @@ __device__ __forceinline__ void rx_stat_add(const IndexView &iv, int which, uint
                   (unsigned long long)v);
 }
 
+// Exclusive prefix of one value per thread over the RX_NT-thread workgroup; *total = sum.  Two barriers.
+__device__ __forceinline__ uint32_t rx_scan_threads(uint32_t v, uint32_t *s_wave8, uint32_t *total)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(inc, d);
+        if (lane >= d)
+            inc += o;
+    }
+    __syncthreads(); // s_wave8 may still be read by the previous call
+    if (lane == 63)
+        s_wave8[wave] = inc;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int x = 0; x < RX_NT / 64; ++x) {
+        const uint32_t t = s_wave8[x];
+        base += x < wave ? t : 0u;
+        tot += t;
+    }
+    *total = tot;
+    return base + inc - v;
+}
+
+// Runs of k-mers that lie contiguous in HBM are copied by RX_LPR-lane copiers, one load per lane.  So that no
+// load waits for another, every run is first cut into sub-runs of at most RX_LPR k-mers, listed in LDS: this
+// thread's run (len k-mers from element offset `src`; dst = where its first k-mer goes, if the caller needs that)
+// owns the sub-run indices [pre, pre + ceil(len / RX_LPR)) (pre from rx_scan_threads) and writes those that fall
+// into the window [win, win + RX_SUBCAP).
+__device__ __forceinline__ void rx_list_subruns(uint32_t pre, uint32_t len, uint64_t src, uint32_t dst, uint32_t win,
+                                                uint64_t *sub_src, uint32_t *sub_meta)
+{
+    const uint32_t nsub = (len + RX_LPR - 1) / RX_LPR;
+    uint32_t j0 = pre > win ? pre : win;
+    const uint32_t j1 = pre + nsub < win + (uint32_t)RX_SUBCAP ? pre + nsub : win + (uint32_t)RX_SUBCAP;
+    for (uint32_t j = j0; j < j1; ++j) {
+        const uint32_t first = (j - pre) * RX_LPR;
+        const uint32_t n = len - first < (uint32_t)RX_LPR ? len - first : (uint32_t)RX_LPR;
+        sub_src[j - win] = src + first;
+        sub_meta[j - win] = ((dst + first) << 6) | n; // n <= 32 in 6 bits, dst < 2^26
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // pass 1
 // ------------------------------------------------------------------------------------------------
@@ -164,7 +219,7 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p1(ReadsView rv, const uint64_t
 {
     __shared__ TileSmem<4> sm[2];
     __shared__ uint64_t sbuf[RX_B];
-    __shared__ uint32_t s_cnt[RX_MAXF], s_base[RX_MAXF + 1], s_wave[4];
+    __shared__ uint32_t s_cnt[RX_MAXF + 1], s_base[RX_MAXF + 1], s_wave[4];
     const int tid = threadIdx.x, half = tid >> 8, ltid = tid & 255;
     TileConst tc;
     tc.kmask = 0; tc.bmask = 0; tc.aligned = false;
@@ -176,6 +231,7 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p1(ReadsView rv, const uint64_t
     const int F1 = (int)rx.F1;
     uint32_t lookups = 0;
     auto key = [&](uint64_t x) { return rx_fine(iv, rx, x) >> rx.f2; };
+    constexpr int TM = MODE == MODE_KMERS ? MODE_UNIFORM : MODE;
     for (uint32_t sb = blockIdx.x; sb < n_src; sb += gridDim.x) {
         uint64_t q[RX_KPT];
         uint32_t valid = 0;
@@ -190,11 +246,15 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p1(ReadsView rv, const uint64_t
                 }
             }
         } else {
+            uint32_t pw[RX_R][4]; // the block's staged 16-byte vectors: all tiles' loads are in flight together
+#pragma unroll
+            for (int r = 0; r < RX_R; ++r)
+                tile_load_vec<4>(rv, tc, tile_begin + ((int64_t)sb * RX_R + r) * 2 + half, ltid, pw[r]);
 #pragma unroll
             for (int r = 0; r < RX_R; ++r) {
                 uint64_t qq[4];
                 const int64_t tile = tile_begin + ((int64_t)sb * RX_R + r) * 2 + half;
-                const uint32_t v = tile_kmers<4, MODE == MODE_KMERS ? MODE_UNIFORM : MODE>(rv, tc, tile, k, sm[half], qq, ltid);
+                const uint32_t v = tile_kmers<4, TM>(rv, tc, tile, k, sm[half], qq, ltid, pw[r]);
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     q[r * 4 + j] = qq[j];
@@ -226,9 +286,21 @@ __global__ void __launch_bounds__(256) k_rx_colsum(RxView rx)
         return;
     const uint32_t b0 = blockIdx.x * RX_CH;
     const uint32_t b1 = b0 + RX_CH < rx.NB ? b0 + RX_CH : rx.NB;
-    const uint16_t *p = rx.start1 + (size_t)b0 * (F1 + 1) + c;
-    uint32_t sum = 0;
-    for (uint32_t b = b0; b < b1; ++b, p += F1 + 1)
+    const size_t ld = F1 + 1;
+    const uint16_t *p = rx.start1 + (size_t)b0 * ld + c;
+    uint32_t sum = 0, b = b0;
+    for (; b + 8 <= b1; b += 8, p += 8 * ld) { // independent loads first: the loop is latency-bound
+        uint32_t lo[8], hi[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            lo[u] = p[u * ld];
+            hi[u] = p[u * ld + 1];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            sum += hi[u] - lo[u];
+    }
+    for (; b < b1; ++b, p += ld)
         sum += (uint32_t)p[1] - (uint32_t)p[0];
     rx.csum[(size_t)blockIdx.x * F1 + c] = sum;
 }
@@ -312,11 +384,12 @@ __global__ void __launch_bounds__(256) k_rx_colscan(RxView rx)
     const uint32_t b1 = b0 + RX_CH < rx.NB ? b0 + RX_CH : rx.NB;
     uint32_t run = rx.csum[(size_t)blockIdx.x * F1 + c];
     const uint32_t ib = rx.item_base[c];
-    const uint16_t *p = rx.start1 + (size_t)b0 * (F1 + 1) + c;
+    const size_t ld = F1 + 1;
+    const uint16_t *p = rx.start1 + (size_t)b0 * ld + c;
     uint32_t *P = rx.P1T + (size_t)c * (rx.NB + 1);
     uint16_t *S = rx.S1T + (size_t)c * rx.NB;
-    for (uint32_t b = b0; b < b1; ++b, p += F1 + 1) {
-        const uint32_t s0 = p[0], cnt = (uint32_t)p[1] - s0;
+    auto step = [&](uint32_t b, uint32_t s0, uint32_t s1) {
+        const uint32_t cnt = s1 - s0;
         P[b] = run;
         S[b] = (uint16_t)s0;
         if (cnt) { // items whose first k-mer lies in this run
@@ -327,7 +400,39 @@ __global__ void __launch_bounds__(256) k_rx_colscan(RxView rx)
             }
         }
         run += cnt;
+    };
+    uint32_t b = b0;
+    for (; b + 8 <= b1; b += 8, p += 8 * ld) {
+        uint32_t lo[8], hi[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            lo[u] = p[u * ld];
+            hi[u] = p[u * ld + 1];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            step(b + u, lo[u], hi[u]);
     }
+    for (; b < b1; ++b, p += ld)
+        step(b, p[0], p[1]);
+}
+
+// start2 [item][F2 + 1] -> start2T [F2 + 1][max_items], 64 items per workgroup through an LDS tile
+__global__ void __launch_bounds__(256) k_rx_tr2(RxView rx)
+{
+    __shared__ uint16_t tile[64][RX_MAXF + 2];
+    const uint32_t n_items = rx.ctrl[0], cols = rx.F2 + 1;
+    const uint32_t i0 = blockIdx.x * 64;
+    if (i0 >= n_items)
+        return;
+    const uint32_t ni = n_items - i0 < 64u ? n_items - i0 : 64u;
+    for (uint32_t e = threadIdx.x; e < ni * cols; e += 256)
+        tile[e / cols][e % cols] = rx.start2[(size_t)i0 * cols + e];
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane < ni)
+        for (uint32_t col = wave; col < cols; col += 4)
+            rx.start2T[(size_t)col * rx.max_items + i0 + lane] = tile[lane][col];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -336,7 +441,9 @@ __global__ void __launch_bounds__(256) k_rx_colscan(RxView rx)
 __global__ void __launch_bounds__(RX_NT, 4) k_rx_p2(IndexView iv, RxView rx)
 {
     __shared__ uint64_t sbuf[RX_B];
-    __shared__ uint32_t s_cnt[RX_MAXF], s_base[RX_MAXF + 1], s_wave[4];
+    __shared__ uint64_t sub_src[RX_SUBCAP];
+    __shared__ uint32_t sub_meta[RX_SUBCAP], s_wave8[RX_NT / 64];
+    __shared__ uint32_t s_cnt[RX_MAXF + 1], s_base[RX_MAXF + 1], s_wave[4];
     __shared__ unsigned long long s_next;
     const int tid = threadIdx.x, grp = tid / RX_LPR, lg = tid % RX_LPR;
     const uint32_t n_items = rx.ctrl[0], NB = rx.NB;
@@ -359,45 +466,44 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p2(IndexView iv, RxView rx)
         const uint32_t n = hi - lo;
         const uint32_t *P = rx.P1T + (size_t)c * (NB + 1);
         const uint16_t *S = rx.S1T + (size_t)c * NB;
-        // gather: copier g takes runs b0 + g, b0 + g + RX_NG, ...; four runs in flight per copier
-        for (uint32_t bb = b0 + grp; bb < NB; bb += RX_NG * 4) {
-            uint32_t vs[4], ve[4], from[4], to[4];
-            const uint64_t *src[4];
+        // gather, in rounds of RX_NT runs: (A) one thread per run reads its descriptor (contiguous in b), the
+        // runs are cut into sub-runs of <= RX_LPR k-mers listed in LDS; (B) copier g copies sub-runs g,
+        // g + RX_NG, ... with RX_U loads in flight per lane, none depending on another
+        for (uint32_t bb = b0;; bb += RX_NT) {
+            const uint32_t b = bb + tid;
+            const uint32_t vs = b < NB ? P[b] : hi;
+            const bool live = vs < hi;
+            const uint32_t ve = live ? P[b + 1] : vs;
+            const uint32_t st = live ? S[b] : 0u;
+            const uint32_t from = vs > lo ? vs : lo, to = ve < hi ? ve : hi;
+            const uint32_t len = live && to > from ? to - from : 0u;
+            const uint64_t src = (uint64_t)b * RX_B + st + (from - vs); // element offset of the run's first wanted k-mer
+            uint32_t n_sub;
+            const uint32_t pre = rx_scan_threads((len + RX_LPR - 1) / RX_LPR, s_wave8, &n_sub);
+            const bool more = __syncthreads_or(tid == RX_NT - 1 && live && ve < hi);
+            for (uint32_t win = 0; win < n_sub; win += RX_SUBCAP) {
+                rx_list_subruns(pre, len, src, from - lo, win, sub_src, sub_meta);
+                __syncthreads();
+                const uint32_t nw = n_sub - win < (uint32_t)RX_SUBCAP ? n_sub - win : (uint32_t)RX_SUBCAP;
+                for (uint32_t j0 = grp; j0 < nw; j0 += RX_NG * RX_U) {
+                    uint64_t x[RX_U];
+                    uint32_t meta[RX_U];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const uint32_t b = bb + u * RX_NG;
-                vs[u] = b < NB ? P[b] : hi;
+                    for (int u = 0; u < RX_U; ++u) {
+                        const uint32_t j = j0 + u * RX_NG;
+                        meta[u] = j < nw ? sub_meta[j] : 0u;
+                        const uint64_t so = j < nw ? sub_src[j] : 0ull;
+                        x[u] = (uint32_t)lg < (meta[u] & 63u) ? __builtin_nontemporal_load(rx.buf1 + so + lg) : 0ull;
+                    }
+#pragma unroll
+                    for (int u = 0; u < RX_U; ++u)
+                        if ((uint32_t)lg < (meta[u] & 63u))
+                            sbuf[(meta[u] >> 6) + lg] = x[u];
+                }
+                __syncthreads(); // the list is rewritten by the next window / round
             }
-            if (vs[0] >= hi)
-                break; // P is non-decreasing: every later run lies beyond the item as well
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const uint32_t b = bb + u * RX_NG;
-                const bool in = b < NB && vs[u] < hi;
-                ve[u] = in ? P[b + 1] : vs[u];
-                const uint32_t s = in ? S[b] : 0u;
-                from[u] = vs[u] > lo ? vs[u] : lo;
-                to[u] = ve[u] < hi ? ve[u] : hi;
-                if (!in)
-                    to[u] = from[u] = 0;
-                src[u] = rx.buf1 + (size_t)b * RX_B + s - vs[u]; // src[u][v] for virtual index v
-            }
-            uint64_t x[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const uint32_t v = from[u] + lg;
-                x[u] = v < to[u] ? __builtin_nontemporal_load(&src[u][v]) : 0ull;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const uint32_t v = from[u] + lg;
-                if (v < to[u])
-                    sbuf[v - lo] = x[u];
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                for (uint32_t v = from[u] + lg + RX_LPR; v < to[u]; v += RX_LPR)
-                    sbuf[v - lo] = __builtin_nontemporal_load(&src[u][v]);
+            if (!more)
+                break; // the round's last run ends the item (or lies beyond it)
         }
         __syncthreads();
         uint64_t q[RX_KPT];
@@ -424,11 +530,14 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p3(IndexView iv, RxView rx, int
     __shared__ uint32_t sdir[RX_WMAX + 1]; // bucket b of the slice holds entries [sdir[b], sdir[b + 1]) - e0
     __shared__ uint64_t skeys[RX_ECAP];
     __shared__ uint32_t scnt[RX_ECAP];
-    __shared__ uint32_t s_wb[RX_MAXF + 1];
+    __shared__ uint64_t sub_src[RX_SUBCAP];
+    __shared__ uint32_t sub_meta[RX_SUBCAP];
+    __shared__ uint32_t s_wb[RX_MAXF + 1], s_wave8[RX_NT / 64];
     __shared__ unsigned long long s_next;
     const int tid = threadIdx.x, grp = tid / RX_LPR, lg = tid % RX_LPR;
     const uint32_t n_work = rx.ctrl[1], F1 = rx.F1, F2 = rx.F2;
     const uint32_t W = 1u << rx.w;
+    const uint64_t M = iv.modulo;
     for (uint32_t i = tid; i <= F1; i += RX_NT)
         s_wb[i] = rx.work_base[i];
     uint32_t hits = 0;
@@ -454,19 +563,49 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p3(IndexView iv, RxView rx, int
         const uint32_t rem = wi - s_wb[c];
         const uint32_t chunk = rem / f2c, g = rem % f2c;
         const uint32_t f = c * F2 + g;
-        const uint64_t h0 = (uint64_t)f << rx.w, M = iv.modulo;
+        const uint64_t h0 = (uint64_t)f << rx.w;
         const uint32_t e0 = rx.pstart[h0], e1 = rx.pstart[h0 + W < M ? h0 + W : M];
         const uint32_t ne = e1 - e0 < (uint32_t)RX_ECAP ? e1 - e0 : (uint32_t)RX_ECAP;
-        for (uint32_t i = tid; i <= W; i += RX_NT)
-            sdir[i] = rx.pstart[h0 + i < M ? h0 + i : M] - e0;
-        for (uint32_t i = tid; i < ne; i += RX_NT) {
-            skeys[i] = rx.pkeys[(size_t)e0 + i];
-            scnt[i] = 0;
-        }
-        __syncthreads();
         const uint32_t it0 = rx.item_base[c] + chunk * RX_IC;
         const uint32_t it_end = rx.item_base[c + 1];
-        const uint32_t it1 = it_end - it0 < (uint32_t)RX_IC ? it_end : it0 + RX_IC;
+        const uint32_t n_it = it_end - it0 < (uint32_t)RX_IC ? it_end - it0 : (uint32_t)RX_IC;
+        // the slice (directory + keys) and this thread's run descriptors: every load is issued before the first
+        // one is consumed
+        uint32_t dv[RX_WMAX / RX_NT + 1];
+        uint64_t kv[RX_ECAP / RX_NT];
+        uint32_t rf[RX_IC / RX_NT], rt[RX_IC / RX_NT];
+#pragma unroll
+        for (int j = 0; j <= RX_WMAX / RX_NT; ++j) {
+            const uint32_t i = tid + j * RX_NT;
+            dv[j] = i <= W ? rx.pstart[h0 + i < M ? h0 + i : M] : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < RX_ECAP / RX_NT; ++j) {
+            const uint32_t i = tid + j * RX_NT;
+            kv[j] = i < ne ? rx.pkeys[(size_t)e0 + i] : 0ull;
+        }
+        const uint16_t *rfp = rx.start2T + (size_t)g * rx.max_items + it0;
+        const uint16_t *rtp = rfp + rx.max_items;
+#pragma unroll
+        for (int j = 0; j < RX_IC / RX_NT; ++j) {
+            const uint32_t i = tid + j * RX_NT;
+            rf[j] = i < n_it ? rfp[i] : 0u;
+            rt[j] = i < n_it ? rtp[i] : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j <= RX_WMAX / RX_NT; ++j) {
+            const uint32_t i = tid + j * RX_NT;
+            if (i <= W)
+                sdir[i] = dv[j] - e0;
+        }
+#pragma unroll
+        for (int j = 0; j < RX_ECAP / RX_NT; ++j) {
+            const uint32_t i = tid + j * RX_NT;
+            if (i < ne) {
+                skeys[i] = kv[j];
+                scnt[i] = 0;
+            }
+        }
         auto probe = [&](uint64_t q) {
             const uint32_t hb = (uint32_t)(fastmod(q, iv.modulo, iv.magic) - h0) & (W - 1u);
             const uint32_t st = sdir[hb], cn = sdir[hb + 1] - st;
@@ -486,35 +625,34 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p3(IndexView iv, RxView rx, int
                 if (skeys[st + j] == q)
                     atomicAdd(&scnt[st + j], 1u);
         };
-        for (uint32_t ib = it0 + grp; ib < it1; ib += RX_NG * 4) {
-            uint32_t from[4], to[4];
-            const uint64_t *src[4];
+        // partition g's run inside every item of the chunk, RX_NT runs per round, cut into sub-runs listed in LDS
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const uint32_t it = ib + u * RX_NG;
-                from[u] = to[u] = 0;
-                src[u] = rx.buf2;
-                if (it < it1) {
-                    const uint16_t *row = rx.start2 + (size_t)it * (F2 + 1) + g;
-                    from[u] = row[0];
-                    to[u] = row[1];
-                    src[u] = rx.buf2 + (size_t)it * RX_B;
+        for (int j = 0; j < RX_IC / RX_NT; ++j) {
+            const uint32_t len = rt[j] - rf[j];
+            uint32_t n_sub;
+            const uint32_t pre = rx_scan_threads((len + RX_LPR - 1) / RX_LPR, s_wave8, &n_sub);
+            const uint64_t src = (uint64_t)(it0 + tid + j * RX_NT) * RX_B + rf[j];
+            for (uint32_t win = 0; win < n_sub; win += RX_SUBCAP) {
+                rx_list_subruns(pre, len, src, 0u, win, sub_src, sub_meta);
+                __syncthreads(); // (first window: also orders the slice's LDS writes before the probes)
+                const uint32_t nw = n_sub - win < (uint32_t)RX_SUBCAP ? n_sub - win : (uint32_t)RX_SUBCAP;
+                for (uint32_t j0 = grp; j0 < nw; j0 += RX_NG * RX_U) {
+                    uint64_t x[RX_U];
+                    uint32_t n[RX_U];
+#pragma unroll
+                    for (int u = 0; u < RX_U; ++u) {
+                        const uint32_t jj = j0 + u * RX_NG;
+                        n[u] = jj < nw ? (sub_meta[jj] & 63u) : 0u;
+                        const uint64_t so = jj < nw ? sub_src[jj] : 0ull;
+                        x[u] = (uint32_t)lg < n[u] ? __builtin_nontemporal_load(rx.buf2 + so + lg) : 0ull;
+                    }
+#pragma unroll
+                    for (int u = 0; u < RX_U; ++u)
+                        if ((uint32_t)lg < n[u])
+                            probe(x[u]);
                 }
+                __syncthreads();
             }
-            uint64_t x[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const uint32_t v = from[u] + lg;
-                x[u] = v < to[u] ? __builtin_nontemporal_load(&src[u][v]) : 0ull;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (from[u] + lg < to[u])
-                    probe(x[u]);
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                for (uint32_t v = from[u] + lg + RX_LPR; v < to[u]; v += RX_LPR)
-                    probe(__builtin_nontemporal_load(&src[u][v]));
         }
         __syncthreads();
         // LDS counters -> per-entry count vector; the frequency filter of mapper.pyx:64-66 is applied here

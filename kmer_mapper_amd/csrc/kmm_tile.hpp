@@ -52,12 +52,46 @@ __device__ __forceinline__ uint32_t flags_to_bits(uint32_t f)
     return ((f >> 7) & 1u) | ((f >> 14) & 2u) | ((f >> 21) & 4u) | ((f >> 28) & 8u);
 }
 
+// The 16 bytes of the tile's staged vector `tid` (bytes t0 + 16*tid ...), zeros beyond the end of the chunk.
+// Split from tile_kmers so that a caller can issue the loads of several tiles before it consumes the first
+// (the radix path's pass 1 keeps a whole block of tiles in flight).
+template <int S>
+__device__ __forceinline__ void tile_load_vec(const ReadsView &rv, const TileConst &tc, int64_t tile, const int tid,
+                                              uint32_t (&w)[4])
+{
+    constexpr int T = TileSmem<S>::T;
+    constexpr int NV = TileSmem<S>::NV;
+    w[0] = w[1] = w[2] = w[3] = 0u;
+    if (tid >= NV)
+        return;
+    const int64_t total = rv.total;
+    const int64_t p = tile * T + (int64_t)tid * 16;
+    if (tc.aligned && p + 16 <= total) {
+        // streamed once: non-temporal so the read bytes do not displace index lines in L2
+        u32x4 x = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(rv.bases + p));
+        w[0] = x[0]; w[1] = x[1]; w[2] = x[2]; w[3] = x[3];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            uint32_t acc = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                int64_t pp = p + i * 4 + j;
+                uint32_t c = (pp < total) ? rv.bases[pp] : 0u;
+                acc |= c << (8 * j);
+            }
+            w[i] = acc;
+        }
+    }
+}
+
 // `tid` is the thread's index inside the 256-thread group that owns the tile: threadIdx.x for 256-thread
 // workgroups; wider workgroups (the radix path) run one tile per 256-thread quarter, every quarter with its
 // own TileSmem, and all of them pass through the same barriers.
 template <int S, int MODE>
 __device__ __forceinline__ uint32_t tile_kmers(const ReadsView &rv, const TileConst &tc, int64_t tile,
-                                               int k, TileSmem<S> &sm, uint64_t (&q)[S], const int tid)
+                                               int k, TileSmem<S> &sm, uint64_t (&q)[S], const int tid,
+                                               const uint32_t (&w)[4])
 {
     constexpr bool UNIFORM = MODE == MODE_UNIFORM;
     constexpr bool RECORDS = MODE == MODE_RECORDS;
@@ -76,27 +110,10 @@ __device__ __forceinline__ uint32_t tile_kmers(const ReadsView &rv, const TileCo
         // ---- records mode, stage 1: raw file bytes.  A byte is a base iff it lies on the sequence
         // line of its record (line index mod period == 1) and is not a line terminator; every other
         // byte is a "break" that no window may contain, so k-mers never leave their read.
-        uint32_t w[4] = {0u, 0u, 0u, 0u};
         uint32_t nl = 0, cr = 0; // 16-bit masks: byte i is '\n' / '\r'
         const int v = tid;
         const int64_t p = t0 + (int64_t)v * 16;
         if (v < NV) {
-            if (tc.aligned && p + 16 <= total) {
-                u32x4 x = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(rv.bases + p));
-                w[0] = x[0]; w[1] = x[1]; w[2] = x[2]; w[3] = x[3];
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    uint32_t acc = 0;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        int64_t pp = p + i * 4 + j;
-                        uint32_t c = (pp < total) ? rv.bases[pp] : 0u;
-                        acc |= c << (8 * j);
-                    }
-                    w[i] = acc;
-                }
-            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 nl |= flags_to_bits(bytes_equal(w[i], 10u)) << (4 * i);
@@ -146,26 +163,9 @@ __device__ __forceinline__ uint32_t tile_kmers(const ReadsView &rv, const TileCo
     } else {
 
     // ---- stage 1: bytes -> 2-bit codes in LDS ----------------------------------------------
-    for (int v = tid; v < NV; v += 256) {
+    if (tid < NV) {
+        const int v = tid;
         const int64_t p = t0 + (int64_t)v * 16;
-        uint32_t w[4];
-        if (tc.aligned && p + 16 <= total) {
-            // streamed once: non-temporal so the read bytes do not displace index lines in L2
-            u32x4 x = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(rv.bases + p));
-            w[0] = x[0]; w[1] = x[1]; w[2] = x[2]; w[3] = x[3];
-        } else {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                uint32_t acc = 0;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    int64_t pp = p + i * 4 + j;
-                    uint32_t c = (pp < total) ? rv.bases[pp] : 0u;
-                    acc |= c << (8 * j);
-                }
-                w[i] = acc;
-            }
-        }
         uint32_t code = 0;
         int bad = -1;
 #pragma unroll
@@ -199,8 +199,8 @@ __device__ __forceinline__ uint32_t tile_kmers(const ReadsView &rv, const TileCo
     const int64_t p0 = t0 + q0;
     uint64_t lo, hi;
     {
-        const int w = q0 >> 4;
-        const uint32_t c0 = sm.codes[w], c1 = sm.codes[w + 1], c2 = sm.codes[w + 2];
+        const int wi = q0 >> 4;
+        const uint32_t c0 = sm.codes[wi], c1 = sm.codes[wi + 1], c2 = sm.codes[wi + 2];
         const int sh = (q0 & 15) * 2;
         lo = ((uint64_t)c1 << 32) | c0;
         hi = c2;
@@ -243,6 +243,15 @@ __device__ __forceinline__ uint32_t tile_kmers(const ReadsView &rv, const TileCo
     for (int j = 0; j < S; ++j)
         q[j] = (j == 0 ? lo : ((lo >> (2 * j)) | (hi << (64 - 2 * j)))) & tc.kmask;
     return valid;
+}
+
+template <int S, int MODE>
+__device__ __forceinline__ uint32_t tile_kmers(const ReadsView &rv, const TileConst &tc, int64_t tile,
+                                               int k, TileSmem<S> &sm, uint64_t (&q)[S], const int tid)
+{
+    uint32_t w[4];
+    tile_load_vec<S>(rv, tc, tile, tid, w);
+    return tile_kmers<S, MODE>(rv, tc, tile, k, sm, q, tid, w);
 }
 
 template <int S, int MODE>
