@@ -461,7 +461,7 @@ int launch_rx(kmm_index *ix, const ReadsView &rv, const uint64_t *kmers_in, int6
         const dim3 g1((unsigned)(n_src < g1cap ? n_src : g1cap));
         hipLaunchKernelGGL((k_rx_p1<MODE>), g1, dim3(RX_NT), 0, ix->stream, rv,
                            kmers_in ? kmers_in + s0 * RX_B : nullptr, n_in - s0 * RX_B, iv, rx, k, also_rc,
-                           s0 * RX_R * 2, n_src);
+                           s0 * (RX_B / (MODE == MODE_RECORDS ? 1024 : 4096)), n_src);
         HIPCHK(hipGetLastError());
         KMMCHK(tm.end());
         KMMCHK(tm.begin(ix, KMM_KERNEL_RX_SCAN));

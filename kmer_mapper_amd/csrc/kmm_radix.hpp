@@ -35,8 +35,9 @@
 // are walked in HBM instead, so results never depend on the layout.
 // ------------------------------------------------------------------------------------------------
 constexpr int RX_NT = 512;            // threads per workgroup of the three passes
-constexpr int RX_R = 4;               // rounds of two 1024-position tiles per pass-1 block
-constexpr int RX_B = 2 * 1024 * RX_R; // 8192: positions per pass-1 block = k-mer capacity of a block area / item
+constexpr int RX_B = 8192;            // positions per pass-1 block = k-mer capacity of a block area / item: each
+                                      // 256-thread half of the workgroup owns 4096 of them (flat reads: one tile of
+                                      // 16 windows per lane; records mode: four tiles of 4 windows per lane)
 constexpr int RX_KPT = RX_B / RX_NT;  // 16 k-mers per thread
 constexpr int RX_MAXF = 256;          // largest fan-out of one pass
 constexpr int RX_CH = 512;            // blocks per chunk of the directory scan
@@ -217,7 +218,10 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p1(ReadsView rv, const uint64_t
                                                  IndexView iv, RxView rx, int k, int also_rc, int64_t tile_begin,
                                                  uint32_t n_src)
 {
-    __shared__ TileSmem<4> sm[2];
+    constexpr int TM = MODE == MODE_KMERS ? MODE_UNIFORM : MODE;
+    constexpr int S = TM == MODE_RECORDS ? 4 : 16; // windows per lane per tile
+    constexpr int R = RX_KPT / S;                  // tiles per half-workgroup per block
+    __shared__ TileSmem<S> sm[2];
     __shared__ uint64_t sbuf[RX_B];
     __shared__ uint32_t s_cnt[RX_MAXF + 1], s_base[RX_MAXF + 1], s_wave[4];
     const int tid = threadIdx.x, half = tid >> 8, ltid = tid & 255;
@@ -231,7 +235,6 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p1(ReadsView rv, const uint64_t
     const int F1 = (int)rx.F1;
     uint32_t lookups = 0;
     auto key = [&](uint64_t x) { return rx_fine(iv, rx, x) >> rx.f2; };
-    constexpr int TM = MODE == MODE_KMERS ? MODE_UNIFORM : MODE;
     for (uint32_t sb = blockIdx.x; sb < n_src; sb += gridDim.x) {
         uint64_t q[RX_KPT];
         uint32_t valid = 0;
@@ -246,19 +249,19 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p1(ReadsView rv, const uint64_t
                 }
             }
         } else {
-            uint32_t pw[RX_R][4]; // the block's staged 16-byte vectors: all tiles' loads are in flight together
+            TileRaw pw[R]; // the block's staged bytes: all tiles' loads are in flight together
 #pragma unroll
-            for (int r = 0; r < RX_R; ++r)
-                tile_load_vec<4>(rv, tc, tile_begin + ((int64_t)sb * RX_R + r) * 2 + half, ltid, pw[r]);
+            for (int r = 0; r < R; ++r)
+                tile_load_vec<S, TM>(rv, tc, tile_begin + ((int64_t)sb * 2 + half) * R + r, ltid, pw[r]);
 #pragma unroll
-            for (int r = 0; r < RX_R; ++r) {
-                uint64_t qq[4];
-                const int64_t tile = tile_begin + ((int64_t)sb * RX_R + r) * 2 + half;
-                const uint32_t v = tile_kmers<4, TM>(rv, tc, tile, k, sm[half], qq, ltid, pw[r]);
+            for (int r = 0; r < R; ++r) {
+                uint64_t qq[S];
+                const int64_t tile = tile_begin + ((int64_t)sb * 2 + half) * R + r;
+                const uint32_t v = tile_kmers<S, TM>(rv, tc, tile, k, sm[half], qq, ltid, pw[r]);
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    q[r * 4 + j] = qq[j];
-                valid |= v << (r * 4);
+                for (int j = 0; j < S; ++j)
+                    q[r * S + j] = qq[j];
+                valid |= v << (r * S);
             }
         }
         lookups += (uint32_t)__popc(valid) * X;

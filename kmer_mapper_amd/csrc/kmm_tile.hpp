@@ -52,36 +52,56 @@ __device__ __forceinline__ uint32_t flags_to_bits(uint32_t f)
     return ((f >> 7) & 1u) | ((f >> 14) & 2u) | ((f >> 21) & 4u) | ((f >> 28) & 8u);
 }
 
-// The 16 bytes of the tile's staged vector `tid` (bytes t0 + 16*tid ...), zeros beyond the end of the chunk.
-// Split from tile_kmers so that a caller can issue the loads of several tiles before it consumes the first
-// (the radix path's pass 1 keeps a whole block of tiles in flight).
-template <int S>
+// What one thread stages of a tile, loaded before tile_kmers consumes it so that a caller can keep the loads of
+// several tiles in flight (the radix path's pass 1).  Flat reads (general / uniform): thread t < T/16 owns the 16
+// bytes at t0 + 16t, and threads t < 12 also one dword of the 48-byte halo behind the tile, so the byte -> code
+// stage is spread over all lanes.  Records mode: thread t < NV owns the 16 bytes at t0 + 16t (halo vectors included).
+struct TileRaw {
+    uint32_t w[4];
+    uint32_t halo;
+};
+
+__device__ __forceinline__ uint32_t tile_load_bytes4(const ReadsView &rv, int64_t p)
+{
+    uint32_t acc = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int64_t pp = p + j;
+        const uint32_t c = (pp < rv.total) ? rv.bases[pp] : 0u;
+        acc |= c << (8 * j);
+    }
+    return acc;
+}
+
+template <int S, int MODE>
 __device__ __forceinline__ void tile_load_vec(const ReadsView &rv, const TileConst &tc, int64_t tile, const int tid,
-                                              uint32_t (&w)[4])
+                                              TileRaw &raw)
 {
     constexpr int T = TileSmem<S>::T;
     constexpr int NV = TileSmem<S>::NV;
-    w[0] = w[1] = w[2] = w[3] = 0u;
-    if (tid >= NV)
-        return;
+    constexpr int NMAIN = MODE == MODE_RECORDS ? NV : T / 16;
+    static_assert(NMAIN <= 256, "one staged 16-byte vector per thread");
+    raw.w[0] = raw.w[1] = raw.w[2] = raw.w[3] = 0u;
+    raw.halo = 0u;
     const int64_t total = rv.total;
-    const int64_t p = tile * T + (int64_t)tid * 16;
-    if (tc.aligned && p + 16 <= total) {
-        // streamed once: non-temporal so the read bytes do not displace index lines in L2
-        u32x4 x = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(rv.bases + p));
-        w[0] = x[0]; w[1] = x[1]; w[2] = x[2]; w[3] = x[3];
-    } else {
+    if (tid < NMAIN) {
+        const int64_t p = tile * T + (int64_t)tid * 16;
+        if (tc.aligned && p + 16 <= total) {
+            // streamed once: non-temporal so the read bytes do not displace index lines in L2
+            u32x4 x = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(rv.bases + p));
+            raw.w[0] = x[0]; raw.w[1] = x[1]; raw.w[2] = x[2]; raw.w[3] = x[3];
+        } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            uint32_t acc = 0;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                int64_t pp = p + i * 4 + j;
-                uint32_t c = (pp < total) ? rv.bases[pp] : 0u;
-                acc |= c << (8 * j);
-            }
-            w[i] = acc;
+            for (int i = 0; i < 4; ++i)
+                raw.w[i] = tile_load_bytes4(rv, p + i * 4);
         }
+    }
+    if (MODE != MODE_RECORDS && tid < 12) {
+        const int64_t p = tile * T + T + (int64_t)tid * 4;
+        if (tc.aligned && p + 4 <= total)
+            raw.halo = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(rv.bases + p));
+        else
+            raw.halo = tile_load_bytes4(rv, p);
     }
 }
 
@@ -91,14 +111,16 @@ __device__ __forceinline__ void tile_load_vec(const ReadsView &rv, const TileCon
 template <int S, int MODE>
 __device__ __forceinline__ uint32_t tile_kmers(const ReadsView &rv, const TileConst &tc, int64_t tile,
                                                int k, TileSmem<S> &sm, uint64_t (&q)[S], const int tid,
-                                               const uint32_t (&w)[4])
+                                               const TileRaw &raw)
 {
+    const uint32_t (&w)[4] = raw.w;
     constexpr bool UNIFORM = MODE == MODE_UNIFORM;
     constexpr bool RECORDS = MODE == MODE_RECORDS;
     constexpr int T = TileSmem<S>::T;
     constexpr int NV = TileSmem<S>::NV;
     constexpr int NB = TileSmem<S>::NB;
-    static_assert(NV <= 256, "one staged 16-byte vector per thread");
+    static_assert(!RECORDS || NV <= 256, "records mode: one staged 16-byte vector per thread");
+    static_assert(T % 1024 == 0, "tile_first / tile_nl are kept per 1024 positions");
     const int64_t total = rv.total;
     const int64_t t0 = tile * T;
     __syncthreads(); // LUT visible; every wave has finished reading the previous tile's LDS words
@@ -127,7 +149,7 @@ __device__ __forceinline__ uint32_t tile_kmers(const ReadsView &rv, const TileCo
         if (v < NV) {
             // newlines before the tile (tiles past the end of the chunk — the radix path rounds the tile
             // count up to whole blocks — hold no bytes and must not index the census arrays)
-            uint32_t line0 = t0 < total ? rv.super_nl[tile >> 10] + rv.tile_nl[tile] : 0u;
+            uint32_t line0 = t0 < total ? rv.super_nl[(tile * (T / 1024)) >> 10] + rv.tile_nl[tile * (T / 1024)] : 0u;
             for (int i = 0; i < v; ++i)
                 line0 += sm.codes[i];
             // first byte of a line: preceded by '\n' (or the very first byte of the chunk)
@@ -163,7 +185,7 @@ __device__ __forceinline__ uint32_t tile_kmers(const ReadsView &rv, const TileCo
     } else {
 
     // ---- stage 1: bytes -> 2-bit codes in LDS ----------------------------------------------
-    if (tid < NV) {
+    if (tid < T / 16) {
         const int v = tid;
         const int64_t p = t0 + (int64_t)v * 16;
         uint32_t code = 0;
@@ -180,10 +202,26 @@ __device__ __forceinline__ uint32_t tile_kmers(const ReadsView &rv, const TileCo
         if (bad >= 0)
             atomicMin(rv.first_bad, (unsigned long long)(p + bad));
     }
+    if (tid < 12) { // the 48 bytes behind the tile, four per thread -> one byte of codes each
+        const int64_t p = t0 + T + (int64_t)tid * 4;
+        uint32_t code = 0;
+        int bad = -1;
+#pragma unroll
+        for (int i = 3; i >= 0; --i) {
+            uint32_t c = (raw.halo >> (8 * i)) & 0xFFu;
+            uint32_t l = sm.lut[c];
+            if (l == 0xFFu && p + i < total)
+                bad = i;
+            code |= (l & 3u) << (2 * i);
+        }
+        reinterpret_cast<uint8_t *>(&sm.codes[T / 16])[tid] = (uint8_t)code;
+        if (bad >= 0)
+            atomicMin(rv.first_bad, (unsigned long long)(p + bad));
+    }
     // ---- stage 2: read starts inside (t0, t0 + T + k - 2] ----------------------------------
     if (MODE == MODE_GENERAL) {
         __syncthreads(); // bitset cleared before any bit is set
-        for (int64_t r = (t0 < total ? rv.tile_first[tile] : rv.n_reads + 1) + tid; r <= rv.n_reads; r += 256) {
+        for (int64_t r = (t0 < total ? rv.tile_first[tile * (T / 1024)] : rv.n_reads + 1) + tid; r <= rv.n_reads; r += 256) {
             int64_t o = rv.offsets[r] - t0;
             if (o > (int64_t)T + k - 2)
                 break;
@@ -249,9 +287,9 @@ template <int S, int MODE>
 __device__ __forceinline__ uint32_t tile_kmers(const ReadsView &rv, const TileConst &tc, int64_t tile,
                                                int k, TileSmem<S> &sm, uint64_t (&q)[S], const int tid)
 {
-    uint32_t w[4];
-    tile_load_vec<S>(rv, tc, tile, tid, w);
-    return tile_kmers<S, MODE>(rv, tc, tile, k, sm, q, tid, w);
+    TileRaw raw;
+    tile_load_vec<S, MODE>(rv, tc, tile, tid, raw);
+    return tile_kmers<S, MODE>(rv, tc, tile, k, sm, q, tid, raw);
 }
 
 template <int S, int MODE>
