@@ -175,7 +175,8 @@ struct kmm_index {
     int64_t rx_min_units = 0; // auto: batches of at least this many positions / k-mers take the radix path
     uint64_t rx_S = 0;        // entries in bucket order
     uint32_t *rx_pstart = nullptr;
-    uint64_t *rx_pkeys = nullptr;
+    uint64_t *rx_pkeys = nullptr;     // packed form for the current (w, f2)
+    uint64_t *rx_pkeys_raw = nullptr; // the k-mers themselves (re-packed when part_shift changes)
     uint16_t *rx_pfreq = nullptr;
     uint32_t *rx_pnodes = nullptr, *rx_porig = nullptr, *rx_ecnt = nullptr, *rx_ecnt_acc = nullptr;
     bool ecnt_dirty = false;  // rx_ecnt holds hits that are not in `counts` yet
@@ -383,7 +384,7 @@ constexpr int TILE_T = 256 * TILE_S;
 // Fan-out of the radix path for 2^w buckets per fine partition: F1 coarse x F2 fine partitions.
 bool rx_configure(kmm_index *ix, int w)
 {
-    if (w < 2 || w > 12)
+    if (w < 2 || w > 12 || ix->modulo >= (1ull << 31)) // (pass 1 divides with a 32-bit remainder)
         return false;
     const uint64_t PF = (ix->modulo + (1ull << w) - 1) >> w;
     if (PF > (uint64_t)RX_MAXF * RX_MAXF)
@@ -391,10 +392,15 @@ bool rx_configure(kmm_index *ix, int w)
     int lg = 0;
     while ((1ull << lg) < PF)
         ++lg;
-    const int f2 = (lg + 1) / 2;
-    const uint64_t F2 = 1ull << f2, F1 = (PF + F2 - 1) / F2;
-    if (F1 > (uint64_t)RX_MAXF || F2 > (uint64_t)RX_MAXF)
+    int f2 = (lg + 1) / 2;
+    // the packed form (kmm_radix.hpp) keeps floor(q / modulo) above w + f2 hash bits: it must fit for EVERY
+    // 64-bit q (callers may hand over arbitrary uint64 values), else give the quotient more room
+    const uint64_t max_quo = ~0ull / ix->modulo;
+    while (f2 > 0 && (w + f2 >= 64 || (max_quo >> (64 - w - f2)) != 0))
+        --f2;
+    if (w + f2 >= 64 || (max_quo >> (64 - w - f2)) != 0)
         return false;
+    const uint64_t F2 = 1ull << f2, F1 = (PF + F2 - 1) / F2;
     ix->rx_w = w;
     ix->rx_f2 = f2;
     ix->rx_PF = (uint32_t)PF;
@@ -459,9 +465,14 @@ int launch_rx(kmm_index *ix, const ReadsView &rv, const uint64_t *kmers_in, int6
         KMMCHK(tm.begin(ix, KMM_KERNEL_RX_P1));
         const int64_t g1cap = (int64_t)ix->n_cu * 8;
         const dim3 g1((unsigned)(n_src < g1cap ? n_src : g1cap));
-        hipLaunchKernelGGL((k_rx_p1<MODE>), g1, dim3(RX_NT), 0, ix->stream, rv,
-                           kmers_in ? kmers_in + s0 * RX_B : nullptr, n_in - s0 * RX_B, iv, rx, k, also_rc,
-                           s0 * (RX_B / (MODE == MODE_RECORDS ? 1024 : 4096)), n_src);
+        const int64_t tile0 = s0 * (RX_B / (MODE == MODE_RECORDS ? 1024 : 4096));
+        const uint64_t *src_kmers = kmers_in ? kmers_in + s0 * RX_B : nullptr;
+        if (also_rc)
+            hipLaunchKernelGGL((k_rx_p1<MODE, true>), g1, dim3(RX_NT), 0, ix->stream, rv, src_kmers, n_in - s0 * RX_B,
+                               iv, rx, k, tile0, n_src);
+        else
+            hipLaunchKernelGGL((k_rx_p1<MODE, false>), g1, dim3(RX_NT), 0, ix->stream, rv, src_kmers, n_in - s0 * RX_B,
+                               iv, rx, k, tile0, n_src);
         HIPCHK(hipGetLastError());
         KMMCHK(tm.end());
         KMMCHK(tm.begin(ix, KMM_KERNEL_RX_SCAN));
@@ -614,7 +625,7 @@ void kmm_index_destroy(kmm_index_t *ix)
     release(ix->rx_meta);
     release(ix->rx_buf1);
     release(ix->rx_buf2);
-    for (void *q : {(void *)ix->rx_pstart, (void *)ix->rx_pkeys, (void *)ix->rx_pfreq, (void *)ix->rx_pnodes,
+    for (void *q : {(void *)ix->rx_pstart, (void *)ix->rx_pkeys, (void *)ix->rx_pkeys_raw, (void *)ix->rx_pfreq, (void *)ix->rx_pnodes,
                     (void *)ix->rx_porig, (void *)ix->rx_ecnt, (void *)ix->rx_ecnt_acc})
         if (q)
             (void)hipFree(q);
@@ -651,6 +662,17 @@ void kmm_index_destroy(kmm_index_t *ix)
     delete ix;
 }
 
+// The entry k-mers in the packed form of the current (w, f2) (kmm_radix.hpp); synchronous.
+static int rx_repack_keys(kmm_index *ix)
+{
+    if (ix->rx_S)
+        hipLaunchKernelGGL(k_rx_pack_keys, dim3(grid_for(ix, (int64_t)((ix->rx_S + 255) / 256), 16)), dim3(256), 0,
+                           ix->stream, ix->rx_pkeys_raw, ix->rx_S, view_of(ix), ix->rx_w + ix->rx_f2, ix->rx_pkeys);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(ix->stream));
+    return KMM_OK;
+}
+
 // Radix-path view of the index (kmm_radix.hpp): entries regrouped in bucket order (whatever order the caller's
 // hashes_to_index uses) + the exclusive prefix of the bucket sizes, which serves as the bucket directory of any
 // 2^w-bucket slice.  Built from the raw arrays while they are still in HBM.
@@ -676,13 +698,14 @@ static int rx_build(kmm_index *ix, const int32_t *h2i, const int32_t *nk, const 
         ix->rx_S = total; // < 2^32: a sum of validated bucket sizes may exceed n_entries only if buckets overlap
         const size_t S = total ? total : 1;
         if ((e = hipMalloc(&ix->rx_pkeys, S * 8))) break;
+        if ((e = hipMalloc(&ix->rx_pkeys_raw, S * 8))) break;
         if ((e = hipMalloc(&ix->rx_pfreq, S * 2))) break;
         if ((e = hipMalloc(&ix->rx_pnodes, S * 4))) break;
         if ((e = hipMalloc(&ix->rx_porig, S * 4))) break;
         if ((e = hipMalloc(&ix->rx_ecnt, S * 4))) break;
         if ((e = hipMemsetAsync(ix->rx_ecnt, 0, S * 4, ix->stream))) break;
         hipLaunchKernelGGL(k_rx_pack, dim3(grid_for(ix, (int64_t)((M + 255) / 256), 16)), dim3(256), 0, ix->stream, h2i,
-                           kmers, nodes, freqs, M, ix->max_node_id, ix->rx_pstart, ix->rx_pkeys, ix->rx_pfreq,
+                           kmers, nodes, freqs, M, ix->max_node_id, ix->rx_pstart, ix->rx_pkeys_raw, ix->rx_pfreq,
                            ix->rx_pnodes, ix->rx_porig);
         if ((e = hipGetLastError())) break;
         if ((e = hipStreamSynchronize(ix->stream))) break;
@@ -700,9 +723,12 @@ static int rx_build(kmm_index *ix, const int32_t *h2i, const int32_t *nk, const 
     if (const char *env = getenv("KMM_RX_W")) // experiments / tests: force the slice width
         w = atoi(env);
     else
-        while (w > 4 && (double)ix->rx_S / (double)M * (double)(1u << w) * 1.3 + 64.0 > (double)RX_ECAP)
+        while (w > 2 && ((double)ix->rx_S / (double)M * (double)(1u << w) * 1.3 + 64.0 > (double)RX_ECAP ||
+                         (1ull << w) > M))
             --w;
     ix->rx_ok = rx_configure(ix, w);
+    if (ix->rx_ok)
+        KMMCHK(rx_repack_keys(ix));
     // auto: the radix path streams the whole directory + key arrays once per batch (4 B x modulo + 14 B x entries),
     // which pays off once the batch's own streams (~40 B per k-mer) dominate
     ix->rx_min_units = (int64_t)((M * 4 + ix->rx_S * 14) / 8);
@@ -1570,6 +1596,10 @@ int kmm_set_param(kmm_index_t *ix, const char *name, int64_t value)
             return fail(KMM_ERR_INVALID_ARG, "part_shift %lld: needs 2 <= shift <= 12 and at most 256 x 256 fine "
                         "partitions", (long long)value);
         ix->rx_ok = ix->rx_pstart != nullptr;
+        if (ix->rx_ok) {
+            KMMCHK(rx_flush(ix)); // nothing of the old layout may be pending
+            KMMCHK(rx_repack_keys(ix));
+        }
     } else if (!strcmp(name, "radix_min_units")) {
         ix->rx_min_units = value;
     } else if (!strcmp(name, "count_kmers")) {

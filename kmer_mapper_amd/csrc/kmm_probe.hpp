@@ -75,6 +75,21 @@ __device__ __forceinline__ uint64_t fastdiv(uint64_t x, uint64_t m, uint64_t mag
     return q;
 }
 
+// Same for m < 2^31 (every index in the reference's int32 format): quotient and 32-bit remainder.  The true
+// remainder before the correction step is < 2m < 2^32, so it is exact modulo 2^32 and one 32-bit multiply
+// replaces the 64-bit product.
+__device__ __forceinline__ uint64_t fastdiv_m31(uint64_t x, uint32_t m, uint64_t magic, uint32_t *rem)
+{
+    uint64_t q = __umul64hi(x, magic);
+    uint32_t r = (uint32_t)x - (uint32_t)q * m;
+    if (r >= m) {
+        r -= m;
+        q += 1;
+    }
+    *rem = r;
+    return q;
+}
+
 // Reverse complement under A,C,G,T = 0,1,2,3, first base in the lowest bits: complement every
 // 2-bit group (NOT), reverse the groups, realign (the `-r` operation).
 __device__ __forceinline__ uint64_t revcomp(uint64_t x, int k)

@@ -29,6 +29,12 @@
 //   flush   k_rx_flush  at the next synchronising call: counts[node[e]] += ecnt[e]  (mapper.pyx:68 summed per
 //                     entry first — the reference's GpuCounter does exactly this, gpu_counter.py:26-37)
 //
+// Between the passes a k-mer q travels as x = (q / modulo) << (w + f2) | (q % modulo) & (2^(w+f2) - 1): the
+// quotient and the hash bits BELOW the coarse partition number.  Inside a coarse partition (and so inside a
+// fine one) x determines q, the fine partition is bits [w, w + f2) of x and the bucket inside the slice bits
+// [0, w): only pass 1 divides by the modulo (mapper.pyx:54), passes 2 and 3 shift and compare.  The index keys
+// are kept in the same form.  rx_configure guarantees that the quotient of ANY 64-bit value fits the upper bits.
+//
 // Nothing depends on partition sizes being balanced: block areas and items are exact, a run that is longer
 // than expected is just a longer contiguous copy, a partition with many items is probed by several work
 // items.  Buckets whose entries lie beyond the slice's LDS key capacity (RX_ECAP entries per fine partition)
@@ -45,7 +51,8 @@ constexpr int RX_IC = 1024;           // pass-2 items per pass-3 work item
 constexpr int RX_LPR = 32;            // lanes that copy one run
 constexpr int RX_NG = RX_NT / RX_LPR; // run copiers per workgroup
 constexpr int RX_SUBCAP = 1024;       // sub-runs (<= RX_LPR k-mers each) listed in LDS per window
-constexpr int RX_U = 8;               // sub-runs in flight per copier
+constexpr int RX_U = 8;               // sub-runs in flight per copier (pass 3)
+constexpr int RX_U2 = 16;             // ... pass 2
 constexpr int RX_WMAX = 4096;         // buckets per fine partition (LDS directory)
 constexpr int RX_ECAP = 4096;         // entries of a fine partition kept in LDS (keys + counters)
 enum { MODE_KMERS = 3 };              // pass-1 source: a uint64 k-mer array instead of read bytes
@@ -54,10 +61,10 @@ struct RxView {
     // index side (built once at kmm_index_create)
     const uint32_t *pstart; // [modulo + 1] first entry of every bucket in bucket order (exclusive prefix of the
                             //              bucket sizes; pstart[modulo] = S): any 2^w-bucket slice is a directory
-    const uint64_t *pkeys;  // [S] entry k-mers in bucket order
+    const uint64_t *pkeys;  // [S] entry k-mers in bucket order, in the packed form the passes carry (rx_pack)
     const uint16_t *pfreq;  // [S]
     uint32_t *ecnt;         // [S] per-entry hit counts not yet added to the node counts
-    int w, f2;
+    int w, f2;              // sh = w + f2: hash bits below the coarse partition number
     uint32_t PF, F1, F2;
     // batch side
     uint32_t NB;           // pass-1 output blocks of this sub-batch
@@ -77,9 +84,13 @@ struct RxView {
     unsigned long long *queue; // [0] pass-2 item queue, [16] pass-3 work queue
 };
 
-__device__ __forceinline__ uint32_t rx_fine(const IndexView &iv, const RxView &rx, uint64_t q)
+// q -> packed form; *coarse gets the coarse partition (= hash >> (w + f2)).
+__device__ __forceinline__ uint64_t rx_pack(const IndexView &iv, int sh, uint64_t q, uint32_t *coarse)
 {
-    return (uint32_t)(fastmod(q, iv.modulo, iv.magic) >> rx.w);
+    uint32_t h; // modulo < 2^31 on this path (rx_configure)
+    const uint64_t quo = fastdiv_m31(q, (uint32_t)iv.modulo, iv.magic, &h);
+    *coarse = h >> sh;
+    return (quo << sh) | (uint64_t)(h & ((1u << sh) - 1u));
 }
 
 // Exclusive scan of s_in[0..n) (n <= 256) into s_out[0..n], s_out[n] = total, by a RX_NT-thread workgroup.
@@ -111,32 +122,34 @@ __device__ __forceinline__ uint32_t rx_scan256(const uint32_t *s_in, uint32_t *s
     return total;
 }
 
-// Counting sort of the workgroup's k-mers (RX_KPT per thread, `valid` = which are real) by key(q) < F inside
-// LDS, then: the sorted run array goes to `out` as one contiguous coalesced copy, where each key's run starts
-// (and the total) to dir_row[0..F].  sbuf may hold the inputs: they are in registers before anything is written.
-template <typename KeyFn>
-__device__ __forceinline__ void rx_sort_emit(const uint64_t (&q)[RX_KPT], uint32_t valid, KeyFn key, int F,
-                                             uint64_t *sbuf, uint32_t *s_cnt, uint32_t *s_base, uint32_t *s_wave,
+// Counting sort of the workgroup's k-mers (RX_KPT per thread) inside LDS.  prep(i) finalises slot i of q (it may
+// rewrite q[i]) and returns its key < F, or F for a slot that holds no k-mer.  Then: the sorted run array goes to
+// `out` as one contiguous coalesced copy, where each key's run starts (and the total) to dir_row[0..F].  sbuf may
+// hold the inputs: they are in registers before anything is written.
+template <int RB, typename PrepFn>
+__device__ __forceinline__ void rx_sort_emit(uint64_t (&q)[RX_KPT], PrepFn prep, int F, uint64_t *sbuf,
+                                             uint32_t *s_cnt, uint32_t *s_base, uint32_t *s_wave,
                                              uint64_t *__restrict__ out, uint16_t *__restrict__ dir_row)
 {
     const int tid = threadIdx.x;
     if (tid <= F)
         s_cnt[tid] = 0;
     __syncthreads();
-    // rank inside the key's run: one returning LDS atomic per k-mer, all of a thread's atomics issued before the
-    // first result is consumed (k-mers that are not real count into the spare slot F)
+    // rank inside the key's run: one returning LDS atomic per k-mer, RB in flight before the first result is
+    // consumed (slots without a k-mer count into the spare counter F); RB at a time also bounds the registers
+    // the key computation (pass 1: a 64-bit division by the modulo) holds at once
     uint32_t cr[RX_KPT]; // key << 16 | rank
 #pragma unroll
-    for (int h = 0; h < RX_KPT; h += 8) { // eight atomics in flight at a time (register budget)
-        uint32_t ck[8], rk[8];
+    for (int h = 0; h < RX_KPT; h += RB) {
+        uint32_t ck[RB], rk[RB];
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-            ck[i] = ((valid >> (h + i)) & 1u) ? key(q[h + i]) : (uint32_t)F;
+        for (int i = 0; i < RB; ++i)
+            ck[i] = prep(h + i);
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+        for (int i = 0; i < RB; ++i)
             rk[i] = atomicAdd(&s_cnt[ck[i]], 1u);
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+        for (int i = 0; i < RB; ++i)
             cr[h + i] = (ck[i] << 16) | rk[i];
     }
     __syncthreads();
@@ -145,7 +158,7 @@ __device__ __forceinline__ void rx_sort_emit(const uint64_t (&q)[RX_KPT], uint32
         dir_row[tid] = (uint16_t)s_base[tid];
 #pragma unroll
     for (int i = 0; i < RX_KPT; ++i)
-        if ((valid >> i) & 1u)
+        if ((cr[i] >> 16) != (uint32_t)F)
             sbuf[s_base[cr[i] >> 16] + (cr[i] & 0xFFFFu)] = q[i];
     __syncthreads();
     const uint4 *s4 = reinterpret_cast<const uint4 *>(sbuf);
@@ -213,10 +226,9 @@ __device__ __forceinline__ void rx_list_subruns(uint32_t pre, uint32_t len, uint
 // ------------------------------------------------------------------------------------------------
 // pass 1
 // ------------------------------------------------------------------------------------------------
-template <int MODE>
+template <int MODE, bool RC>
 __global__ void __launch_bounds__(RX_NT, 4) k_rx_p1(ReadsView rv, const uint64_t *__restrict__ kmers_in, int64_t n_in,
-                                                 IndexView iv, RxView rx, int k, int also_rc, int64_t tile_begin,
-                                                 uint32_t n_src)
+                                                 IndexView iv, RxView rx, int k, int64_t tile_begin, uint32_t n_src)
 {
     constexpr int TM = MODE == MODE_KMERS ? MODE_UNIFORM : MODE;
     constexpr int S = TM == MODE_RECORDS ? 4 : 16; // windows per lane per tile
@@ -231,10 +243,10 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p1(ReadsView rv, const uint64_t
         sm[half].lut[ltid] = rv.lut[ltid];
         tc = tile_const(rv, k);
     }
-    const uint32_t X = also_rc ? 2u : 1u;
+    constexpr uint32_t X = RC ? 2u : 1u;
     const int F1 = (int)rx.F1;
     uint32_t lookups = 0;
-    auto key = [&](uint64_t x) { return rx_fine(iv, rx, x) >> rx.f2; };
+    const int sh = rx.w + rx.f2;
     for (uint32_t sb = blockIdx.x; sb < n_src; sb += gridDim.x) {
         uint64_t q[RX_KPT];
         uint32_t valid = 0;
@@ -265,15 +277,31 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p1(ReadsView rv, const uint64_t
             }
         }
         lookups += (uint32_t)__popc(valid) * X;
-        for (uint32_t pass = 0; pass < X; ++pass) {
-            if (pass) {
-#pragma unroll
-                for (int i = 0; i < RX_KPT; ++i)
-                    q[i] = revcomp(q[i], k);
-            }
-            const size_t ob = (size_t)sb * X + pass;
-            rx_sort_emit(q, valid, key, F1, sbuf, s_cnt, s_base, s_wave, rx.buf1 + ob * RX_B,
-                         rx.start1 + ob * (size_t)(F1 + 1));
+        // the only division by the modulo of the whole path (mapper.pyx:54) happens here
+        if (RC) {
+            uint64_t x[RX_KPT];
+            auto fwd = [&](int i) {
+                uint32_t c;
+                x[i] = rx_pack(iv, sh, q[i], &c);
+                return ((valid >> i) & 1u) ? c : (uint32_t)F1;
+            };
+            rx_sort_emit<4>(x, fwd, F1, sbuf, s_cnt, s_base, s_wave, rx.buf1 + (size_t)sb * 2 * RX_B,
+                         rx.start1 + (size_t)sb * 2 * (size_t)(F1 + 1));
+            auto rev = [&](int i) {
+                uint32_t c;
+                x[i] = rx_pack(iv, sh, revcomp(q[i], k), &c);
+                return ((valid >> i) & 1u) ? c : (uint32_t)F1;
+            };
+            rx_sort_emit<4>(x, rev, F1, sbuf, s_cnt, s_base, s_wave, rx.buf1 + ((size_t)sb * 2 + 1) * RX_B,
+                         rx.start1 + ((size_t)sb * 2 + 1) * (size_t)(F1 + 1));
+        } else {
+            auto fwd = [&](int i) {
+                uint32_t c;
+                q[i] = rx_pack(iv, sh, q[i], &c);
+                return ((valid >> i) & 1u) ? c : (uint32_t)F1;
+            };
+            rx_sort_emit<4>(q, fwd, F1, sbuf, s_cnt, s_base, s_wave, rx.buf1 + (size_t)sb * RX_B,
+                         rx.start1 + (size_t)sb * (size_t)(F1 + 1));
         }
     }
     rx_stat_add(iv, 0, lookups);
@@ -447,20 +475,12 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p2(IndexView iv, RxView rx)
     __shared__ uint64_t sub_src[RX_SUBCAP];
     __shared__ uint32_t sub_meta[RX_SUBCAP], s_wave8[RX_NT / 64];
     __shared__ uint32_t s_cnt[RX_MAXF + 1], s_base[RX_MAXF + 1], s_wave[4];
-    __shared__ unsigned long long s_next;
     const int tid = threadIdx.x, grp = tid / RX_LPR, lg = tid % RX_LPR;
     const uint32_t n_items = rx.ctrl[0], NB = rx.NB;
     const int F2 = (int)rx.F2;
-    auto key = [&](uint64_t x) { return rx_fine(iv, rx, x) & (uint32_t)(F2 - 1); };
-    for (;;) {
-        if (tid == 0)
-            s_next = atomicAdd(&rx.queue[0], 1ull);
-        __syncthreads();
-        const unsigned long long nx = s_next;
-        const uint32_t item = (uint32_t)nx;
-        __syncthreads(); // s_next may be rewritten only after everyone has read it
-        if (nx >= (unsigned long long)n_items)
-            break;
+    // items all hold RX_B k-mers (but the last of a coarse partition): a static round-robin is balanced, and the
+    // item's descriptor chain (item_desc -> item_base / T1 -> P / S) needs no queue pop and no broadcast in front
+    for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
         const uint2 d = rx.item_desc[item];
         const uint32_t b0 = d.x, c = d.y;
         const uint32_t lo = (item - rx.item_base[c]) * RX_B;
@@ -471,7 +491,7 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p2(IndexView iv, RxView rx)
         const uint16_t *S = rx.S1T + (size_t)c * NB;
         // gather, in rounds of RX_NT runs: (A) one thread per run reads its descriptor (contiguous in b), the
         // runs are cut into sub-runs of <= RX_LPR k-mers listed in LDS; (B) copier g copies sub-runs g,
-        // g + RX_NG, ... with RX_U loads in flight per lane, none depending on another
+        // g + RX_NG, ... with RX_U2 loads in flight per lane, none depending on another
         for (uint32_t bb = b0;; bb += RX_NT) {
             const uint32_t b = bb + tid;
             const uint32_t vs = b < NB ? P[b] : hi;
@@ -488,18 +508,18 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p2(IndexView iv, RxView rx)
                 rx_list_subruns(pre, len, src, from - lo, win, sub_src, sub_meta);
                 __syncthreads();
                 const uint32_t nw = n_sub - win < (uint32_t)RX_SUBCAP ? n_sub - win : (uint32_t)RX_SUBCAP;
-                for (uint32_t j0 = grp; j0 < nw; j0 += RX_NG * RX_U) {
-                    uint64_t x[RX_U];
-                    uint32_t meta[RX_U];
+                for (uint32_t j0 = grp; j0 < nw; j0 += RX_NG * RX_U2) {
+                    uint64_t x[RX_U2];
+                    uint32_t meta[RX_U2];
 #pragma unroll
-                    for (int u = 0; u < RX_U; ++u) {
+                    for (int u = 0; u < RX_U2; ++u) {
                         const uint32_t j = j0 + u * RX_NG;
                         meta[u] = j < nw ? sub_meta[j] : 0u;
                         const uint64_t so = j < nw ? sub_src[j] : 0ull;
                         x[u] = (uint32_t)lg < (meta[u] & 63u) ? __builtin_nontemporal_load(rx.buf1 + so + lg) : 0ull;
                     }
 #pragma unroll
-                    for (int u = 0; u < RX_U; ++u)
+                    for (int u = 0; u < RX_U2; ++u)
                         if ((uint32_t)lg < (meta[u] & 63u))
                             sbuf[(meta[u] >> 6) + lg] = x[u];
                 }
@@ -520,7 +540,10 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p2(IndexView iv, RxView rx)
                 valid |= 1u << i;
             }
         }
-        rx_sort_emit(q, valid, key, F2, sbuf, s_cnt, s_base, s_wave, rx.buf2 + (size_t)item * RX_B,
+        auto fine = [&](int i) {
+            return ((valid >> i) & 1u) ? ((uint32_t)(q[i] >> rx.w) & (uint32_t)(F2 - 1)) : (uint32_t)F2;
+        };
+        rx_sort_emit<8>(q, fine, F2, sbuf, s_cnt, s_base, s_wave, rx.buf2 + (size_t)item * RX_B,
                      rx.start2 + (size_t)item * (F2 + 1));
     }
 }
@@ -610,7 +633,7 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p3(IndexView iv, RxView rx, int
             }
         }
         auto probe = [&](uint64_t q) {
-            const uint32_t hb = (uint32_t)(fastmod(q, iv.modulo, iv.magic) - h0) & (W - 1u);
+            const uint32_t hb = (uint32_t)q & (W - 1u); // packed form: bucket inside the slice = low w bits
             const uint32_t st = sdir[hb], cn = sdir[hb + 1] - st;
             if (cn == 0u)
                 return;
@@ -691,6 +714,16 @@ __global__ void __launch_bounds__(256) k_rx_flush(IndexView iv, uint32_t *__rest
     }
     __syncthreads();
     agg_flush_counts(iv, agg);
+}
+
+// raw entry k-mers (bucket order) -> packed form for the current (w, f2)
+__global__ void k_rx_pack_keys(const uint64_t *__restrict__ raw, uint64_t n, IndexView iv, int sh,
+                               uint64_t *__restrict__ packed)
+{
+    for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t c;
+        packed[e] = rx_pack(iv, sh, raw[e], &c);
+    }
 }
 
 // per-entry counts in the index's own entry order (GpuCounter semantics, gpu_counter.py:29-34)

@@ -19,7 +19,7 @@ struct TileSmem {
     static constexpr int T = 256 * S;
     static constexpr int NV = T / 16 + 3; // 16-base words staged per tile (T + 48 positions)
     static constexpr int NB = T / 32 + 3; // 32-position words of the read-start bitset
-    uint8_t lut[256];
+    uint32_t lut[256]; // one dword per entry: lanes looking up different letters hit different banks
     uint32_t codes[NV + 1];
     uint32_t bits[NB + 1];
 };
@@ -251,13 +251,28 @@ __device__ __forceinline__ uint32_t tile_kmers(const ReadsView &rv, const TileCo
     if (UNIFORM) {
         uint64_t o;
         (void)fastdiv((uint64_t)p0, rv.read_len, rv.read_len_magic, &o);
+        if (rv.read_len >= (uint64_t)(k + S)) {
+            // offsets o, o+1, ... wrap at most once inside the lane's S windows and the windows after the wrap are
+            // whole again: the invalid ones are exactly those at offsets (L-k, L-1], a single run of bits
+            const int64_t L = (int64_t)rv.read_len;
+            const int64_t a = L - k + 1 - (int64_t)o, b = L - 1 - (int64_t)o; // window indices of that run
+            const int64_t lim = total - p0;                                    // windows that start inside the chunk
+            uint32_t m = lim >= S ? ((S >= 32) ? 0xFFFFFFFFu : ((1u << S) - 1u)) : (lim > 0 ? ((1u << lim) - 1u) : 0u);
+            if (a < S) {
+                const uint32_t lo_bit = a > 0 ? (uint32_t)a : 0u;
+                const uint32_t hi_bit = b < S - 1 ? (uint32_t)b : (uint32_t)(S - 1);
+                m &= ~(((2u << hi_bit) - 1u) & ~((1u << lo_bit) - 1u));
+            }
+            valid = m;
+        } else {
 #pragma unroll
-        for (int j = 0; j < S; ++j) {
-            uint64_t oj = o + j;
-            if (oj >= rv.read_len)
-                oj -= rv.read_len;
-            if (oj + k <= rv.read_len && p0 + j < total)
-                valid |= 1u << j;
+            for (int j = 0; j < S; ++j) {
+                uint64_t oj = o + j;
+                if (oj >= rv.read_len)
+                    oj -= rv.read_len;
+                if (oj + k <= rv.read_len && p0 + j < total)
+                    valid |= 1u << j;
+            }
         }
     } else {
         const int sw = q0 >> 5, off = q0 & 31;
