@@ -384,7 +384,7 @@ constexpr int TILE_T = 256 * TILE_S;
 // Fan-out of the radix path for 2^w buckets per fine partition: F1 coarse x F2 fine partitions.
 bool rx_configure(kmm_index *ix, int w)
 {
-    if (w < 2 || w > 12 || ix->modulo >= (1ull << 31)) // (pass 1 divides with a 32-bit remainder)
+    if (w < 0 || w > 12 || ix->modulo >= (1ull << 31)) // (pass 1 divides with a 32-bit remainder)
         return false;
     const uint64_t PF = (ix->modulo + (1ull << w) - 1) >> w;
     if (PF > (uint64_t)RX_MAXF * RX_MAXF)
@@ -396,9 +396,10 @@ bool rx_configure(kmm_index *ix, int w)
     // the packed form (kmm_radix.hpp) keeps floor(q / modulo) above w + f2 hash bits: it must fit for EVERY
     // 64-bit q (callers may hand over arbitrary uint64 values), else give the quotient more room
     const uint64_t max_quo = ~0ull / ix->modulo;
-    while (f2 > 0 && (w + f2 >= 64 || (max_quo >> (64 - w - f2)) != 0))
+    auto fits = [&](int sh) { return sh == 0 || (sh < 64 && (max_quo >> (64 - sh)) == 0); };
+    while (f2 > 0 && !fits(w + f2))
         --f2;
-    if (w + f2 >= 64 || (max_quo >> (64 - w - f2)) != 0)
+    if (!fits(w + f2))
         return false;
     const uint64_t F2 = 1ull << f2, F1 = (PF + F2 - 1) / F2;
     ix->rx_w = w;
@@ -447,7 +448,7 @@ int launch_rx(kmm_index *ix, const ReadsView &rv, const uint64_t *kmers_in, int6
                      o_T1 = carve((size_t)F1 * 4), o_ib = carve((size_t)(F1 + 1) * 4), o_wb = carve((size_t)(F1 + 1) * 4),
                      o_desc = carve(max_items * 8), o_start2 = carve(max_items * (F2 + 1) * 2), o_start2T = carve(max_items * (F2 + 1) * 2 + 256),
                      o_ctrl = carve(64),
-                     o_queue = carve(256);
+                     o_queue = carve(2048);
         KMMCHK(ensure(ix->rx_meta, off));
         KMMCHK(ensure(ix->rx_buf1, (size_t)NB * RX_B * 8));
         KMMCHK(ensure(ix->rx_buf2, max_items * RX_B * 8));
@@ -460,7 +461,7 @@ int launch_rx(kmm_index *ix, const ReadsView &rv, const uint64_t *kmers_in, int6
         rx.queue = (unsigned long long *)(m + o_queue);
         rx.buf1 = (uint64_t *)ix->rx_buf1.p;
         rx.buf2 = (uint64_t *)ix->rx_buf2.p;
-        HIPCHK(hipMemsetAsync(m + o_ctrl, 0, align256(64) + 256, ix->stream));
+        HIPCHK(hipMemsetAsync(m + o_ctrl, 0, align256(64) + 2048, ix->stream));
         ScopedTimer tm;
         KMMCHK(tm.begin(ix, KMM_KERNEL_RX_P1));
         const int64_t g1cap = (int64_t)ix->n_cu * 8;
@@ -723,7 +724,7 @@ static int rx_build(kmm_index *ix, const int32_t *h2i, const int32_t *nk, const 
     if (const char *env = getenv("KMM_RX_W")) // experiments / tests: force the slice width
         w = atoi(env);
     else
-        while (w > 2 && ((double)ix->rx_S / (double)M * (double)(1u << w) * 1.3 + 64.0 > (double)RX_ECAP ||
+        while (w > 0 && ((double)ix->rx_S / (double)M * (double)(1u << w) * 1.3 + 64.0 > (double)RX_ECAP ||
                          (1ull << w) > M))
             --w;
     ix->rx_ok = rx_configure(ix, w);
@@ -1593,8 +1594,9 @@ int kmm_set_param(kmm_index_t *ix, const char *name, int64_t value)
         ix->path = (int)value;
     } else if (!strcmp(name, "part_shift")) {
         if (!rx_configure(ix, (int)value))
-            return fail(KMM_ERR_INVALID_ARG, "part_shift %lld: needs 2 <= shift <= 12 and at most 256 x 256 fine "
-                        "partitions", (long long)value);
+            return fail(KMM_ERR_INVALID_ARG, "part_shift %lld: needs 0 <= shift <= 12, at most 256 x 256 fine partitions "
+                        "and 2^shift small enough for the quotient of a 64-bit k-mer by the modulo to fit beside "
+                        "the hash bits", (long long)value);
         ix->rx_ok = ix->rx_pstart != nullptr;
         if (ix->rx_ok) {
             KMMCHK(rx_flush(ix)); // nothing of the old layout may be pending
@@ -1652,6 +1654,19 @@ int kmm_get_param(kmm_index_t *ix, const char *name, int64_t *value)
         *value = ix->rx_ecnt_acc ? 1 : 0;
     else if (!strcmp(name, "n_coarse_partitions"))
         *value = ix->rx_ok ? ix->rx_F1 : 0;
+    else if (!strcmp(name, "radix_p2_kmers") || !strcmp(name, "radix_p3_kmers")) {
+        // conservation check of the radix path: k-mers gathered by pass 2 / probed by pass 3 since the last
+        // kmm_get_stats(reset): both must equal the lookups pass 1 emitted
+        HIPCHK(hipSetDevice(ix->device));
+        KMMCHK(drain(ix));
+        std::vector<unsigned long long> st(KMM_STAT_BYTES / 8);
+        HIPCHK(hipMemcpy(st.data(), ix->stats, KMM_STAT_BYTES, hipMemcpyDeviceToHost));
+        const int slot = name[7] == '2' ? 2 : 3;
+        unsigned long long t = 0;
+        for (int i = 0; i < KMM_STAT_SHARDS; ++i)
+            t += st[(size_t)i * KMM_STAT_STRIDE + slot];
+        *value = (int64_t)t;
+    }
     else if (!strcmp(name, "grid_per_cu"))
         *value = ix->grid_per_cu;
     else if (!strcmp(name, "dynamic_schedule"))

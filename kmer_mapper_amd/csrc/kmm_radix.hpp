@@ -76,12 +76,12 @@ struct RxView {
     uint32_t *csum;        // [chunks][F1]
     uint32_t *T1;          // [F1]
     uint32_t *item_base;   // [F1 + 1]
-    uint32_t *work_base;   // [F1 + 1]
+    uint32_t *work_base;   // [F1 + 1] pass-3 rows (coarse partition, chunk of RX_IC items) before coarse partition c
     uint2 *item_desc;      // [max_items] {first block, coarse partition}
     uint16_t *start2;      // [max_items][F2 + 1]
     uint16_t *start2T;     // [F2 + 1][max_items] (transposed for pass 3: one fine partition's run starts are contiguous)
-    uint32_t *ctrl;        // [0] items, [1] pass-3 work items
-    unsigned long long *queue; // [0] pass-2 item queue, [16] pass-3 work queue
+    uint32_t *ctrl;        // [0] items, [1] pass-3 rows, [2] most items of one coarse partition
+    unsigned long long *queue; // 2 x 8 work counters, 128 bytes apart: [16 x] pass 2, [128 + 16 x] pass 3, x = XCD
 };
 
 // q -> packed form; *coarse gets the coarse partition (= hash >> (w + f2)).
@@ -221,6 +221,25 @@ __device__ __forceinline__ void rx_list_subruns(uint32_t pre, uint32_t len, uint
         sub_src[j - win] = src + first;
         sub_meta[j - win] = ((dst + first) << 6) | n; // n <= 32 in 6 bits, dst < 2^26
     }
+}
+
+// Work distribution of passes 2 and 3.  Work items that read NEIGHBOURING bytes of the previous pass's output
+// (runs of adjacent partitions inside one block / item share their first and last 128-byte line) are handed to
+// workgroups of ONE XCD at about the same time, so that the shared lines are fetched from HBM once and hit in
+// that XCD's L2: the index space is cut into 8 sub-spaces, one counter each; a workgroup works through the
+// sub-space of the XCD it really runs on (HW_REG_XCC_ID) and then through the others in turn.  Every index is
+// popped exactly once whatever the placement (placement only decides what hits in L2); a workgroup ends after it
+// has seen all 8 counters exhausted.  The next index is popped while the current one is being worked on.
+__device__ __forceinline__ uint32_t rx_xcc_id()
+{
+    return (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u; // HW_REG_XCC_ID, bits [3:0]
+}
+
+// next index of sub-space `sub`, or `limit` when it is exhausted (thread 0 only)
+__device__ __forceinline__ uint32_t rx_pop(unsigned long long *counters, uint32_t sub, uint32_t limit)
+{
+    const unsigned long long u = atomicAdd(&counters[sub * 16], 1ull);
+    return u < (unsigned long long)limit ? (uint32_t)u : limit;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -387,22 +406,33 @@ __global__ void __launch_bounds__(256) k_rx_mid(RxView rx, uint32_t n_chunks)
         rx.P1T[(size_t)c * (rx.NB + 1) + rx.NB] = run;
     }
     const uint32_t n_items = c < F1 ? (run + RX_B - 1) / RX_B : 0u;
-    uint32_t f2c = 0;
-    if (c < F1)
-        f2c = rx.PF - c * rx.F2 < rx.F2 ? rx.PF - c * rx.F2 : rx.F2;
-    const uint32_t works = ((n_items + RX_IC - 1) / RX_IC) * f2c;
-    uint32_t tot_items, tot_works;
+    const uint32_t rows = (n_items + RX_IC - 1) / RX_IC;
+    uint32_t tot_items, tot_rows;
     const uint32_t ib = scan256_excl(n_items, s_wave4, &tot_items);
-    const uint32_t wb = scan256_excl(works, s_wave4, &tot_works);
+    const uint32_t wb = scan256_excl(rows, s_wave4, &tot_rows);
+    uint32_t jmax = n_items;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        const uint32_t o = __shfl_xor(jmax, d);
+        jmax = o > jmax ? o : jmax;
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0)
+        s_wave4[threadIdx.x >> 6] = jmax;
+    __syncthreads();
     if (c < F1) {
         rx.item_base[c] = ib;
         rx.work_base[c] = wb;
     }
     if (c == 0) {
+        uint32_t m = s_wave4[0];
+        for (int x = 1; x < 4; ++x)
+            m = s_wave4[x] > m ? s_wave4[x] : m;
         rx.item_base[F1] = tot_items;
-        rx.work_base[F1] = tot_works;
+        rx.work_base[F1] = tot_rows;
         rx.ctrl[0] = tot_items;
-        rx.ctrl[1] = tot_works;
+        rx.ctrl[1] = tot_rows;
+        rx.ctrl[2] = m;
     }
 }
 
@@ -475,12 +505,34 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p2(IndexView iv, RxView rx)
     __shared__ uint64_t sub_src[RX_SUBCAP];
     __shared__ uint32_t sub_meta[RX_SUBCAP], s_wave8[RX_NT / 64];
     __shared__ uint32_t s_cnt[RX_MAXF + 1], s_base[RX_MAXF + 1], s_wave[4];
+    __shared__ uint32_t s_idx;
     const int tid = threadIdx.x, grp = tid / RX_LPR, lg = tid % RX_LPR;
-    const uint32_t n_items = rx.ctrl[0], NB = rx.NB;
+    const uint32_t NB = rx.NB;
+    uint32_t gathered = 0; // conservation check (kmm_get_param "radix_p2_kmers"): must equal pass 1's lookups
     const int F2 = (int)rx.F2;
-    // items all hold RX_B k-mers (but the last of a coarse partition): a static round-robin is balanced, and the
-    // item's descriptor chain (item_desc -> item_base / T1 -> P / S) needs no queue pop and no broadcast in front
-    for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
+    // XCD x takes the coarse partitions [x cs, (x+1) cs), items j-major: the workgroups of one XCD work on item j
+    // of ~cs adjacent coarse partitions together, whose runs are neighbours inside every pass-1 block
+    const uint32_t cs = (rx.F1 + 7u) / 8u, limit = rx.ctrl[2] * cs;
+    const uint32_t home = rx_xcc_id();
+    for (uint32_t turn = 0; turn < 8u; ++turn) {
+    const uint32_t sub = (home + turn) & 7u;
+    uint32_t nxt = limit;
+    if (tid == 0)
+        nxt = rx_pop(rx.queue, sub, limit);
+    for (;;) {
+        if (tid == 0)
+            s_idx = nxt;
+        __syncthreads();
+        const uint32_t idx = s_idx;
+        __syncthreads();
+        if (idx >= limit)
+            break;
+        if (tid == 0)
+            nxt = rx_pop(rx.queue, sub, limit); // needed at the next turn of the loop: the round trip hides behind the item
+        const uint32_t cj = idx / cs, cc = sub * cs + idx % cs;
+        if (cc >= rx.F1 || cj >= rx.item_base[cc + 1] - rx.item_base[cc])
+            continue; // (uniform) no such item: partition sizes differ, or F1 is no multiple of 8
+        const uint32_t item = rx.item_base[cc] + cj;
         const uint2 d = rx.item_desc[item];
         const uint32_t b0 = d.x, c = d.y;
         const uint32_t lo = (item - rx.item_base[c]) * RX_B;
@@ -540,12 +592,15 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p2(IndexView iv, RxView rx)
                 valid |= 1u << i;
             }
         }
+        gathered += (uint32_t)__popc(valid);
         auto fine = [&](int i) {
             return ((valid >> i) & 1u) ? ((uint32_t)(q[i] >> rx.w) & (uint32_t)(F2 - 1)) : (uint32_t)F2;
         };
         rx_sort_emit<8>(q, fine, F2, sbuf, s_cnt, s_base, s_wave, rx.buf2 + (size_t)item * RX_B,
                      rx.start2 + (size_t)item * (F2 + 1));
     }
+    }
+    rx_stat_add(iv, 2, gathered);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -559,35 +614,49 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p3(IndexView iv, RxView rx, int
     __shared__ uint64_t sub_src[RX_SUBCAP];
     __shared__ uint32_t sub_meta[RX_SUBCAP];
     __shared__ uint32_t s_wb[RX_MAXF + 1], s_wave8[RX_NT / 64];
-    __shared__ unsigned long long s_next;
+    __shared__ uint32_t s_idx;
     const int tid = threadIdx.x, grp = tid / RX_LPR, lg = tid % RX_LPR;
-    const uint32_t n_work = rx.ctrl[1], F1 = rx.F1, F2 = rx.F2;
+    const uint32_t n_rows = rx.ctrl[1], F1 = rx.F1, F2 = rx.F2;
     const uint32_t W = 1u << rx.w;
     const uint64_t M = iv.modulo;
     for (uint32_t i = tid; i <= F1; i += RX_NT)
         s_wb[i] = rx.work_base[i];
-    uint32_t hits = 0;
+    // XCD x takes the fine partitions g in [x gs, (x+1) gs) of every row (coarse partition, chunk of items), g
+    // fastest: its workgroups read neighbouring runs of the same items together
+    const uint32_t gs = (F2 + 7u) / 8u, limit = n_rows * gs;
+    unsigned long long *counters = rx.queue + 128;
+    const uint32_t home = rx_xcc_id();
+    uint32_t hits = 0, probed = 0;
+    __syncthreads(); // s_wb is loaded
+    for (uint32_t turn = 0; turn < 8u; ++turn) {
+    const uint32_t sub = (home + turn) & 7u;
+    uint32_t nxt = limit;
+    if (tid == 0)
+        nxt = rx_pop(counters, sub, limit);
     for (;;) {
         if (tid == 0)
-            s_next = atomicAdd(&rx.queue[16], 1ull);
-        __syncthreads(); // also: s_wb is loaded; the previous work item's flush is done
-        const uint32_t wi = (uint32_t)s_next;
-        const bool done = s_next >= (unsigned long long)n_work;
+            s_idx = nxt;
+        __syncthreads(); // also: the previous work item's flush is done
+        const uint32_t idx = s_idx;
         __syncthreads();
-        if (done)
+        if (idx >= limit)
             break;
-        uint32_t c_lo = 0, c_hi = F1; // largest c with s_wb[c] <= wi
+        if (tid == 0)
+            nxt = rx_pop(counters, sub, limit);
+        const uint32_t row = idx / gs, g = sub * gs + idx % gs;
+        uint32_t c_lo = 0, c_hi = F1; // largest c with s_wb[c] <= row
         while (c_hi - c_lo > 1) {
             const uint32_t mid = (c_lo + c_hi) >> 1;
-            if (s_wb[mid] <= wi)
+            if (s_wb[mid] <= row)
                 c_lo = mid;
             else
                 c_hi = mid;
         }
         const uint32_t c = c_lo;
         const uint32_t f2c = rx.PF - c * F2 < F2 ? rx.PF - c * F2 : F2;
-        const uint32_t rem = wi - s_wb[c];
-        const uint32_t chunk = rem / f2c, g = rem % f2c;
+        const uint32_t chunk = row - s_wb[c];
+        if (g >= f2c)
+            continue; // (uniform) the last coarse partition holds fewer fine partitions, or F2 < 8
         const uint32_t f = c * F2 + g;
         const uint64_t h0 = (uint64_t)f << rx.w;
         const uint32_t e0 = rx.pstart[h0], e1 = rx.pstart[h0 + W < M ? h0 + W : M];
@@ -632,13 +701,11 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p3(IndexView iv, RxView rx, int
                 scnt[i] = 0;
             }
         }
-        auto probe = [&](uint64_t q) {
-            const uint32_t hb = (uint32_t)q & (W - 1u); // packed form: bucket inside the slice = low w bits
-            const uint32_t st = sdir[hb], cn = sdir[hb + 1] - st;
-            if (cn == 0u)
-                return;
-            if (st + cn > ne) { // the bucket's entries lie beyond the LDS copy: same walk over the HBM arrays
-                for (uint32_t j = 0; j < cn; ++j) {
+        // entries j >= j_first of bucket [st, st + cn) against q: every matching entry counts (mapper.pyx:57-68; a
+        // k-mer present under several nodes is several entries).  Entries beyond the LDS copy are walked in HBM.
+        auto probe_rest = [&](uint64_t q, uint32_t st, uint32_t cn, uint32_t j_first) {
+            if (st + cn > ne) {
+                for (uint32_t j = j_first; j < cn; ++j) {
                     const size_t e = (size_t)e0 + st + j;
                     if (rx.pkeys[e] == q && (int)rx.pfreq[e] <= max_freq) {
                         atomicAdd(&rx.ecnt[e], 1u);
@@ -647,7 +714,7 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p3(IndexView iv, RxView rx, int
                 }
                 return;
             }
-            for (uint32_t j = 0; j < cn; ++j)
+            for (uint32_t j = j_first; j < cn; ++j)
                 if (skeys[st + j] == q)
                     atomicAdd(&scnt[st + j], 1u);
         };
@@ -672,10 +739,32 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p3(IndexView iv, RxView rx, int
                         const uint64_t so = jj < nw ? sub_src[jj] : 0ull;
                         x[u] = (uint32_t)lg < n[u] ? __builtin_nontemporal_load(rx.buf2 + so + lg) : 0ull;
                     }
+                    // probe (mapper.pyx:53-69 on the LDS slice), the RX_U k-mers side by side so that their LDS
+                    // reads overlap: bucket bounds, then the first entry's key, then the count; buckets with more
+                    // entries (collisions, k-mers under several nodes) and buckets beyond the LDS copy go on alone
+                    uint32_t st[RX_U], cn[RX_U];
+#pragma unroll
+                    for (int u = 0; u < RX_U; ++u) {
+                        const uint32_t hb = (uint32_t)x[u] & (W - 1u); // packed form: bucket = low w bits
+                        const bool act = (uint32_t)lg < n[u];
+                        probed += act ? 1u : 0u;
+                        st[u] = act ? sdir[hb] : 0u;
+                        cn[u] = act ? sdir[hb + 1] - st[u] : 0u;
+                    }
+                    uint64_t k0[RX_U];
 #pragma unroll
                     for (int u = 0; u < RX_U; ++u)
-                        if ((uint32_t)lg < n[u])
-                            probe(x[u]);
+                        k0[u] = (cn[u] != 0u && st[u] + cn[u] <= ne) ? skeys[st[u]] : ~x[u];
+#pragma unroll
+                    for (int u = 0; u < RX_U; ++u)
+                        if (k0[u] == x[u])
+                            atomicAdd(&scnt[st[u]], 1u);
+#pragma unroll
+                    for (int u = 0; u < RX_U; ++u) {
+                        const bool in_lds = st[u] + cn[u] <= ne;
+                        if (cn[u] > (in_lds ? 1u : 0u))
+                            probe_rest(x[u], st[u], cn[u], in_lds ? 1u : 0u);
+                    }
                 }
                 __syncthreads();
             }
@@ -690,7 +779,9 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p3(IndexView iv, RxView rx, int
             }
         }
     }
+    }
     rx_stat_add(iv, 1, hits);
+    rx_stat_add(iv, 3, probed); // conservation check ("radix_p3_kmers")
 }
 
 // ------------------------------------------------------------------------------------------------

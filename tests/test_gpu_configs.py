@@ -49,6 +49,8 @@ def test_full_batch_at_config_size(kmm, oracle, n_index):
             else:
                 dev.map_reads_uniform(reads, R, L, k)
             res[name] = dev.get_node_counts()
+            if path != 1:      # radix path: conservation of k-mers through the passes
+                assert dev.get_param("radix_p2_kmers") == n_kmers and dev.get_param("radix_p3_kmers") == n_kmers, name
             assert dev.get_stats(reset=True)[0] == n_kmers, name
         t = dev.get_timing()
         assert t["k_rx_p1"][1] == 2, "a 10 M-read batch takes the radix path by itself (auto)"

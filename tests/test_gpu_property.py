@@ -64,7 +64,11 @@ def test_random_cases_bit_exact(oracle, c):
     with DeviceIndex.from_index(index, c["max_node"]) as dev:
         dev.set_param("path", c["path"])
         if c["path"] == 2:
-            dev.set_param("part_shift", 4)
+            try:
+                dev.set_param("part_shift", 4)     # many partitions even for these tiny indexes ...
+            except ValueError:
+                pass                               # ... unless 16 buckets per slice do not fit this modulo
+            assert dev.get_param("radix_available") == 1
         dev.map_reads(c["bases"], c["offs"], c["k"], c["max_freq"], also_revcomp=c["revcomp"])
         assert np.array_equal(dev.get_node_counts(), expect)
         dev.reset()

@@ -39,7 +39,10 @@ def test_radix_equals_oracle_at_every_slice_width(kmm, syn, oracle, shift, revco
         assert dev.get_param("n_partitions") == -(-index._modulo // (1 << shift))
         dev.map_reads(bases, offs, 31, also_revcomp=revcomp)
         assert np.array_equal(dev.get_node_counts(), expect)
-        assert dev.get_stats(reset=True) == ((2 if revcomp else 1) * n, int(expect.sum()))
+        lookups = (2 if revcomp else 1) * n
+        # conservation through the passes: every k-mer pass 1 emits is gathered once by pass 2 and probed once by pass 3
+        assert dev.get_param("radix_p2_kmers") == lookups and dev.get_param("radix_p3_kmers") == lookups
+        assert dev.get_stats(reset=True) == (lookups, int(expect.sum()))
         dev.reset()
         dev.map_kmers(km, also_revcomp=revcomp, k=31)          # operator entry point through the same passes
         assert np.array_equal(dev.get_node_counts(), expect)
