@@ -17,7 +17,7 @@
 //   pass 1  k_rx_p1   reads (or a k-mer array) -> k-mers; every workgroup sorts a block of 8192 positions
 //                     by COARSE partition inside LDS and writes the sorted block contiguously into its own
 //                     block area, plus a directory row start1[block][0..F1] (where each run starts)
-//           k_rx_colsum / k_rx_mid / k_rx_colscan   column prefix of the directory: P1T[c][block] = k-mers of
+//           k_rx_colsum / k_rx_chunkscan / k_rx_tables / k_rx_colscan   column prefix of the directory: P1T[c][block] = k-mers of
 //                     coarse partition c before that block, so that c's runs form one virtual array; it is
 //                     cut into items of 8192 k-mers (item_desc = first block, c)
 //   pass 2  k_rx_p2   item (c, j): gathers its 8192 k-mers from the runs (each ~B/F1 k-mers, contiguous),
@@ -377,34 +377,33 @@ __device__ __forceinline__ uint32_t scan256_excl(uint32_t v, uint32_t *s_wave4, 
     return base + inc - v;
 }
 
-// One workgroup: chunk sums -> exclusive chunk offsets per coarse partition, the partition totals, the item
-// table (items of RX_B k-mers per coarse partition) and the pass-3 work table.
-__global__ void __launch_bounds__(256) k_rx_mid(RxView rx, uint32_t n_chunks)
+// One workgroup per coarse partition: its chunk sums -> exclusive chunk offsets (in place), the partition total.
+__global__ void __launch_bounds__(256) k_rx_chunkscan(RxView rx, uint32_t n_chunks)
+{
+    __shared__ uint32_t s_wave4[4];
+    const uint32_t c = blockIdx.x, F1 = rx.F1;
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < n_chunks; base += 256) {
+        const uint32_t ch = base + threadIdx.x;
+        const uint32_t v = ch < n_chunks ? rx.csum[(size_t)ch * F1 + c] : 0u;
+        uint32_t tot;
+        const uint32_t ex = scan256_excl(v, s_wave4, &tot);
+        if (ch < n_chunks)
+            rx.csum[(size_t)ch * F1 + c] = carry + ex;
+        carry += tot;
+    }
+    if (threadIdx.x == 0) {
+        rx.T1[c] = carry;
+        rx.P1T[(size_t)c * (rx.NB + 1) + rx.NB] = carry;
+    }
+}
+
+// One workgroup: the item table (items of RX_B k-mers per coarse partition) and the pass-3 row table.
+__global__ void __launch_bounds__(256) k_rx_tables(RxView rx)
 {
     __shared__ uint32_t s_wave4[4];
     const uint32_t c = threadIdx.x, F1 = rx.F1;
-    uint32_t run = 0;
-    if (c < F1) {
-        uint32_t ch = 0;
-        for (; ch + 8 <= n_chunks; ch += 8) { // independent loads first: this loop is latency-bound
-            uint32_t t[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-                t[u] = rx.csum[(size_t)(ch + u) * F1 + c];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                rx.csum[(size_t)(ch + u) * F1 + c] = run;
-                run += t[u];
-            }
-        }
-        for (; ch < n_chunks; ++ch) {
-            const uint32_t t = rx.csum[(size_t)ch * F1 + c];
-            rx.csum[(size_t)ch * F1 + c] = run;
-            run += t;
-        }
-        rx.T1[c] = run;
-        rx.P1T[(size_t)c * (rx.NB + 1) + rx.NB] = run;
-    }
+    const uint32_t run = c < F1 ? rx.T1[c] : 0u;
     const uint32_t n_items = c < F1 ? (run + RX_B - 1) / RX_B : 0u;
     const uint32_t rows = (n_items + RX_IC - 1) / RX_IC;
     uint32_t tot_items, tot_rows;
@@ -436,46 +435,57 @@ __global__ void __launch_bounds__(256) k_rx_mid(RxView rx, uint32_t n_chunks)
     }
 }
 
+// Prefix of every coarse partition's runs over the blocks of one chunk.  Thread c walks column c of the directory
+// rows (coalesced across c); the results leave through an LDS tile of 32 blocks so that each partition's 32
+// consecutive values are written as one 128-byte (P1T) / 64-byte (S1T) piece.
 __global__ void __launch_bounds__(256) k_rx_colscan(RxView rx)
 {
-    const uint32_t c = threadIdx.x, F1 = rx.F1;
-    if (c >= F1)
-        return;
+    constexpr int TB = 32;
+    __shared__ uint32_t tP[RX_MAXF][TB + 1];
+    __shared__ uint16_t tS[RX_MAXF][TB + 2];
+    const uint32_t c = threadIdx.x, F1 = rx.F1, NB = rx.NB;
     const uint32_t b0 = blockIdx.x * RX_CH;
-    const uint32_t b1 = b0 + RX_CH < rx.NB ? b0 + RX_CH : rx.NB;
-    uint32_t run = rx.csum[(size_t)blockIdx.x * F1 + c];
-    const uint32_t ib = rx.item_base[c];
+    const uint32_t b1 = b0 + RX_CH < NB ? b0 + RX_CH : NB;
+    uint32_t run = c < F1 ? rx.csum[(size_t)blockIdx.x * F1 + c] : 0u;
+    const uint32_t ib = c < F1 ? rx.item_base[c] : 0u;
     const size_t ld = F1 + 1;
-    const uint16_t *p = rx.start1 + (size_t)b0 * ld + c;
-    uint32_t *P = rx.P1T + (size_t)c * (rx.NB + 1);
-    uint16_t *S = rx.S1T + (size_t)c * rx.NB;
-    auto step = [&](uint32_t b, uint32_t s0, uint32_t s1) {
-        const uint32_t cnt = s1 - s0;
-        P[b] = run;
-        S[b] = (uint16_t)s0;
-        if (cnt) { // items whose first k-mer lies in this run
-            uint32_t m = (run + RX_B - 1) / RX_B;
-            while ((uint64_t)m * RX_B < (uint64_t)run + cnt) {
-                rx.item_desc[ib + m] = make_uint2(b, c);
-                ++m;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (uint32_t t0 = b0; t0 < b1; t0 += TB) {
+        const uint32_t nb = b1 - t0 < (uint32_t)TB ? b1 - t0 : (uint32_t)TB;
+        if (c < F1) {
+            const uint16_t *p = rx.start1 + (size_t)t0 * ld + c;
+            uint32_t lo[TB], hi[TB];
+#pragma unroll
+            for (int u = 0; u < TB; ++u) { // independent loads first: the walk is latency-bound
+                lo[u] = (uint32_t)u < nb ? p[u * ld] : 0u;
+                hi[u] = (uint32_t)u < nb ? p[u * ld + 1] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < TB; ++u) {
+                const uint32_t cnt = hi[u] - lo[u];
+                tP[c][u] = run;
+                tS[c][u] = (uint16_t)lo[u];
+                if (cnt) { // items whose first k-mer lies in this run
+                    uint32_t m = (run + RX_B - 1) / RX_B;
+                    while ((uint64_t)m * RX_B < (uint64_t)run + cnt) {
+                        rx.item_desc[ib + m] = make_uint2(t0 + u, c);
+                        ++m;
+                    }
+                }
+                run += cnt;
             }
         }
-        run += cnt;
-    };
-    uint32_t b = b0;
-    for (; b + 8 <= b1; b += 8, p += 8 * ld) {
-        uint32_t lo[8], hi[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            lo[u] = p[u * ld];
-            hi[u] = p[u * ld + 1];
+        __syncthreads();
+        // two partitions per wavefront instruction, 32 consecutive blocks each
+        const uint32_t bi = lane & 31;
+        for (uint32_t cc = wave * 2 + (lane >> 5); cc < F1; cc += 8) {
+            if (bi < nb) {
+                rx.P1T[(size_t)cc * (NB + 1) + t0 + bi] = tP[cc][bi];
+                rx.S1T[(size_t)cc * NB + t0 + bi] = tS[cc][bi];
+            }
         }
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-            step(b + u, lo[u], hi[u]);
+        __syncthreads();
     }
-    for (; b < b1; ++b, p += ld)
-        step(b, p[0], p[1]);
 }
 
 // start2 [item][F2 + 1] -> start2T [F2 + 1][max_items], 64 items per workgroup through an LDS tile
@@ -701,11 +711,11 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p3(IndexView iv, RxView rx, int
                 scnt[i] = 0;
             }
         }
-        // entries j >= j_first of bucket [st, st + cn) against q: every matching entry counts (mapper.pyx:57-68; a
-        // k-mer present under several nodes is several entries).  Entries beyond the LDS copy are walked in HBM.
-        auto probe_rest = [&](uint64_t q, uint32_t st, uint32_t cn, uint32_t j_first) {
+        // the entries of bucket [st, st + cn) against q: every matching entry counts (mapper.pyx:57-68; a k-mer
+        // present under several nodes is several entries).  Entries beyond the LDS copy are walked in HBM.
+        auto probe_bucket = [&](uint64_t q, uint32_t st, uint32_t cn) {
             if (st + cn > ne) {
-                for (uint32_t j = j_first; j < cn; ++j) {
+                for (uint32_t j = 0; j < cn; ++j) {
                     const size_t e = (size_t)e0 + st + j;
                     if (rx.pkeys[e] == q && (int)rx.pfreq[e] <= max_freq) {
                         atomicAdd(&rx.ecnt[e], 1u);
@@ -714,7 +724,7 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p3(IndexView iv, RxView rx, int
                 }
                 return;
             }
-            for (uint32_t j = j_first; j < cn; ++j)
+            for (uint32_t j = 0; j < cn; ++j)
                 if (skeys[st + j] == q)
                     atomicAdd(&scnt[st + j], 1u);
         };
@@ -739,31 +749,17 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p3(IndexView iv, RxView rx, int
                         const uint64_t so = jj < nw ? sub_src[jj] : 0ull;
                         x[u] = (uint32_t)lg < n[u] ? __builtin_nontemporal_load(rx.buf2 + so + lg) : 0ull;
                     }
-                    // probe (mapper.pyx:53-69 on the LDS slice), the RX_U k-mers side by side so that their LDS
-                    // reads overlap: bucket bounds, then the first entry's key, then the count; buckets with more
-                    // entries (collisions, k-mers under several nodes) and buckets beyond the LDS copy go on alone
-                    uint32_t st[RX_U], cn[RX_U];
+                    // probe (mapper.pyx:53-69 on the LDS slice).  (Probing the RX_U k-mers side by side — all bucket
+                    // bounds, then all first keys — measured 9 % slower than one after the other: 4.65 vs 4.28 ms.)
 #pragma unroll
                     for (int u = 0; u < RX_U; ++u) {
-                        const uint32_t hb = (uint32_t)x[u] & (W - 1u); // packed form: bucket = low w bits
-                        const bool act = (uint32_t)lg < n[u];
-                        probed += act ? 1u : 0u;
-                        st[u] = act ? sdir[hb] : 0u;
-                        cn[u] = act ? sdir[hb + 1] - st[u] : 0u;
-                    }
-                    uint64_t k0[RX_U];
-#pragma unroll
-                    for (int u = 0; u < RX_U; ++u)
-                        k0[u] = (cn[u] != 0u && st[u] + cn[u] <= ne) ? skeys[st[u]] : ~x[u];
-#pragma unroll
-                    for (int u = 0; u < RX_U; ++u)
-                        if (k0[u] == x[u])
-                            atomicAdd(&scnt[st[u]], 1u);
-#pragma unroll
-                    for (int u = 0; u < RX_U; ++u) {
-                        const bool in_lds = st[u] + cn[u] <= ne;
-                        if (cn[u] > (in_lds ? 1u : 0u))
-                            probe_rest(x[u], st[u], cn[u], in_lds ? 1u : 0u);
+                        if ((uint32_t)lg < n[u]) {
+                            ++probed;
+                            const uint32_t hb = (uint32_t)x[u] & (W - 1u); // packed form: bucket = low w bits
+                            const uint32_t st = sdir[hb], cn = sdir[hb + 1] - st;
+                            if (cn)
+                                probe_bucket(x[u], st, cn);
+                        }
                     }
                 }
                 __syncthreads();
