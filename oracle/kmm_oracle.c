@@ -17,6 +17,7 @@
  *
  * Every function cites the reference file:line it restates (paths relative to the reference root).
  */
+#define _POSIX_C_SOURCE 200809L /* pthread_barrier_t under -std=c11 */
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -171,7 +172,22 @@ typedef struct {
     int64_t chunk_reads;
     uint32_t *counts; /* private */
     int64_t n_mapped;
+    /* parallel sum of the private vectors (every worker adds one slice of all of them) */
+    pthread_barrier_t *barrier;
+    uint32_t **all_counts;
 } oracle_worker_t;
+
+static void oracle_sum_slice(oracle_worker_t *w)
+{
+    const int64_t n = w->max_node_id + 1;
+    const int64_t lo = n * w->tid / w->n_threads, hi = n * (w->tid + 1) / w->n_threads;
+    uint32_t *dst = w->all_counts[0];
+    for (int t = 1; t < w->n_threads; ++t) {
+        const uint32_t *src = w->all_counts[t];
+        for (int64_t i = lo; i < hi; ++i)
+            dst[i] += src[i];
+    }
+}
 
 static void *oracle_worker(void *arg)
 {
@@ -190,14 +206,13 @@ static void *oracle_worker(void *arg)
             buf = (uint64_t *)malloc((size_t)(cap > 0 ? cap : 1) * sizeof(uint64_t));
             if (!buf) {
                 w->n_mapped = INT64_MIN;
-                return NULL;
+                break;
             }
         }
         int64_t nkm = oracle_extract_kmers(w->bases, w->offs + c0, c1 - c0, w->k, w->lut, buf);
         if (nkm < 0) {
             w->n_mapped = nkm;
-            free(buf);
-            return NULL;
+            break;
         }
         oracle_map_kmers(w->h2i, w->nk, w->modulo, w->ikmers, w->nodes, w->freqs, buf, nkm,
                          w->max_freq, w->counts);
@@ -210,6 +225,8 @@ static void *oracle_worker(void *arg)
         w->n_mapped += nkm;
     }
     free(buf);
+    pthread_barrier_wait(w->barrier); /* every private vector is complete */
+    oracle_sum_slice(w);
     return NULL;
 }
 
@@ -231,8 +248,11 @@ int64_t oracle_map_reads(const int32_t *hashes_to_index, const int32_t *n_kmers,
         chunk_reads = 16384;
     oracle_worker_t *ws = (oracle_worker_t *)calloc((size_t)n_threads, sizeof(*ws));
     pthread_t *th = (pthread_t *)calloc((size_t)n_threads, sizeof(*th));
-    if (!ws || !th)
+    uint32_t **all = (uint32_t **)calloc((size_t)n_threads, sizeof(*all));
+    pthread_barrier_t barrier;
+    if (!ws || !th || !all)
         return INT64_MIN;
+    pthread_barrier_init(&barrier, NULL, (unsigned)n_threads);
     for (int t = 0; t < n_threads; ++t) {
         oracle_worker_t *w = &ws[t];
         w->h2i = hashes_to_index; w->nk = n_kmers; w->nodes = nodes; w->ikmers = index_kmers;
@@ -245,6 +265,9 @@ int64_t oracle_map_reads(const int32_t *hashes_to_index, const int32_t *n_kmers,
                              : (uint32_t *)calloc((size_t)max_node_id + 1, sizeof(uint32_t));
         if (!w->counts)
             return INT64_MIN;
+        all[t] = w->counts;
+        w->all_counts = all;
+        w->barrier = &barrier;
     }
     for (int t = 1; t < n_threads; ++t)
         pthread_create(&th[t], NULL, oracle_worker, &ws[t]);
@@ -258,10 +281,10 @@ int64_t oracle_map_reads(const int32_t *hashes_to_index, const int32_t *n_kmers,
         } else {
             total += ws[t].n_mapped;
         }
-        for (int64_t i = 0; i <= max_node_id; ++i)
-            node_counts[i] += ws[t].counts[i];
         free(ws[t].counts);
     }
+    pthread_barrier_destroy(&barrier);
+    free(all);
     free(ws);
     free(th);
     return err ? err : total;

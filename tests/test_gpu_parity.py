@@ -36,6 +36,21 @@ def test_lookup_reference_vectors(kmm, v):
         assert m.dtype == np.uint8 and m.tolist() == v["expected_in_index"]
 
 
+@pytest.mark.parametrize("v", reference_vectors()["string_lookup"], ids=lambda v: v["name"])
+def test_reference_test_mapping_lowercase_query(kmm, v):
+    """reference tests/test_mapping.py:33-40 through the drop-in entry points."""
+    from kmer_mapper_amd.kmer_index import KmerIndex
+    from kmer_mapper_amd.mapper import map_kmers_to_graph_index
+    from kmer_mapper_amd.util import get_kmer_hashes_from_chunk_sequence
+    node_kmers = get_kmer_hashes_from_chunk_sequence(batch(v["node_kmers"]), v["k"])
+    index = KmerIndex.from_flat_kmers(node_kmers, np.arange(len(node_kmers), dtype=np.int64), v["modulo"])
+    qk = get_kmer_hashes_from_chunk_sequence(batch([v["query"]]), v["k"])
+    counts = map_kmers_to_graph_index(index, v["max_node_id"], qk, v["max_index_lookup_frequency"])
+    assert counts.dtype == np.uint32 and counts.sum() == 1 and counts[v["expected_node"]] == 1
+    counts = map_kmers_to_graph_index(index, v["max_node_id"], node_kmers, v["max_index_lookup_frequency"])
+    assert counts[:len(node_kmers)].tolist() == v["expected_counts_of_node_kmers"]
+
+
 def test_gpu_counter_reference_known_answer(kmm):
     """reference tests/test_gpucounter.py:41-48."""
     from kmer_mapper_amd.gpu_counter import GpuCounter

@@ -16,6 +16,23 @@ def test_lookup_reference_vectors(oracle, v):
         assert oracle.in_index(index, q).tolist() == v["expected_in_index"]
 
 
+@pytest.mark.parametrize("v", reference_vectors()["string_lookup"], ids=lambda v: v["name"])
+def test_oracle_matches_reference_test_mapping(oracle, v):
+    """reference tests/test_mapping.py:33-40: four 3-mers as strings (one in mixed case) -> nodes 0..3, modulo 21;
+    the lower-case query 'ccg' must resolve to node 2."""
+    from kmer_mapper_amd.kmer_index import KmerIndex
+    b = batch(v["node_kmers"])
+    node_kmers = oracle.extract(b.bases, b.offsets, v["k"])
+    assert node_kmers.shape == (len(v["node_kmers"]),)
+    index = KmerIndex.from_flat_kmers(node_kmers, np.arange(len(node_kmers), dtype=np.int64), v["modulo"])
+    q = batch([v["query"]])
+    qk = oracle.extract(q.bases, q.offsets, v["k"])
+    counts = oracle.map_kmers(index, v["max_node_id"], qk, v["max_index_lookup_frequency"])
+    assert counts.shape == (v["max_node_id"] + 1,) and counts.sum() == 1 and counts[v["expected_node"]] == 1
+    counts = oracle.map_kmers(index, v["max_node_id"], node_kmers, v["max_index_lookup_frequency"])
+    assert counts[:len(node_kmers)].tolist() == v["expected_counts_of_node_kmers"] and counts.sum() == len(node_kmers)
+
+
 @pytest.mark.parametrize("v", reference_vectors()["extract"], ids=lambda v: v["name"])
 def test_extract_known_answers(oracle, v):
     b = batch(v["reads"])
