@@ -11,8 +11,10 @@ Differences that follow from replacing the engine (all documented in DESIGN.md):
     holds here unless `--apply-max-hits-per-kmer` is given;
   * `-r` works (the reference only supports it in its experimental GPU mode, :107);
   * `-b/--index-bundle`, Minimal/Counter index variants (util.py:52-66) are out of scope -> error.
-  * launched under torchrun (WORLD_SIZE > 1) chunk i goes to rank i mod WORLD_SIZE and the count
-    vectors are summed with one RCCL reduce; rank 0 writes the output.
+  * launched under torchrun (WORLD_SIZE > 1) every rank maps its own BYTE RANGE of the read file (both ends
+    re-synchronised to record starts, reads_io.rank_byte_range: no rank reads or scans another rank's bytes);
+    ranks sharing one .gz stream (not seekable) take chunk i mod WORLD_SIZE and only look at the last lines
+    of the chunks they skip; the count vectors are summed with one RCCL reduce; rank 0 writes the output.
 """
 import argparse
 import logging
@@ -26,7 +28,7 @@ from .distributed import chunk_owner
 from .engine import DeviceIndex
 from .kmer_index import KmerIndex
 from . import _lib
-from .reads_io import RawChunker, prefetch, read_chunks, sniff_format
+from .reads_io import RawChunker, last_record_start, prefetch, rank_byte_range, read_chunks, sniff_format
 
 
 def main():
@@ -80,7 +82,7 @@ def map_gpu(index, chunks, k, hash_map_size=0, map_reverse_complements=False,
     n_kmers = 0
     try:
         for i, chunk in enumerate(chunks):
-            if chunk_owner(i, world_size) != rank:
+            if chunk is None:          # a chunk of a shared .gz stream that another rank maps
                 continue
             t0 = time.perf_counter()
             L = chunk.uniform_length
@@ -108,7 +110,12 @@ def map_gpu_raw(index, path, chunk_size, fmt, k, map_reverse_complements=False,
     (kmm_map_records): the host only reads (and for .gz inflates) raw bytes."""
     max_node_id = index.max_node_id() if hasattr(index, "max_node_id") else int(np.max(index._nodes))
     dev = DeviceIndex.from_index(index, max_node_id, device=device)
-    chunker = RawChunker(path, chunk_size)
+    seekable = not str(path).endswith(".gz")
+    byte_range = rank_byte_range(path, fmt, rank, world_size) if (world_size > 1 and seekable) else None
+    if byte_range is not None:
+        logging.info("Rank %d of %d maps bytes [%d, %d) of %s", rank, world_size, byte_range[0], byte_range[1], path)
+    chunker = RawChunker(path, chunk_size, byte_range)
+    owns = (lambda i: True) if (world_size == 1 or seekable) else (lambda i: chunk_owner(i, world_size) == rank)
     kfmt = _lib.FORMAT_FASTQ if fmt == "fastq" else _lib.FORMAT_FASTA2
     t_start = time.perf_counter()
     n_reads = n_bytes = 0
@@ -118,20 +125,17 @@ def map_gpu_raw(index, path, chunk_size, fmt, k, map_reverse_complements=False,
             buf = chunker.next_chunk()
             if buf is None:
                 break
-            if chunk_owner(i, world_size) == rank:
+            if owns(i):
                 used, n_rec = dev.map_records(buf, buf.shape[0], kfmt, k, max_index_lookup_frequency,
                                               also_revcomp=map_reverse_complements)
-            else:   # other ranks still need the record boundary: count lines on the host
-                nl = np.flatnonzero(buf == 10)
-                per = 4 if fmt == "fastq" else 2
-                whole = (nl.shape[0] // per) * per
-                used, n_rec = (int(nl[whole - 1]) + 1, whole // per) if whole else (0, 0)
+            else:   # a chunk of a shared .gz stream that another rank maps: only its record boundary is needed
+                used, n_rec = (buf.shape[0] if chunker.eof else last_record_start(buf, fmt)), 0
             if used == 0:
                 if chunker.eof:
                     raise ValueError("trailing bytes at end of %s do not form a complete record" % path)
                 chunker.chunk_size *= 2          # a record longer than the chunk: read more
                 continue
-            n_reads += n_rec if chunk_owner(i, world_size) == rank else 0
+            n_reads += n_rec
             n_bytes += used
             chunker.consumed(used)
             i += 1
@@ -179,7 +183,16 @@ def map_bnp(args):
                                   device=device, rank=rank, world_size=world)
     else:
         logging.info("Using the host FASTA/FASTQ parser")
-        chunks = prefetch(read_chunks(args.reads, min_chunk_size=args.chunk_size))
+        seekable = not str(args.reads).endswith(".gz")
+        if world > 1 and seekable:
+            chunks = read_chunks(args.reads, min_chunk_size=args.chunk_size,
+                                 byte_range=rank_byte_range(args.reads, fmt, rank, world))
+        elif world > 1:
+            chunks = read_chunks(args.reads, min_chunk_size=args.chunk_size,
+                                 owned=lambda i: chunk_owner(i, world) == rank)
+        else:
+            chunks = read_chunks(args.reads, min_chunk_size=args.chunk_size)
+        chunks = prefetch(chunks)
         node_counts = map_gpu(kmer_index, chunks, k, getattr(args, "gpu_hash_map_size", 0), revcomp,
                               max_freq, device=device, rank=rank, world_size=world)
 

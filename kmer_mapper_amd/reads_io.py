@@ -123,14 +123,25 @@ def _last_record_boundary(buf, fmt, at_eof):
     return int(headers[-1]) if headers.shape[0] > 1 else 0
 
 
-def read_chunks(path, min_chunk_size=2_500_000):
-    """Yield ReadBatch objects of ~min_chunk_size file bytes each, in file order."""
+def read_chunks(path, min_chunk_size=2_500_000, byte_range=None, owned=None):
+    """Yield ReadBatch objects of ~min_chunk_size file bytes each, in file order.  byte_range = (lo, hi):
+    only that part of an uncompressed file (both ends record starts, rank_byte_range).  owned(i) -> bool:
+    chunks this rank does not own are cut at the record boundary (a look at their last lines) but not parsed,
+    and come out as None (ranks sharing one .gz stream)."""
     f = _open(path)
+    left = None
+    if byte_range is not None:
+        f.seek(byte_range[0])
+        left = byte_range[1] - byte_range[0]
     try:
         carry = np.zeros(0, dtype=np.uint8)
         fmt = None
+        n_chunks = 0
         while True:
-            raw = f.read(int(min_chunk_size))
+            want = int(min_chunk_size) if left is None else min(int(min_chunk_size), left)
+            raw = f.read(want) if want else b""
+            if left is not None:
+                left -= len(raw)
             at_eof = len(raw) == 0
             if at_eof and carry.shape[0] == 0:
                 return
@@ -142,10 +153,18 @@ def read_chunks(path, min_chunk_size=2_500_000):
                 fmt = _detect_format(int(buf[0]), path)
             if at_eof and fmt == "fastq" and buf[-1] != _NL:
                 buf = np.concatenate([buf, np.array([_NL], dtype=np.uint8)])
-            cut = _last_record_boundary(buf, fmt, at_eof)
+            mine = owned is None or owned(n_chunks)
+            if mine:
+                cut = _last_record_boundary(buf, fmt, at_eof)
+            else:
+                cut = buf.shape[0] if at_eof else last_record_start(buf, fmt)
             if cut:
                 part = buf[:cut]
-                yield parse_fastq_block(part) if fmt == "fastq" else parse_fasta_block(part)
+                n_chunks += 1
+                if not mine:
+                    yield None
+                else:
+                    yield parse_fastq_block(part) if fmt == "fastq" else parse_fasta_block(part)
             carry = buf[cut:].copy()
             if at_eof:
                 return
@@ -200,6 +219,110 @@ def write_fastq(path, batch, gz=False):
 
 
 # ------------------------------------------------------------------------------------------------
+# Byte-range sharding of a read file over ranks (multi-GPU file input).  The reference hands each chunk to one
+# worker (command_line_interface.py:109-111); here rank g owns the records that START inside
+# [g*size/G, (g+1)*size/G), found by re-synchronising to the record structure at both ends of the range, so
+# that no rank ever reads (or scans) bytes outside its own range.
+# ------------------------------------------------------------------------------------------------
+def _is_record_start(buf, starts, i, fmt, at_eof):
+    """Is line i (starts[i] = offset of its first byte in buf; starts[-1] = len(buf) sentinel when the buffer ends
+    with a newline) the first line of a record?  Returns True / False, or None if the buffer holds too few lines
+    after it to tell."""
+    n_lines = len(starts) - 1                      # complete lines in buf
+    if i >= n_lines:
+        return None if not at_eof else False
+    if fmt != "fastq":                             # FASTA: '>' never starts a sequence line
+        return bool(buf[starts[i]] == ord(">"))
+    if buf[starts[i]] != ord("@"):
+        return False
+    if i + 4 > n_lines:                            # need the whole record: header, sequence, '+', quality
+        return None if not at_eof else False
+
+    def line_len(j):
+        e = starts[j + 1] - 1                      # position of the newline
+        if e > starts[j] and buf[e - 1] == _CR:
+            e -= 1
+        return e - starts[j]
+    # a quality line may start with '@' too, but then the line two below it is a sequence, never '+'
+    if buf[starts[i + 2]] != ord("+") or line_len(i + 1) != line_len(i + 3):
+        return False
+    if i + 4 < n_lines and buf[starts[i + 4]] != ord("@"):
+        return False
+    return True
+
+
+def find_record_start(path, pos, fmt, size=None, window=1 << 16):
+    """Offset of the first record of an UNCOMPRESSED FASTA/FASTQ file that starts at or after byte `pos`
+    (`size` if there is none)."""
+    import os
+    size = os.stat(path).st_size if size is None else size
+    if pos <= 0:
+        return 0
+    if pos >= size:
+        return size
+    with open(path, "rb", buffering=0) as f:
+        while True:
+            f.seek(pos - 1)                       # one byte early: `pos` is a line start iff byte pos-1 is a newline
+            raw = f.read(window)
+            at_eof = pos - 1 + len(raw) >= size
+            buf = np.frombuffer(raw, dtype=np.uint8)
+            if at_eof and buf[-1] != _NL:
+                buf = np.concatenate([buf, np.array([_NL], dtype=np.uint8)])
+            starts = (np.flatnonzero(buf == _NL) + 1).astype(np.int64)   # last one: sentinel or an unfinished line
+            for i in range(len(starts) - 1):
+                r = _is_record_start(buf, starts, i, fmt, at_eof)
+                if r is None:
+                    break
+                if r:
+                    return pos - 1 + int(starts[i])
+            if at_eof:
+                return size
+            window *= 2                               # nothing decided yet (long records): look further
+
+
+def rank_byte_range(path, fmt, rank, world_size):
+    """[lo, hi) of the uncompressed file `path` whose records belong to `rank`: both ends are record starts, the
+    ranges of ranks 0..world_size-1 partition the file exactly."""
+    import os
+    size = os.stat(path).st_size
+    lo = find_record_start(path, size * rank // world_size, fmt, size)
+    hi = find_record_start(path, size * (rank + 1) // world_size, fmt, size)
+    return lo, hi
+
+
+def last_record_start(buf, fmt):
+    """Number of leading bytes of the uint8 buffer `buf` (which starts at a record start) that form whole
+    records — found by looking at the last few lines only: ranks that merely skip a chunk of a .gz stream need
+    nothing else.  FASTA: a record counts as whole once the next header has been seen."""
+    n = buf.shape[0]
+    back = 1 << 12
+    while True:
+        lo = max(n - back, 0)
+        nl = np.flatnonzero(buf[lo:] == _NL) + lo
+        starts = np.concatenate([np.zeros(1 if lo == 0 else 0, dtype=np.int64), nl + 1]).astype(np.int64)
+        if starts.shape[0] == 0 or starts[-1] != n:
+            starts = np.concatenate([starts, [n]])           # sentinel; the line before it is unfinished ...
+            n_lines = len(starts) - 2                          # ... so it is no complete line
+        else:
+            n_lines = len(starts) - 1
+        view = starts[:n_lines + 1]
+        if fmt != "fastq":
+            cand = starts[(starts > 0) & (starts < n)]          # an unfinished header line is a record start too
+            cand = cand[buf[cand] == ord(">")]
+            if cand.shape[0]:
+                return int(cand[-1])
+            if lo == 0:
+                return 0
+        else:
+            for i in range(n_lines - 4, -1, -1):
+                if _is_record_start(buf, view, i, "fastq", True):
+                    return int(view[i + 4])
+            if lo == 0:
+                return 0
+        back *= 4
+
+
+# ------------------------------------------------------------------------------------------------
 # Raw-chunk reader for the GPU record parser (kmm_map_records): the host only moves bytes.
 # ------------------------------------------------------------------------------------------------
 def sniff_format(path, probe_bytes=1 << 16):
@@ -222,12 +345,18 @@ class RawChunker:
     """Feeds successive raw file chunks of ~chunk_size bytes to a consumer that reports how many
     bytes it used (the end of the last complete record); the unused tail is carried over."""
 
-    def __init__(self, path, chunk_size):
+    def __init__(self, path, chunk_size, byte_range=None):
+        """byte_range = (lo, hi): only that part of an uncompressed file (both ends record starts,
+        rank_byte_range)."""
         self.f = _open(path)
         self.chunk_size = int(chunk_size)
         self.buf = np.empty(self.chunk_size + (1 << 20), dtype=np.uint8)
         self.fill = 0
         self.eof = False
+        self.left = None
+        if byte_range is not None:
+            self.f.seek(byte_range[0])
+            self.left = byte_range[1] - byte_range[0]
 
     def next_chunk(self):
         """Returns a uint8 view (valid until the next call) or None at end of input."""
@@ -236,7 +365,12 @@ class RawChunker:
         if self.fill == self.buf.shape[0]:          # one record larger than the buffer: grow
             self.buf = np.concatenate([self.buf, np.empty_like(self.buf)])
         while not self.eof and self.fill < min(self.chunk_size, self.buf.shape[0]):
-            got = self.f.readinto(memoryview(self.buf)[self.fill:])
+            want = memoryview(self.buf)[self.fill:]
+            if self.left is not None:
+                want = want[:min(len(want), self.left)]
+            got = self.f.readinto(want) if len(want) else 0
+            if self.left is not None:
+                self.left -= got or 0
             if not got:
                 self.eof = True
                 if self.fill and self.buf[self.fill - 1] != _NL:     # last line without newline

@@ -105,3 +105,94 @@ def test_raw_chunker_adds_final_newline(tmp_path):
     assert buf.tobytes().endswith(b"II\n")
     ch.consumed(buf.shape[0])
     assert ch.next_chunk() is None
+
+
+# ---------------------------------------------------------------- byte-range sharding over ranks
+def _random_fastq(path, n, rng, crlf=False):
+    """Records with 0..300 bases and quality lines full of '@' and '+' (the characters that make naive
+    re-synchronisation fail).  Returns (record start offsets, file size)."""
+    nlb = b"\r\n" if crlf else b"\n"
+    starts, out, pos = [], [], 0
+    for i in range(n):
+        L = int(rng.integers(0, 300))
+        seq = bytes(rng.choice(list(b"ACGT"), size=L))
+        qual = bytes(rng.choice(list(b"@+IF#"), size=L))
+        rec = b"@r%d x" % i + nlb + seq + nlb + b"+" + nlb + qual + nlb
+        starts.append(pos)
+        pos += len(rec)
+        out.append(rec)
+    with open(path, "wb") as f:
+        f.write(b"".join(out))
+    return np.array(starts), pos
+
+
+@pytest.mark.parametrize("crlf", [False, True])
+def test_rank_byte_ranges_partition_a_fastq_exactly(tmp_path, crlf):
+    """Rank g owns exactly the records that start inside [g*size/G, (g+1)*size/G) — for G in {1,2,3,8,37}, with
+    '@'-leading quality lines; the ranges tile the file (reference: one chunk -> one worker,
+    command_line_interface.py:109-111)."""
+    from kmer_mapper_amd import reads_io as rio
+    rng = np.random.default_rng(7 + crlf)
+    p = str(tmp_path / "t.fq")
+    starts, size = _random_fastq(p, 3000, rng, crlf)
+    for G in (1, 2, 3, 8, 37):
+        prev = 0
+        for g in range(G):
+            lo, hi = rio.rank_byte_range(p, "fastq", g, G)
+            assert lo == prev
+            want = starts[(starts >= size * g // G) & (starts < size * (g + 1) // G)]
+            assert np.array_equal(starts[(starts >= lo) & (starts < hi)], want), (G, g)
+            prev = hi
+        assert prev == size
+    # every rank's reads, parsed from its own range only, put together = the reads of the whole file
+    whole = np.concatenate([b.bases for b in rio.read_chunks(p, 50_000)])
+    for G in (3, 8):
+        parts = [b.bases for g in range(G)
+                 for b in rio.read_chunks(p, 50_000, byte_range=rio.rank_byte_range(p, "fastq", g, G))]
+        assert np.array_equal(np.concatenate(parts), whole)
+    # the cut a rank makes in a chunk it only skips (shared .gz stream) = the end of the last whole record
+    buf = np.fromfile(p, dtype=np.uint8)
+    ends = np.append(starts[1:], size)
+    for cut in rng.integers(1, size, size=300):
+        e = ends[ends <= cut]
+        assert rio.last_record_start(buf[:cut], "fastq") == (e[-1] if e.shape[0] else 0)
+
+
+def test_rank_byte_ranges_fasta_and_shared_gz_stream(tmp_path):
+    from kmer_mapper_amd import reads_io as rio
+    rng = np.random.default_rng(11)
+    recs, starts, pos = [], [], 0
+    for i in range(2000):
+        L = int(rng.integers(0, 200))
+        rec = b">r%d\n" % i + bytes(rng.choice(list(b"ACGT"), size=L)) + b"\n"
+        starts.append(pos)
+        pos += len(rec)
+        recs.append(rec)
+    p = str(tmp_path / "t.fa")
+    with open(p, "wb") as f:
+        f.write(b"".join(recs))
+    starts, size = np.array(starts), pos
+    for G in (2, 3, 8):
+        prev = 0
+        for g in range(G):
+            lo, hi = rio.rank_byte_range(p, "fasta", g, G)
+            assert lo == prev
+            assert np.array_equal(starts[(starts >= lo) & (starts < hi)],
+                                  starts[(starts >= size * g // G) & (starts < size * (g + 1) // G)])
+            prev = hi
+        assert prev == size
+    # ranks sharing one gzip stream: chunk i -> rank i mod G; skipped chunks come out as None, owned ones parsed
+    import gzip
+    pz = str(tmp_path / "t.fa.gz")
+    with gzip.open(pz, "wb") as f:
+        f.write(b"".join(recs))
+    whole = [b for b in rio.read_chunks(pz, 20_000)]
+    for G in (2, 3):
+        got = [None] * len(whole)
+        for g in range(G):
+            for i, b in enumerate(rio.read_chunks(pz, 20_000, owned=lambda i, g=g: i % G == g)):
+                if b is not None:
+                    assert i % G == g and got[i] is None
+                    got[i] = b
+        assert all(np.array_equal(a.bases, b.bases) and np.array_equal(a.offsets, b.offsets)
+                   for a, b in zip(whole, got))

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Rehearsal of the multi-rank CLI flow on a 1-GPU box: run under
    KMM_DIST_BACKEND=gloo python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 tools/cli_two_rank_rehearsal.py
-Chunk i goes to rank i mod 2, counts are summed with one reduce; rank 0 compares with the oracle."""
+Every rank maps its own byte range of the plain FASTQ (reads_io.rank_byte_range); for the .gz copy (one stream,
+not seekable) chunk i goes to rank i mod WORLD_SIZE.  Counts are summed with one reduce; rank 0 compares with
+the oracle."""
 import os
 import sys
 
@@ -23,18 +25,27 @@ def main():
     if rank == 0:
         index.to_file(idx_path)
         reads_io.write_fastq(fq, ReadBatch(bases, offs))
+        reads_io.write_fastq(fq + ".gz", ReadBatch(bases, offs), gz=True)
     import torch.distributed as dist
     dist.init_process_group(os.environ.get("KMM_DIST_BACKEND", "gloo"))
     dist.barrier()
-    out = os.path.join(d, "out")
-    run_argument_parser(["map", "-i", idx_path, "-f", fq, "-o", out, "-c", "300000"])
-    dist.barrier()
-    if rank == 0:
-        from oracle import oracle
-        expect, _ = oracle.map_reads(index, index.max_node_id(), bases, offs, 31, n_threads=4)
-        got = np.load(out + ".npy")
-        print("two-rank CLI rehearsal:", "BIT-EXACT" if np.array_equal(got, expect) else "MISMATCH", flush=True)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    ok = True
+    for path in (fq, fq + ".gz"):
+        out = os.path.join(d, "out_gz" if path.endswith(".gz") else "out")
+        run_argument_parser(["map", "-i", idx_path, "-f", path, "-o", out, "-c", "300000"])
+        dist.barrier()
+        if rank == 0:
+            from oracle import oracle
+            expect, _ = oracle.map_reads(index, index.max_node_id(), bases, offs, 31, n_threads=4)
+            got = np.load(out + ".npy")
+            same = bool(np.array_equal(got, expect))
+            ok = ok and same
+            print("%d-rank CLI rehearsal on %s: %s" % (world, os.path.basename(path),
+                                                        "BIT-EXACT" if same else "MISMATCH"), flush=True)
     dist.destroy_process_group()
+    if not ok:
+        sys.exit(1)
 
 
 if __name__ == "__main__":
