@@ -111,7 +111,7 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
     from kmer_mapper_amd import synthetic as syn
-    from kmer_mapper_amd.distributed import reduce_node_counts
+    from kmer_mapper_amd.distributed import init_rccl_comm, reduce_node_counts
     from kmer_mapper_amd.engine import DeviceIndex
 
     k, L, R = args.kmer_size, args.read_len, args.reads
@@ -194,9 +194,17 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    if world > 1 and args.dist_backend == "nccl":
+        init_rccl_comm(dev)                          # the library's own communicator (kmm_comm_init_rank)
+
     def reduce_counts(t):
         if args.dist_backend == "nccl":
-            reduce_node_counts(t, dst=0)            # RCCL sum of the uint32 count vectors over xGMI
+            # RCCL sum of the uint32 count vectors over xGMI, behind the C ABI (kmm_comm_reduce_counts): in place
+            # on the bound vector `counts`
+            if t is counts:
+                dev.comm_reduce_counts(root=0)
+            else:
+                reduce_node_counts(t, dst=0)
         else:                                        # rehearsal only
             h = t.cpu()
             reduce_node_counts(h, dst=0)
@@ -326,7 +334,8 @@ def main():
                 "occupancy_bits_per_bucket": dev.get_param("occupancy_bits_per_bucket"),
                 "bloom_filter_bytes": dev.get_param("bloom_filter_bytes"),
                 "final_reduce_ms": round(reduce_s * 1e3, 3) if world > 1 else 0.0,
-                "parallelism": "reads sharded by batch over %d GPU(s), index replicated, one RCCL sum" % world,
+                "parallelism": "reads sharded by batch over %d GPU(s), index replicated, one RCCL sum "
+                               "(kmm_comm_reduce_counts)" % world,
                 "kernel_ms_per_step": {n: round(t[0] / args.steps, 3) for n, t in timing.items() if t[1]},
             },
             "roofline": {

@@ -90,6 +90,32 @@ int kmm_get_node_counts(kmm_index_t *idx, uint32_t *out);
 int kmm_synchronize(kmm_index_t *idx);
 
 /*
+ * The one exchange step of the path: the sum of the per-GPU node-count vectors over RCCL / xGMI.  Replaces the
+ * additive reduce of per-chunk vectors, command_line_interface.py:124-130 (shared_memory_wrapper's
+ * additative_shared_array_map_reduce).  uint32 addition wraps modulo 2^32 like mapper.pyx:37,68, so the result
+ * is bit-exact whatever the reduction order.  RCCL is loaded at first use (dlopen), not linked.
+ *
+ * One process, several GPUs (one handle per GPU, same index on each):
+ *   kmm_reduce_counts(handles, n_gpus, root)  root >= 0: handles[root]'s count vector becomes the sum (the others are
+ *                                             unspecified afterwards); root = -1: every vector becomes the sum.
+ * One process per GPU (what bench.py and the CLI use under torchrun):
+ *   kmm_comm_get_unique_id(id)                on rank 0; the caller hands the 128 bytes to the other ranks by any
+ *                                             means (a file, MPI, torch.distributed's store, ...)
+ *   kmm_comm_init_rank(idx, id, n_ranks, rank)  collective: every rank joins with its own handle
+ *   kmm_comm_reduce_counts(idx, root)         collective, in place on the handle's (library-owned or bound) count
+ *                                             vector; root as above
+ *   kmm_comm_destroy(idx)                     (kmm_index_destroy does it too)
+ * All of them synchronise like kmm_get_node_counts (pending per-entry hits of the radix path are flushed first,
+ * deferred device-side errors are reported).
+ */
+#define KMM_COMM_ID_BYTES 128
+int kmm_reduce_counts(kmm_index_t **per_gpu, int n_gpus, int root);
+int kmm_comm_get_unique_id(uint8_t id[KMM_COMM_ID_BYTES]);
+int kmm_comm_init_rank(kmm_index_t *idx, const uint8_t id[KMM_COMM_ID_BYTES], int n_ranks, int rank);
+int kmm_comm_reduce_counts(kmm_index_t *idx, int root);
+int kmm_comm_destroy(kmm_index_t *idx);
+
+/*
  * kmm_map_kmers — replaces map_kmers_to_graph_index (mapper.pyx:19-72, loop :53-69) and
  * GpuCounter.count (gpu_counter.py:23-24): for each of the n packed k-mers q,
  * h = q % modulo, scan bucket h, and for every entry with kmer == q and

@@ -44,6 +44,11 @@ SIGNATURES = {
     "kmm_get_node_counts": (_c.c_int, [_P, _P]),
     "kmm_synchronize": (_c.c_int, [_P]),
     "kmm_get_kmer_counts": (_c.c_int, [_P, _P]),
+    "kmm_reduce_counts": (_c.c_int, [_P, _c.c_int, _c.c_int]),
+    "kmm_comm_get_unique_id": (_c.c_int, [_P]),
+    "kmm_comm_init_rank": (_c.c_int, [_P, _P, _c.c_int, _c.c_int]),
+    "kmm_comm_reduce_counts": (_c.c_int, [_P, _c.c_int]),
+    "kmm_comm_destroy": (_c.c_int, [_P]),
     "kmm_map_kmers": (_c.c_int, [_P, _P, _c.c_int64, _c.c_int, _c.c_int, _c.c_int]),
     "kmm_map_reads": (_c.c_int, [_P, _P, _P, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _P]),
     "kmm_map_reads_uniform": (_c.c_int, [_P, _P, _c.c_int64, _c.c_int64, _c.c_int, _c.c_int,

@@ -136,6 +136,8 @@ constexpr unsigned long long NO_BAD = ~0ull;
 
 } // namespace
 
+#include "kmm_comm.hpp"
+
 struct TimedEvent {
     hipEvent_t start, stop;
     int kernel_id;
@@ -185,6 +187,8 @@ struct kmm_index {
     int sticky_rc = KMM_OK;
     std::string sticky_msg;
     uint64_t map_calls = 0;   // sequence number of map calls on this handle (error reports name the call)
+    ncclComm_t comm = nullptr; // multi-process communicator of this handle (kmm_comm_init_rank)
+    int comm_rank = -1, comm_size = 0;
     // timing
     bool timing = false;
     std::vector<TimedEvent> ev_used;
@@ -657,6 +661,8 @@ void kmm_index_destroy(kmm_index_t *ix)
         (void)hipFree(ix->stats);
     if (ix->queue)
         (void)hipFree(ix->queue);
+    if (ix->comm && g_rccl.lib)
+        (void)g_rccl.CommDestroy(ix->comm);
     if (ix->copy_stream)
         (void)hipStreamDestroy(ix->copy_stream);
     if (ix->stream)
@@ -989,6 +995,127 @@ int kmm_get_node_counts(kmm_index_t *ix, uint32_t *out)
     HIPCHK(hipMemcpy(out, ix->counts, sizeof(uint32_t) * (size_t)(ix->max_node_id + 1),
                      is_device_ptr(out) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost));
     return KMM_OK;
+}
+
+int kmm_comm_get_unique_id(uint8_t id[KMM_COMM_ID_BYTES])
+{
+    if (!id)
+        return fail(KMM_ERR_INVALID_ARG, "id is NULL");
+    static_assert(KMM_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "kmm.h and rccl.h disagree on the id size");
+    KMMCHK(rccl_load());
+    ncclUniqueId u;
+    RCCLCHK(g_rccl.GetUniqueId(&u));
+    memcpy(id, u.internal, KMM_COMM_ID_BYTES);
+    return KMM_OK;
+}
+
+int kmm_comm_init_rank(kmm_index_t *ix, const uint8_t id[KMM_COMM_ID_BYTES], int n_ranks, int rank)
+{
+    if (!ix || !id)
+        return fail(KMM_ERR_INVALID_ARG, "NULL argument");
+    if (n_ranks < 1 || rank < 0 || rank >= n_ranks)
+        return fail(KMM_ERR_INVALID_ARG, "rank %d outside [0, %d)", rank, n_ranks);
+    KMMCHK(rccl_load());
+    HIPCHK(hipSetDevice(ix->device));
+    if (ix->comm) {
+        RCCLCHK(g_rccl.CommDestroy(ix->comm));
+        ix->comm = nullptr;
+    }
+    ncclUniqueId u;
+    memcpy(u.internal, id, KMM_COMM_ID_BYTES);
+    RCCLCHK(g_rccl.CommInitRank(&ix->comm, n_ranks, u, rank));
+    ix->comm_rank = rank;
+    ix->comm_size = n_ranks;
+    return KMM_OK;
+}
+
+int kmm_comm_reduce_counts(kmm_index_t *ix, int root)
+{
+    if (!ix)
+        return fail(KMM_ERR_INVALID_ARG, "idx is NULL");
+    if (!ix->comm)
+        return fail(KMM_ERR_INVALID_ARG, "kmm_comm_init_rank has not been called on this handle");
+    if (root < -1 || root >= ix->comm_size)
+        return fail(KMM_ERR_INVALID_ARG, "root %d outside [-1, %d)", root, ix->comm_size);
+    HIPCHK(hipSetDevice(ix->device));
+    KMMCHK(rx_flush(ix)); // every hit mapped so far is in `counts` before it travels
+    const size_t n = (size_t)ix->max_node_id + 1;
+    // uint32 addition wraps modulo 2^32 like mapper.pyx:37,68, whatever the order of the reduction
+    if (root < 0)
+        RCCLCHK(g_rccl.AllReduce(ix->counts, ix->counts, n, ncclUint32, ncclSum, ix->comm, ix->stream));
+    else
+        RCCLCHK(g_rccl.Reduce(ix->counts, ix->counts, n, ncclUint32, ncclSum, root, ix->comm, ix->stream));
+    return drain(ix);
+}
+
+int kmm_comm_destroy(kmm_index_t *ix)
+{
+    if (!ix)
+        return fail(KMM_ERR_INVALID_ARG, "idx is NULL");
+    if (ix->comm) {
+        HIPCHK(hipSetDevice(ix->device));
+        HIPCHK(hipStreamSynchronize(ix->stream));
+        RCCLCHK(g_rccl.CommDestroy(ix->comm));
+        ix->comm = nullptr;
+        ix->comm_rank = -1;
+        ix->comm_size = 0;
+    }
+    return KMM_OK;
+}
+
+int kmm_reduce_counts(kmm_index_t **per_gpu, int n_gpus, int root)
+{
+    if (!per_gpu || n_gpus < 1)
+        return fail(KMM_ERR_INVALID_ARG, "per_gpu is NULL or n_gpus < 1");
+    if (root < -1 || root >= n_gpus)
+        return fail(KMM_ERR_INVALID_ARG, "root %d outside [-1, %d)", root, n_gpus);
+    std::vector<int> devs(n_gpus);
+    for (int i = 0; i < n_gpus; ++i) {
+        if (!per_gpu[i])
+            return fail(KMM_ERR_INVALID_ARG, "per_gpu[%d] is NULL", i);
+        if (per_gpu[i]->max_node_id != per_gpu[0]->max_node_id)
+            return fail(KMM_ERR_INVALID_ARG, "handles disagree on max_node_id");
+        devs[i] = per_gpu[i]->device;
+        for (int j = 0; j < i; ++j)
+            if (devs[j] == devs[i])
+                return fail(KMM_ERR_INVALID_ARG, "handles %d and %d share device %d: one handle per GPU", j, i, devs[i]);
+    }
+    if (n_gpus == 1) {
+        HIPCHK(hipSetDevice(per_gpu[0]->device));
+        return drain(per_gpu[0]);
+    }
+    KMMCHK(rccl_load());
+    std::vector<ncclComm_t> comms(n_gpus);
+    RCCLCHK(g_rccl.CommInitAll(comms.data(), n_gpus, devs.data()));
+    int rc = KMM_OK;
+    const size_t n = (size_t)per_gpu[0]->max_node_id + 1;
+    for (int i = 0; i < n_gpus && rc == KMM_OK; ++i) {
+        if (hipSetDevice(devs[i]) != hipSuccess)
+            rc = fail(KMM_ERR_HIP, "hipSetDevice(%d) failed", devs[i]);
+        else
+            rc = rx_flush(per_gpu[i]);
+    }
+    if (rc == KMM_OK) {
+        ncclResult_t r = g_rccl.GroupStart();
+        for (int i = 0; i < n_gpus && r == ncclSuccess; ++i) {
+            kmm_index *ix = per_gpu[i];
+            r = root < 0 ? g_rccl.AllReduce(ix->counts, ix->counts, n, ncclUint32, ncclSum, comms[i], ix->stream)
+                         : g_rccl.Reduce(ix->counts, ix->counts, n, ncclUint32, ncclSum, root, comms[i], ix->stream);
+        }
+        const ncclResult_t r2 = g_rccl.GroupEnd();
+        if (r == ncclSuccess)
+            r = r2;
+        if (r != ncclSuccess)
+            rc = fail(KMM_ERR_HIP, "RCCL reduce of the node counts: %s", g_rccl.GetErrorString(r));
+    }
+    for (int i = 0; i < n_gpus; ++i) {
+        (void)hipSetDevice(devs[i]);
+        const int d = drain(per_gpu[i]);
+        if (rc == KMM_OK)
+            rc = d;
+        (void)g_rccl.CommDestroy(comms[i]);
+    }
+    return rc;
 }
 
 int kmm_get_kmer_counts(kmm_index_t *ix, uint32_t *out)

@@ -53,3 +53,20 @@ def reduce_node_counts(counts, dst=0, group=None, all_ranks=False):
     else:
         dist.reduce(t, dst=dst, op=dist.ReduceOp.SUM, group=group)
     return counts
+
+
+def init_rccl_comm(dev, group=None):
+    """Join the library's own RCCL communicator (include/kmm.h: kmm_comm_*) with the DeviceIndex `dev`, using an
+    initialised torch.distributed group only to hand rank 0's 128-byte unique id to the other ranks.  Afterwards
+    dev.comm_reduce_counts() needs no torch."""
+    import torch
+    import torch.distributed as dist
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    on_gpu = dist.get_backend(group) == "nccl"
+    t = torch.zeros(128, dtype=torch.uint8)
+    if rank == 0:
+        t = torch.frombuffer(bytearray(dev.comm_unique_id()), dtype=torch.uint8).clone()
+    if on_gpu:
+        t = t.cuda(dev.device)
+    dist.broadcast(t, src=0, group=group)
+    dev.comm_init(bytes(t.cpu().numpy().tobytes()), world, rank)

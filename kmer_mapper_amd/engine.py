@@ -137,6 +137,24 @@ class DeviceIndex:
         _lib.check(_lib.lib().kmm_get_kmer_counts(self._h, ptr))
         return out
 
+    # -- multi-GPU: one process per GPU, RCCL behind the C ABI -------------------------------------
+    @staticmethod
+    def comm_unique_id():
+        """128 bytes created on rank 0 (kmm_comm_get_unique_id); hand them to every rank."""
+        buf = (ctypes.c_uint8 * 128)()
+        _lib.check(_lib.lib().kmm_comm_get_unique_id(buf))
+        return bytes(buf)
+
+    def comm_init(self, unique_id, n_ranks, rank):
+        """Collective: join the communicator of the job with this handle."""
+        buf = (ctypes.c_uint8 * 128).from_buffer_copy(bytes(unique_id))
+        _lib.check(_lib.lib().kmm_comm_init_rank(self._h, buf, int(n_ranks), int(rank)))
+
+    def comm_reduce_counts(self, root=0):
+        """Collective: sum of the ranks' count vectors, in place (root = -1: on every rank).  Replaces the additive
+        reduce of command_line_interface.py:124-130."""
+        _lib.check(_lib.lib().kmm_comm_reduce_counts(self._h, int(root)))
+
     # -- the hot path ----------------------------------------------------------------------------
     def map_kmers(self, kmers, max_index_lookup_frequency=1000, also_revcomp=False, k=31):
         a = _Arg(kmers, np.uint64, "kmers")
