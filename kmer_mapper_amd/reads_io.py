@@ -21,7 +21,8 @@ _CR = 13
 
 def _open(path):
     if str(path).endswith(".gz"):
-        return gzip.open(path, "rb")
+        from .gz_io import open_gz
+        return open_gz(path)            # BGZF members are inflated on several cores, plain gzip on one
     return open(path, "rb", buffering=0)
 
 

@@ -196,3 +196,57 @@ def test_rank_byte_ranges_fasta_and_shared_gz_stream(tmp_path):
                     got[i] = b
         assert all(np.array_equal(a.bases, b.bases) and np.array_equal(a.offsets, b.offsets)
                    for a, b in zip(whole, got))
+
+
+# ---------------------------------------------------------------- .gz input inflated on several cores
+def test_bgzf_is_inflated_member_parallel_and_plain_gzip_still_works(tmp_path):
+    """BGZF (independent members with their size in the header, what bgzip writes) is inflated on a thread pool;
+    a plain gzip file — also several concatenated members — by one thread.  Both give the same reads as the
+    uncompressed file through read_chunks and RawChunker (reference: '.fa.gz, or fq.gz', Readme.md:11; igzip intent
+    kmer_mapper/util.py:78-101)."""
+    import gzip
+    from kmer_mapper_amd import gz_io, reads_io as rio
+    rng = np.random.default_rng(21)
+    p = str(tmp_path / "t.fq")
+    _random_fastq(p, 4000, rng)
+    data = open(p, "rb").read()
+    pb, pg, pm = str(tmp_path / "b.fq.gz"), str(tmp_path / "g.fq.gz"), str(tmp_path / "m.fq.gz")
+    gz_io.write_bgzf(pb, data, block=20_000)                  # many members
+    assert gz_io.is_bgzf(pb) and gzip.open(pb, "rb").read() == data    # ... and a valid gzip file for everyone else
+    with gzip.open(pg, "wb") as f:
+        f.write(data)
+    half = data.index(b"\n@r2000 x") + 1
+    with open(pm, "wb") as f:                                  # two concatenated plain members
+        f.write(gzip.compress(data[:half]) + gzip.compress(data[half:]))
+    assert not gz_io.is_bgzf(pg)
+    for path in (pb, pg, pm):
+        for n_threads in (1, 4):
+            with gz_io.open_gz(path, n_threads) as s:
+                got = bytearray()
+                while True:
+                    piece = s.read(70_001)
+                    if not piece:
+                        break
+                    got += piece
+            assert bytes(got) == data, (path, n_threads)
+    whole = list(rio.read_chunks(p, 60_000))
+    for path in (pb, pm):
+        chunks = list(rio.read_chunks(path, 60_000))
+        assert np.array_equal(np.concatenate([c.bases for c in chunks]), np.concatenate([c.bases for c in whole]))
+        ch = rio.RawChunker(path, 50_000)
+        out = bytearray()
+        while True:
+            buf = ch.next_chunk()
+            if buf is None:
+                break
+            used = buf.shape[0] if ch.eof else rio.last_record_start(buf, "fastq")
+            out += buf[:used].tobytes()
+            ch.consumed(used)
+        ch.close()
+        assert bytes(out) == data
+    with pytest.raises(ValueError):
+        bad = bytearray(open(pb, "rb").read())
+        bad[len(bad) // 2] ^= 0xFF                              # corrupt a member: zlib or the size check objects
+        open(pb, "wb").write(bad)
+        with gz_io.open_gz(pb, 4) as s:
+            s.read()
