@@ -238,7 +238,21 @@ __device__ __forceinline__ uint32_t tile_kmers(const ReadsView &rv, const TileCo
     uint64_t lo, hi;
     {
         const int wi = q0 >> 4;
+#ifdef KMM_WINDOW_SHUFFLE
+        // A/B variant (profiles/r02/window_shift_ab.md): the lane reads only the packed word its own positions lie
+        // in and pulls the 30-base halo from the lanes that own the next two words (ds_bpermute / DPP); the lanes
+        // whose neighbours sit in the next wavefront read LDS like the default build.
+        constexpr int LPW = 16 / S >= 1 ? 16 / S : 1;      // lanes per packed word
+        const uint32_t c0 = sm.codes[wi];
+        uint32_t c1 = __shfl_down(c0, LPW), c2 = __shfl_down(c0, 2 * LPW);
+        const int lane = tid & 63;
+        if (lane + LPW > 63)
+            c1 = sm.codes[wi + 1];
+        if (lane + 2 * LPW > 63)
+            c2 = sm.codes[wi + 2];
+#else
         const uint32_t c0 = sm.codes[wi], c1 = sm.codes[wi + 1], c2 = sm.codes[wi + 2];
+#endif
         const int sh = (q0 & 15) * 2;
         lo = ((uint64_t)c1 << 32) | c0;
         hi = c2;
