@@ -251,12 +251,12 @@ def main():
         per_kernel = None
         if dom.startswith("k_rx"):
             used = [n for n in RX_KERNELS if timing[n][1]]
-            launches = max(timing[n][1] for n in used)
-            avg_kernel_s = sum(timing[n][0] / max(timing[n][1], 1) for n in used) / 1e3
+            launches = timing["k_rx_p1"][1]                      # one pipeline (one launch of every kernel) per step
+            avg_kernel_s = sum(timing[n][0] for n in used) / max(launches, 1) / 1e3
             kmers_per_launch = kmers_per_step * args.steps / max(launches, 1)
             per_kernel = {}
             for n in used:
-                t_s = timing[n][0] / max(timing[n][1], 1) / 1e3
+                t_s = timing[n][0] / max(launches, 1) / 1e3
                 per_kernel[n] = {"avg_ms": round(t_s * 1e3, 3)}
                 if n in RX_STREAM_BYTES:
                     gbps = kmers_per_launch * RX_STREAM_BYTES[n] / t_s / 1e9
@@ -282,6 +282,15 @@ def main():
                             or tj.get("kernel") != dom):
                         continue
                     traffic = tj.get("hbm_bytes_per_launch")
+                    if per_kernel and "per_kernel" in tj:          # measured HBM bytes of every kernel of the pipeline
+                        for n, pk in per_kernel.items():
+                            m = [v for kk, v in tj["per_kernel"].items()
+                                 if kk == n or (n == "k_rx_scan" and kk in ("k_rx_colsum", "k_rx_chunkscan", "k_rx_tables",
+                                                                            "k_rx_colscan", "k_rx_tr2"))]
+                            if m:
+                                b = sum(v["read_bytes"] + v["write_bytes"] for v in m)
+                                pk["measured_hbm_bytes"] = round(b)
+                                pk["measured_hbm_GB_per_s"] = round(b / (pk["avg_ms"] * 1e-3) / 1e9, 1)
                     if "l2_miss_read_requests_per_kmer" in tj:
                         # request-granular view: random probes are bound by the NUMBER of
                         # requests — ~55 G/s for L2-missing reads, ~254 G/s for L2 hits, and the two add
