@@ -1451,11 +1451,17 @@ int kmm_extract_kmers(int device, const uint8_t *bases, const int64_t *read_offs
     DevBuf d_bases, d_offs, d_lut, d_out, d_bad, d_tf, d_cnt, d_sup;
     int rc = KMM_OK;
     hipError_t e = hipSuccess;
+    hipStream_t st = nullptr; // a stream of its own: other handles' work on this device is not stalled
+    HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    auto copy = [&](void *dst, const void *src, size_t bytes, hipMemcpyKind kind) -> hipError_t {
+        hipError_t x = hipMemcpyAsync(dst, src, bytes, kind, st);
+        return x == hipSuccess ? hipStreamSynchronize(st) : x;
+    };
     const bool out_dev = n_out == 0 || is_device_ptr(out);
     uint8_t lutbuf[256];
     if (lut) {
         if (is_device_ptr(lut))
-            e = hipMemcpy(lutbuf, lut, 256, hipMemcpyDeviceToHost);
+            e = copy(lutbuf, lut, 256, hipMemcpyDeviceToHost);
         else
             memcpy(lutbuf, lut, 256);
     } else {
@@ -1475,14 +1481,14 @@ int kmm_extract_kmers(int device, const uint8_t *bases, const int64_t *read_offs
             rv.bases = bases;
         } else {
             if ((rc = ensure(d_bases, (size_t)total))) break;
-            if ((e = hipMemcpy(d_bases.p, bases, (size_t)total, hipMemcpyHostToDevice))) break;
+            if ((e = copy(d_bases.p, bases, (size_t)total, hipMemcpyHostToDevice))) break;
             rv.bases = (const uint8_t *)d_bases.p;
         }
         if (offs_dev) {
             rv.offsets = read_offsets;
         } else {
             if ((rc = ensure(d_offs, (size_t)(n_reads + 1) * 8))) break;
-            if ((e = hipMemcpy(d_offs.p, read_offsets, (size_t)(n_reads + 1) * 8, hipMemcpyHostToDevice))) break;
+            if ((e = copy(d_offs.p, read_offsets, (size_t)(n_reads + 1) * 8, hipMemcpyHostToDevice))) break;
             rv.offsets = (const int64_t *)d_offs.p;
         }
         uint64_t *p_out = out;
@@ -1497,12 +1503,12 @@ int kmm_extract_kmers(int device, const uint8_t *bases, const int64_t *read_offs
         if ((rc = ensure(d_tf, (size_t)n_tiles * 8))) break;
         if ((rc = ensure(d_cnt, (size_t)max_super * 1024 * 4))) break;
         if ((rc = ensure(d_sup, (size_t)max_super * 4 + 16))) break;
-        if ((e = hipMemcpy(d_lut.p, lutbuf, 256, hipMemcpyHostToDevice))) break;
-        if ((e = hipMemcpy(d_bad.p, bad, 16, hipMemcpyHostToDevice))) break;
+        if ((e = copy(d_lut.p, lutbuf, 256, hipMemcpyHostToDevice))) break;
+        if ((e = copy(d_bad.p, bad, 16, hipMemcpyHostToDevice))) break;
         rv.lut = (const uint8_t *)d_lut.p;
         rv.first_bad = (unsigned long long *)d_bad.p;
         rv.tile_first = (const int64_t *)d_tf.p;
-        hipLaunchKernelGGL(k_tile_first, dim3((unsigned)((n_tiles + 255) / 256)), dim3(256), 0, 0, rv.offsets,
+        hipLaunchKernelGGL(k_tile_first, dim3((unsigned)((n_tiles + 255) / 256)), dim3(256), 0, st, rv.offsets,
                            n_reads, n_tiles, TILE_T, (int64_t *)d_tf.p);
         uint32_t *tile_cnt = (uint32_t *)d_cnt.p;
         uint32_t *super_tot = (uint32_t *)d_sup.p;
@@ -1512,37 +1518,39 @@ int kmm_extract_kmers(int device, const uint8_t *bases, const int64_t *read_offs
             const int n_super = (int)((t1 - t0 + 1023) / 1024);
             int64_t g = t1 - t0;
             if (g > 65536) g = 65536;
-            if ((e = hipMemsetAsync(tile_cnt, 0, (size_t)n_super * 1024 * 4, 0))) break;
-            hipLaunchKernelGGL((k_extract_count<TILE_S, MODE_GENERAL>), dim3((unsigned)g), dim3(256), 0, 0, rv,
+            if ((e = hipMemsetAsync(tile_cnt, 0, (size_t)n_super * 1024 * 4, st))) break;
+            hipLaunchKernelGGL((k_extract_count<TILE_S, MODE_GENERAL>), dim3((unsigned)g), dim3(256), 0, st, rv,
                                k, t0, t1, tile_cnt);
-            hipLaunchKernelGGL(k_rec_scan1, dim3(n_super), dim3(1024), 0, 0, tile_cnt, super_tot);
-            hipLaunchKernelGGL(k_super_scan, dim3(1), dim3(1024), 0, 0, super_tot, n_super, d_total);
+            hipLaunchKernelGGL(k_rec_scan1, dim3(n_super), dim3(1024), 0, st, tile_cnt, super_tot);
+            hipLaunchKernelGGL(k_super_scan, dim3(1), dim3(1024), 0, st, super_tot, n_super, d_total);
             uint32_t sub_total = 0;
             if ((e = hipGetLastError())) break;
-            if ((e = hipMemcpy(&sub_total, d_total, 4, hipMemcpyDeviceToHost))) break;
+            if ((e = copy(&sub_total, d_total, 4, hipMemcpyDeviceToHost))) break;
             if (produced + (int64_t)sub_total > n_out) { // never write past the caller's buffer
                 rc = fail(KMM_ERR_INVALID_ARG, "n_out=%lld but the reads hold more k-mers", (long long)n_out);
                 break;
             }
             if (sub_total)
-                hipLaunchKernelGGL((k_extract_write<TILE_S, MODE_GENERAL>), dim3((unsigned)g), dim3(256), 0, 0,
+                hipLaunchKernelGGL((k_extract_write<TILE_S, MODE_GENERAL>), dim3((unsigned)g), dim3(256), 0, st,
                                    rv, k, t0, t1, tile_cnt, super_tot, p_out + produced);
             produced += sub_total;
         }
         if (rc != KMM_OK || e != hipSuccess) break;
         if ((e = hipGetLastError())) break;
-        if ((e = hipDeviceSynchronize())) break;
-        if ((e = hipMemcpy(bad, d_bad.p, 16, hipMemcpyDeviceToHost))) break;
+        if ((e = hipStreamSynchronize(st))) break;
+        if ((e = copy(bad, d_bad.p, 16, hipMemcpyDeviceToHost))) break;
         if (produced != n_out) {
             rc = fail(KMM_ERR_INVALID_ARG, "n_out=%lld but the reads hold %lld k-mers", (long long)n_out,
                       (long long)produced);
             break;
         }
         if (!out_dev && n_out)
-            if ((e = hipMemcpy(out, d_out.p, (size_t)n_out * 8, hipMemcpyDeviceToHost))) break;
+            if ((e = copy(out, d_out.p, (size_t)n_out * 8, hipMemcpyDeviceToHost))) break;
     } while (0);
     release(d_bases); release(d_offs); release(d_lut); release(d_out); release(d_bad); release(d_tf);
     release(d_cnt); release(d_sup);
+    (void)hipStreamSynchronize(st);
+    (void)hipStreamDestroy(st);
     if (rc != KMM_OK)
         return rc;
     if (e != hipSuccess)
@@ -1572,10 +1580,12 @@ int kmm_build_index(int device, const uint64_t *kmers, const int32_t *nodes, int
     HIPCHK(hipSetDevice(device));
     const uint64_t M = modulo;
     const uint64_t magic = magic_for(M);
-    DevBuf d_km, d_nd, d_nk, d_h2i, d_cur, d_src, d_ko, d_no, d_fo;
+    DevBuf d_km, d_nd, d_nk, d_h2i, d_cur, d_src, d_ko, d_no, d_fo, d_list, d_ksort;
     std::vector<DevBuf> scratch(2 * SCAN_MAX_LEVELS);
     int rc = KMM_OK;
     hipError_t e = hipSuccess;
+    hipStream_t st = nullptr; // a stream of its own: other handles' work on this device is not stalled
+    HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     auto up = [&](DevBuf &b, const void *src, size_t bytes, const void **dev) -> bool {
         if (bytes == 0 || is_device_ptr(src)) {
             *dev = src;
@@ -1583,7 +1593,7 @@ int kmm_build_index(int device, const uint64_t *kmers, const int32_t *nodes, int
         }
         if ((rc = ensure(b, bytes)))
             return false;
-        if ((e = hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice)))
+        if ((e = hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, st)))
             return false;
         *dev = b.p;
         return true;
@@ -1591,7 +1601,9 @@ int kmm_build_index(int device, const uint64_t *kmers, const int32_t *nodes, int
     auto down = [&](void *dst, const void *dev, size_t bytes) -> bool {
         if (bytes == 0 || dst == dev)
             return true;
-        e = hipMemcpy(dst, dev, bytes, is_device_ptr(dst) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost);
+        e = hipMemcpyAsync(dst, dev, bytes, is_device_ptr(dst) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess)
+            e = hipStreamSynchronize(st);
         return e == hipSuccess;
     };
     do {
@@ -1604,14 +1616,14 @@ int kmm_build_index(int device, const uint64_t *kmers, const int32_t *nodes, int
         if (!w_nk) { if ((rc = ensure(d_nk, (size_t)M * 4))) break; w_nk = (uint32_t *)d_nk.p; }
         if (!w_h2i) { if ((rc = ensure(d_h2i, (size_t)M * 4))) break; w_h2i = (uint32_t *)d_h2i.p; }
         if ((rc = ensure(d_cur, (size_t)M * 4))) break;
-        if ((e = hipMemsetAsync(w_nk, 0, (size_t)M * 4, 0))) break;
-        if ((e = hipMemsetAsync(d_cur.p, 0, (size_t)M * 4, 0))) break;
+        if ((e = hipMemsetAsync(w_nk, 0, (size_t)M * 4, st))) break;
+        if ((e = hipMemsetAsync(d_cur.p, 0, (size_t)M * 4, st))) break;
         int64_t g = (n + 255) / 256;
         if (g > 65536) g = 65536;
         if (g < 1) g = 1;
         if (n > 0)
-            hipLaunchKernelGGL(k_bi_hist, dim3((unsigned)g), dim3(256), 0, 0, (const uint64_t *)p_km, n, M, magic, w_nk);
-        if ((rc = scan_exclusive(w_nk, w_h2i, M, scratch, 0, 0))) break;
+            hipLaunchKernelGGL(k_bi_hist, dim3((unsigned)g), dim3(256), 0, st, (const uint64_t *)p_km, n, M, magic, w_nk);
+        if ((rc = scan_exclusive(w_nk, w_h2i, M, scratch, 0, st))) break;
         if (n > 0) {
             uint64_t *w_ko = is_device_ptr(kmers_out) ? kmers_out : nullptr;
             int32_t *w_no = is_device_ptr(nodes_out) ? nodes_out : nullptr;
@@ -1620,13 +1632,27 @@ int kmm_build_index(int device, const uint64_t *kmers, const int32_t *nodes, int
             if (!w_no) { if ((rc = ensure(d_no, (size_t)n * 4))) break; w_no = (int32_t *)d_no.p; }
             if (!w_fo) { if ((rc = ensure(d_fo, (size_t)n * 2))) break; w_fo = (uint16_t *)d_fo.p; }
             if ((rc = ensure(d_src, (size_t)n * 4))) break;
-            hipLaunchKernelGGL(k_bi_scatter, dim3((unsigned)g), dim3(256), 0, 0, (const uint64_t *)p_km, n, M, magic,
+            hipLaunchKernelGGL(k_bi_scatter, dim3((unsigned)g), dim3(256), 0, st, (const uint64_t *)p_km, n, M, magic,
                                w_h2i, (uint32_t *)d_cur.p, (uint32_t *)d_src.p);
-            hipLaunchKernelGGL(k_bi_place, dim3((unsigned)g), dim3(256), 0, 0, (const uint64_t *)p_km,
+            hipLaunchKernelGGL(k_bi_place, dim3((unsigned)g), dim3(256), 0, st, (const uint64_t *)p_km,
                                (const int32_t *)p_nd, n, M, magic, w_h2i, w_nk, (const uint32_t *)d_src.p, w_ko,
                                w_no, w_fo);
+            // buckets with more than BI_BIG entries: listed, then ordered by one workgroup each
+            const size_t list_cap = (size_t)n / BI_BIG + 2;
+            if ((rc = ensure(d_list, (list_cap + 1) * 4))) break;
+            if ((rc = ensure(d_ksort, (size_t)n * 8))) break;
+            uint32_t *d_count = (uint32_t *)d_list.p + list_cap;
+            if ((e = hipMemsetAsync(d_count, 0, 4, st))) break;
+            {
+                uint64_t gm = (M + 255) / 256;
+                if (gm > 65536) gm = 65536;
+                hipLaunchKernelGGL(k_bi_list_big, dim3((unsigned)gm), dim3(256), 0, st, w_nk, M, (uint32_t *)d_list.p, d_count);
+            }
+            hipLaunchKernelGGL(k_bi_big, dim3(1024), dim3(1024), 0, st, (const uint64_t *)p_km, (const int32_t *)p_nd, w_h2i,
+                               w_nk, (const uint32_t *)d_list.p, d_count, (uint32_t *)d_src.p, (uint64_t *)d_ksort.p, w_ko,
+                               w_no, w_fo);
             if ((e = hipGetLastError())) break;
-            if ((e = hipDeviceSynchronize())) break;
+            if ((e = hipStreamSynchronize(st))) break;
             if (!down(kmers_out, w_ko, (size_t)n * 8)) break;
             if (!down(nodes_out, w_no, (size_t)n * 4)) break;
             if (!down(frequencies_out, w_fo, (size_t)n * 2)) break;
@@ -1634,17 +1660,21 @@ int kmm_build_index(int device, const uint64_t *kmers, const int32_t *nodes, int
         {   // the format leaves hashes_to_index = 0 for empty buckets (upstream fills only the used ones)
             uint64_t gm = (M + 255) / 256;
             if (gm > 65536) gm = 65536;
-            hipLaunchKernelGGL(k_bi_zero_empty, dim3((unsigned)gm), dim3(256), 0, 0, w_h2i, w_nk, M);
+            hipLaunchKernelGGL(k_bi_zero_empty, dim3((unsigned)gm), dim3(256), 0, st, w_h2i, w_nk, M);
         }
         if ((e = hipGetLastError())) break;
-        if ((e = hipDeviceSynchronize())) break;
+        if ((e = hipStreamSynchronize(st))) break;
         if (!down(n_kmers, w_nk, (size_t)M * 4)) break;
         if (!down(hashes_to_index, w_h2i, (size_t)M * 4)) break;
     } while (0);
     release(d_km); release(d_nd); release(d_nk); release(d_h2i); release(d_cur); release(d_src);
-    release(d_ko); release(d_no); release(d_fo);
+    release(d_ko); release(d_no); release(d_fo); release(d_list); release(d_ksort);
     for (DevBuf &b : scratch)
         release(b);
+    if (st) {
+        (void)hipStreamSynchronize(st);
+        (void)hipStreamDestroy(st);
+    }
     if (rc != KMM_OK)
         return rc;
     if (e != hipSuccess)

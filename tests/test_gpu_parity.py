@@ -856,3 +856,25 @@ def test_index_arrays_may_live_in_hbm(kmm, syn, oracle):
     with kmm.DeviceIndex(dev_arrays[0], dev_arrays[1], index._modulo, km, nd, fr, mx) as dev:
         dev.map_reads(bases, offs, 31)
         assert np.array_equal(dev.get_node_counts(), expect)
+
+
+def test_gpu_index_builder_with_huge_buckets(kmm):
+    """a k-mer with 100 000 hits (one bucket of 100 000+ entries) and a dense collision bucket must not cost
+    O(bucket^2): buckets above 64 entries are ordered by bitonic sorts.  Result identical to the stable numpy
+    construction (what from_flat_kmers does upstream, reference tests/test_mapping.py:36-38)."""
+    from kmer_mapper_amd.kmer_index import KmerIndex
+    rng = np.random.default_rng(77)
+    modulo = 50_021
+    base = rng.integers(0, 1 << 62, size=60_000, dtype=np.uint64)
+    heavy = np.uint64(987654321987)
+    coll = np.uint64(modulo) * rng.integers(1, 1 << 40, size=5000, dtype=np.uint64) + np.uint64(123)  # one bucket
+    coll = np.concatenate([coll, coll[:700]])                                                     # with repeats
+    kmers = np.concatenate([base, np.full(100_000, heavy, dtype=np.uint64), coll])
+    perm = rng.permutation(len(kmers))
+    kmers = kmers[perm]
+    nodes = rng.integers(0, 1 << 20, size=len(kmers)).astype(np.int64)
+    a = KmerIndex.from_flat_kmers(kmers, nodes, modulo)
+    b = KmerIndex.from_flat_kmers_gpu(kmers, nodes, modulo)
+    for name in ("_hashes_to_index", "_n_kmers", "_kmers", "_nodes", "_frequencies"):
+        assert np.array_equal(getattr(a, name), getattr(b, name)), name
+    assert a._frequencies.max() == 65535 and a._n_kmers.max() >= 100_000
