@@ -281,8 +281,9 @@ int64_t oracle_map_reads(const int32_t *hashes_to_index, const int32_t *n_kmers,
         } else {
             total += ws[t].n_mapped;
         }
-        free(ws[t].counts);
     }
+    for (int t = 1; t < n_threads; ++t) /* only now: every worker reads every private vector while it sums its slice */
+        free(ws[t].counts);
     pthread_barrier_destroy(&barrier);
     free(all);
     free(ws);
