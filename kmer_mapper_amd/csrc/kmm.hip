@@ -524,7 +524,11 @@ int launch_map_reads(kmm_index *ix, const ReadsView &rv, int k, int max_freq, in
 {
     const IndexView iv = view_of(ix);
     const int64_t n_tiles = (rv.total + TILE_T - 1) / TILE_T;
-    if (!use_radix(ix, rv.total)) {
+    // records mode: pass 1's front end (line numbering of raw file bytes) costs more than the direct kernel hides
+    // behind its gathers (profiles/r02/README.md: 34 vs 45 G k-mers/s at the 10 M index), so raw chunks take the
+    // radix path only when it is forced
+    const bool radix = MODE == MODE_RECORDS ? (ix->rx_ok && (ix->path == 2 || ix->rx_ecnt_acc)) : use_radix(ix, rv.total);
+    if (!radix) {
         ScopedTimer tm;
         KMMCHK(tm.begin(ix, KMM_KERNEL_MAP_READS));
         // large launches: persistent workgroups + dynamic tile queue; small ones: static schedule
