@@ -237,7 +237,7 @@ int kmm_get_kmer_counts(kmm_index_t *idx, uint32_t *out);
  *   "path"             0 = auto (by batch size), 1 = direct fused kernel (one HBM gather per k-mer),
  *                      2 = radix path (two partition passes by hash range + probe of LDS-resident index
  *                      slices)
- *   "part_shift"       log2 of the number of hash buckets per fine partition of the radix path (0..12)
+ *   "part_shift"       log2 of the number of hash buckets per fine partition of the radix path (0..13)
  *   "radix_min_units"  auto: smallest batch (positions / k-mers) that takes the radix path
  *   "count_kmers"      1 = per-k-mer counting mode (see kmm_get_kmer_counts)
  * Unknown names return KMM_ERR_INVALID_ARG.

@@ -388,7 +388,7 @@ constexpr int TILE_T = 256 * TILE_S;
 // Fan-out of the radix path for 2^w buckets per fine partition: F1 coarse x F2 fine partitions.
 bool rx_configure(kmm_index *ix, int w)
 {
-    if (w < 0 || w > 12 || ix->modulo >= (1ull << 31)) // (pass 1 divides with a 32-bit remainder)
+    if (w < 0 || w > 13 || ix->modulo >= (1ull << 31)) // (pass 1 divides with a 32-bit remainder)
         return false;
     const uint64_t PF = (ix->modulo + (1ull << w) - 1) >> w;
     if (PF > (uint64_t)RX_MAXF * RX_MAXF)
@@ -496,7 +496,12 @@ int launch_rx(kmm_index *ix, const ReadsView &rv, const uint64_t *kmers_in, int6
         HIPCHK(hipGetLastError());
         KMMCHK(tm.end());
         KMMCHK(tm.begin(ix, KMM_KERNEL_RX_P3));
-        hipLaunchKernelGGL(k_rx_p3, dim3(ix->n_cu * 2), dim3(RX_NT), 0, ix->stream, iv, rx, max_freq);
+        if (ix->rx_w > 12)
+            hipLaunchKernelGGL((k_rx_p3<RX_WMAX_BIG, RX_ECAP_BIG, 2>), dim3(ix->n_cu), dim3(RX_NT), 0, ix->stream, iv, rx,
+                               max_freq);
+        else
+            hipLaunchKernelGGL((k_rx_p3<RX_WMAX, RX_ECAP, 4>), dim3(ix->n_cu * 2), dim3(RX_NT), 0, ix->stream, iv, rx,
+                               max_freq);
         HIPCHK(hipGetLastError());
         KMMCHK(tm.end());
         ix->ecnt_dirty = true;
@@ -739,6 +744,10 @@ static int rx_build(kmm_index *ix, const int32_t *h2i, const int32_t *nk, const 
                          (1ull << w) > M))
             --w;
     ix->rx_ok = rx_configure(ix, w);
+    // more than 256 x 256 slices of 4096 buckets: slices of 8192 (one workgroup of pass 3 per CU) if their entries fit
+    if (!ix->rx_ok && w == 12 && !getenv("KMM_RX_W") &&
+        (double)ix->rx_S / (double)M * 8192.0 * 1.3 + 64.0 <= (double)RX_ECAP_BIG)
+        ix->rx_ok = rx_configure(ix, 13);
     if (ix->rx_ok)
         KMMCHK(rx_repack_keys(ix));
     // auto: the radix path streams the whole directory + key arrays once per batch (4 B x modulo + 14 B x entries),
@@ -1756,7 +1765,7 @@ int kmm_set_param(kmm_index_t *ix, const char *name, int64_t value)
         ix->path = (int)value;
     } else if (!strcmp(name, "part_shift")) {
         if (!rx_configure(ix, (int)value))
-            return fail(KMM_ERR_INVALID_ARG, "part_shift %lld: needs 0 <= shift <= 12, at most 256 x 256 fine partitions "
+            return fail(KMM_ERR_INVALID_ARG, "part_shift %lld: needs 0 <= shift <= 13, at most 256 x 256 fine partitions "
                         "and 2^shift small enough for the quotient of a 64-bit k-mer by the modulo to fit beside "
                         "the hash bits", (long long)value);
         ix->rx_ok = ix->rx_pstart != nullptr;

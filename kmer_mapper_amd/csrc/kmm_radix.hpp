@@ -53,8 +53,10 @@ constexpr int RX_NG = RX_NT / RX_LPR; // run copiers per workgroup
 constexpr int RX_SUBCAP = 1024;       // sub-runs (<= RX_LPR k-mers each) listed in LDS per window
 constexpr int RX_U = 8;               // sub-runs in flight per copier (pass 3)
 constexpr int RX_U2 = 16;             // ... pass 2
-constexpr int RX_WMAX = 4096;         // buckets per fine partition (LDS directory)
+constexpr int RX_WMAX = 4096;         // buckets per fine partition (LDS directory): two workgroups of pass 3 per CU
 constexpr int RX_ECAP = 4096;         // entries of a fine partition kept in LDS (keys + counters)
+constexpr int RX_WMAX_BIG = 8192;     // slices of indexes with more than 256 x 256 x 4096 buckets (e.g. the customary
+constexpr int RX_ECAP_BIG = 8192;     // modulo 452 930 477): 140 KB of LDS, one workgroup of pass 3 per CU
 enum { MODE_KMERS = 3 };              // pass-1 source: a uint64 k-mer array instead of read bytes
 
 struct RxView {
@@ -616,11 +618,12 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p2(IndexView iv, RxView rx)
 // ------------------------------------------------------------------------------------------------
 // pass 3
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(RX_NT, 4) k_rx_p3(IndexView iv, RxView rx, int max_freq)
+template <int WMAX, int ECAP, int WPS>
+__global__ void __launch_bounds__(RX_NT, WPS) k_rx_p3(IndexView iv, RxView rx, int max_freq)
 {
-    __shared__ uint32_t sdir[RX_WMAX + 1]; // bucket b of the slice holds entries [sdir[b], sdir[b + 1]) - e0
-    __shared__ uint64_t skeys[RX_ECAP];
-    __shared__ uint32_t scnt[RX_ECAP];
+    __shared__ uint32_t sdir[WMAX + 1]; // bucket b of the slice holds entries [sdir[b], sdir[b + 1]) - e0
+    __shared__ uint64_t skeys[ECAP];
+    __shared__ uint32_t scnt[ECAP];
     __shared__ uint64_t sub_src[RX_SUBCAP];
     __shared__ uint32_t sub_meta[RX_SUBCAP];
     __shared__ uint32_t s_wb[RX_MAXF + 1], s_wave8[RX_NT / 64];
@@ -670,22 +673,22 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p3(IndexView iv, RxView rx, int
         const uint32_t f = c * F2 + g;
         const uint64_t h0 = (uint64_t)f << rx.w;
         const uint32_t e0 = rx.pstart[h0], e1 = rx.pstart[h0 + W < M ? h0 + W : M];
-        const uint32_t ne = e1 - e0 < (uint32_t)RX_ECAP ? e1 - e0 : (uint32_t)RX_ECAP;
+        const uint32_t ne = e1 - e0 < (uint32_t)ECAP ? e1 - e0 : (uint32_t)ECAP;
         const uint32_t it0 = rx.item_base[c] + chunk * RX_IC;
         const uint32_t it_end = rx.item_base[c + 1];
         const uint32_t n_it = it_end - it0 < (uint32_t)RX_IC ? it_end - it0 : (uint32_t)RX_IC;
         // the slice (directory + keys) and this thread's run descriptors: every load is issued before the first
         // one is consumed
-        uint32_t dv[RX_WMAX / RX_NT + 1];
-        uint64_t kv[RX_ECAP / RX_NT];
+        uint32_t dv[WMAX / RX_NT + 1];
+        uint64_t kv[ECAP / RX_NT];
         uint32_t rf[RX_IC / RX_NT], rt[RX_IC / RX_NT];
 #pragma unroll
-        for (int j = 0; j <= RX_WMAX / RX_NT; ++j) {
+        for (int j = 0; j <= WMAX / RX_NT; ++j) {
             const uint32_t i = tid + j * RX_NT;
             dv[j] = i <= W ? rx.pstart[h0 + i < M ? h0 + i : M] : 0u;
         }
 #pragma unroll
-        for (int j = 0; j < RX_ECAP / RX_NT; ++j) {
+        for (int j = 0; j < ECAP / RX_NT; ++j) {
             const uint32_t i = tid + j * RX_NT;
             kv[j] = i < ne ? rx.pkeys[(size_t)e0 + i] : 0ull;
         }
@@ -698,13 +701,13 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p3(IndexView iv, RxView rx, int
             rt[j] = i < n_it ? rtp[i] : 0u;
         }
 #pragma unroll
-        for (int j = 0; j <= RX_WMAX / RX_NT; ++j) {
+        for (int j = 0; j <= WMAX / RX_NT; ++j) {
             const uint32_t i = tid + j * RX_NT;
             if (i <= W)
                 sdir[i] = dv[j] - e0;
         }
 #pragma unroll
-        for (int j = 0; j < RX_ECAP / RX_NT; ++j) {
+        for (int j = 0; j < ECAP / RX_NT; ++j) {
             const uint32_t i = tid + j * RX_NT;
             if (i < ne) {
                 skeys[i] = kv[j];

@@ -86,3 +86,21 @@ def test_full_batch_at_config_size(kmm, oracle, n_index):
             dev.map_kmers(km)
             assert np.array_equal(dev.get_node_counts(), expect), path
         assert np.array_equal(dev.in_index(km[:2_000_000]), oracle.in_index(index, km[:2_000_000]))
+
+
+def test_customary_large_modulo_uses_8192_bucket_slices(kmm, oracle):
+    """graph_kmer_index's customary modulo 452 930 477 ([UPSTREAM-UNVERIFIED]) needs more than
+    256 x 256 slices of 4096 buckets: the radix path then runs with 8192-bucket slices."""
+    from kmer_mapper_amd import synthetic as syn
+    index, genome = syn.make_index(2_000_000, k=31, seed=11, modulo=452_930_477, gpu_builder=True)
+    mx = index.max_node_id()
+    bases, offs = syn.make_reads(genome, 300_000, 150, seed=12)
+    expect, n = oracle.map_reads(index, mx, bases, offs, 31, n_threads=16)
+    with kmm.DeviceIndex.from_index(index, mx) as dev:
+        assert dev.get_param("radix_available") == 1 and dev.get_param("part_shift") == 13
+        for path in (1, 2):
+            dev.reset()
+            dev.set_param("path", path)
+            dev.map_reads_uniform(bases, 300_000, 150, 31)
+            assert np.array_equal(dev.get_node_counts(), expect), path
+        assert dev.get_param("radix_p3_kmers") == n
