@@ -174,6 +174,7 @@ struct kmm_index {
     bool rx_ok = false;   // the index fits the radix path's fan-out (<= 256 x 256 fine partitions)
     int rx_w = 12, rx_f2 = 0; // log2 buckets per fine partition, log2 fine partitions per coarse one
     uint32_t rx_PF = 1, rx_F1 = 1, rx_F2 = 1;
+    int rx_grid_per_cu = 2;   // persistent workgroups of passes 2 and 3 per CU (1: leave room for another stream's kernels)
     int64_t rx_min_units = 0; // auto: batches of at least this many positions / k-mers take the radix path
     uint64_t rx_S = 0;        // entries in bucket order
     uint32_t *rx_pstart = nullptr;
@@ -488,7 +489,7 @@ int launch_rx(kmm_index *ix, const ReadsView &rv, const uint64_t *kmers_in, int6
         HIPCHK(hipGetLastError());
         KMMCHK(tm.end());
         KMMCHK(tm.begin(ix, KMM_KERNEL_RX_P2));
-        hipLaunchKernelGGL(k_rx_p2, dim3(ix->n_cu * 2), dim3(RX_NT), 0, ix->stream, iv, rx);
+        hipLaunchKernelGGL(k_rx_p2, dim3(ix->n_cu * ix->rx_grid_per_cu), dim3(RX_NT), 0, ix->stream, iv, rx);
         HIPCHK(hipGetLastError());
         KMMCHK(tm.end());
         KMMCHK(tm.begin(ix, KMM_KERNEL_RX_SCAN));
@@ -500,7 +501,7 @@ int launch_rx(kmm_index *ix, const ReadsView &rv, const uint64_t *kmers_in, int6
             hipLaunchKernelGGL((k_rx_p3<RX_WMAX_BIG, RX_ECAP_BIG, 2>), dim3(ix->n_cu), dim3(RX_NT), 0, ix->stream, iv, rx,
                                max_freq);
         else
-            hipLaunchKernelGGL((k_rx_p3<RX_WMAX, RX_ECAP, 4>), dim3(ix->n_cu * 2), dim3(RX_NT), 0, ix->stream, iv, rx,
+            hipLaunchKernelGGL((k_rx_p3<RX_WMAX, RX_ECAP, 4>), dim3(ix->n_cu * ix->rx_grid_per_cu), dim3(RX_NT), 0, ix->stream, iv, rx,
                                max_freq);
         HIPCHK(hipGetLastError());
         KMMCHK(tm.end());
@@ -1775,6 +1776,10 @@ int kmm_set_param(kmm_index_t *ix, const char *name, int64_t value)
         }
     } else if (!strcmp(name, "radix_min_units")) {
         ix->rx_min_units = value;
+    } else if (!strcmp(name, "radix_grid_per_cu")) {
+        if (value < 1 || value > 2)
+            return fail(KMM_ERR_INVALID_ARG, "radix_grid_per_cu must be 1 or 2");
+        ix->rx_grid_per_cu = (int)value;
     } else if (!strcmp(name, "count_kmers")) {
         // per-k-mer counting mode (GpuCounter semantics, gpu_counter.py:23-37): every batch takes the radix path
         // and the per-entry hit counts are kept (kmm_get_kmer_counts) besides being summed into the node counts
@@ -1819,20 +1824,25 @@ int kmm_get_param(kmm_index_t *ix, const char *name, int64_t *value)
         *value = ix->rx_w;
     else if (!strcmp(name, "radix_min_units"))
         *value = ix->rx_min_units;
+    else if (!strcmp(name, "radix_grid_per_cu"))
+        *value = ix->rx_grid_per_cu;
     else if (!strcmp(name, "radix_available"))
         *value = ix->rx_ok ? 1 : 0;
     else if (!strcmp(name, "count_kmers"))
         *value = ix->rx_ecnt_acc ? 1 : 0;
     else if (!strcmp(name, "n_coarse_partitions"))
         *value = ix->rx_ok ? ix->rx_F1 : 0;
-    else if (!strcmp(name, "radix_p2_kmers") || !strcmp(name, "radix_p3_kmers")) {
+    else if (!strcmp(name, "radix_p2_kmers") || !strcmp(name, "radix_p3_kmers") || !strncmp(name, "stats_slot_", 11)) {
         // conservation check of the radix path: k-mers gathered by pass 2 / probed by pass 3 since the last
         // kmm_get_stats(reset): both must equal the lookups pass 1 emitted
         HIPCHK(hipSetDevice(ix->device));
         KMMCHK(drain(ix));
         std::vector<unsigned long long> st(KMM_STAT_BYTES / 8);
         HIPCHK(hipMemcpy(st.data(), ix->stats, KMM_STAT_BYTES, hipMemcpyDeviceToHost));
-        const int slot = name[7] == '2' ? 2 : 3;
+        // ("stats_slot_<n>": raw counter n of the statistics block; slots 4.. are only written by diagnostic builds)
+        const int slot = name[0] == 's' ? atoi(name + 11) : name[7] == '2' ? 2 : 3;
+        if (slot < 0 || slot >= KMM_STAT_STRIDE)
+            return fail(KMM_ERR_INVALID_ARG, "unknown parameter '%s'", name);
         unsigned long long t = 0;
         for (int i = 0; i < KMM_STAT_SHARDS; ++i)
             t += st[(size_t)i * KMM_STAT_STRIDE + slot];

@@ -51,12 +51,38 @@ constexpr int RX_IC = 1024;           // pass-2 items per pass-3 work item
 constexpr int RX_LPR = 32;            // lanes that copy one run
 constexpr int RX_NG = RX_NT / RX_LPR; // run copiers per workgroup
 constexpr int RX_SUBCAP = 1024;       // sub-runs (<= RX_LPR k-mers each) listed in LDS per window
-constexpr int RX_U = 8;               // sub-runs in flight per copier (pass 3)
-constexpr int RX_U2 = 16;             // ... pass 2
+#ifndef RX_LPR3
+#define RX_LPR3 16
+#endif
+constexpr int RX_LPR_P3 = RX_LPR3;    // ... pass 3 (its runs are shorter: ~32 k-mers)
+constexpr int RX_NG3 = RX_NT / RX_LPR_P3;
+#ifndef RX_U3
+#define RX_U3 8
+#endif
+constexpr int RX_U = RX_U3;           // sub-runs in flight per copier (pass 3)
+#ifndef RX_P3_GROUP
+#define RX_P3_GROUP 4
+#endif
+constexpr int RX_G3 = RX_P3_GROUP;    // k-mers probed side by side (pass 3)
+#ifndef RX_U2V
+#define RX_U2V 16
+#endif
+constexpr int RX_U2 = RX_U2V;         // ... pass 2
+// The runs passes 2 and 3 copy are read with PLAIN loads: neighbouring runs share their first and last 128-byte
+// line, the XCD-aware work distribution (rx_pop) makes one XCD read them at about the same time, and a non-temporal
+// load would drop the shared line from L2 in between (measured: pass 2 4.42 -> 4.21 ms, pass 3 4.01 -> 3.88 ms).
+#ifdef RX_NT_LOADS
+#define RX_LOAD2(p) __builtin_nontemporal_load(p)
+#define RX_LOAD3(p) __builtin_nontemporal_load(p)
+#else
+#define RX_LOAD2(p) (*(p))
+#define RX_LOAD3(p) (*(p))
+#endif
 constexpr int RX_WMAX = 4096;         // buckets per fine partition (LDS directory): two workgroups of pass 3 per CU
 constexpr int RX_ECAP = 4096;         // entries of a fine partition kept in LDS (keys + counters)
 constexpr int RX_WMAX_BIG = 8192;     // slices of indexes with more than 256 x 256 x 4096 buckets (e.g. the customary
 constexpr int RX_ECAP_BIG = 8192;     // modulo 452 930 477): 140 KB of LDS, one workgroup of pass 3 per CU
+constexpr uint32_t RX_FILTERED = 0x80000000u; // pass 3: top bit of an LDS hit counter = entry excluded by max_freq
 enum { MODE_KMERS = 3 };              // pass-1 source: a uint64 k-mer array instead of read bytes
 
 struct RxView {
@@ -124,6 +150,33 @@ __device__ __forceinline__ uint32_t rx_scan256(const uint32_t *s_in, uint32_t *s
     return total;
 }
 
+// Diagnostic builds (-DRX_PHASE_TIMERS): thread 0 of every workgroup sums the shader-clock cycles it spends in
+// each phase of a pass into statistics slots 4.. (kmm_get_param "stats_slot_<n>"); product builds compile to nothing.
+#ifdef RX_PHASE_TIMERS
+#define RX_PT_DECL unsigned long long pt_acc[7] = {0, 0, 0, 0, 0, 0, (unsigned long long)clock64()}
+#define RX_PT_ARG , pt_acc
+#define RX_PT(slot)                                                                                                   \
+    do {                                                                                                              \
+        if (threadIdx.x == 0) {                                                                                       \
+            const unsigned long long pt_now = (unsigned long long)clock64();                                                            \
+            pt_acc[slot] += pt_now - pt_acc[6];                                                                       \
+            pt_acc[6] = pt_now;                                                                                       \
+        }                                                                                                             \
+    } while (0)
+#define RX_PT_END(iv, base)                                                                                           \
+    do {                                                                                                              \
+        if (threadIdx.x == 0)                                                                                         \
+            for (int pt_i = 0; pt_i < 6; ++pt_i)                                                                      \
+                atomicAdd(&(iv).stats[(size_t)(blockIdx.x % KMM_STAT_SHARDS) * KMM_STAT_STRIDE + (base) + pt_i],     \
+                          pt_acc[pt_i]);                                                                              \
+    } while (0)
+#else
+#define RX_PT_DECL
+#define RX_PT_ARG
+#define RX_PT(slot)
+#define RX_PT_END(iv, base)
+#endif
+
 // Counting sort of the workgroup's k-mers (RX_KPT per thread) inside LDS.  prep(i) finalises slot i of q (it may
 // rewrite q[i]) and returns its key < F, or F for a slot that holds no k-mer.  Then: the sorted run array goes to
 // `out` as one contiguous coalesced copy, where each key's run starts (and the total) to dir_row[0..F].  sbuf may
@@ -131,9 +184,11 @@ __device__ __forceinline__ uint32_t rx_scan256(const uint32_t *s_in, uint32_t *s
 template <int RB, typename PrepFn>
 __device__ __forceinline__ void rx_sort_emit(uint64_t (&q)[RX_KPT], PrepFn prep, int F, uint64_t *sbuf,
                                              uint32_t *s_cnt, uint32_t *s_base, uint32_t *s_wave,
-                                             uint64_t *__restrict__ out, uint16_t *__restrict__ dir_row)
+                                             uint64_t *__restrict__ out, uint16_t *__restrict__ dir_row,
+                                             unsigned long long *pt_acc = nullptr)
 {
     const int tid = threadIdx.x;
+    (void)pt_acc;
     if (tid <= F)
         s_cnt[tid] = 0;
     __syncthreads();
@@ -155,6 +210,7 @@ __device__ __forceinline__ void rx_sort_emit(uint64_t (&q)[RX_KPT], PrepFn prep,
             cr[h + i] = (ck[i] << 16) | rk[i];
     }
     __syncthreads();
+    RX_PT(2); // keys + ranks
     const uint32_t total = rx_scan256(s_cnt, s_base, F, s_wave);
     if (tid <= F)
         dir_row[tid] = (uint16_t)s_base[tid];
@@ -163,11 +219,13 @@ __device__ __forceinline__ void rx_sort_emit(uint64_t (&q)[RX_KPT], PrepFn prep,
         if ((cr[i] >> 16) != (uint32_t)F)
             sbuf[s_base[cr[i] >> 16] + (cr[i] & 0xFFFFu)] = q[i];
     __syncthreads();
+    RX_PT(3); // scan + placement
     const uint4 *s4 = reinterpret_cast<const uint4 *>(sbuf);
     uint4 *o4 = reinterpret_cast<uint4 *>(out);
     for (uint32_t i = tid; i < (total + 1) / 2; i += RX_NT)
         o4[i] = s4[i];
     __syncthreads();
+    RX_PT(4); // copy-out
 }
 
 __device__ __forceinline__ void rx_stat_add(const IndexView &iv, int which, uint32_t v)
@@ -211,17 +269,31 @@ __device__ __forceinline__ uint32_t rx_scan_threads(uint32_t v, uint32_t *s_wave
 // thread's run (len k-mers from element offset `src`; dst = where its first k-mer goes, if the caller needs that)
 // owns the sub-run indices [pre, pre + ceil(len / RX_LPR)) (pre from rx_scan_threads) and writes those that fall
 // into the window [win, win + RX_SUBCAP).
+template <int LPR = RX_LPR>
 __device__ __forceinline__ void rx_list_subruns(uint32_t pre, uint32_t len, uint64_t src, uint32_t dst, uint32_t win,
                                                 uint64_t *sub_src, uint32_t *sub_meta)
 {
-    const uint32_t nsub = (len + RX_LPR - 1) / RX_LPR;
+    const uint32_t nsub = (len + LPR - 1) / LPR;
     uint32_t j0 = pre > win ? pre : win;
     const uint32_t j1 = pre + nsub < win + (uint32_t)RX_SUBCAP ? pre + nsub : win + (uint32_t)RX_SUBCAP;
     for (uint32_t j = j0; j < j1; ++j) {
-        const uint32_t first = (j - pre) * RX_LPR;
-        const uint32_t n = len - first < (uint32_t)RX_LPR ? len - first : (uint32_t)RX_LPR;
+        const uint32_t first = (j - pre) * LPR;
+        const uint32_t n = len - first < (uint32_t)LPR ? len - first : (uint32_t)LPR;
         sub_src[j - win] = src + first;
         sub_meta[j - win] = ((dst + first) << 6) | n; // n <= 32 in 6 bits, dst < 2^26
+    }
+}
+
+// The copiers read the list in batches of STEP sub-runs without checking for its end: entries [n, n rounded up to
+// STEP) are cleared (0 k-mers from offset 0) before the barrier that publishes the list.  STEP divides RX_SUBCAP.
+template <int STEP>
+__device__ __forceinline__ void rx_pad_list(uint32_t n, uint64_t *sub_src, uint32_t *sub_meta)
+{
+    static_assert(RX_SUBCAP % STEP == 0, "a padded list must fit the window");
+    const uint32_t n_pad = (n + STEP - 1) / STEP * STEP;
+    for (uint32_t i = n + threadIdx.x; i < n_pad; i += RX_NT) {
+        sub_src[i] = 0ull;
+        sub_meta[i] = 0u;
     }
 }
 
@@ -268,6 +340,13 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p1(ReadsView rv, const uint64_t
     const int F1 = (int)rx.F1;
     uint32_t lookups = 0;
     const int sh = rx.w + rx.f2;
+    RX_PT_DECL;
+#ifndef RX_P1_NO_PREFETCH
+    constexpr bool PREFETCH = R == 1 && MODE != MODE_KMERS;
+#else
+    constexpr bool PREFETCH = false;
+#endif
+    TileRaw pw[R];
     for (uint32_t sb = blockIdx.x; sb < n_src; sb += gridDim.x) {
         uint64_t q[RX_KPT];
         uint32_t valid = 0;
@@ -282,10 +361,13 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p1(ReadsView rv, const uint64_t
                 }
             }
         } else {
-            TileRaw pw[R]; // the block's staged bytes: all tiles' loads are in flight together
+            // the block's staged bytes: all tiles' loads are in flight together; flat reads (one tile per half):
+            // the NEXT block's bytes are requested before this block is sorted, so their latency hides behind it
+            if (!PREFETCH || sb == blockIdx.x) {
 #pragma unroll
-            for (int r = 0; r < R; ++r)
-                tile_load_vec<S, TM>(rv, tc, tile_begin + ((int64_t)sb * 2 + half) * R + r, ltid, pw[r]);
+                for (int r = 0; r < R; ++r)
+                    tile_load_vec<S, TM>(rv, tc, tile_begin + ((int64_t)sb * 2 + half) * R + r, ltid, pw[r]);
+            }
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 uint64_t qq[S];
@@ -296,8 +378,14 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p1(ReadsView rv, const uint64_t
                     q[r * S + j] = qq[j];
                 valid |= v << (r * S);
             }
+            if (PREFETCH && sb + gridDim.x < n_src) {
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+                    tile_load_vec<S, TM>(rv, tc, tile_begin + ((int64_t)(sb + gridDim.x) * 2 + half) * R + r, ltid, pw[r]);
+            }
         }
         lookups += (uint32_t)__popc(valid) * X;
+        RX_PT(0); // front end: loads + k-mer windows
         // the only division by the modulo of the whole path (mapper.pyx:54) happens here
         if (RC) {
             uint64_t x[RX_KPT];
@@ -307,14 +395,14 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p1(ReadsView rv, const uint64_t
                 return ((valid >> i) & 1u) ? c : (uint32_t)F1;
             };
             rx_sort_emit<4>(x, fwd, F1, sbuf, s_cnt, s_base, s_wave, rx.buf1 + (size_t)sb * 2 * RX_B,
-                         rx.start1 + (size_t)sb * 2 * (size_t)(F1 + 1));
+                         rx.start1 + (size_t)sb * 2 * (size_t)(F1 + 1) RX_PT_ARG);
             auto rev = [&](int i) {
                 uint32_t c;
                 x[i] = rx_pack(iv, sh, revcomp(q[i], k), &c);
                 return ((valid >> i) & 1u) ? c : (uint32_t)F1;
             };
             rx_sort_emit<4>(x, rev, F1, sbuf, s_cnt, s_base, s_wave, rx.buf1 + ((size_t)sb * 2 + 1) * RX_B,
-                         rx.start1 + ((size_t)sb * 2 + 1) * (size_t)(F1 + 1));
+                         rx.start1 + ((size_t)sb * 2 + 1) * (size_t)(F1 + 1) RX_PT_ARG);
         } else {
             auto fwd = [&](int i) {
                 uint32_t c;
@@ -322,9 +410,12 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p1(ReadsView rv, const uint64_t
                 return ((valid >> i) & 1u) ? c : (uint32_t)F1;
             };
             rx_sort_emit<4>(q, fwd, F1, sbuf, s_cnt, s_base, s_wave, rx.buf1 + (size_t)sb * RX_B,
-                         rx.start1 + (size_t)sb * (size_t)(F1 + 1));
+                         rx.start1 + (size_t)sb * (size_t)(F1 + 1) RX_PT_ARG);
         }
     }
+#ifdef RX_PT_P1
+    RX_PT_END(iv, 10);
+#endif
     rx_stat_add(iv, 0, lookups);
 }
 
@@ -526,6 +617,7 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p2(IndexView iv, RxView rx)
     // of ~cs adjacent coarse partitions together, whose runs are neighbours inside every pass-1 block
     const uint32_t cs = (rx.F1 + 7u) / 8u, limit = rx.ctrl[2] * cs;
     const uint32_t home = rx_xcc_id();
+    RX_PT_DECL;
     for (uint32_t turn = 0; turn < 8u; ++turn) {
     const uint32_t sub = (home + turn) & 7u;
     uint32_t nxt = limit;
@@ -539,6 +631,7 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p2(IndexView iv, RxView rx)
         __syncthreads();
         if (idx >= limit)
             break;
+        RX_PT(0); // waiting for the work item
         if (tid == 0)
             nxt = rx_pop(rx.queue, sub, limit); // needed at the next turn of the loop: the round trip hides behind the item
         const uint32_t cj = idx / cs, cc = sub * cs + idx % cs;
@@ -568,20 +661,25 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p2(IndexView iv, RxView rx)
             uint32_t n_sub;
             const uint32_t pre = rx_scan_threads((len + RX_LPR - 1) / RX_LPR, s_wave8, &n_sub);
             const bool more = __syncthreads_or(tid == RX_NT - 1 && live && ve < hi);
+            RX_PT(1); // item + run descriptors, scan
             for (uint32_t win = 0; win < n_sub; win += RX_SUBCAP) {
                 rx_list_subruns(pre, len, src, from - lo, win, sub_src, sub_meta);
-                __syncthreads();
                 const uint32_t nw = n_sub - win < (uint32_t)RX_SUBCAP ? n_sub - win : (uint32_t)RX_SUBCAP;
+                rx_pad_list<RX_NG * RX_U2>(nw, sub_src, sub_meta);
+                __syncthreads();
                 for (uint32_t j0 = grp; j0 < nw; j0 += RX_NG * RX_U2) {
-                    uint64_t x[RX_U2];
+                    uint64_t x[RX_U2], so[RX_U2];
                     uint32_t meta[RX_U2];
 #pragma unroll
                     for (int u = 0; u < RX_U2; ++u) {
-                        const uint32_t j = j0 + u * RX_NG;
-                        meta[u] = j < nw ? sub_meta[j] : 0u;
-                        const uint64_t so = j < nw ? sub_src[j] : 0ull;
-                        x[u] = (uint32_t)lg < (meta[u] & 63u) ? __builtin_nontemporal_load(rx.buf1 + so + lg) : 0ull;
+                        meta[u] = sub_meta[j0 + u * RX_NG];
+                        so[u] = sub_src[j0 + u * RX_NG];
                     }
+                    // (lanes past the sub-run's end stay masked: letting them re-read its first k-mer, as pass 3
+                    // does, measured 4 % slower here: 4.65 vs 4.47 ms)
+#pragma unroll
+                    for (int u = 0; u < RX_U2; ++u)
+                        x[u] = (uint32_t)lg < (meta[u] & 63u) ? RX_LOAD2(rx.buf1 + so[u] + lg) : 0ull;
 #pragma unroll
                     for (int u = 0; u < RX_U2; ++u)
                         if ((uint32_t)lg < (meta[u] & 63u))
@@ -605,13 +703,17 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p2(IndexView iv, RxView rx)
             }
         }
         gathered += (uint32_t)__popc(valid);
+        RX_PT(5); // sub-run list, gather into LDS and back into registers
         auto fine = [&](int i) {
             return ((valid >> i) & 1u) ? ((uint32_t)(q[i] >> rx.w) & (uint32_t)(F2 - 1)) : (uint32_t)F2;
         };
         rx_sort_emit<8>(q, fine, F2, sbuf, s_cnt, s_base, s_wave, rx.buf2 + (size_t)item * RX_B,
-                     rx.start2 + (size_t)item * (F2 + 1));
+                     rx.start2 + (size_t)item * (F2 + 1) RX_PT_ARG);
     }
     }
+#ifndef RX_PT_P1
+    RX_PT_END(iv, 10);
+#endif
     rx_stat_add(iv, 2, gathered);
 }
 
@@ -628,7 +730,7 @@ __global__ void __launch_bounds__(RX_NT, WPS) k_rx_p3(IndexView iv, RxView rx, i
     __shared__ uint32_t sub_meta[RX_SUBCAP];
     __shared__ uint32_t s_wb[RX_MAXF + 1], s_wave8[RX_NT / 64];
     __shared__ uint32_t s_idx;
-    const int tid = threadIdx.x, grp = tid / RX_LPR, lg = tid % RX_LPR;
+    const int tid = threadIdx.x, grp = tid / RX_LPR_P3, lg = tid % RX_LPR_P3;
     const uint32_t n_rows = rx.ctrl[1], F1 = rx.F1, F2 = rx.F2;
     const uint32_t W = 1u << rx.w;
     const uint64_t M = iv.modulo;
@@ -641,6 +743,7 @@ __global__ void __launch_bounds__(RX_NT, WPS) k_rx_p3(IndexView iv, RxView rx, i
     const uint32_t home = rx_xcc_id();
     uint32_t hits = 0, probed = 0;
     __syncthreads(); // s_wb is loaded
+    RX_PT_DECL;
     for (uint32_t turn = 0; turn < 8u; ++turn) {
     const uint32_t sub = (home + turn) & 7u;
     uint32_t nxt = limit;
@@ -654,6 +757,7 @@ __global__ void __launch_bounds__(RX_NT, WPS) k_rx_p3(IndexView iv, RxView rx, i
         __syncthreads();
         if (idx >= limit)
             break;
+        RX_PT(0); // waiting for the work item
         if (tid == 0)
             nxt = rx_pop(counters, sub, limit);
         const uint32_t row = idx / gs, g = sub * gs + idx % gs;
@@ -681,6 +785,7 @@ __global__ void __launch_bounds__(RX_NT, WPS) k_rx_p3(IndexView iv, RxView rx, i
         // one is consumed
         uint32_t dv[WMAX / RX_NT + 1];
         uint64_t kv[ECAP / RX_NT];
+        uint32_t fv[ECAP / RX_NT];
         uint32_t rf[RX_IC / RX_NT], rt[RX_IC / RX_NT];
 #pragma unroll
         for (int j = 0; j <= WMAX / RX_NT; ++j) {
@@ -691,6 +796,7 @@ __global__ void __launch_bounds__(RX_NT, WPS) k_rx_p3(IndexView iv, RxView rx, i
         for (int j = 0; j < ECAP / RX_NT; ++j) {
             const uint32_t i = tid + j * RX_NT;
             kv[j] = i < ne ? rx.pkeys[(size_t)e0 + i] : 0ull;
+            fv[j] = i < ne ? rx.pfreq[(size_t)e0 + i] : 0u;
         }
         const uint16_t *rfp = rx.start2T + (size_t)g * rx.max_items + it0;
         const uint16_t *rtp = rfp + rx.max_items;
@@ -711,74 +817,109 @@ __global__ void __launch_bounds__(RX_NT, WPS) k_rx_p3(IndexView iv, RxView rx, i
             const uint32_t i = tid + j * RX_NT;
             if (i < ne) {
                 skeys[i] = kv[j];
-                scnt[i] = 0;
+                scnt[i] = (int)fv[j] <= max_freq ? 0u : RX_FILTERED; // the frequency filter of mapper.pyx:64-66
             }
         }
+        RX_PT(1); // slice + run descriptors loaded, slice written to LDS
         // the entries of bucket [st, st + cn) against q: every matching entry counts (mapper.pyx:57-68; a k-mer
         // present under several nodes is several entries).  Entries beyond the LDS copy are walked in HBM.
-        auto probe_bucket = [&](uint64_t q, uint32_t st, uint32_t cn) {
-            if (st + cn > ne) {
-                for (uint32_t j = 0; j < cn; ++j) {
-                    const size_t e = (size_t)e0 + st + j;
-                    if (rx.pkeys[e] == q && (int)rx.pfreq[e] <= max_freq) {
-                        atomicAdd(&rx.ecnt[e], 1u);
-                        ++hits;
-                    }
+        auto probe_bucket_hbm = [&](uint64_t q, uint32_t st, uint32_t cn) {
+            for (uint32_t j = 0; j < cn; ++j) {
+                const size_t e = (size_t)e0 + st + j;
+                if (rx.pkeys[e] == q && (int)rx.pfreq[e] <= max_freq) {
+                    atomicAdd(&rx.ecnt[e], 1u);
+                    ++hits;
                 }
-                return;
             }
-            for (uint32_t j = 0; j < cn; ++j)
-                if (skeys[st + j] == q)
-                    atomicAdd(&scnt[st + j], 1u);
         };
         // partition g's run inside every item of the chunk, RX_NT runs per round, cut into sub-runs listed in LDS
 #pragma unroll
         for (int j = 0; j < RX_IC / RX_NT; ++j) {
             const uint32_t len = rt[j] - rf[j];
             uint32_t n_sub;
-            const uint32_t pre = rx_scan_threads((len + RX_LPR - 1) / RX_LPR, s_wave8, &n_sub);
+            const uint32_t pre = rx_scan_threads((len + RX_LPR_P3 - 1) / RX_LPR_P3, s_wave8, &n_sub);
             const uint64_t src = (uint64_t)(it0 + tid + j * RX_NT) * RX_B + rf[j];
             for (uint32_t win = 0; win < n_sub; win += RX_SUBCAP) {
-                rx_list_subruns(pre, len, src, 0u, win, sub_src, sub_meta);
-                __syncthreads(); // (first window: also orders the slice's LDS writes before the probes)
+                rx_list_subruns<RX_LPR_P3>(pre, len, src, 0u, win, sub_src, sub_meta);
                 const uint32_t nw = n_sub - win < (uint32_t)RX_SUBCAP ? n_sub - win : (uint32_t)RX_SUBCAP;
-                for (uint32_t j0 = grp; j0 < nw; j0 += RX_NG * RX_U) {
-                    uint64_t x[RX_U];
+                rx_pad_list<RX_NG3 * RX_U>(nw, sub_src, sub_meta);
+                __syncthreads(); // (first window: also orders the slice's LDS writes before the probes)
+                RX_PT(2); // scan + sub-run list
+                for (uint32_t j0 = grp; j0 < nw; j0 += RX_NG3 * RX_U) {
+                    // list entries first, then the loads, nothing conditional in between: the RX_U loads of a lane
+                    // leave back to back (a lane past its sub-run's end re-reads the sub-run's first k-mer)
+                    uint64_t x[RX_U], so[RX_U];
                     uint32_t n[RX_U];
 #pragma unroll
                     for (int u = 0; u < RX_U; ++u) {
-                        const uint32_t jj = j0 + u * RX_NG;
-                        n[u] = jj < nw ? (sub_meta[jj] & 63u) : 0u;
-                        const uint64_t so = jj < nw ? sub_src[jj] : 0ull;
-                        x[u] = (uint32_t)lg < n[u] ? __builtin_nontemporal_load(rx.buf2 + so + lg) : 0ull;
+                        n[u] = sub_meta[j0 + u * RX_NG3] & 63u;
+                        so[u] = sub_src[j0 + u * RX_NG3];
                     }
-                    // probe (mapper.pyx:53-69 on the LDS slice).  (Probing the RX_U k-mers side by side — all bucket
-                    // bounds, then all first keys — measured 9 % slower than one after the other: 4.65 vs 4.28 ms.)
 #pragma unroll
                     for (int u = 0; u < RX_U; ++u) {
-                        if ((uint32_t)lg < n[u]) {
-                            ++probed;
-                            const uint32_t hb = (uint32_t)x[u] & (W - 1u); // packed form: bucket = low w bits
-                            const uint32_t st = sdir[hb], cn = sdir[hb + 1] - st;
-                            if (cn)
-                                probe_bucket(x[u], st, cn);
+#ifdef RX_ABL3_NOLOAD
+                        x[u] = (so[u] + lg) * 0x9E3779B97F4A7C15ull;
+#else
+#ifdef RX_P3_MASKED
+                        x[u] = (uint32_t)lg < n[u] ? RX_LOAD3(rx.buf2 + so[u] + lg) : 0ull;
+#else
+                        x[u] = RX_LOAD3(rx.buf2 + so[u] + ((uint32_t)lg < n[u] ? (uint32_t)lg : 0u));
+#endif
+#endif
+                    }
+                    // probe (mapper.pyx:53-69 on the LDS slice), RX_G3 k-mers side by side so that their LDS round
+                    // trips overlap: all bucket bounds; then entry j of every bucket, j = 0, 1, ... (a lane whose
+                    // bucket has no entry j reads key 0 and ignores it) — nothing conditional between the reads
+#pragma unroll
+                    for (int g0 = 0; g0 < RX_U; g0 += RX_G3) {
+                        uint32_t st[RX_G3], cn[RX_G3];
+#pragma unroll
+                        for (int i = 0; i < RX_G3; ++i) {
+                            const uint32_t hb = (uint32_t)x[g0 + i] & (W - 1u); // packed form: bucket = low w bits
+                            st[i] = sdir[hb];
+                            cn[i] = sdir[hb + 1];
+                        }
+                        uint32_t mx = 0;
+#pragma unroll
+                        for (int i = 0; i < RX_G3; ++i) {
+                            const bool act = (uint32_t)lg < n[g0 + i];
+                            probed += act ? 1u : 0u;
+                            cn[i] = act ? cn[i] - st[i] : 0u;
+                            if (cn[i] && st[i] + cn[i] > ne) { // (rare) entries beyond the LDS copy
+                                probe_bucket_hbm(x[g0 + i], st[i], cn[i]);
+                                cn[i] = 0;
+                            }
+                            mx = cn[i] > mx ? cn[i] : mx;
+                        }
+                        for (uint32_t j = 0; j < mx; ++j) {
+                            uint64_t key[RX_G3];
+#pragma unroll
+                            for (int i = 0; i < RX_G3; ++i)
+                                key[i] = skeys[j < cn[i] ? st[i] + j : 0u];
+#pragma unroll
+                            for (int i = 0; i < RX_G3; ++i)
+                                if (j < cn[i] && key[i] == x[g0 + i])
+                                    atomicAdd(&scnt[st[i] + j], 1u);
                         }
                     }
                 }
                 __syncthreads();
+                RX_PT(3); // streaming + probing
             }
         }
         __syncthreads();
-        // LDS counters -> per-entry count vector; the frequency filter of mapper.pyx:64-66 is applied here
+        // LDS counters -> per-entry count vector (entries the frequency filter excludes carry RX_FILTERED)
         for (uint32_t i = tid; i < ne; i += RX_NT) {
             const uint32_t cn = scnt[i];
-            if (cn && (int)rx.pfreq[(size_t)e0 + i] <= max_freq) {
+            if (cn - 1u < RX_FILTERED - 1u) {
                 atomicAdd(&rx.ecnt[(size_t)e0 + i], cn);
                 hits += cn;
             }
         }
+        RX_PT(4); // LDS counters -> ecnt
     }
     }
+    RX_PT_END(iv, 4);
     rx_stat_add(iv, 1, hits);
     rx_stat_add(iv, 3, probed); // conservation check ("radix_p3_kmers")
 }
