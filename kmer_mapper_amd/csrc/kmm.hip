@@ -501,8 +501,8 @@ int launch_rx(kmm_index *ix, const ReadsView &rv, const uint64_t *kmers_in, int6
             hipLaunchKernelGGL((k_rx_p3<RX_WMAX_BIG, RX_ECAP_BIG, 2>), dim3(ix->n_cu), dim3(RX_NT), 0, ix->stream, iv, rx,
                                max_freq);
         else
-            hipLaunchKernelGGL((k_rx_p3<RX_WMAX, RX_ECAP, 4>), dim3(ix->n_cu * ix->rx_grid_per_cu), dim3(RX_NT), 0, ix->stream, iv, rx,
-                               max_freq);
+            hipLaunchKernelGGL((k_rx_p3<RX_WMAX, RX_ECAP, 4>), dim3(ix->n_cu * ix->rx_grid_per_cu), dim3(RX_NT), 0,
+                               ix->stream, iv, rx, max_freq);
         HIPCHK(hipGetLastError());
         KMMCHK(tm.end());
         ix->ecnt_dirty = true;

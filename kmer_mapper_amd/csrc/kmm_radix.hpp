@@ -48,12 +48,16 @@ constexpr int RX_KPT = RX_B / RX_NT;  // 16 k-mers per thread
 constexpr int RX_MAXF = 256;          // largest fan-out of one pass
 constexpr int RX_CH = 512;            // blocks per chunk of the directory scan
 constexpr int RX_IC = 1024;           // pass-2 items per pass-3 work item
-constexpr int RX_LPR = 32;            // lanes that copy one run
+#ifndef RX_LPR2V
+#define RX_LPR2V 16
+#endif
+constexpr int RX_LPR = RX_LPR2V;      // lanes of a run copier (pass 2)
 constexpr int RX_NG = RX_NT / RX_LPR; // run copiers per workgroup
 constexpr int RX_SUBCAP = 1024;       // sub-runs (<= RX_LPR k-mers each) listed in LDS per window
 #ifndef RX_LPR3
 #define RX_LPR3 16
 #endif
+constexpr bool RX_P3_LINECUT = false;
 constexpr int RX_LPR_P3 = RX_LPR3;    // ... pass 3 (its runs are shorter: ~32 k-mers)
 constexpr int RX_NG3 = RX_NT / RX_LPR_P3;
 #ifndef RX_U3
@@ -65,7 +69,7 @@ constexpr int RX_U = RX_U3;           // sub-runs in flight per copier (pass 3)
 #endif
 constexpr int RX_G3 = RX_P3_GROUP;    // k-mers probed side by side (pass 3)
 #ifndef RX_U2V
-#define RX_U2V 16
+#define RX_U2V 8
 #endif
 constexpr int RX_U2 = RX_U2V;         // ... pass 2
 // The runs passes 2 and 3 copy are read with PLAIN loads: neighbouring runs share their first and last 128-byte
@@ -155,6 +159,7 @@ __device__ __forceinline__ uint32_t rx_scan256(const uint32_t *s_in, uint32_t *s
 #ifdef RX_PHASE_TIMERS
 #define RX_PT_DECL unsigned long long pt_acc[7] = {0, 0, 0, 0, 0, 0, (unsigned long long)clock64()}
 #define RX_PT_ARG , pt_acc
+#define RX_PT_ARG2 , pt_acc
 #define RX_PT(slot)                                                                                                   \
     do {                                                                                                              \
         if (threadIdx.x == 0) {                                                                                       \
@@ -173,6 +178,7 @@ __device__ __forceinline__ uint32_t rx_scan256(const uint32_t *s_in, uint32_t *s
 #else
 #define RX_PT_DECL
 #define RX_PT_ARG
+#define RX_PT_ARG2 , nullptr
 #define RX_PT(slot)
 #define RX_PT_END(iv, base)
 #endif
@@ -181,11 +187,16 @@ __device__ __forceinline__ uint32_t rx_scan256(const uint32_t *s_in, uint32_t *s
 // rewrite q[i]) and returns its key < F, or F for a slot that holds no k-mer.  Then: the sorted run array goes to
 // `out` as one contiguous coalesced copy, where each key's run starts (and the total) to dir_row[0..F].  sbuf may
 // hold the inputs: they are in registers before anything is written.
-template <int RB, typename PrepFn>
+struct RxNoHook {
+    __device__ __forceinline__ void operator()() const {}
+};
+
+// `mid` runs between the ranking and the scan (pass 2 issues the next item's descriptor loads there).
+template <int RB, typename PrepFn, typename MidFn = RxNoHook>
 __device__ __forceinline__ void rx_sort_emit(uint64_t (&q)[RX_KPT], PrepFn prep, int F, uint64_t *sbuf,
                                              uint32_t *s_cnt, uint32_t *s_base, uint32_t *s_wave,
                                              uint64_t *__restrict__ out, uint16_t *__restrict__ dir_row,
-                                             unsigned long long *pt_acc = nullptr)
+                                             unsigned long long *pt_acc = nullptr, MidFn mid = MidFn())
 {
     const int tid = threadIdx.x;
     (void)pt_acc;
@@ -193,7 +204,7 @@ __device__ __forceinline__ void rx_sort_emit(uint64_t (&q)[RX_KPT], PrepFn prep,
         s_cnt[tid] = 0;
     __syncthreads();
     // rank inside the key's run: one returning LDS atomic per k-mer, RB in flight before the first result is
-    // consumed (slots without a k-mer count into the spare counter F); RB at a time also bounds the registers
+    // consumed; RB at a time also bounds the registers
     // the key computation (pass 1: a 64-bit division by the modulo) holds at once
     uint32_t cr[RX_KPT]; // key << 16 | rank
 #pragma unroll
@@ -202,22 +213,37 @@ __device__ __forceinline__ void rx_sort_emit(uint64_t (&q)[RX_KPT], PrepFn prep,
 #pragma unroll
         for (int i = 0; i < RB; ++i)
             ck[i] = prep(h + i);
+        // (a slot without a k-mer counts into a spare counter of its own lane: with one shared spare counter the
+        // ~20 % of windows that cross a read boundary serialise every atomic instruction on one LDS address)
 #pragma unroll
         for (int i = 0; i < RB; ++i)
-            rk[i] = atomicAdd(&s_cnt[ck[i]], 1u);
+            rk[i] = atomicAdd(&s_cnt[ck[i] == (uint32_t)F ? (uint32_t)RX_MAXF + 1u + (tid & 63) : ck[i]], 1u);
 #pragma unroll
         for (int i = 0; i < RB; ++i)
-            cr[h + i] = (ck[i] << 16) | rk[i];
+            cr[h + i] = (ck[i] << 16) | (rk[i] & 0xFFFFu); // (a spare counter is never cleared: its rank means nothing)
     }
     __syncthreads();
     RX_PT(2); // keys + ranks
+    mid();
     const uint32_t total = rx_scan256(s_cnt, s_base, F, s_wave);
     if (tid <= F)
         dir_row[tid] = (uint16_t)s_base[tid];
+    // (one slot after the other: reading all 16 run starts first and then writing — 16 overlapping LDS round trips —
+    // measured SLOWER, pass 1 4.41 vs 3.62 ms, pass 2 4.75 vs 4.30 ms)
+#ifndef RX_PLACE_BATCH
+#define RX_PLACE_BATCH 1
+#endif
 #pragma unroll
-    for (int i = 0; i < RX_KPT; ++i)
-        if ((cr[i] >> 16) != (uint32_t)F)
-            sbuf[s_base[cr[i] >> 16] + (cr[i] & 0xFFFFu)] = q[i];
+    for (int h = 0; h < RX_KPT; h += RX_PLACE_BATCH) {
+        uint32_t pos[RX_PLACE_BATCH];
+#pragma unroll
+        for (int i = 0; i < RX_PLACE_BATCH; ++i)
+            pos[i] = s_base[cr[h + i] >> 16] + (cr[h + i] & 0xFFFFu);
+#pragma unroll
+        for (int i = 0; i < RX_PLACE_BATCH; ++i)
+            if ((cr[h + i] >> 16) != (uint32_t)F)
+                sbuf[pos[i]] = q[h + i];
+    }
     __syncthreads();
     RX_PT(3); // scan + placement
     const uint4 *s4 = reinterpret_cast<const uint4 *>(sbuf);
@@ -264,23 +290,39 @@ __device__ __forceinline__ uint32_t rx_scan_threads(uint32_t v, uint32_t *s_wave
     return base + inc - v;
 }
 
-// Runs of k-mers that lie contiguous in HBM are copied by RX_LPR-lane copiers, one load per lane.  So that no
-// load waits for another, every run is first cut into sub-runs of at most RX_LPR k-mers, listed in LDS: this
-// thread's run (len k-mers from element offset `src`; dst = where its first k-mer goes, if the caller needs that)
-// owns the sub-run indices [pre, pre + ceil(len / RX_LPR)) (pre from rx_scan_threads) and writes those that fall
-// into the window [win, win + RX_SUBCAP).
-template <int LPR = RX_LPR>
+// Runs of k-mers that lie contiguous in HBM are copied by LPR-lane copiers, one 8-byte load per lane.  So that no
+// load waits for another, every run is first cut into pieces listed in LDS, and the cuts are made at LPR-element
+// boundaries of the BUFFER (LPR = 16: 128-byte lines), not of the run: every load instruction of a copier then
+// touches one line (tools/chunk_read_bench.hip: 4.2 vs 3.85 TB/s useful on 256-byte runs, 4.6 vs 3.8 on 344-byte
+// runs).  A piece = aligned start `sub_src`, first lane a, n lanes: lane l of the copier holds element sub_src + l
+// of the buffer, for a <= l < a + n; sub_meta = dst << 12 | a << 6 | n (dst = where the piece's first k-mer goes,
+// if the caller needs that; < 2^20).  This thread's run (len k-mers from element offset src) owns the piece
+// indices [pre, pre + rx_n_pieces(len, src)) (pre from rx_scan_threads) and writes those that fall into the window
+// [win, win + RX_SUBCAP).
+// LINECUT = false cuts every LPR k-mers from the run's start instead (fewer, fuller pieces): pass 3, whose probes
+// cost as much as its loads, is faster that way (3.19 vs 3.56 ms), pass 2 with the line cuts (4.16 vs 4.28 ms).
+template <int LPR, bool LINECUT>
+__device__ __forceinline__ uint32_t rx_n_pieces(uint32_t len, uint64_t src)
+{
+    const uint32_t off = LINECUT ? (uint32_t)src & (uint32_t)(LPR - 1) : 0u;
+    return len ? (off + len + LPR - 1) / LPR : 0u;
+}
+
+template <int LPR, bool LINECUT>
 __device__ __forceinline__ void rx_list_subruns(uint32_t pre, uint32_t len, uint64_t src, uint32_t dst, uint32_t win,
                                                 uint64_t *sub_src, uint32_t *sub_meta)
 {
-    const uint32_t nsub = (len + LPR - 1) / LPR;
-    uint32_t j0 = pre > win ? pre : win;
+    const uint32_t off = LINECUT ? (uint32_t)src & (uint32_t)(LPR - 1) : 0u;
+    const uint32_t nsub = rx_n_pieces<LPR, LINECUT>(len, src);
+    const uint32_t j0 = pre > win ? pre : win;
     const uint32_t j1 = pre + nsub < win + (uint32_t)RX_SUBCAP ? pre + nsub : win + (uint32_t)RX_SUBCAP;
     for (uint32_t j = j0; j < j1; ++j) {
-        const uint32_t first = (j - pre) * LPR;
-        const uint32_t n = len - first < (uint32_t)LPR ? len - first : (uint32_t)LPR;
-        sub_src[j - win] = src + first;
-        sub_meta[j - win] = ((dst + first) << 6) | n; // n <= 32 in 6 bits, dst < 2^26
+        const uint32_t p = j - pre;
+        const uint32_t a = p ? 0u : off;
+        const uint32_t done = p ? p * LPR - off : 0u; // k-mers of the run before this piece
+        const uint32_t n = len - done < (uint32_t)LPR - a ? len - done : (uint32_t)LPR - a;
+        sub_src[j - win] = src - off + (uint64_t)p * LPR;
+        sub_meta[j - win] = ((dst + done) << 12) | (a << 6) | n;
     }
 }
 
@@ -328,7 +370,7 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p1(ReadsView rv, const uint64_t
     constexpr int R = RX_KPT / S;                  // tiles per half-workgroup per block
     __shared__ TileSmem<S> sm[2];
     __shared__ uint64_t sbuf[RX_B];
-    __shared__ uint32_t s_cnt[RX_MAXF + 1], s_base[RX_MAXF + 1], s_wave[4];
+    __shared__ uint32_t s_cnt[RX_MAXF + 1 + 64], s_base[RX_MAXF + 1], s_wave[4];
     const int tid = threadIdx.x, half = tid >> 8, ltid = tid & 255;
     TileConst tc;
     tc.kmask = 0; tc.bmask = 0; tc.aligned = false;
@@ -607,7 +649,7 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p2(IndexView iv, RxView rx)
     __shared__ uint64_t sbuf[RX_B];
     __shared__ uint64_t sub_src[RX_SUBCAP];
     __shared__ uint32_t sub_meta[RX_SUBCAP], s_wave8[RX_NT / 64];
-    __shared__ uint32_t s_cnt[RX_MAXF + 1], s_base[RX_MAXF + 1], s_wave[4];
+    __shared__ uint32_t s_cnt[RX_MAXF + 1 + 64], s_base[RX_MAXF + 1], s_wave[4];
     __shared__ uint32_t s_idx;
     const int tid = threadIdx.x, grp = tid / RX_LPR, lg = tid % RX_LPR;
     const uint32_t NB = rx.NB;
@@ -617,98 +659,159 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p2(IndexView iv, RxView rx)
     // of ~cs adjacent coarse partitions together, whose runs are neighbours inside every pass-1 block
     const uint32_t cs = (rx.F1 + 7u) / 8u, limit = rx.ctrl[2] * cs;
     const uint32_t home = rx_xcc_id();
+    // An item's description (uniform) and this thread's run descriptor of its first round.  Both are loaded while
+    // the PREVIOUS item is being sorted: the two dependent round trips (item table, then run descriptors) would
+    // otherwise stand at the head of every item (measured: 27 % of the pass).
+    struct Item {
+        uint32_t valid, c, item, b0, lo, hi;
+    };
+    struct RunDesc {
+        uint32_t vs, ve, st;
+    };
+    auto describe = [&](uint32_t sub, uint32_t idx) {
+        Item d;
+        d.valid = 0; d.c = 0; d.item = 0; d.b0 = 0; d.lo = 0; d.hi = 0;
+        if (idx >= limit)
+            return d;
+        const uint32_t cj = idx / cs, cc = sub * cs + idx % cs;
+        if (cc >= rx.F1)
+            return d; // F1 is no multiple of 8
+        const uint32_t ib = rx.item_base[cc];
+        if (cj >= rx.item_base[cc + 1] - ib)
+            return d; // partition sizes differ
+        d.valid = 1;
+        d.c = cc;
+        d.item = ib + cj;
+        d.b0 = rx.item_desc[d.item].x;
+        d.lo = cj * RX_B;
+        const uint32_t Tc = rx.T1[cc];
+        d.hi = Tc - d.lo < (uint32_t)RX_B ? Tc : d.lo + RX_B;
+        return d;
+    };
+    auto run_desc = [&](const Item &d, uint32_t bb) {
+        RunDesc r;
+        r.vs = 0xFFFFFFFFu; r.ve = 0xFFFFFFFFu; r.st = 0;
+        const uint32_t b = bb + tid;
+        if (d.valid && b < NB) {
+            const uint32_t *P = rx.P1T + (size_t)d.c * (NB + 1);
+            r.vs = P[b];
+            r.ve = P[b + 1];
+            r.st = rx.S1T[(size_t)d.c * NB + b];
+        }
+        return r;
+    };
     RX_PT_DECL;
     for (uint32_t turn = 0; turn < 8u; ++turn) {
     const uint32_t sub = (home + turn) & 7u;
     uint32_t nxt = limit;
     if (tid == 0)
         nxt = rx_pop(rx.queue, sub, limit);
+    if (tid == 0)
+        s_idx = nxt;
+    __syncthreads();
+    uint32_t idx = s_idx;
+    __syncthreads();
+    if (idx >= limit)
+        continue;
+    if (tid == 0)
+        nxt = rx_pop(rx.queue, sub, limit); // the next index is popped while this one is being worked on
+    Item it = describe(sub, idx);
+    RunDesc rd = run_desc(it, it.b0);
     for (;;) {
+        RX_PT(0); // waiting for the work item
+        const uint32_t lo = it.lo, hi = it.hi, n = hi - lo;
+        if (it.valid) {
+            // gather, in rounds of RX_NT runs: (A) one thread per run has its descriptor (contiguous in b), the
+            // runs are cut into sub-runs of <= RX_LPR k-mers listed in LDS; (B) copier g copies sub-runs g,
+            // g + RX_NG, ... with RX_U2 loads in flight per lane, none depending on another
+            for (uint32_t bb = it.b0;; bb += RX_NT) {
+                if (bb != it.b0)
+                    rd = run_desc(it, bb); // (an item of more than RX_NT runs: tiny runs only)
+                const uint32_t b = bb + tid;
+                const uint32_t vs = rd.vs < hi ? rd.vs : hi;
+                const bool live = vs < hi;
+                const uint32_t ve = live ? rd.ve : vs;
+                const uint32_t st = live ? rd.st : 0u;
+                const uint32_t from = vs > lo ? vs : lo, to = ve < hi ? ve : hi;
+                const uint32_t len = live && to > from ? to - from : 0u;
+                const uint64_t src = (uint64_t)b * RX_B + st + (from - vs); // element offset of the run's first wanted k-mer
+                uint32_t n_sub;
+                const uint32_t pre = rx_scan_threads(rx_n_pieces<RX_LPR, true>(len, src), s_wave8, &n_sub);
+                const bool more = __syncthreads_or(tid == RX_NT - 1 && live && ve < hi);
+                RX_PT(1); // run descriptors, scan
+                for (uint32_t win = 0; win < n_sub; win += RX_SUBCAP) {
+                    rx_list_subruns<RX_LPR, true>(pre, len, src, from - lo, win, sub_src, sub_meta);
+                    const uint32_t nw = n_sub - win < (uint32_t)RX_SUBCAP ? n_sub - win : (uint32_t)RX_SUBCAP;
+                    rx_pad_list<RX_NG * RX_U2>(nw, sub_src, sub_meta);
+                    __syncthreads();
+                    for (uint32_t j0 = grp; j0 < nw; j0 += RX_NG * RX_U2) {
+                        uint64_t x[RX_U2], so[RX_U2];
+                        uint32_t meta[RX_U2];
+#pragma unroll
+                        for (int u = 0; u < RX_U2; ++u) {
+                            meta[u] = sub_meta[j0 + u * RX_NG];
+                            so[u] = sub_src[j0 + u * RX_NG];
+                        }
+                        // (lanes past the sub-run's end stay masked: letting them re-read its first k-mer, as pass
+                        // 3 does, measured 4 % slower here: 4.65 vs 4.47 ms)
+#pragma unroll
+                        for (int u = 0; u < RX_U2; ++u) {
+                            const uint32_t rel = (uint32_t)lg - ((meta[u] >> 6) & 63u);
+                            x[u] = rel < (meta[u] & 63u) ? RX_LOAD2(rx.buf1 + so[u] + lg) : 0ull;
+                        }
+#pragma unroll
+                        for (int u = 0; u < RX_U2; ++u) {
+                            const uint32_t rel = (uint32_t)lg - ((meta[u] >> 6) & 63u);
+                            if (rel < (meta[u] & 63u))
+                                sbuf[(meta[u] >> 12) + rel] = x[u];
+                        }
+                    }
+                    __syncthreads(); // the list is rewritten by the next window / round
+                }
+                if (!more)
+                    break; // the round's last run ends the item (or lies beyond it)
+            }
+        }
+        // the next item: index now (popped during the gather), description while the k-mers are ranked, run
+        // descriptors while they are placed and copied out
         if (tid == 0)
             s_idx = nxt;
-        __syncthreads();
-        const uint32_t idx = s_idx;
-        __syncthreads();
-        if (idx >= limit)
-            break;
-        RX_PT(0); // waiting for the work item
-        if (tid == 0)
-            nxt = rx_pop(rx.queue, sub, limit); // needed at the next turn of the loop: the round trip hides behind the item
-        const uint32_t cj = idx / cs, cc = sub * cs + idx % cs;
-        if (cc >= rx.F1 || cj >= rx.item_base[cc + 1] - rx.item_base[cc])
-            continue; // (uniform) no such item: partition sizes differ, or F1 is no multiple of 8
-        const uint32_t item = rx.item_base[cc] + cj;
-        const uint2 d = rx.item_desc[item];
-        const uint32_t b0 = d.x, c = d.y;
-        const uint32_t lo = (item - rx.item_base[c]) * RX_B;
-        const uint32_t Tc = rx.T1[c];
-        const uint32_t hi = Tc - lo < (uint32_t)RX_B ? Tc : lo + RX_B;
-        const uint32_t n = hi - lo;
-        const uint32_t *P = rx.P1T + (size_t)c * (NB + 1);
-        const uint16_t *S = rx.S1T + (size_t)c * NB;
-        // gather, in rounds of RX_NT runs: (A) one thread per run reads its descriptor (contiguous in b), the
-        // runs are cut into sub-runs of <= RX_LPR k-mers listed in LDS; (B) copier g copies sub-runs g,
-        // g + RX_NG, ... with RX_U2 loads in flight per lane, none depending on another
-        for (uint32_t bb = b0;; bb += RX_NT) {
-            const uint32_t b = bb + tid;
-            const uint32_t vs = b < NB ? P[b] : hi;
-            const bool live = vs < hi;
-            const uint32_t ve = live ? P[b + 1] : vs;
-            const uint32_t st = live ? S[b] : 0u;
-            const uint32_t from = vs > lo ? vs : lo, to = ve < hi ? ve : hi;
-            const uint32_t len = live && to > from ? to - from : 0u;
-            const uint64_t src = (uint64_t)b * RX_B + st + (from - vs); // element offset of the run's first wanted k-mer
-            uint32_t n_sub;
-            const uint32_t pre = rx_scan_threads((len + RX_LPR - 1) / RX_LPR, s_wave8, &n_sub);
-            const bool more = __syncthreads_or(tid == RX_NT - 1 && live && ve < hi);
-            RX_PT(1); // item + run descriptors, scan
-            for (uint32_t win = 0; win < n_sub; win += RX_SUBCAP) {
-                rx_list_subruns(pre, len, src, from - lo, win, sub_src, sub_meta);
-                const uint32_t nw = n_sub - win < (uint32_t)RX_SUBCAP ? n_sub - win : (uint32_t)RX_SUBCAP;
-                rx_pad_list<RX_NG * RX_U2>(nw, sub_src, sub_meta);
-                __syncthreads();
-                for (uint32_t j0 = grp; j0 < nw; j0 += RX_NG * RX_U2) {
-                    uint64_t x[RX_U2], so[RX_U2];
-                    uint32_t meta[RX_U2];
+        __syncthreads(); // also: the gather's LDS writes are complete
+        const uint32_t idx_n = s_idx;
+        if (tid == 0 && idx_n < limit)
+            nxt = rx_pop(rx.queue, sub, limit);
+        const Item it_n = describe(sub, idx_n);
+        RunDesc rd_n;
+        rd_n.vs = 0xFFFFFFFFu; rd_n.ve = 0xFFFFFFFFu; rd_n.st = 0;
+        if (it.valid) {
+            uint64_t q[RX_KPT];
+            uint32_t valid = 0;
 #pragma unroll
-                    for (int u = 0; u < RX_U2; ++u) {
-                        meta[u] = sub_meta[j0 + u * RX_NG];
-                        so[u] = sub_src[j0 + u * RX_NG];
-                    }
-                    // (lanes past the sub-run's end stay masked: letting them re-read its first k-mer, as pass 3
-                    // does, measured 4 % slower here: 4.65 vs 4.47 ms)
-#pragma unroll
-                    for (int u = 0; u < RX_U2; ++u)
-                        x[u] = (uint32_t)lg < (meta[u] & 63u) ? RX_LOAD2(rx.buf1 + so[u] + lg) : 0ull;
-#pragma unroll
-                    for (int u = 0; u < RX_U2; ++u)
-                        if ((uint32_t)lg < (meta[u] & 63u))
-                            sbuf[(meta[u] >> 6) + lg] = x[u];
+            for (int i = 0; i < RX_KPT; ++i) {
+                const uint32_t e = i * RX_NT + tid;
+                q[i] = 0;
+                if (e < n) {
+                    q[i] = sbuf[e];
+                    valid |= 1u << i;
                 }
-                __syncthreads(); // the list is rewritten by the next window / round
             }
-            if (!more)
-                break; // the round's last run ends the item (or lies beyond it)
+            gathered += (uint32_t)__popc(valid);
+            RX_PT(5); // sub-run list, gather into LDS and back into registers
+            auto fine = [&](int i) {
+                return ((valid >> i) & 1u) ? ((uint32_t)(q[i] >> rx.w) & (uint32_t)(F2 - 1)) : (uint32_t)F2;
+            };
+            auto mid = [&]() { rd_n = run_desc(it_n, it_n.b0); };
+            rx_sort_emit<8>(q, fine, F2, sbuf, s_cnt, s_base, s_wave, rx.buf2 + (size_t)it.item * RX_B,
+                            rx.start2 + (size_t)it.item * (F2 + 1) RX_PT_ARG2, mid);
+        } else {
+            rd_n = run_desc(it_n, it_n.b0);
+            __syncthreads(); // s_idx is read by everyone before it is written again
         }
-        __syncthreads();
-        uint64_t q[RX_KPT];
-        uint32_t valid = 0;
-#pragma unroll
-        for (int i = 0; i < RX_KPT; ++i) {
-            const uint32_t idx = i * RX_NT + tid;
-            q[i] = 0;
-            if (idx < n) {
-                q[i] = sbuf[idx];
-                valid |= 1u << i;
-            }
-        }
-        gathered += (uint32_t)__popc(valid);
-        RX_PT(5); // sub-run list, gather into LDS and back into registers
-        auto fine = [&](int i) {
-            return ((valid >> i) & 1u) ? ((uint32_t)(q[i] >> rx.w) & (uint32_t)(F2 - 1)) : (uint32_t)F2;
-        };
-        rx_sort_emit<8>(q, fine, F2, sbuf, s_cnt, s_base, s_wave, rx.buf2 + (size_t)item * RX_B,
-                     rx.start2 + (size_t)item * (F2 + 1) RX_PT_ARG);
+        if (idx_n >= limit)
+            break;
+        idx = idx_n;
+        it = it_n;
+        rd = rd_n;
     }
     }
 #ifndef RX_PT_P1
@@ -743,23 +846,17 @@ __global__ void __launch_bounds__(RX_NT, WPS) k_rx_p3(IndexView iv, RxView rx, i
     const uint32_t home = rx_xcc_id();
     uint32_t hits = 0, probed = 0;
     __syncthreads(); // s_wb is loaded
-    RX_PT_DECL;
-    for (uint32_t turn = 0; turn < 8u; ++turn) {
-    const uint32_t sub = (home + turn) & 7u;
-    uint32_t nxt = limit;
-    if (tid == 0)
-        nxt = rx_pop(counters, sub, limit);
-    for (;;) {
-        if (tid == 0)
-            s_idx = nxt;
-        __syncthreads(); // also: the previous work item's flush is done
-        const uint32_t idx = s_idx;
-        __syncthreads();
+    // A work item's description (uniform): its fine partition's place in the index and its items.  It is worked
+    // out — two dependent loads — while the PREVIOUS work item streams its k-mers.
+    struct Slice {
+        uint32_t valid, g, e0, ne, it0, n_it;
+        uint64_t h0;
+    };
+    auto describe = [&](uint32_t sub, uint32_t idx) {
+        Slice d;
+        d.valid = 0; d.g = 0; d.e0 = 0; d.ne = 0; d.it0 = 0; d.n_it = 0; d.h0 = 0;
         if (idx >= limit)
-            break;
-        RX_PT(0); // waiting for the work item
-        if (tid == 0)
-            nxt = rx_pop(counters, sub, limit);
+            return d;
         const uint32_t row = idx / gs, g = sub * gs + idx % gs;
         uint32_t c_lo = 0, c_hi = F1; // largest c with s_wb[c] <= row
         while (c_hi - c_lo > 1) {
@@ -771,22 +868,50 @@ __global__ void __launch_bounds__(RX_NT, WPS) k_rx_p3(IndexView iv, RxView rx, i
         }
         const uint32_t c = c_lo;
         const uint32_t f2c = rx.PF - c * F2 < F2 ? rx.PF - c * F2 : F2;
-        const uint32_t chunk = row - s_wb[c];
         if (g >= f2c)
-            continue; // (uniform) the last coarse partition holds fewer fine partitions, or F2 < 8
-        const uint32_t f = c * F2 + g;
-        const uint64_t h0 = (uint64_t)f << rx.w;
-        const uint32_t e0 = rx.pstart[h0], e1 = rx.pstart[h0 + W < M ? h0 + W : M];
-        const uint32_t ne = e1 - e0 < (uint32_t)ECAP ? e1 - e0 : (uint32_t)ECAP;
-        const uint32_t it0 = rx.item_base[c] + chunk * RX_IC;
+            return d; // the last coarse partition holds fewer fine partitions, or F2 < 8
+        const uint32_t chunk = row - s_wb[c];
+        d.valid = 1;
+        d.g = g;
+        d.h0 = (uint64_t)(c * F2 + g) << rx.w;
+        d.e0 = rx.pstart[d.h0];
+        const uint32_t e1 = rx.pstart[d.h0 + W < M ? d.h0 + W : M];
+        d.ne = e1 - d.e0 < (uint32_t)ECAP ? e1 - d.e0 : (uint32_t)ECAP;
+        d.it0 = rx.item_base[c] + chunk * RX_IC;
         const uint32_t it_end = rx.item_base[c + 1];
-        const uint32_t n_it = it_end - it0 < (uint32_t)RX_IC ? it_end - it0 : (uint32_t)RX_IC;
+        d.n_it = it_end - d.it0 < (uint32_t)RX_IC ? it_end - d.it0 : (uint32_t)RX_IC;
+        return d;
+    };
+    RX_PT_DECL;
+    for (uint32_t turn = 0; turn < 8u; ++turn) {
+    const uint32_t sub = (home + turn) & 7u;
+    uint32_t nxt = limit;
+    if (tid == 0)
+        nxt = rx_pop(counters, sub, limit);
+    if (tid == 0)
+        s_idx = nxt;
+    __syncthreads();
+    const uint32_t idx_first = s_idx;
+    __syncthreads();
+    if (idx_first >= limit)
+        continue;
+    if (tid == 0)
+        nxt = rx_pop(counters, sub, limit); // the next index is popped while this one is being worked on
+    Slice sl = describe(sub, idx_first);
+    for (;;) {
+        RX_PT(0);
+        const uint32_t g = sl.g, e0 = sl.e0, ne = sl.ne, it0 = sl.it0, n_it = sl.n_it;
+        const uint64_t h0 = sl.h0;
+        uint32_t rf[RX_IC / RX_NT], rt[RX_IC / RX_NT];
+#pragma unroll
+        for (int j = 0; j < RX_IC / RX_NT; ++j)
+            rf[j] = rt[j] = 0;
+        if (sl.valid) {
         // the slice (directory + keys) and this thread's run descriptors: every load is issued before the first
         // one is consumed
         uint32_t dv[WMAX / RX_NT + 1];
         uint64_t kv[ECAP / RX_NT];
         uint32_t fv[ECAP / RX_NT];
-        uint32_t rf[RX_IC / RX_NT], rt[RX_IC / RX_NT];
 #pragma unroll
         for (int j = 0; j <= WMAX / RX_NT; ++j) {
             const uint32_t i = tid + j * RX_NT;
@@ -820,7 +945,16 @@ __global__ void __launch_bounds__(RX_NT, WPS) k_rx_p3(IndexView iv, RxView rx, i
                 scnt[i] = (int)fv[j] <= max_freq ? 0u : RX_FILTERED; // the frequency filter of mapper.pyx:64-66
             }
         }
+        }
         RX_PT(1); // slice + run descriptors loaded, slice written to LDS
+        // the next work item: its index (popped at the start of this one) now, its description during the stream
+        if (tid == 0)
+            s_idx = nxt;
+        __syncthreads(); // also orders the slice's LDS writes before the probes
+        const uint32_t idx_n = s_idx;
+        if (tid == 0 && idx_n < limit)
+            nxt = rx_pop(counters, sub, limit);
+        const Slice sl_n = describe(sub, idx_n);
         // the entries of bucket [st, st + cn) against q: every matching entry counts (mapper.pyx:57-68; a k-mer
         // present under several nodes is several entries).  Entries beyond the LDS copy are walked in HBM.
         auto probe_bucket_hbm = [&](uint64_t q, uint32_t st, uint32_t cn) {
@@ -833,40 +967,34 @@ __global__ void __launch_bounds__(RX_NT, WPS) k_rx_p3(IndexView iv, RxView rx, i
             }
         };
         // partition g's run inside every item of the chunk, RX_NT runs per round, cut into sub-runs listed in LDS
+        if (sl.valid) {
 #pragma unroll
         for (int j = 0; j < RX_IC / RX_NT; ++j) {
             const uint32_t len = rt[j] - rf[j];
             uint32_t n_sub;
-            const uint32_t pre = rx_scan_threads((len + RX_LPR_P3 - 1) / RX_LPR_P3, s_wave8, &n_sub);
             const uint64_t src = (uint64_t)(it0 + tid + j * RX_NT) * RX_B + rf[j];
+            const uint32_t pre = rx_scan_threads(rx_n_pieces<RX_LPR_P3, RX_P3_LINECUT>(len, src), s_wave8, &n_sub);
             for (uint32_t win = 0; win < n_sub; win += RX_SUBCAP) {
-                rx_list_subruns<RX_LPR_P3>(pre, len, src, 0u, win, sub_src, sub_meta);
+                rx_list_subruns<RX_LPR_P3, RX_P3_LINECUT>(pre, len, src, 0u, win, sub_src, sub_meta);
                 const uint32_t nw = n_sub - win < (uint32_t)RX_SUBCAP ? n_sub - win : (uint32_t)RX_SUBCAP;
                 rx_pad_list<RX_NG3 * RX_U>(nw, sub_src, sub_meta);
                 __syncthreads(); // (first window: also orders the slice's LDS writes before the probes)
                 RX_PT(2); // scan + sub-run list
                 for (uint32_t j0 = grp; j0 < nw; j0 += RX_NG3 * RX_U) {
                     // list entries first, then the loads, nothing conditional in between: the RX_U loads of a lane
-                    // leave back to back (a lane past its sub-run's end re-reads the sub-run's first k-mer)
+                    // leave back to back (a lane outside its piece re-reads the piece's first k-mer)
                     uint64_t x[RX_U], so[RX_U];
-                    uint32_t n[RX_U];
+                    uint32_t rel[RX_U], n[RX_U]; // lane's position inside the piece, k-mers of the piece
 #pragma unroll
                     for (int u = 0; u < RX_U; ++u) {
-                        n[u] = sub_meta[j0 + u * RX_NG3] & 63u;
+                        const uint32_t m = sub_meta[j0 + u * RX_NG3];
+                        n[u] = m & 63u;
+                        rel[u] = (uint32_t)lg - ((m >> 6) & 63u);
                         so[u] = sub_src[j0 + u * RX_NG3];
                     }
 #pragma unroll
-                    for (int u = 0; u < RX_U; ++u) {
-#ifdef RX_ABL3_NOLOAD
-                        x[u] = (so[u] + lg) * 0x9E3779B97F4A7C15ull;
-#else
-#ifdef RX_P3_MASKED
-                        x[u] = (uint32_t)lg < n[u] ? RX_LOAD3(rx.buf2 + so[u] + lg) : 0ull;
-#else
-                        x[u] = RX_LOAD3(rx.buf2 + so[u] + ((uint32_t)lg < n[u] ? (uint32_t)lg : 0u));
-#endif
-#endif
-                    }
+                    for (int u = 0; u < RX_U; ++u)
+                        x[u] = RX_LOAD3(rx.buf2 + so[u] + (rel[u] < n[u] ? (uint32_t)lg : (uint32_t)lg - rel[u]));
                     // probe (mapper.pyx:53-69 on the LDS slice), RX_G3 k-mers side by side so that their LDS round
                     // trips overlap: all bucket bounds; then entry j of every bucket, j = 0, 1, ... (a lane whose
                     // bucket has no entry j reads key 0 and ignores it) — nothing conditional between the reads
@@ -882,7 +1010,7 @@ __global__ void __launch_bounds__(RX_NT, WPS) k_rx_p3(IndexView iv, RxView rx, i
                         uint32_t mx = 0;
 #pragma unroll
                         for (int i = 0; i < RX_G3; ++i) {
-                            const bool act = (uint32_t)lg < n[g0 + i];
+                            const bool act = rel[g0 + i] < n[g0 + i];
                             probed += act ? 1u : 0u;
                             cn[i] = act ? cn[i] - st[i] : 0u;
                             if (cn[i] && st[i] + cn[i] > ne) { // (rare) entries beyond the LDS copy
@@ -916,7 +1044,12 @@ __global__ void __launch_bounds__(RX_NT, WPS) k_rx_p3(IndexView iv, RxView rx, i
                 hits += cn;
             }
         }
+        }
         RX_PT(4); // LDS counters -> ecnt
+        __syncthreads(); // the flush has read the counters; s_idx has been read by everyone
+        if (idx_n >= limit)
+            break;
+        sl = sl_n;
     }
     }
     RX_PT_END(iv, 4);

@@ -191,3 +191,4 @@ def test_radix_records_mode_and_long_reads(kmm, syn, oracle):
             used, n_rec = dev.map_records(raw, fmt=_lib.FORMAT_FASTQ)
             assert used == raw.shape[0] and n_rec == n_reads
             assert np.array_equal(dev.get_node_counts(), expect)
+

@@ -47,6 +47,49 @@ __global__ void __launch_bounds__(512) k_chunks(const uint64_t *__restrict__ buf
         *sink = acc;
 }
 
+// 16-lane copiers, runs cut at 128-byte line boundaries: every load instruction of a copier touches ONE line
+template <int LPR, int U>
+__global__ void __launch_bounds__(512) k_chunks_linecut(const uint64_t *__restrict__ buf, uint64_t n_words, int words,
+                                                        int runs, uint64_t *sink)
+{
+    const int lg = threadIdx.x % LPR;
+    const uint64_t copier = ((uint64_t)blockIdx.x * 512 + threadIdx.x) / LPR;
+    uint64_t acc = 0;
+    const int steps = (words + LPR - 2) / LPR + 1; // most pieces a run can be cut into
+    for (int r = 0; r < runs; r += U) {
+        for (int piece = 0; piece < steps; ++piece) {
+            uint64_t v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint64_t rr = mix(copier * 1315423911ull + (uint64_t)r + u);
+                const uint64_t start = __umul64hi(rr, n_words - words - 16);
+                const uint64_t w = (start / LPR + piece) * LPR + lg;
+                v[u] = (w >= start && w < start + words) ? buf[w] : 0ull;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                acc += v[u];
+        }
+    }
+    if (acc == 0x1234567887654321ull)
+        *sink = acc;
+}
+
+template <int LPR, int U>
+double run_linecut(const uint64_t *buf, size_t bytes, int words, int runs_per_copier)
+{
+    uint64_t *sink; CK(hipMalloc(&sink, 8));
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    const int grid = 256 * 8;
+    hipLaunchKernelGGL((k_chunks_linecut<LPR, U>), dim3(grid), dim3(512), 0, 0, buf, bytes / 8, words, U, sink);
+    CK(hipEventRecord(a));
+    hipLaunchKernelGGL((k_chunks_linecut<LPR, U>), dim3(grid), dim3(512), 0, 0, buf, bytes / 8, words, runs_per_copier, sink);
+    CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+    float ms; CK(hipEventElapsedTime(&ms, a, b));
+    CK(hipFree(sink));
+    return (double)grid * 512 / LPR * runs_per_copier * words * 8.0 / (ms * 1e-3) / 1e12;
+}
+
 template <int LPR, int U, bool ALIGNED>
 double run(const uint64_t *buf, size_t bytes, int words, int runs_per_copier)
 {
@@ -88,6 +131,13 @@ int main()
     for (int c : {128, 256, 344, 512, 1024}) {
         const double x = run<16, 16, false>(buf, bytes, c / 8, 256);
         printf("%8d %8d %10.2f\n", c, 16, x);
+        fflush(stdout);
+    }
+    printf("# runs cut at copier-width boundaries (16 lanes: one 128-byte line per load instruction; 32 lanes: two), 8 runs in flight\n");
+    printf("%8s %10s %10s\n", "bytes", "16_lanes", "32_lanes");
+    for (int c : {128, 256, 344, 512, 1024}) {
+        const double x = run_linecut<16, 8>(buf, bytes, c / 8, 256), y = run_linecut<32, 8>(buf, bytes, c / 8, 256);
+        printf("%8d %10.2f %10.2f\n", c, x, y);
         fflush(stdout);
     }
     return 0;
