@@ -174,6 +174,7 @@ struct kmm_index {
     bool rx_ok = false;   // the index fits the radix path's fan-out (<= 256 x 256 fine partitions)
     int rx_w = 12, rx_f2 = 0; // log2 buckets per fine partition, log2 fine partitions per coarse one
     uint32_t rx_PF = 1, rx_F1 = 1, rx_F2 = 1;
+    uint32_t rx_max_slice = 0; // most entries in one fine partition's slice (for the current part_shift)
     int rx_grid_per_cu = 2;   // persistent workgroups of passes 2 and 3 per CU (1: leave room for another stream's kernels)
     int64_t rx_min_units = 0; // auto: batches of at least this many positions / k-mers take the radix path
     uint64_t rx_S = 0;        // entries in bucket order
@@ -497,11 +498,15 @@ int launch_rx(kmm_index *ix, const ReadsView &rv, const uint64_t *kmers_in, int6
         HIPCHK(hipGetLastError());
         KMMCHK(tm.end());
         KMMCHK(tm.begin(ix, KMM_KERNEL_RX_P3));
-        if (ix->rx_w > 12)
-            hipLaunchKernelGGL((k_rx_p3<RX_WMAX_BIG, RX_ECAP_BIG, 2>), dim3(ix->n_cu), dim3(RX_NT), 0, ix->stream, iv, rx,
-                               max_freq);
+        if (ix->rx_w > 12 && ix->rx_max_slice <= (uint32_t)RX_ECAP)
+            // 8192-bucket slices whose entries all fit 4096 keys: 16-bit directory, two workgroups per CU
+            hipLaunchKernelGGL((k_rx_p3<RX_WMAX_BIG, RX_ECAP, 4, uint16_t>), dim3(ix->n_cu * ix->rx_grid_per_cu), dim3(RX_NT),
+                               0, ix->stream, iv, rx, max_freq);
+        else if (ix->rx_w > 12)
+            hipLaunchKernelGGL((k_rx_p3<RX_WMAX_BIG, RX_ECAP_BIG, 2, uint32_t>), dim3(ix->n_cu), dim3(RX_NT), 0, ix->stream,
+                               iv, rx, max_freq);
         else
-            hipLaunchKernelGGL((k_rx_p3<RX_WMAX, RX_ECAP, 4>), dim3(ix->n_cu * ix->rx_grid_per_cu), dim3(RX_NT), 0,
+            hipLaunchKernelGGL((k_rx_p3<RX_WMAX, RX_ECAP, 4, uint32_t>), dim3(ix->n_cu * ix->rx_grid_per_cu), dim3(RX_NT), 0,
                                ix->stream, iv, rx, max_freq);
         HIPCHK(hipGetLastError());
         KMMCHK(tm.end());
@@ -687,7 +692,15 @@ static int rx_repack_keys(kmm_index *ix)
         hipLaunchKernelGGL(k_rx_pack_keys, dim3(grid_for(ix, (int64_t)((ix->rx_S + 255) / 256), 16)), dim3(256), 0,
                            ix->stream, ix->rx_pkeys_raw, ix->rx_S, view_of(ix), ix->rx_w + ix->rx_f2, ix->rx_pkeys);
     HIPCHK(hipGetLastError());
+    // most entries of one slice: decides whether pass 3 may keep a 16-bit directory (ix->queue serves as the cell)
+    HIPCHK(hipMemsetAsync(ix->queue, 0, sizeof(unsigned long long), ix->stream));
+    hipLaunchKernelGGL(k_rx_max_slice, dim3(grid_for(ix, (int64_t)((ix->rx_PF + 255) / 256), 16)), dim3(256), 0, ix->stream,
+                       ix->rx_pstart, ix->modulo, ix->rx_w, ix->rx_PF, ix->queue);
+    HIPCHK(hipGetLastError());
+    unsigned long long mx = 0;
+    HIPCHK(hipMemcpyAsync(&mx, ix->queue, sizeof mx, hipMemcpyDeviceToHost, ix->stream));
     HIPCHK(hipStreamSynchronize(ix->stream));
+    ix->rx_max_slice = (uint32_t)mx;
     return KMM_OK;
 }
 

@@ -823,10 +823,12 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p2(IndexView iv, RxView rx)
 // ------------------------------------------------------------------------------------------------
 // pass 3
 // ------------------------------------------------------------------------------------------------
-template <int WMAX, int ECAP, int WPS>
+// DirT: type of the LDS directory; uint16_t (half the LDS: 8192-bucket slices with two workgroups per CU) only when
+// no slice of the index holds more than 65535 entries (launch_rx checks).
+template <int WMAX, int ECAP, int WPS, typename DirT>
 __global__ void __launch_bounds__(RX_NT, WPS) k_rx_p3(IndexView iv, RxView rx, int max_freq)
 {
-    __shared__ uint32_t sdir[WMAX + 1]; // bucket b of the slice holds entries [sdir[b], sdir[b + 1]) - e0
+    __shared__ DirT sdir[WMAX + 1]; // bucket b of the slice holds entries [sdir[b], sdir[b + 1]) - e0
     __shared__ uint64_t skeys[ECAP];
     __shared__ uint32_t scnt[ECAP];
     __shared__ uint64_t sub_src[RX_SUBCAP];
@@ -935,7 +937,7 @@ __global__ void __launch_bounds__(RX_NT, WPS) k_rx_p3(IndexView iv, RxView rx, i
         for (int j = 0; j <= WMAX / RX_NT; ++j) {
             const uint32_t i = tid + j * RX_NT;
             if (i <= W)
-                sdir[i] = dv[j] - e0;
+                sdir[i] = (DirT)(dv[j] - e0);
         }
 #pragma unroll
         for (int j = 0; j < ECAP / RX_NT; ++j) {
@@ -1067,17 +1069,57 @@ __global__ void __launch_bounds__(256) k_rx_flush(IndexView iv, uint32_t *__rest
     __shared__ NodeAgg agg;
     agg_init(agg);
     __syncthreads();
-    for (uint64_t e = (uint64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (uint64_t)gridDim.x * 256) {
+    auto one = [&](uint64_t e, uint32_t cn, uint32_t node) {
+        if (cn) {
+            if (ecnt_acc)
+                ecnt_acc[e] += cn; // per-k-mer counting mode: what GpuCounter's table holds (gpu_counter.py:29-34)
+            agg_add_n(iv, agg, node, cn);
+        }
+    };
+    // four entries per lane and step: counts and nodes are requested together (one round trip per step; the nodes of
+    // entries without hits are read for nothing, 4 bytes each), the counts are cleared with whole 16-byte stores
+    const uint64_t n4 = n / 4, gid = (uint64_t)blockIdx.x * 256 + threadIdx.x, stride = (uint64_t)gridDim.x * 256;
+    uint4 *c4 = reinterpret_cast<uint4 *>(ecnt);
+    const uint4 *n4p = reinterpret_cast<const uint4 *>(pnodes);
+    for (uint64_t i = gid; i < n4; i += stride) {
+        const uint4 c = c4[i];
+        const uint4 nd = n4p[i];
+        if (c.x | c.y | c.z | c.w) {
+            c4[i] = make_uint4(0u, 0u, 0u, 0u);
+            one(4 * i, c.x, nd.x);
+            one(4 * i + 1, c.y, nd.y);
+            one(4 * i + 2, c.z, nd.z);
+            one(4 * i + 3, c.w, nd.w);
+        }
+    }
+    for (uint64_t e = n4 * 4 + gid; e < n; e += stride) {
         const uint32_t cn = ecnt[e];
         if (cn) {
             ecnt[e] = 0;
-            if (ecnt_acc)
-                ecnt_acc[e] += cn; // per-k-mer counting mode: what GpuCounter's table holds (gpu_counter.py:29-34)
-            agg_add_n(iv, agg, pnodes[e], cn);
+            one(e, cn, pnodes[e]);
         }
     }
     __syncthreads();
     agg_flush_counts(iv, agg);
+}
+
+// most entries in one slice of 2^w buckets
+__global__ void __launch_bounds__(256) k_rx_max_slice(const uint32_t *__restrict__ pstart, uint64_t modulo, int w,
+                                                      uint32_t PF, unsigned long long *out)
+{
+    uint32_t m = 0;
+    for (uint64_t f = (uint64_t)blockIdx.x * 256 + threadIdx.x; f < PF; f += (uint64_t)gridDim.x * 256) {
+        const uint64_t h0 = f << w, h1 = h0 + (1ull << w) < modulo ? h0 + (1ull << w) : modulo;
+        const uint32_t c = pstart[h1] - pstart[h0];
+        m = c > m ? c : m;
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        const uint32_t o = __shfl_xor(m, d);
+        m = o > m ? o : m;
+    }
+    if ((threadIdx.x & 63) == 0 && m)
+        atomicMax(out, (unsigned long long)m);
 }
 
 // raw entry k-mers (bucket order) -> packed form for the current (w, f2)

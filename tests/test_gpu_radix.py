@@ -94,7 +94,7 @@ def test_slice_with_more_entries_than_lds_capacity(kmm, oracle):
     """One bucket with 6000 entries (same k-mer under 6000 nodes) and a fine partition whose entries exceed
     the 4096 keys a slice keeps in LDS: those buckets are walked in HBM, results unchanged."""
     rng = np.random.default_rng(331)
-    modulo = 8191
+    modulo = 16381
     base = rng.integers(0, 1 << 62, size=3000, dtype=np.uint64)
     heavy = np.uint64(123456789012345)
     dense = (np.uint64(modulo) * np.arange(1, 3001, dtype=np.uint64) + np.uint64(77))   # 3000 k-mers, one bucket
@@ -115,7 +115,29 @@ def test_slice_with_more_entries_than_lds_capacity(kmm, oracle):
             dev.set_param("part_shift", 3)
             dev.map_kmers(q, mf)
             assert np.array_equal(dev.get_node_counts(), expect), mf
+            # one slice of 8192 buckets holds all 12 000 entries: the 8192-key variant of pass 3 (32-bit directory,
+            # one workgroup per CU), the rest of the heavy bucket still walked in HBM
+            dev.reset()
+            dev.set_param("part_shift", 13)
+            dev.map_kmers(q, mf)
+            assert np.array_equal(dev.get_node_counts(), expect), mf
     assert oracle.map_kmers(index, mx, q, 65535).sum() >= 7 * 6000
+
+
+@pytest.mark.parametrize("n_entries", [3000, 30000])
+def test_slices_of_8192_buckets(kmm, syn, oracle, n_entries):
+    """part_shift 13: a sparse table (every slice's entries fit 4096 keys: 16-bit LDS directory, two workgroups of
+    pass 3 per CU) and a dense one (8192-key slices, 32-bit directory)."""
+    index, genome = syn.make_index(n_entries, seed=341, modulo=40009)
+    mx = index.max_node_id()
+    bases, offs = syn.make_ragged_reads(genome, 20000, 0, 260, seed=342)
+    expect, n = oracle.map_reads(index, mx, bases, offs, 31, also_revcomp=True, n_threads=4)
+    with kmm.DeviceIndex.from_index(index, mx) as dev:
+        dev.set_param("part_shift", 13)
+        dev.set_param("path", 2)
+        dev.map_reads(bases, offs, 31, also_revcomp=True)
+        assert np.array_equal(dev.get_node_counts(), expect)
+        assert dev.get_param("radix_p3_kmers") == 2 * n
 
 
 def test_per_kmer_counting_mode(kmm, syn, oracle):
