@@ -127,7 +127,7 @@ void default_lut(uint8_t lut[256])
 }
 
 struct Stage {
-    DevBuf bases, offsets, tile_first, kmers, lut;
+    DevBuf bases, offsets, tile_first, start_bits, kmers, lut;
     hipEvent_t done = nullptr; // the last kernel that read this stage has finished
     bool used = false;
 };
@@ -638,6 +638,7 @@ void kmm_index_destroy(kmm_index_t *ix)
         release(s.bases);
         release(s.offsets);
         release(s.tile_first);
+        release(s.start_bits);
         release(s.kmers);
         release(s.lut);
         if (s.done)
@@ -1296,11 +1297,14 @@ static int map_reads_common(kmm_index_t *ix, const uint8_t *bases, const int64_t
             KMMCHK(stage_in<int64_t>(ix, s.offsets, read_offsets, (size_t)(n_reads + 1), &rv.offsets,
                                      &staged));
         }
-        KMMCHK(ensure(s.tile_first, (size_t)n_tiles * 8));
-        rv.tile_first = (const int64_t *)s.tile_first.p;
+        const int64_t n_words = total / 32 + 2;
+        KMMCHK(ensure(s.start_bits, (size_t)n_words * 4));
+        rv.start_bits = (const uint32_t *)s.start_bits.p;
+        rv.n_start_words = n_words;
         KMMCHK(stage_copies_done(ix));
-        hipLaunchKernelGGL(k_tile_first, dim3((unsigned)((n_tiles + 255) / 256)), dim3(256), 0,
-                           ix->stream, rv.offsets, n_reads, n_tiles, TILE_T, (int64_t *)s.tile_first.p);
+        HIPCHK(hipMemsetAsync(s.start_bits.p, 0, (size_t)n_words * 4, ix->stream));
+        hipLaunchKernelGGL(k_mark_starts, dim3(grid_for(ix, (n_reads + 256) / 256, 8)), dim3(256), 0, ix->stream,
+                           rv.offsets, n_reads, total, (uint32_t *)s.start_bits.p);
         if (!uniform)
             hipLaunchKernelGGL(k_check_offsets, dim3(grid_for(ix, (n_reads + 255) / 256, 8)), dim3(256), 0,
                                ix->stream, rv.offsets, n_reads, ix->first_bad);
@@ -1527,16 +1531,18 @@ int kmm_extract_kmers(int device, const uint8_t *bases, const int64_t *read_offs
         const int max_super = (int)((max_tiles + 1023) / 1024);
         if ((rc = ensure(d_lut, 256))) break;
         if ((rc = ensure(d_bad, 16))) break;
-        if ((rc = ensure(d_tf, (size_t)n_tiles * 8))) break;
+        if ((rc = ensure(d_tf, (size_t)(total / 32 + 2) * 4))) break; // read-start bitset
         if ((rc = ensure(d_cnt, (size_t)max_super * 1024 * 4))) break;
         if ((rc = ensure(d_sup, (size_t)max_super * 4 + 16))) break;
         if ((e = copy(d_lut.p, lutbuf, 256, hipMemcpyHostToDevice))) break;
         if ((e = copy(d_bad.p, bad, 16, hipMemcpyHostToDevice))) break;
         rv.lut = (const uint8_t *)d_lut.p;
         rv.first_bad = (unsigned long long *)d_bad.p;
-        rv.tile_first = (const int64_t *)d_tf.p;
-        hipLaunchKernelGGL(k_tile_first, dim3((unsigned)((n_tiles + 255) / 256)), dim3(256), 0, st, rv.offsets,
-                           n_reads, n_tiles, TILE_T, (int64_t *)d_tf.p);
+        rv.start_bits = (const uint32_t *)d_tf.p;
+        rv.n_start_words = total / 32 + 2;
+        if ((e = hipMemsetAsync(d_tf.p, 0, (size_t)rv.n_start_words * 4, st))) break;
+        hipLaunchKernelGGL(k_mark_starts, dim3((unsigned)((n_reads + 256) / 256 < 65536 ? (n_reads + 256) / 256 : 65536)),
+                           dim3(256), 0, st, rv.offsets, n_reads, total, (uint32_t *)d_tf.p);
         uint32_t *tile_cnt = (uint32_t *)d_cnt.p;
         uint32_t *super_tot = (uint32_t *)d_sup.p;
         uint32_t *d_total = super_tot + max_super;

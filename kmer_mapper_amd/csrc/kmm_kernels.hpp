@@ -124,24 +124,15 @@ __global__ void __launch_bounds__(256) k_map_kmers(const uint64_t *__restrict__ 
     agg_flush(iv, agg);
 }
 
-// General path helper: for every tile, the first read index r in [0, n_reads+1] whose start lies
-// strictly after the tile's first position (upper bound over the n_reads+1 offsets).
-__global__ void k_tile_first(const int64_t *__restrict__ offs, int64_t n_reads, int64_t n_tiles,
-                             int T, int64_t *__restrict__ out)
+// General path helper: the read-start bitset of the chunk, bit p set iff some read starts at base position p
+// (offsets[r] for r = 0..n_reads; offsets[n_reads] = total marks the end).  The words are cleared by the caller.
+__global__ void k_mark_starts(const int64_t *__restrict__ offs, int64_t n_reads, int64_t total, uint32_t *__restrict__ bits)
 {
-    int64_t tile = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (tile >= n_tiles)
-        return;
-    const int64_t t0 = tile * T;
-    int64_t lo = 0, hi = n_reads + 1;
-    while (lo < hi) {
-        int64_t mid = (lo + hi) >> 1;
-        if (offs[mid] <= t0)
-            lo = mid + 1;
-        else
-            hi = mid;
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r <= n_reads; r += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t o = offs[r];
+        if (o >= 0 && o <= total) // (out-of-range offsets are reported by k_check_offsets / the host checks)
+            atomicOr(&bits[o >> 5], 1u << (o & 31));
     }
-    out[tile] = lo;
 }
 
 // read_offsets must be non-decreasing; checked here (off the host's critical path) and reported at the

@@ -37,7 +37,8 @@ struct ReadsView {
     int64_t total;             // number of base bytes
     const int64_t *offsets;    // n_reads + 1 (general path)
     int64_t n_reads;
-    const int64_t *tile_first; // per tile: first r with offsets[r] > tile start (general path)
+    const uint32_t *start_bits; // general path: bit p is set iff a read starts at base position p (k_mark_starts)
+    int64_t n_start_words;
     uint64_t read_len;         // uniform path
     uint64_t read_len_magic;   // floor(2^64 / read_len)
     const uint8_t *lut;        // 256 bytes in HBM

@@ -56,9 +56,11 @@ __device__ __forceinline__ uint32_t flags_to_bits(uint32_t f)
 // several tiles in flight (the radix path's pass 1).  Flat reads (general / uniform): thread t < T/16 owns the 16
 // bytes at t0 + 16t, and threads t < 12 also one dword of the 48-byte halo behind the tile, so the byte -> code
 // stage is spread over all lanes.  Records mode: thread t < NV owns the 16 bytes at t0 + 16t (halo vectors included).
+// Ragged reads: thread t <= NB also owns word t of the tile's slice of the read-start bitset.
 struct TileRaw {
     uint32_t w[4];
     uint32_t halo;
+    uint32_t sbits;
 };
 
 __device__ __forceinline__ uint32_t tile_load_bytes4(const ReadsView &rv, int64_t p)
@@ -83,7 +85,13 @@ __device__ __forceinline__ void tile_load_vec(const ReadsView &rv, const TileCon
     static_assert(NMAIN <= 256, "one staged 16-byte vector per thread");
     raw.w[0] = raw.w[1] = raw.w[2] = raw.w[3] = 0u;
     raw.halo = 0u;
+    raw.sbits = 0u;
     const int64_t total = rv.total;
+    if (MODE == MODE_GENERAL && tid <= TileSmem<S>::NB) { // T is a multiple of 1024: the slice starts at a word
+        const int64_t wi = tile * (T / 32) + tid;
+        if (wi < rv.n_start_words)
+            raw.sbits = rv.start_bits[wi];
+    }
     if (tid < NMAIN) {
         const int64_t p = tile * T + (int64_t)tid * 16;
         if (tc.aligned && p + 16 <= total) {
@@ -124,9 +132,8 @@ __device__ __forceinline__ uint32_t tile_kmers(const ReadsView &rv, const TileCo
     const int64_t total = rv.total;
     const int64_t t0 = tile * T;
     __syncthreads(); // LUT visible; every wave has finished reading the previous tile's LDS words
-    if (MODE == MODE_GENERAL) // cleared only now: a fast wave must not wipe bits a slow one still reads
-        for (int i = tid; i < NB + 1; i += 256)
-            sm.bits[i] = 0;
+    if (MODE == MODE_GENERAL && tid <= NB) // read starts inside [t0, t0 + 32 (NB + 1)): the bitset's own words
+        sm.bits[tid] = raw.sbits;
 
     if (RECORDS) {
         // ---- records mode, stage 1: raw file bytes.  A byte is a base iff it lies on the sequence
@@ -218,17 +225,6 @@ __device__ __forceinline__ uint32_t tile_kmers(const ReadsView &rv, const TileCo
         if (bad >= 0)
             atomicMin(rv.first_bad, (unsigned long long)(p + bad));
     }
-    // ---- stage 2: read starts inside (t0, t0 + T + k - 2] ----------------------------------
-    if (MODE == MODE_GENERAL) {
-        __syncthreads(); // bitset cleared before any bit is set
-        for (int64_t r = (t0 < total ? rv.tile_first[tile * (T / 1024)] : rv.n_reads + 1) + tid; r <= rv.n_reads; r += 256) {
-            int64_t o = rv.offsets[r] - t0;
-            if (o > (int64_t)T + k - 2)
-                break;
-            if (o >= 1)
-                atomicOr(&sm.bits[o >> 5], 1u << (o & 31));
-        }
-    }
     __syncthreads();
     } // !RECORDS
 
@@ -299,11 +295,23 @@ __device__ __forceinline__ uint32_t tile_kmers(const ReadsView &rv, const TileCo
             for (int j = 0; j < S; ++j)
                 if (((B >> j) & wmask) == 0 && p0 + j + k <= total)
                     valid |= 1u << j;
-        } else {       // no read start inside (p, p+k-1]
-#pragma unroll
-            for (int j = 0; j < S; ++j)
-                if (((B >> (j + 1)) & tc.bmask) == 0 && p0 + j + k <= total)
-                    valid |= 1u << j;
+        } else {       // no read start inside (p, p+k-1] (util.py:72: no k-mer spans reads).  A start at relative
+            // position b kills the windows j in [b - k + 1, b - 1]; a lane sees few starts (reads are longer than
+            // a few bases), so it walks the set bits instead of testing every window.
+            uint64_t X = B >> 1; // bit i: a start at relative position i + 1
+            if (S + k - 2 < 64)
+                X &= (1ull << (S + k - 2)) - 1ull; // starts beyond the last window's reach
+            uint32_t dead = 0;
+            while (X) {
+                const int b = __builtin_ctzll(X) + 1;
+                X &= X - 1ull;
+                const int lo_j = b - k + 1 > 0 ? b - k + 1 : 0, hi_j = b - 1 < S - 1 ? b - 1 : S - 1;
+                if (lo_j <= hi_j)
+                    dead |= ((2u << hi_j) - 1u) & ~((1u << lo_j) - 1u);
+            }
+            const int64_t lim = total - p0 - (k - 1); // windows that end inside the chunk
+            const uint32_t inside = lim >= S ? ((S >= 32) ? 0xFFFFFFFFu : ((1u << S) - 1u)) : (lim > 0 ? ((1u << lim) - 1u) : 0u);
+            valid = inside & ~dead;
         }
     }
 #pragma unroll
