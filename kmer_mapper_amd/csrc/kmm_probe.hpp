@@ -91,6 +91,10 @@ __device__ __forceinline__ uint64_t fastdiv_m31(uint64_t x, uint32_t m, uint64_t
     return q;
 }
 
+// (Dividing through the FP64 pipe instead — t = fma(x, 1/m, 2^52), quotient from t's mantissa, 32-bit remainder
+// correction; exact for m >= 2^14 — was measured and dropped: pass 1 5.68 ms against 3.51 ms with the integer
+// multiplies above: v_cvt_f64_u32 / v_fma_f64 are no cheaper than the quarter-rate 32-bit multiplies here.)
+
 // Reverse complement under A,C,G,T = 0,1,2,3, first base in the lowest bits: complement every
 // 2-bit group (NOT), reverse the groups, realign (the `-r` operation).
 __device__ __forceinline__ uint64_t revcomp(uint64_t x, int k)

@@ -214,3 +214,29 @@ def test_radix_records_mode_and_long_reads(kmm, syn, oracle):
             assert used == raw.shape[0] and n_rec == n_reads
             assert np.array_equal(dev.get_node_counts(), expect)
 
+
+@pytest.mark.parametrize("modulo", [16411, 40009, 200_000_033, 452_930_477, 2_147_483_629])
+def test_division_edge_values(kmm, oracle, modulo):
+    """Pass 1 divides by the modulo with a magic multiply and a 32-bit remainder (fastdiv_m31): values around every
+    kind of boundary — multiples of the modulo +-1, 2^32 and 2^52 boundaries, the top of the 64-bit range — must land
+    on the same index entries as the oracle's hardware divide (mapper.pyx:54), on both paths."""
+    rng = np.random.default_rng(351)
+    M = np.uint64(modulo)
+    n_mult = rng.integers(0, (2 ** 64 - 1) // modulo, size=3000, dtype=np.uint64)
+    edge = np.concatenate([n_mult * M, n_mult * M + np.uint64(1), n_mult * M + (M - np.uint64(1)),
+                           np.array([0, 1, modulo - 1, modulo, modulo + 1, 2 ** 32 - 1, 2 ** 32, 2 ** 32 + 1, 2 ** 52 - 1,
+                                     2 ** 52, 2 ** 53 + 1, 2 ** 62 - 1, 2 ** 63, 2 ** 64 - 1], dtype=np.uint64),
+                           rng.integers(0, 2 ** 64 - 1, size=3000, dtype=np.uint64)])
+    from kmer_mapper_amd.kmer_index import KmerIndex
+    keys = np.unique(edge[rng.integers(0, len(edge), 4000)])
+    index = KmerIndex.from_flat_kmers(keys, np.arange(len(keys), dtype=np.int64), modulo)
+    mx = len(keys) - 1
+    q = np.concatenate([edge, edge[::3] + np.uint64(1), edge[::5] - np.uint64(1)])
+    expect = oracle.map_kmers(index, mx, q)
+    assert expect.sum() >= len(keys)
+    with kmm.DeviceIndex.from_index(index, mx) as dev:
+        for path in ((2, 1) if dev.get_param("radix_available") == 1 else (1,)):
+            dev.set_param("path", path)
+            dev.reset()
+            dev.map_kmers(q)
+            assert np.array_equal(dev.get_node_counts(), expect), path
