@@ -64,6 +64,7 @@ def main():
     ap.add_argument("--skewed", action="store_true", help="node = i mod 1000 (atomic contention)")
     ap.add_argument("--path", type=int, default=0, help="0 auto (by batch size), 1 direct fused kernel, 2 radix path")
     ap.add_argument("--part-shift", type=int, default=None)
+    ap.add_argument("--bucket-order-flush", action="store_true", help="radix path: flush the per-entry counts in bucket order (scattered atomics)")
     ap.add_argument("--grid-per-cu", type=int, default=None)
     ap.add_argument("--static-schedule", action="store_true", help="disable the dynamic tile queue")
     ap.add_argument("--dyn-chunk", type=int, default=None)
@@ -133,6 +134,8 @@ def main():
         dev.set_param("grid_per_cu", args.grid_per_cu)
     if args.part_shift is not None:
         dev.set_param("part_shift", args.part_shift)
+    if args.bucket_order_flush:
+        dev.set_param("radix_sorted_flush", 0)
     counts = torch.zeros(mx + 1, dtype=torch.int32, device=dev_t)    # uint32 bits; wrap-add == int32 add
     dev.bind_counts(counts)
 

@@ -240,6 +240,8 @@ int kmm_get_kmer_counts(kmm_index_t *idx, uint32_t *out);
  *   "part_shift"       log2 of the number of hash buckets per fine partition of the radix path (0..13)
  *   "radix_min_units"  auto: smallest batch (positions / k-mers) that takes the radix path
  *   "radix_grid_per_cu" persistent workgroups per CU of passes 2 and 3 (1 or 2; 2 by default)
+ *   "radix_sorted_flush" 1 (default) = per-entry counts are added to the node counts through the node-ordered entry
+ *                      list (built when an index has fewer than 8 entries per node on average); 0 = in bucket order
  *   "count_kmers"      1 = per-k-mer counting mode (see kmm_get_kmer_counts)
  * Unknown names return KMM_ERR_INVALID_ARG.
  */

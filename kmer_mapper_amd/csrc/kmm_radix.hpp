@@ -46,7 +46,10 @@ constexpr int RX_B = 8192;            // positions per pass-1 block = k-mer capa
                                       // 16 windows per lane; records mode: four tiles of 4 windows per lane)
 constexpr int RX_KPT = RX_B / RX_NT;  // 16 k-mers per thread
 constexpr int RX_MAXF = 256;          // largest fan-out of one pass
-constexpr int RX_CH = 512;            // blocks per chunk of the directory scan
+#ifndef RX_CHV
+#define RX_CHV 512
+#endif
+constexpr int RX_CH = RX_CHV;            // blocks per chunk of the directory scan
 constexpr int RX_IC = 1024;           // pass-2 items per pass-3 work item
 #ifndef RX_LPR2V
 #define RX_LPR2V 16
@@ -1101,6 +1104,63 @@ __global__ void __launch_bounds__(256) k_rx_flush(IndexView iv, uint32_t *__rest
     }
     __syncthreads();
     agg_flush_counts(iv, agg);
+}
+
+// ------------------------------------------------------------------------------------------------
+// flush in node order.  counts[node[e]] += ecnt[e] over entries in bucket order is ~S scattered atomics (24 G/s on
+// this chip: 4 ms for 10^8 entries).  With the entries listed in NODE order once per index (norder[j] = entry,
+// nnode[j] = its node, non-decreasing) the scattered side becomes a gather of 4-byte counts (55 G requests/s) and
+// the atomics walk the count vector front to back; entries of one node are neighbours and are summed inside the
+// wavefront first (node skew costs one atomic per wavefront and node).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_rx_node_hist(const uint32_t *__restrict__ pnodes, uint64_t n, uint32_t *__restrict__ hist)
+{
+    for (uint64_t e = (uint64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (uint64_t)gridDim.x * 256)
+        atomicAdd(&hist[pnodes[e]], 1u);
+}
+
+__global__ void __launch_bounds__(256) k_rx_node_scatter(const uint32_t *__restrict__ pnodes, uint64_t n,
+                                                         uint32_t *__restrict__ cursor, uint32_t *__restrict__ norder,
+                                                         uint32_t *__restrict__ nnode)
+{
+    for (uint64_t e = (uint64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (uint64_t)gridDim.x * 256) {
+        const uint32_t nd = pnodes[e];
+        const uint32_t j = atomicAdd(&cursor[nd], 1u);
+        norder[j] = (uint32_t)e;
+        nnode[j] = nd;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_rx_flush_sorted(IndexView iv, const uint32_t *__restrict__ ecnt,
+                                                         const uint32_t *__restrict__ norder,
+                                                         const uint32_t *__restrict__ nnode, uint64_t n)
+{
+    constexpr int U = 4; // independent gathers in flight per lane
+    const int lane = threadIdx.x & 63;
+    const uint64_t n_round = (n + 255) / 256 * 256; // whole workgroups stay in the loop: shuffles need all lanes
+    for (uint64_t j0 = ((uint64_t)blockIdx.x * U) * 256 + threadIdx.x; j0 < n_round; j0 += (uint64_t)gridDim.x * U * 256) {
+        uint32_t nd[U], c[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint64_t j = j0 + (uint64_t)u * 256;
+            nd[u] = j < n ? nnode[j] : 0xFFFFFFFFu;
+            c[u] = j < n ? ecnt[norder[j]] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            // segmented inclusive sum over the wavefront's lanes (segments = equal nodes, which are contiguous)
+            uint32_t sum = c[u];
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t os = __shfl_up(sum, d), on = __shfl_up(nd[u], d);
+                if (lane >= d && on == nd[u])
+                    sum += os;
+            }
+            const uint32_t next = __shfl_down(nd[u], 1);
+            if ((lane == 63 || next != nd[u]) && sum) // last lane of its segment holds the segment's sum
+                atomicAdd(&iv.counts[nd[u]], sum);
+        }
+    }
 }
 
 // most entries in one slice of 2^w buckets
