@@ -240,3 +240,23 @@ def test_division_edge_values(kmm, oracle, modulo):
             dev.reset()
             dev.map_kmers(q)
             assert np.array_equal(dev.get_node_counts(), expect), path
+
+
+@pytest.mark.parametrize("skewed", [False, True])
+def test_flush_orders_agree(kmm, syn, oracle, skewed):
+    """Per-entry counts -> node counts (gpu_counter.py:26-37) through the node-ordered entry list (indexes with few
+    entries per node) and in bucket order with LDS aggregation (hot nodes): same vector, also when flushes of both
+    kinds alternate on one handle and counts wrap around 2^32."""
+    index, genome = syn.make_index(60000, seed=361, skewed=skewed)
+    mx = index.max_node_id()
+    bases, offs = syn.make_reads(genome, 30000, 150, seed=362)
+    expect, _ = oracle.map_reads(index, mx, bases, offs, 31, n_threads=4)
+    with kmm.DeviceIndex.from_index(index, mx) as dev:
+        dev.set_param("path", 2)
+        assert dev.get_param("radix_sorted_flush") == (0 if skewed else 1)   # 60 entries per node when skewed
+        total = np.zeros_like(expect)
+        for rep, order in enumerate((1, 0, 1, 1, 0)):
+            dev.set_param("radix_sorted_flush", order)
+            dev.map_reads_uniform(bases, 30000, 150, 31)
+            total = total + expect                                             # uint32: wraps like the device vector
+            assert np.array_equal(dev.get_node_counts(), total), (rep, order)
