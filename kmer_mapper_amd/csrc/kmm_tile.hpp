@@ -195,19 +195,24 @@ __device__ __forceinline__ uint32_t tile_kmers(const ReadsView &rv, const TileCo
     if (tid < T / 16) {
         const int v = tid;
         const int64_t p = t0 + (int64_t)v * 16;
-        uint32_t code = 0;
-        int bad = -1;
+        // (bad: bit i = byte i has no code.  Tried instead: a flag above the code bits in the LDS table and one OR per
+        // byte, the position worked out only when the flag shows up — pass 1 3.39 vs 3.35 ms, not kept.)
+        uint32_t code = 0, bad = 0;
 #pragma unroll
-        for (int i = 15; i >= 0; --i) {
-            uint32_t c = (w[i >> 2] >> (8 * (i & 3))) & 0xFFu;
-            uint32_t l = sm.lut[c];
-            if (l == 0xFFu && p + i < total)
-                bad = i;
+        for (int i = 0; i < 16; ++i) {
+            const uint32_t c = (w[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+            const uint32_t l = sm.lut[c];
+            bad |= (l == 0xFFu ? 1u : 0u) << i;
             code |= (l & 3u) << (2 * i);
         }
         sm.codes[v] = code;
-        if (bad >= 0)
-            atomicMin(rv.first_bad, (unsigned long long)(p + bad));
+        if (bad) {
+            const int64_t left = total - p; // bytes of this vector inside the chunk (those past its end are staged as 0)
+            if (left < 16)
+                bad &= left > 0 ? (1u << left) - 1u : 0u;
+            if (bad)
+                atomicMin(rv.first_bad, (unsigned long long)(p + __builtin_ctz(bad)));
+        }
     }
     if (tid < 12) { // the 48 bytes behind the tile, four per thread -> one byte of codes each
         const int64_t p = t0 + T + (int64_t)tid * 4;
