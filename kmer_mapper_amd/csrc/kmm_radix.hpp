@@ -971,16 +971,29 @@ __global__ void __launch_bounds__(RX_NT, WPS) k_rx_p3(IndexView iv, RxView rx, i
                 }
             }
         };
-        // partition g's run inside every item of the chunk, RX_NT runs per round, cut into sub-runs listed in LDS
+        // partition g's run inside every item of the chunk (RX_IC / RX_NT runs per thread, one scan for all of them),
+        // cut into sub-runs listed in LDS, RX_SUBCAP at a time
         if (sl.valid) {
+        {
+            constexpr int NR = RX_IC / RX_NT;
+            uint32_t len[NR], np[NR], np_sum = 0;
+            uint64_t src[NR];
 #pragma unroll
-        for (int j = 0; j < RX_IC / RX_NT; ++j) {
-            const uint32_t len = rt[j] - rf[j];
+            for (int j = 0; j < NR; ++j) {
+                len[j] = rt[j] - rf[j];
+                src[j] = (uint64_t)(it0 + tid + j * RX_NT) * RX_B + rf[j];
+                np[j] = rx_n_pieces<RX_LPR_P3, RX_P3_LINECUT>(len[j], src[j]);
+                np_sum += np[j];
+            }
             uint32_t n_sub;
-            const uint64_t src = (uint64_t)(it0 + tid + j * RX_NT) * RX_B + rf[j];
-            const uint32_t pre = rx_scan_threads(rx_n_pieces<RX_LPR_P3, RX_P3_LINECUT>(len, src), s_wave8, &n_sub);
+            const uint32_t pre = rx_scan_threads(np_sum, s_wave8, &n_sub);
             for (uint32_t win = 0; win < n_sub; win += RX_SUBCAP) {
-                rx_list_subruns<RX_LPR_P3, RX_P3_LINECUT>(pre, len, src, 0u, win, sub_src, sub_meta);
+                uint32_t first = pre;
+#pragma unroll
+                for (int j = 0; j < NR; ++j) {
+                    rx_list_subruns<RX_LPR_P3, RX_P3_LINECUT>(first, len[j], src[j], 0u, win, sub_src, sub_meta);
+                    first += np[j];
+                }
                 const uint32_t nw = n_sub - win < (uint32_t)RX_SUBCAP ? n_sub - win : (uint32_t)RX_SUBCAP;
                 rx_pad_list<RX_NG3 * RX_U>(nw, sub_src, sub_meta);
                 __syncthreads(); // (first window: also orders the slice's LDS writes before the probes)
