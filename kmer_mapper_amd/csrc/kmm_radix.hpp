@@ -1053,8 +1053,8 @@ __global__ void __launch_bounds__(RX_NT, WPS) k_rx_p3(IndexView iv, RxView rx, i
                 RX_PT(3); // streaming + probing
             }
         }
-        __syncthreads();
-        // LDS counters -> per-entry count vector (entries the frequency filter excludes carry RX_FILTERED)
+        // LDS counters -> per-entry count vector (entries the frequency filter excludes carry RX_FILTERED); the last
+        // window's closing barrier (or, without any window, the scan's) has completed the counters
         for (uint32_t i = tid; i < ne; i += RX_NT) {
             const uint32_t cn = scnt[i];
             if (cn - 1u < RX_FILTERED - 1u) {
