@@ -129,7 +129,8 @@ __device__ __forceinline__ uint64_t rx_pack(const IndexView &iv, int sh, uint64_
 }
 
 // Exclusive scan of s_in[0..n) (n <= 256) into s_out[0..n], s_out[n] = total, by a RX_NT-thread workgroup.
-// Call after a barrier that completes s_in; ends with a barrier.
+// Call after a barrier that completes s_in; ends with a barrier.  (Letting every wavefront scan all the counters
+// for itself instead — no barriers — measured slower: pass 1 3.58 vs 3.20 ms.)
 __device__ __forceinline__ uint32_t rx_scan256(const uint32_t *s_in, uint32_t *s_out, int n, uint32_t *s_wave)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -195,7 +196,10 @@ struct RxNoHook {
 };
 
 // `mid` runs between the ranking and the scan (pass 2 issues the next item's descriptor loads there).
-template <int RB, typename PrepFn, typename MidFn = RxNoHook>
+// Barriers: one after the ranking, two in the scan, one after the placement.  ENDBAR = false leaves out the one after the copy-out:
+// the caller then guarantees a barrier of its own before sbuf is written again and before the next call's ranking
+// (which needs the counters this call clears during its copy-out).
+template <int RB, bool ENDBAR, typename PrepFn, typename MidFn = RxNoHook>
 __device__ __forceinline__ void rx_sort_emit(uint64_t (&q)[RX_KPT], PrepFn prep, int F, uint64_t *sbuf,
                                              uint32_t *s_cnt, uint32_t *s_base, uint32_t *s_wave,
                                              uint64_t *__restrict__ out, uint16_t *__restrict__ dir_row,
@@ -203,9 +207,8 @@ __device__ __forceinline__ void rx_sort_emit(uint64_t (&q)[RX_KPT], PrepFn prep,
 {
     const int tid = threadIdx.x;
     (void)pt_acc;
-    if (tid <= F)
-        s_cnt[tid] = 0;
-    __syncthreads();
+    // s_cnt[0..F] is zero on entry: cleared by the caller before its first call (followed by a barrier) and by every
+    // call for the next one, right after the scan has consumed the counts
     // rank inside the key's run: one returning LDS atomic per k-mer, RB in flight before the first result is
     // consumed; RB at a time also bounds the registers
     // the key computation (pass 1: a 64-bit division by the modulo) holds at once
@@ -249,11 +252,14 @@ __device__ __forceinline__ void rx_sort_emit(uint64_t (&q)[RX_KPT], PrepFn prep,
     }
     __syncthreads();
     RX_PT(3); // scan + placement
+    if (tid <= F)
+        s_cnt[tid] = 0; // for the next call (every wavefront's scan has read the counts: they lie before the barrier)
     const uint4 *s4 = reinterpret_cast<const uint4 *>(sbuf);
     uint4 *o4 = reinterpret_cast<uint4 *>(out);
     for (uint32_t i = tid; i < (total + 1) / 2; i += RX_NT)
         o4[i] = s4[i];
-    __syncthreads();
+    if (ENDBAR)
+        __syncthreads();
     RX_PT(4); // copy-out
 }
 
@@ -392,6 +398,9 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p1(ReadsView rv, const uint64_t
     constexpr bool PREFETCH = false;
 #endif
     TileRaw pw[R];
+    if (tid <= F1)
+        s_cnt[tid] = 0; // (rx_sort_emit)
+    __syncthreads(); // also: the code table is in LDS
     for (uint32_t sb = blockIdx.x; sb < n_src; sb += gridDim.x) {
         uint64_t q[RX_KPT];
         uint32_t valid = 0;
@@ -417,7 +426,9 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p1(ReadsView rv, const uint64_t
             for (int r = 0; r < R; ++r) {
                 uint64_t qq[S];
                 const int64_t tile = tile_begin + ((int64_t)sb * 2 + half) * R + r;
-                const uint32_t v = tile_kmers<S, TM>(rv, tc, tile, k, sm[half], qq, ltid, pw[r]);
+                // (the first tile of a block needs no opening barrier: the previous block's sort lies in between)
+                const uint32_t v = r == 0 ? tile_kmers<S, TM, false>(rv, tc, tile, k, sm[half], qq, ltid, pw[r])
+                                          : tile_kmers<S, TM, true>(rv, tc, tile, k, sm[half], qq, ltid, pw[r]);
 #pragma unroll
                 for (int j = 0; j < S; ++j)
                     q[r * S + j] = qq[j];
@@ -439,14 +450,14 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p1(ReadsView rv, const uint64_t
                 x[i] = rx_pack(iv, sh, q[i], &c);
                 return ((valid >> i) & 1u) ? c : (uint32_t)F1;
             };
-            rx_sort_emit<4>(x, fwd, F1, sbuf, s_cnt, s_base, s_wave, rx.buf1 + (size_t)sb * 2 * RX_B,
+            rx_sort_emit<4, true>(x, fwd, F1, sbuf, s_cnt, s_base, s_wave, rx.buf1 + (size_t)sb * 2 * RX_B,
                          rx.start1 + (size_t)sb * 2 * (size_t)(F1 + 1) RX_PT_ARG);
             auto rev = [&](int i) {
                 uint32_t c;
                 x[i] = rx_pack(iv, sh, revcomp(q[i], k), &c);
                 return ((valid >> i) & 1u) ? c : (uint32_t)F1;
             };
-            rx_sort_emit<4>(x, rev, F1, sbuf, s_cnt, s_base, s_wave, rx.buf1 + ((size_t)sb * 2 + 1) * RX_B,
+            rx_sort_emit<4, MODE == MODE_KMERS>(x, rev, F1, sbuf, s_cnt, s_base, s_wave, rx.buf1 + ((size_t)sb * 2 + 1) * RX_B,
                          rx.start1 + ((size_t)sb * 2 + 1) * (size_t)(F1 + 1) RX_PT_ARG);
         } else {
             auto fwd = [&](int i) {
@@ -454,7 +465,7 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p1(ReadsView rv, const uint64_t
                 q[i] = rx_pack(iv, sh, q[i], &c);
                 return ((valid >> i) & 1u) ? c : (uint32_t)F1;
             };
-            rx_sort_emit<4>(q, fwd, F1, sbuf, s_cnt, s_base, s_wave, rx.buf1 + (size_t)sb * RX_B,
+            rx_sort_emit<4, MODE == MODE_KMERS>(q, fwd, F1, sbuf, s_cnt, s_base, s_wave, rx.buf1 + (size_t)sb * RX_B,
                          rx.start1 + (size_t)sb * (size_t)(F1 + 1) RX_PT_ARG);
         }
     }
@@ -662,6 +673,8 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p2(IndexView iv, RxView rx)
     // of ~cs adjacent coarse partitions together, whose runs are neighbours inside every pass-1 block
     const uint32_t cs = (rx.F1 + 7u) / 8u, limit = rx.ctrl[2] * cs;
     const uint32_t home = rx_xcc_id();
+    if (tid <= F2)
+        s_cnt[tid] = 0; // (rx_sort_emit; the barriers of the first index broadcast lie before the first use)
     // An item's description (uniform) and this thread's run descriptor of its first round.  Both are loaded while
     // the PREVIOUS item is being sorted: the two dependent round trips (item table, then run descriptors) would
     // otherwise stand at the head of every item (measured: 27 % of the pass).
@@ -738,9 +751,12 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p2(IndexView iv, RxView rx)
                 const uint32_t from = vs > lo ? vs : lo, to = ve < hi ? ve : hi;
                 const uint32_t len = live && to > from ? to - from : 0u;
                 const uint64_t src = (uint64_t)b * RX_B + st + (from - vs); // element offset of the run's first wanted k-mer
+                // (the last thread's "my run does not end the item" rides on the scan's total as bit 31)
                 uint32_t n_sub;
-                const uint32_t pre = rx_scan_threads(rx_n_pieces<RX_LPR, true>(len, src), s_wave8, &n_sub);
-                const bool more = __syncthreads_or(tid == RX_NT - 1 && live && ve < hi);
+                const uint32_t last_more = (tid == RX_NT - 1 && live && ve < hi) ? 0x80000000u : 0u;
+                const uint32_t pre = rx_scan_threads(rx_n_pieces<RX_LPR, true>(len, src) | last_more, s_wave8, &n_sub);
+                const bool more = n_sub >> 31;
+                n_sub &= 0x7FFFFFFFu;
                 RX_PT(1); // run descriptors, scan
                 for (uint32_t win = 0; win < n_sub; win += RX_SUBCAP) {
                     rx_list_subruns<RX_LPR, true>(pre, len, src, from - lo, win, sub_src, sub_meta);
@@ -769,7 +785,9 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p2(IndexView iv, RxView rx)
                                 sbuf[(meta[u] >> 12) + rel] = x[u];
                         }
                     }
-                    __syncthreads(); // the list is rewritten by the next window / round
+                    if (more || win + RX_SUBCAP < n_sub)
+                        __syncthreads(); // the list is rewritten by the next window / round (after the last one the
+                                         // barrier of the index exchange below follows anyway)
                 }
                 if (!more)
                     break; // the round's last run ends the item (or lies beyond it)
@@ -804,7 +822,7 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p2(IndexView iv, RxView rx)
                 return ((valid >> i) & 1u) ? ((uint32_t)(q[i] >> rx.w) & (uint32_t)(F2 - 1)) : (uint32_t)F2;
             };
             auto mid = [&]() { rd_n = run_desc(it_n, it_n.b0); };
-            rx_sort_emit<8>(q, fine, F2, sbuf, s_cnt, s_base, s_wave, rx.buf2 + (size_t)it.item * RX_B,
+            rx_sort_emit<8, false>(q, fine, F2, sbuf, s_cnt, s_base, s_wave, rx.buf2 + (size_t)it.item * RX_B,
                             rx.start2 + (size_t)it.item * (F2 + 1) RX_PT_ARG2, mid);
         } else {
             rd_n = run_desc(it_n, it_n.b0);

@@ -116,7 +116,9 @@ __device__ __forceinline__ void tile_load_vec(const ReadsView &rv, const TileCon
 // `tid` is the thread's index inside the 256-thread group that owns the tile: threadIdx.x for 256-thread
 // workgroups; wider workgroups (the radix path) run one tile per 256-thread quarter, every quarter with its
 // own TileSmem, and all of them pass through the same barriers.
-template <int S, int MODE>
+// TOPBAR = false: the caller guarantees that a workgroup barrier already lies between the previous tile's last LDS
+// read (and the code table's staging) and this call.
+template <int S, int MODE, bool TOPBAR = true>
 __device__ __forceinline__ uint32_t tile_kmers(const ReadsView &rv, const TileConst &tc, int64_t tile,
                                                int k, TileSmem<S> &sm, uint64_t (&q)[S], const int tid,
                                                const TileRaw &raw)
@@ -131,7 +133,8 @@ __device__ __forceinline__ uint32_t tile_kmers(const ReadsView &rv, const TileCo
     static_assert(T % 1024 == 0, "tile_first / tile_nl are kept per 1024 positions");
     const int64_t total = rv.total;
     const int64_t t0 = tile * T;
-    __syncthreads(); // LUT visible; every wave has finished reading the previous tile's LDS words
+    if (TOPBAR)
+        __syncthreads(); // LUT visible; every wave has finished reading the previous tile's LDS words
     if (MODE == MODE_GENERAL && tid <= NB) // read starts inside [t0, t0 + 32 (NB + 1)): the bitset's own words
         sm.bits[tid] = raw.sbits;
 
