@@ -95,6 +95,21 @@ __device__ __forceinline__ uint64_t fastdiv_m31(uint64_t x, uint32_t m, uint64_t
 // correction; exact for m >= 2^14 — was measured and dropped: pass 1 5.68 ms against 3.51 ms with the integer
 // multiplies above: v_cvt_f64_u32 / v_fma_f64 are no cheaper than the quarter-rate 32-bit multiplies here.)
 
+// Inclusive prefix sum over the 64 lanes of a wavefront with six DPP additions (row shifts by 1, 2, 4, 8 inside the
+// rows of 16 lanes, then lane 15's and lane 31's broadcasts into the following rows) instead of six ds_bpermute
+// round trips through the LDS crossbar: the scans of the radix passes sit on the critical path between two
+// workgroup barriers.  Call with every lane of the wavefront active.
+__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v)
+{
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false); // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false); // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false); // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false); // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false); // row_bcast:15 -> rows 1, 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false); // row_bcast:31 -> rows 2, 3
+    return v;
+}
+
 // Reverse complement under A,C,G,T = 0,1,2,3, first base in the lowest bits: complement every
 // 2-bit group (NOT), reverse the groups, realign (the `-r` operation).
 __device__ __forceinline__ uint64_t revcomp(uint64_t x, int k)

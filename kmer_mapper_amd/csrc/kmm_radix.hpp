@@ -135,13 +135,7 @@ __device__ __forceinline__ uint32_t rx_scan256(const uint32_t *s_in, uint32_t *s
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t v = tid < n ? s_in[tid] : 0u;
-    uint32_t inc = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t o = __shfl_up(inc, d);
-        if (lane >= d)
-            inc += o;
-    }
+    const uint32_t inc = wave_scan_incl(v);
     if (wave < 4 && lane == 63)
         s_wave[wave] = inc;
     __syncthreads();
@@ -277,13 +271,7 @@ __device__ __forceinline__ void rx_stat_add(const IndexView &iv, int which, uint
 __device__ __forceinline__ uint32_t rx_scan_threads(uint32_t v, uint32_t *s_wave8, uint32_t *total)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t inc = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t o = __shfl_up(inc, d);
-        if (lane >= d)
-            inc += o;
-    }
+    const uint32_t inc = wave_scan_incl(v);
     __syncthreads(); // s_wave8 may still be read by the previous call
     if (lane == 63)
         s_wave8[wave] = inc;
@@ -508,13 +496,7 @@ __global__ void __launch_bounds__(256) k_rx_colsum(RxView rx)
 __device__ __forceinline__ uint32_t scan256_excl(uint32_t v, uint32_t *s_wave4, uint32_t *total)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t inc = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t o = __shfl_up(inc, d);
-        if (lane >= d)
-            inc += o;
-    }
+    const uint32_t inc = wave_scan_incl(v);
     __syncthreads(); // s_wave4 may still be read by the previous call
     if (lane == 63)
         s_wave4[wave] = inc;
