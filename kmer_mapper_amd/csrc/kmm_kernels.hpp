@@ -211,13 +211,7 @@ __global__ void __launch_bounds__(256) k_extract_write(ReadsView rv, int k, int6
         uint64_t q[S];
         const uint32_t valid = tile_kmers<S, MODE>(rv, tc, tile, k, sm, q);
         const uint32_t c = (uint32_t)__popc(valid);
-        uint32_t inc = c;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t o = __shfl_up(inc, d);
-            if (lane >= d)
-                inc += o;
-        }
+        const uint32_t inc = wave_scan_incl(c);
         if (lane == 63)
             s_wave[wave] = inc;
         __syncthreads();

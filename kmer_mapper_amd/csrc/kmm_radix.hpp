@@ -56,6 +56,12 @@ constexpr int RX_IC = 1024;           // pass-2 items per pass-3 work item
 #endif
 constexpr int RX_LPR = RX_LPR2V;      // lanes of a run copier (pass 2)
 constexpr int RX_NG = RX_NT / RX_LPR; // run copiers per workgroup
+#ifndef RX_RB1
+#define RX_RB1 4
+#endif
+#ifndef RX_RB2
+#define RX_RB2 8
+#endif
 constexpr int RX_SUBCAP = 1024;       // sub-runs (<= RX_LPR k-mers each) listed in LDS per window
 #ifndef RX_LPR3
 #define RX_LPR3 16
@@ -438,14 +444,14 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p1(ReadsView rv, const uint64_t
                 x[i] = rx_pack(iv, sh, q[i], &c);
                 return ((valid >> i) & 1u) ? c : (uint32_t)F1;
             };
-            rx_sort_emit<4, true>(x, fwd, F1, sbuf, s_cnt, s_base, s_wave, rx.buf1 + (size_t)sb * 2 * RX_B,
+            rx_sort_emit<RX_RB1, true>(x, fwd, F1, sbuf, s_cnt, s_base, s_wave, rx.buf1 + (size_t)sb * 2 * RX_B,
                          rx.start1 + (size_t)sb * 2 * (size_t)(F1 + 1) RX_PT_ARG);
             auto rev = [&](int i) {
                 uint32_t c;
                 x[i] = rx_pack(iv, sh, revcomp(q[i], k), &c);
                 return ((valid >> i) & 1u) ? c : (uint32_t)F1;
             };
-            rx_sort_emit<4, MODE == MODE_KMERS>(x, rev, F1, sbuf, s_cnt, s_base, s_wave, rx.buf1 + ((size_t)sb * 2 + 1) * RX_B,
+            rx_sort_emit<RX_RB1, MODE == MODE_KMERS>(x, rev, F1, sbuf, s_cnt, s_base, s_wave, rx.buf1 + ((size_t)sb * 2 + 1) * RX_B,
                          rx.start1 + ((size_t)sb * 2 + 1) * (size_t)(F1 + 1) RX_PT_ARG);
         } else {
             auto fwd = [&](int i) {
@@ -453,7 +459,7 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p1(ReadsView rv, const uint64_t
                 q[i] = rx_pack(iv, sh, q[i], &c);
                 return ((valid >> i) & 1u) ? c : (uint32_t)F1;
             };
-            rx_sort_emit<4, MODE == MODE_KMERS>(q, fwd, F1, sbuf, s_cnt, s_base, s_wave, rx.buf1 + (size_t)sb * RX_B,
+            rx_sort_emit<RX_RB1, MODE == MODE_KMERS>(q, fwd, F1, sbuf, s_cnt, s_base, s_wave, rx.buf1 + (size_t)sb * RX_B,
                          rx.start1 + (size_t)sb * (size_t)(F1 + 1) RX_PT_ARG);
         }
     }
@@ -804,7 +810,7 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p2(IndexView iv, RxView rx)
                 return ((valid >> i) & 1u) ? ((uint32_t)(q[i] >> rx.w) & (uint32_t)(F2 - 1)) : (uint32_t)F2;
             };
             auto mid = [&]() { rd_n = run_desc(it_n, it_n.b0); };
-            rx_sort_emit<8, false>(q, fine, F2, sbuf, s_cnt, s_base, s_wave, rx.buf2 + (size_t)it.item * RX_B,
+            rx_sort_emit<RX_RB2, false>(q, fine, F2, sbuf, s_cnt, s_base, s_wave, rx.buf2 + (size_t)it.item * RX_B,
                             rx.start2 + (size_t)it.item * (F2 + 1) RX_PT_ARG2, mid);
         } else {
             rd_n = run_desc(it_n, it_n.b0);
