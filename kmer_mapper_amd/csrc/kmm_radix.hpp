@@ -273,19 +273,23 @@ __device__ __forceinline__ void rx_stat_add(const IndexView &iv, int which, uint
                   (unsigned long long)v);
 }
 
-// Exclusive prefix of one value per thread over the RX_NT-thread workgroup; *total = sum.  Two barriers.
-__device__ __forceinline__ uint32_t rx_scan_threads(uint32_t v, uint32_t *s_wave8, uint32_t *total)
+// Exclusive prefix of one value per thread over the RX_NT-thread workgroup; *total = sum.  One barrier: the
+// wavefront totals go to one of two LDS rows in turn (`flip`, uniform, toggled here), so that a wavefront still
+// reading the previous call's totals is never overtaken — the call in between has its own barrier.
+__device__ __forceinline__ uint32_t rx_scan_threads(uint32_t v, uint32_t (*s_wave8)[RX_NT / 64], uint32_t &flip,
+                                                    uint32_t *total)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t inc = wave_scan_incl(v);
-    __syncthreads(); // s_wave8 may still be read by the previous call
+    uint32_t *row = s_wave8[flip];
+    flip ^= 1u;
     if (lane == 63)
-        s_wave8[wave] = inc;
+        row[wave] = inc;
     __syncthreads();
     uint32_t base = 0, tot = 0;
 #pragma unroll
     for (int x = 0; x < RX_NT / 64; ++x) {
-        const uint32_t t = s_wave8[x];
+        const uint32_t t = row[x];
         base += x < wave ? t : 0u;
         tot += t;
     }
@@ -650,12 +654,13 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p2(IndexView iv, RxView rx)
 {
     __shared__ uint64_t sbuf[RX_B];
     __shared__ uint64_t sub_src[RX_SUBCAP];
-    __shared__ uint32_t sub_meta[RX_SUBCAP], s_wave8[RX_NT / 64];
+    __shared__ uint32_t sub_meta[RX_SUBCAP], s_wave8[2][RX_NT / 64];
     __shared__ uint32_t s_cnt[RX_MAXF + 1 + 64], s_base[RX_MAXF + 1], s_wave[4];
     __shared__ uint32_t s_idx;
     const int tid = threadIdx.x, grp = tid / RX_LPR, lg = tid % RX_LPR;
     const uint32_t NB = rx.NB;
     uint32_t gathered = 0; // conservation check (kmm_get_param "radix_p2_kmers"): must equal pass 1's lookups
+    uint32_t scan_flip = 0;
     const int F2 = (int)rx.F2;
     // XCD x takes the coarse partitions [x cs, (x+1) cs), items j-major: the workgroups of one XCD work on item j
     // of ~cs adjacent coarse partitions together, whose runs are neighbours inside every pass-1 block
@@ -742,7 +747,7 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p2(IndexView iv, RxView rx)
                 // (the last thread's "my run does not end the item" rides on the scan's total as bit 31)
                 uint32_t n_sub;
                 const uint32_t last_more = (tid == RX_NT - 1 && live && ve < hi) ? 0x80000000u : 0u;
-                const uint32_t pre = rx_scan_threads(rx_n_pieces<RX_LPR, true>(len, src) | last_more, s_wave8, &n_sub);
+                const uint32_t pre = rx_scan_threads(rx_n_pieces<RX_LPR, true>(len, src) | last_more, s_wave8, scan_flip, &n_sub);
                 const bool more = n_sub >> 31;
                 n_sub &= 0x7FFFFFFFu;
                 RX_PT(1); // run descriptors, scan
@@ -842,7 +847,7 @@ __global__ void __launch_bounds__(RX_NT, WPS) k_rx_p3(IndexView iv, RxView rx, i
     __shared__ uint32_t scnt[ECAP];
     __shared__ uint64_t sub_src[RX_SUBCAP];
     __shared__ uint32_t sub_meta[RX_SUBCAP];
-    __shared__ uint32_t s_wb[RX_MAXF + 1], s_wave8[RX_NT / 64];
+    __shared__ uint32_t s_wb[RX_MAXF + 1], s_wave8[2][RX_NT / 64];
     __shared__ uint32_t s_idx;
     const int tid = threadIdx.x, grp = tid / RX_LPR_P3, lg = tid % RX_LPR_P3;
     const uint32_t n_rows = rx.ctrl[1], F1 = rx.F1, F2 = rx.F2;
@@ -855,7 +860,7 @@ __global__ void __launch_bounds__(RX_NT, WPS) k_rx_p3(IndexView iv, RxView rx, i
     const uint32_t gs = (F2 + 7u) / 8u, limit = n_rows * gs;
     unsigned long long *counters = rx.queue + 128;
     const uint32_t home = rx_xcc_id();
-    uint32_t hits = 0, probed = 0;
+    uint32_t hits = 0, probed = 0, scan_flip = 0;
     __syncthreads(); // s_wb is loaded
     // A work item's description (uniform): its fine partition's place in the index and its items.  It is worked
     // out — two dependent loads — while the PREVIOUS work item streams its k-mers.
@@ -992,7 +997,7 @@ __global__ void __launch_bounds__(RX_NT, WPS) k_rx_p3(IndexView iv, RxView rx, i
                 np_sum += np[j];
             }
             uint32_t n_sub;
-            const uint32_t pre = rx_scan_threads(np_sum, s_wave8, &n_sub);
+            const uint32_t pre = rx_scan_threads(np_sum, s_wave8, scan_flip, &n_sub);
             for (uint32_t win = 0; win < n_sub; win += RX_SUBCAP) {
                 uint32_t first = pre;
 #pragma unroll
