@@ -135,10 +135,34 @@ __device__ __forceinline__ uint64_t rx_pack(const IndexView &iv, int sh, uint64_
 }
 
 // Exclusive scan of s_in[0..n) (n <= 256) into s_out[0..n], s_out[n] = total, by a RX_NT-thread workgroup.
-// Call after a barrier that completes s_in; ends with a barrier.  (Letting every wavefront scan all the counters
-// for itself instead — no barriers — measured slower: pass 1 3.58 vs 3.20 ms.)
+// Call after a barrier that completes s_in; ends with a barrier.  ONEBAR: the wavefront that scans counters
+// [64 w, 64 w + 64) sums the counters before them itself (DPP reductions) instead of waiting at a second barrier for
+// the other wavefronts' totals: pass 1 2.91 -> 2.80 ms, pass 2 3.89 -> 3.96 ms (so pass 2 keeps the exchange).
+// (Letting EVERY wavefront scan all the counters for itself — no barrier at all — measured slower: pass 1 3.58 vs
+// 3.20 ms; so did the one-barrier form while the reductions still went through ds_bpermute: 3.78.)
+template <bool ONEBAR>
 __device__ __forceinline__ uint32_t rx_scan256(const uint32_t *s_in, uint32_t *s_out, int n, uint32_t *s_wave)
 {
+    if (ONEBAR) {
+    (void)s_wave;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (wave < 4) {
+        const uint32_t v = tid < n ? s_in[tid] : 0u;
+        const uint32_t inc = wave_scan_incl(v);
+        uint32_t before = 0;
+        for (int x = 0; x < wave; ++x) {
+            const uint32_t t = x * 64 + lane < n ? s_in[x * 64 + lane] : 0u;
+            before += (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_incl(t), 63);
+        }
+        if (tid < n)
+            s_out[tid] = before + inc - v;
+        if (tid == 255)
+            s_out[n] = before + inc; // wavefront 3 has seen every counter
+    }
+    __syncthreads();
+    return s_out[n];
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t v = tid < n ? s_in[tid] : 0u;
     const uint32_t inc = wave_scan_incl(v);
@@ -196,10 +220,10 @@ struct RxNoHook {
 };
 
 // `mid` runs between the ranking and the scan (pass 2 issues the next item's descriptor loads there).
-// Barriers: one after the ranking, two in the scan, one after the placement.  ENDBAR = false leaves out the one after the copy-out:
+// Barriers: one after the ranking, one or two in the scan (ONEBAR), one after the placement.  ENDBAR = false leaves out the one after the copy-out:
 // the caller then guarantees a barrier of its own before sbuf is written again and before the next call's ranking
 // (which needs the counters this call clears during its copy-out).
-template <int RB, bool ENDBAR, typename PrepFn, typename MidFn = RxNoHook>
+template <int RB, bool ENDBAR, bool ONEBAR, typename PrepFn, typename MidFn = RxNoHook>
 __device__ __forceinline__ void rx_sort_emit(uint64_t (&q)[RX_KPT], PrepFn prep, int F, uint64_t *sbuf,
                                              uint32_t *s_cnt, uint32_t *s_base, uint32_t *s_wave,
                                              uint64_t *__restrict__ out, uint16_t *__restrict__ dir_row,
@@ -231,7 +255,7 @@ __device__ __forceinline__ void rx_sort_emit(uint64_t (&q)[RX_KPT], PrepFn prep,
     __syncthreads();
     RX_PT(2); // keys + ranks
     mid();
-    const uint32_t total = rx_scan256(s_cnt, s_base, F, s_wave);
+    const uint32_t total = rx_scan256<ONEBAR>(s_cnt, s_base, F, s_wave);
     if (tid <= F)
         dir_row[tid] = (uint16_t)s_base[tid];
     // (one slot after the other: reading all 16 run starts first and then writing — 16 overlapping LDS round trips —
@@ -448,14 +472,14 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p1(ReadsView rv, const uint64_t
                 x[i] = rx_pack(iv, sh, q[i], &c);
                 return ((valid >> i) & 1u) ? c : (uint32_t)F1;
             };
-            rx_sort_emit<RX_RB1, true>(x, fwd, F1, sbuf, s_cnt, s_base, s_wave, rx.buf1 + (size_t)sb * 2 * RX_B,
+            rx_sort_emit<RX_RB1, true, true>(x, fwd, F1, sbuf, s_cnt, s_base, s_wave, rx.buf1 + (size_t)sb * 2 * RX_B,
                          rx.start1 + (size_t)sb * 2 * (size_t)(F1 + 1) RX_PT_ARG);
             auto rev = [&](int i) {
                 uint32_t c;
                 x[i] = rx_pack(iv, sh, revcomp(q[i], k), &c);
                 return ((valid >> i) & 1u) ? c : (uint32_t)F1;
             };
-            rx_sort_emit<RX_RB1, MODE == MODE_KMERS>(x, rev, F1, sbuf, s_cnt, s_base, s_wave, rx.buf1 + ((size_t)sb * 2 + 1) * RX_B,
+            rx_sort_emit<RX_RB1, MODE == MODE_KMERS, true>(x, rev, F1, sbuf, s_cnt, s_base, s_wave, rx.buf1 + ((size_t)sb * 2 + 1) * RX_B,
                          rx.start1 + ((size_t)sb * 2 + 1) * (size_t)(F1 + 1) RX_PT_ARG);
         } else {
             auto fwd = [&](int i) {
@@ -463,7 +487,7 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p1(ReadsView rv, const uint64_t
                 q[i] = rx_pack(iv, sh, q[i], &c);
                 return ((valid >> i) & 1u) ? c : (uint32_t)F1;
             };
-            rx_sort_emit<RX_RB1, MODE == MODE_KMERS>(q, fwd, F1, sbuf, s_cnt, s_base, s_wave, rx.buf1 + (size_t)sb * RX_B,
+            rx_sort_emit<RX_RB1, MODE == MODE_KMERS, true>(q, fwd, F1, sbuf, s_cnt, s_base, s_wave, rx.buf1 + (size_t)sb * RX_B,
                          rx.start1 + (size_t)sb * (size_t)(F1 + 1) RX_PT_ARG);
         }
     }
@@ -815,7 +839,7 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p2(IndexView iv, RxView rx)
                 return ((valid >> i) & 1u) ? ((uint32_t)(q[i] >> rx.w) & (uint32_t)(F2 - 1)) : (uint32_t)F2;
             };
             auto mid = [&]() { rd_n = run_desc(it_n, it_n.b0); };
-            rx_sort_emit<RX_RB2, false>(q, fine, F2, sbuf, s_cnt, s_base, s_wave, rx.buf2 + (size_t)it.item * RX_B,
+            rx_sort_emit<RX_RB2, false, false>(q, fine, F2, sbuf, s_cnt, s_base, s_wave, rx.buf2 + (size_t)it.item * RX_B,
                             rx.start2 + (size_t)it.item * (F2 + 1) RX_PT_ARG2, mid);
         } else {
             rd_n = run_desc(it_n, it_n.b0);
