@@ -267,21 +267,49 @@ __device__ __forceinline__ uint32_t tile_kmers(const ReadsView &rv, const TileCo
     }
     uint32_t valid = 0;
     if (UNIFORM) {
+        // o = offset of the lane's first position inside its read.  The 64-bit division is done ONCE per tile, on a
+        // value every lane shares (the tile's start; readfirstlane lets it run on the scalar unit); the lane adds
+        // its own position in the tile and reduces with 32-bit arithmetic.  (One 64-bit division per lane and 64-bit
+        // mask arithmetic cost pass 1 ~11 VALU instructions per k-mer: the ragged-read kernel was FASTER, 2.50 vs
+        // 2.81 ms.)
         uint64_t o;
-        (void)fastdiv((uint64_t)p0, rv.read_len, rv.read_len_magic, &o);
+        if (rv.read_len < (1ull << 30)) {
+            const uint32_t L32 = (uint32_t)rv.read_len;
+            const uint64_t t0u = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)t0 >> 32)) << 32) |
+                                 (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)t0);
+            uint64_t bo;
+            (void)fastdiv(t0u, rv.read_len, rv.read_len_magic, &bo);
+            uint32_t sft = (uint32_t)bo + (uint32_t)q0; // < L + T
+            if (L32 >= (uint32_t)T) {
+                sft = sft >= L32 ? sft - L32 : sft;
+            } else { // < 2 T <= 2^14: a float reciprocal is exact to +-1
+                const uint32_t qe = (uint32_t)((float)sft * __builtin_amdgcn_rcpf((float)L32));
+                int32_t r = (int32_t)(sft - __umul24(qe, L32));
+                r = r < 0 ? r + (int32_t)L32 : r;
+                r = r >= (int32_t)L32 ? r - (int32_t)L32 : r;
+                sft = (uint32_t)r;
+            }
+            o = sft;
+        } else {
+            (void)fastdiv((uint64_t)p0, rv.read_len, rv.read_len_magic, &o);
+        }
         if (rv.read_len >= (uint64_t)(k + S)) {
             // offsets o, o+1, ... wrap at most once inside the lane's S windows and the windows after the wrap are
             // whole again: the invalid ones are exactly those at offsets (L-k, L-1], a single run of bits
-            const int64_t L = (int64_t)rv.read_len;
-            const int64_t a = L - k + 1 - (int64_t)o, b = L - 1 - (int64_t)o; // window indices of that run
-            const int64_t lim = total - p0;                                    // windows that start inside the chunk
-            uint32_t m = lim >= S ? ((S >= 32) ? 0xFFFFFFFFu : ((1u << S) - 1u)) : (lim > 0 ? ((1u << lim) - 1u) : 0u);
-            if (a < S) {
-                const uint32_t lo_bit = a > 0 ? (uint32_t)a : 0u;
-                const uint32_t hi_bit = b < S - 1 ? (uint32_t)b : (uint32_t)(S - 1);
-                m &= ~(((2u << hi_bit) - 1u) & ~((1u << lo_bit) - 1u));
-            }
-            valid = m;
+            // [a, b] of window indices (32-bit arithmetic for every read length below 2^30)
+            auto run_mask = [&](auto L, auto oo) {
+                const auto ra = L - k + 1 - oo, rb = L - 1 - oo;
+                const int64_t lim = total - p0; // windows that start inside the chunk
+                uint32_t m = lim >= S ? ((S >= 32) ? 0xFFFFFFFFu : ((1u << S) - 1u)) : (lim > 0 ? ((1u << lim) - 1u) : 0u);
+                if (ra < S) {
+                    const uint32_t lo_bit = ra > 0 ? (uint32_t)ra : 0u;
+                    const uint32_t hi_bit = rb < S - 1 ? (uint32_t)rb : (uint32_t)(S - 1);
+                    m &= ~(((2u << hi_bit) - 1u) & ~((1u << lo_bit) - 1u));
+                }
+                return m;
+            };
+            valid = rv.read_len < (1ull << 30) ? run_mask((int32_t)rv.read_len, (int32_t)o)
+                                               : run_mask((int64_t)rv.read_len, (int64_t)o);
         } else {
 #pragma unroll
             for (int j = 0; j < S; ++j) {

@@ -260,3 +260,22 @@ def test_flush_orders_agree(kmm, syn, oracle, skewed):
             dev.map_reads_uniform(bases, 30000, 150, 31)
             total = total + expect                                             # uint32: wraps like the device vector
             assert np.array_equal(dev.get_node_counts(), total), (rep, order)
+
+
+@pytest.mark.parametrize("read_len", [31, 47, 150, 4095, 4096, 5000, 70001])
+def test_uniform_reads_of_any_length(kmm, syn, oracle, read_len):
+    """kmm_map_reads_uniform works out every lane's offset inside its read from one division per tile plus 32-bit
+    arithmetic per lane (reads shorter than a tile: float reciprocal; longer: one conditional subtraction): read
+    lengths on both sides of the 4096-position tile, of k itself, and far beyond a tile."""
+    index, genome = syn.make_index(30000, seed=371)
+    mx = index.max_node_id()
+    n_reads = max(3, 3_000_000 // read_len)
+    bases, offs = syn.make_reads(genome, n_reads, read_len, seed=372)
+    expect, n = oracle.map_reads(index, mx, bases, offs, 31, n_threads=4)
+    assert n == n_reads * (read_len - 30)
+    with kmm.DeviceIndex.from_index(index, mx) as dev:
+        for path in (2, 1):
+            dev.set_param("path", path)
+            dev.reset()
+            dev.map_reads_uniform(bases, n_reads, read_len, 31)
+            assert np.array_equal(dev.get_node_counts(), expect), path
