@@ -220,7 +220,8 @@ struct RxNoHook {
 };
 
 // `mid` runs between the ranking and the scan (pass 2 issues the next item's descriptor loads there).
-// Barriers: one after the ranking, one or two in the scan (ONEBAR), one after the placement.  ENDBAR = false leaves out the one after the copy-out:
+// Barriers: one after the ranking, one or two in the scan (ONEBAR = pass 1's flavour: one-barrier scan and
+// non-temporal copy-out), one after the placement.  ENDBAR = false leaves out the one after the copy-out:
 // the caller then guarantees a barrier of its own before sbuf is written again and before the next call's ranking
 // (which needs the counters this call clears during its copy-out).
 template <int RB, bool ENDBAR, bool ONEBAR, typename PrepFn, typename MidFn = RxNoHook>
@@ -280,8 +281,16 @@ __device__ __forceinline__ void rx_sort_emit(uint64_t (&q)[RX_KPT], PrepFn prep,
         s_cnt[tid] = 0; // for the next call (every wavefront's scan has read the counts: they lie before the barrier)
     const uint4 *s4 = reinterpret_cast<const uint4 *>(sbuf);
     uint4 *o4 = reinterpret_cast<uint4 *>(out);
-    for (uint32_t i = tid; i < (total + 1) / 2; i += RX_NT)
-        o4[i] = s4[i];
+    for (uint32_t i = tid; i < (total + 1) / 2; i += RX_NT) {
+        if (ONEBAR) { // (pass 1) streamed out past L2: the directory rows the scan kernels read next stay there
+            typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+            const uint4 v = s4[i];
+            const u32x4_t w = {v.x, v.y, v.z, v.w};
+            __builtin_nontemporal_store(w, reinterpret_cast<u32x4_t *>(o4) + i);
+        } else {      // (pass 2: measured slower with non-temporal stores, 4.20 vs 4.15 ms)
+            o4[i] = s4[i];
+        }
+    }
     if (ENDBAR)
         __syncthreads();
     RX_PT(4); // copy-out
