@@ -197,14 +197,25 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    own_comm = False
     if world > 1 and args.dist_backend == "nccl":
-        init_rccl_comm(dev)                          # the library's own communicator (kmm_comm_init_rank)
+        # the library's own communicator (kmm_comm_init_rank); every rank must have it, else all of them reduce
+        # through torch.distributed (same RCCL sum of the same vector)
+        try:
+            init_rccl_comm(dev)
+            ok = 1
+        except Exception as e:                       # noqa: BLE001 - any failure means "fall back", on every rank
+            log("kmm_comm_init_rank failed (%s): reducing through torch.distributed" % e)
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device=dev_t)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        own_comm = bool(flag.item())
 
     def reduce_counts(t):
         if args.dist_backend == "nccl":
             # RCCL sum of the uint32 count vectors over xGMI, behind the C ABI (kmm_comm_reduce_counts): in place
             # on the bound vector `counts`
-            if t is counts:
+            if t is counts and own_comm:
                 dev.comm_reduce_counts(root=0)
             else:
                 reduce_node_counts(t, dst=0)
@@ -346,8 +357,8 @@ def main():
                 "occupancy_bits_per_bucket": dev.get_param("occupancy_bits_per_bucket"),
                 "bloom_filter_bytes": dev.get_param("bloom_filter_bytes"),
                 "final_reduce_ms": round(reduce_s * 1e3, 3) if world > 1 else 0.0,
-                "parallelism": "reads sharded by batch over %d GPU(s), index replicated, one RCCL sum "
-                               "(kmm_comm_reduce_counts)" % world,
+                "parallelism": "reads sharded by batch over %d GPU(s), index replicated, one RCCL sum (%s)"
+                               % (world, "kmm_comm_reduce_counts" if own_comm or world == 1 else "torch.distributed"),
                 "kernel_ms_per_step": {n: round(t[0] / args.steps, 3) for n, t in timing.items() if t[1]},
             },
             "roofline": {
