@@ -24,10 +24,16 @@
 //                     sorts them by FINE partition inside LDS, writes the sorted item + directory row start2
 //   pass 3  k_rx_p3   work item (fine partition f, up to 1024 items of its coarse partition): loads f's slice
 //                     (directory, keys) into LDS, streams f's runs from the items, probes LDS, counts hits per
-//                     entry in LDS, then adds the counters to the per-entry count vector `ecnt` (contiguous
-//                     atomics), applying the frequency filter (mapper.pyx:64-66) there
-//   flush   k_rx_flush  at the next synchronising call: counts[node[e]] += ecnt[e]  (mapper.pyx:68 summed per
-//                     entry first — the reference's GpuCounter does exactly this, gpu_counter.py:26-37)
+//                     entry in LDS (an entry the frequency filter of mapper.pyx:64-66 excludes carries a flag in
+//                     its counter), then adds the counters to the per-entry count vector `ecnt` (contiguous atomics)
+//   flush   k_rx_flush_sorted / k_rx_flush  at the next synchronising call: counts[node[e]] += ecnt[e]  (mapper.pyx:68
+//                     summed per entry first — the reference's GpuCounter does exactly this, gpu_counter.py:26-37)
+//
+// What the passes are tuned against (profiles/r02/README.md): pass 1 is VALU-bound, pass 2 moves 16 B per k-mer at
+// the chip's mixed read/write rate, pass 3 streams ~256-byte runs at the rate tools/chunk_read_bench.hip gives for
+// that shape.  Work between two workgroup barriers is kept short: wavefront prefix sums use DPP additions, not
+// ds_bpermute; counters are cleared off the critical path; the next block / item is requested before the current
+// one is sorted.
 //
 // Between the passes a k-mer q travels as x = (q / modulo) << (w + f2) | (q % modulo) & (2^(w+f2) - 1): the
 // quotient and the hash bits BELOW the coarse partition number.  Inside a coarse partition (and so inside a
