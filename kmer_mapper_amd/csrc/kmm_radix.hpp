@@ -217,8 +217,14 @@ __device__ __forceinline__ uint32_t rx_scan256(const uint32_t *s_in, uint32_t *s
 #define RX_PT_END(iv, base)
 #endif
 
+// Key of a slot that holds no k-mer: any value >= F; the lane's own spare counter behind the real ones.
+__device__ __forceinline__ uint32_t rx_spare_key()
+{
+    return (uint32_t)RX_MAXF + 1u + (threadIdx.x & 63);
+}
+
 // Counting sort of the workgroup's k-mers (RX_KPT per thread) inside LDS.  prep(i) finalises slot i of q (it may
-// rewrite q[i]) and returns its key < F, or F for a slot that holds no k-mer.  Then: the sorted run array goes to
+// rewrite q[i]) and returns its key < F, or rx_spare_key() for a slot that holds no k-mer.  Then: the sorted run array goes to
 // `out` as one contiguous coalesced copy, where each key's run starts (and the total) to dir_row[0..F].  sbuf may
 // hold the inputs: they are in registers before anything is written.
 struct RxNoHook {
@@ -250,11 +256,12 @@ __device__ __forceinline__ void rx_sort_emit(uint64_t (&q)[RX_KPT], PrepFn prep,
 #pragma unroll
         for (int i = 0; i < RB; ++i)
             ck[i] = prep(h + i);
-        // (a slot without a k-mer counts into a spare counter of its own lane: with one shared spare counter the
-        // ~20 % of windows that cross a read boundary serialise every atomic instruction on one LDS address)
+        // (prep returns rx_spare_key() for a slot without a k-mer: a spare counter of the slot's own lane — with
+        // one shared spare counter the ~20 % of windows that cross a read boundary serialise every atomic
+        // instruction on one LDS address)
 #pragma unroll
         for (int i = 0; i < RB; ++i)
-            rk[i] = atomicAdd(&s_cnt[ck[i] == (uint32_t)F ? (uint32_t)RX_MAXF + 1u + (tid & 63) : ck[i]], 1u);
+            rk[i] = atomicAdd(&s_cnt[ck[i]], 1u);
 #pragma unroll
         for (int i = 0; i < RB; ++i)
             cr[h + i] = (ck[i] << 16) | (rk[i] & 0xFFFFu); // (a spare counter is never cleared: its rank means nothing)
@@ -278,7 +285,7 @@ __device__ __forceinline__ void rx_sort_emit(uint64_t (&q)[RX_KPT], PrepFn prep,
             pos[i] = s_base[cr[h + i] >> 16] + (cr[h + i] & 0xFFFFu);
 #pragma unroll
         for (int i = 0; i < RX_PLACE_BATCH; ++i)
-            if ((cr[h + i] >> 16) != (uint32_t)F)
+            if ((cr[h + i] >> 16) < (uint32_t)F)
                 sbuf[pos[i]] = q[h + i];
     }
     __syncthreads();
@@ -428,6 +435,7 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p1(ReadsView rv, const uint64_t
     const int F1 = (int)rx.F1;
     uint32_t lookups = 0;
     const int sh = rx.w + rx.f2;
+    const uint32_t spare = rx_spare_key();
     RX_PT_DECL;
 #ifndef RX_P1_NO_PREFETCH
     constexpr bool PREFETCH = R == 1 && MODE != MODE_KMERS;
@@ -485,14 +493,14 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p1(ReadsView rv, const uint64_t
             auto fwd = [&](int i) {
                 uint32_t c;
                 x[i] = rx_pack(iv, sh, q[i], &c);
-                return ((valid >> i) & 1u) ? c : (uint32_t)F1;
+                return ((valid >> i) & 1u) ? c : spare;
             };
             rx_sort_emit<RX_RB1, true, true>(x, fwd, F1, sbuf, s_cnt, s_base, s_wave, rx.buf1 + (size_t)sb * 2 * RX_B,
                          rx.start1 + (size_t)sb * 2 * (size_t)(F1 + 1) RX_PT_ARG);
             auto rev = [&](int i) {
                 uint32_t c;
                 x[i] = rx_pack(iv, sh, revcomp(q[i], k), &c);
-                return ((valid >> i) & 1u) ? c : (uint32_t)F1;
+                return ((valid >> i) & 1u) ? c : spare;
             };
             rx_sort_emit<RX_RB1, MODE == MODE_KMERS, true>(x, rev, F1, sbuf, s_cnt, s_base, s_wave, rx.buf1 + ((size_t)sb * 2 + 1) * RX_B,
                          rx.start1 + ((size_t)sb * 2 + 1) * (size_t)(F1 + 1) RX_PT_ARG);
@@ -500,7 +508,7 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p1(ReadsView rv, const uint64_t
             auto fwd = [&](int i) {
                 uint32_t c;
                 q[i] = rx_pack(iv, sh, q[i], &c);
-                return ((valid >> i) & 1u) ? c : (uint32_t)F1;
+                return ((valid >> i) & 1u) ? c : spare;
             };
             rx_sort_emit<RX_RB1, MODE == MODE_KMERS, true>(q, fwd, F1, sbuf, s_cnt, s_base, s_wave, rx.buf1 + (size_t)sb * RX_B,
                          rx.start1 + (size_t)sb * (size_t)(F1 + 1) RX_PT_ARG);
@@ -700,6 +708,7 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p2(IndexView iv, RxView rx)
     const uint32_t NB = rx.NB;
     uint32_t gathered = 0; // conservation check (kmm_get_param "radix_p2_kmers"): must equal pass 1's lookups
     uint32_t scan_flip = 0;
+    const uint32_t spare = rx_spare_key();
     const int F2 = (int)rx.F2;
     // XCD x takes the coarse partitions [x cs, (x+1) cs), items j-major: the workgroups of one XCD work on item j
     // of ~cs adjacent coarse partitions together, whose runs are neighbours inside every pass-1 block
@@ -851,7 +860,7 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p2(IndexView iv, RxView rx)
             gathered += (uint32_t)__popc(valid);
             RX_PT(5); // sub-run list, gather into LDS and back into registers
             auto fine = [&](int i) {
-                return ((valid >> i) & 1u) ? ((uint32_t)(q[i] >> rx.w) & (uint32_t)(F2 - 1)) : (uint32_t)F2;
+                return ((valid >> i) & 1u) ? ((uint32_t)(q[i] >> rx.w) & (uint32_t)(F2 - 1)) : spare;
             };
             auto mid = [&]() { rd_n = run_desc(it_n, it_n.b0); };
             rx_sort_emit<RX_RB2, false, false>(q, fine, F2, sbuf, s_cnt, s_base, s_wave, rx.buf2 + (size_t)it.item * RX_B,
