@@ -38,6 +38,7 @@ def test_full_batch_at_config_size(kmm, oracle, n_index):
         else:
             assert dev.get_param("wide_buckets") == 1 and dev.get_param("occupancy_filter") == 0
         assert dev.get_param("radix_available") == 1
+        assert dev.get_param("radix_sorted_flush") == 1     # one entry per node: the node-ordered entry list is built
         dev.set_timing(True)
         res = {}
         for name, path, general in (("direct_uniform", 1, False), ("direct_general", 1, True),
