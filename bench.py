@@ -66,6 +66,7 @@ def main():
     ap.add_argument("--part-shift", type=int, default=None)
     ap.add_argument("--bucket-order-flush", action="store_true", help="radix path: flush the per-entry counts in bucket order (scattered atomics)")
     ap.add_argument("--grid-per-cu", type=int, default=None)
+    ap.add_argument("--radix-grid-per-cu", type=int, default=None, help="persistent workgroups per CU of radix passes 2 and 3 (1 or 2)")
     ap.add_argument("--static-schedule", action="store_true", help="disable the dynamic tile queue")
     ap.add_argument("--dyn-chunk", type=int, default=None)
     ap.add_argument("--no-filter", action="store_true", help="disable the L2 occupancy-bitmap prefilter")
@@ -134,6 +135,8 @@ def main():
         dev.set_param("grid_per_cu", args.grid_per_cu)
     if args.part_shift is not None:
         dev.set_param("part_shift", args.part_shift)
+    if args.radix_grid_per_cu is not None:
+        dev.set_param("radix_grid_per_cu", args.radix_grid_per_cu)
     if args.bucket_order_flush:
         dev.set_param("radix_sorted_flush", 0)
     counts = torch.zeros(mx + 1, dtype=torch.int32, device=dev_t)    # uint32 bits; wrap-add == int32 add

@@ -13,8 +13,8 @@ Differences that follow from replacing the engine (all documented in DESIGN.md):
   * `-b/--index-bundle`, Minimal/Counter index variants (util.py:52-66) are out of scope -> error.
   * launched under torchrun (WORLD_SIZE > 1) every rank maps its own BYTE RANGE of the read file (both ends
     re-synchronised to record starts, reads_io.rank_byte_range: no rank reads or scans another rank's bytes);
-    ranks sharing one .gz stream (not seekable) take chunk i mod WORLD_SIZE and only look at the last lines
-    of the chunks they skip; the count vectors are summed with one RCCL reduce; rank 0 writes the output.
+    ranks sharing one .gz stream (not seekable) take chunk i mod WORLD_SIZE and cut the chunks they skip by the
+    record parser's own rule (newline count, reads_io.records_cut); the count vectors are summed with one RCCL reduce; rank 0 writes the output.
 """
 import argparse
 import logging
@@ -28,7 +28,7 @@ from .distributed import chunk_owner
 from .engine import DeviceIndex
 from .kmer_index import KmerIndex
 from . import _lib
-from .reads_io import RawChunker, last_record_start, prefetch, rank_byte_range, read_chunks, sniff_format
+from .reads_io import RawChunker, prefetch, rank_byte_range, read_chunks, records_cut, sniff_format
 
 
 def main():
@@ -128,8 +128,9 @@ def map_gpu_raw(index, path, chunk_size, fmt, k, map_reverse_complements=False,
             if owns(i):
                 used, n_rec = dev.map_records(buf, buf.shape[0], kfmt, k, max_index_lookup_frequency,
                                               also_revcomp=map_reverse_complements)
-            else:   # a chunk of a shared .gz stream that another rank maps: only its record boundary is needed
-                used, n_rec = (buf.shape[0] if chunker.eof else last_record_start(buf, fmt)), 0
+            else:   # a chunk of a shared .gz stream that another rank maps: only its record boundary is needed,
+                    # cut by the SAME rule as the GPU parser's `consumed` (newline count), at end of input too
+                used, n_rec = records_cut(buf, fmt), 0
             if used == 0:
                 if chunker.eof:
                     raise ValueError("trailing bytes at end of %s do not form a complete record" % path)

@@ -37,8 +37,11 @@ def _inflate_member(raw):
         out = zlib.decompress(raw[12 + xlen:-8], wbits=-15)
     except zlib.error as exc:
         raise ValueError("corrupt BGZF member: %s" % exc) from None
-    if len(out) != struct.unpack_from("<I", raw, len(raw) - 4)[0]:
+    crc, isize = struct.unpack_from("<II", raw, len(raw) - 8)
+    if len(out) != isize:
         raise ValueError("BGZF member inflates to %d bytes, its trailer says otherwise" % len(out))
+    if (zlib.crc32(out) & 0xFFFFFFFF) != crc:
+        raise ValueError("corrupt BGZF member: CRC32 of the inflated bytes differs from the trailer")
     return out
 
 
@@ -131,20 +134,28 @@ def _gzip_pieces(path, piece=1 << 24):
     """One (or several concatenated) plain gzip member(s): a single thread, large reads."""
     with open(path, "rb", buffering=0) as f:
         d = zlib.decompressobj(wbits=31)
+        fed = False                            # has the current member received any input?
         while True:
             raw = f.read(piece)
             if not raw:
                 tail = d.flush()
                 if tail:
                     yield tail
+                if fed and not d.eof:          # gzip.open raises EOFError here; partial counts must never pass silently
+                    raise EOFError("%s: compressed file ended before the end-of-stream marker was reached" % path)
                 return
             while raw:
-                out = d.decompress(raw)
+                try:
+                    out = d.decompress(raw)
+                except zlib.error as exc:
+                    raise ValueError("%s: corrupt gzip stream: %s" % (path, exc)) from None
+                fed = True
                 if out:
                     yield out
-                if d.eof:                      # next member of a concatenated file
+                if d.eof:                      # next member of a concatenated file (zlib has checked CRC32 + ISIZE)
                     raw = d.unused_data
                     d = zlib.decompressobj(wbits=31)
+                    fed = False
                 else:
                     raw = b""
 

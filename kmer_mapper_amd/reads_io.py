@@ -323,6 +323,19 @@ def last_record_start(buf, fmt):
         back *= 4
 
 
+def records_cut(buf, fmt):
+    """Number of leading bytes of `buf` that kmm_map_records would consume: the byte after the last newline whose
+    1-based count is a multiple of the record's line count (4 for FASTQ, 2 for two-line FASTA) — the rule of the GPU
+    record parser (csrc/kmm_records.hpp, k_rec_scan2: target = total - total % period).  Ranks that skip a chunk of
+    a shared .gz stream MUST cut it with this rule: the owner advances by the parser's `consumed`, and a rule that
+    holds a FASTA record back until the next '>' has been seen (last_record_start) disagrees whenever a chunk ends
+    exactly on a record's last newline — the stream positions of the ranks would drift apart."""
+    period = 4 if fmt == "fastq" else 2
+    nl = np.flatnonzero(buf == _NL)
+    whole = (nl.shape[0] // period) * period
+    return int(nl[whole - 1]) + 1 if whole else 0
+
+
 # ------------------------------------------------------------------------------------------------
 # Raw-chunk reader for the GPU record parser (kmm_map_records): the host only moves bytes.
 # ------------------------------------------------------------------------------------------------

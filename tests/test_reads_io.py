@@ -1,4 +1,7 @@
 """CPU tests of the chunked FASTA/FASTQ(+gz) reader."""
+import struct
+import zlib
+
 import numpy as np
 import pytest
 
@@ -198,6 +201,75 @@ def test_rank_byte_ranges_fasta_and_shared_gz_stream(tmp_path):
                    for a, b in zip(whole, got))
 
 
+def _gpu_parser_consumed(buf, period):
+    """Byte-wise restatement of kmm_map_records' `consumed` (csrc/kmm_records.hpp k_rec_scan2): the byte after the
+    last newline whose 1-based count is a multiple of `period`."""
+    cut = count = 0
+    for i, c in enumerate(bytes(buf)):
+        if c == 10:
+            count += 1
+            if count % period == 0:
+                cut = i + 1
+    return cut
+
+
+@pytest.mark.parametrize("fmt", ["fasta", "fastq"])
+def test_ranks_sharing_a_gz_stream_cut_skipped_chunks_like_the_gpu_parser(tmp_path, fmt):
+    """the owner of a chunk advances by the GPU parser's `consumed` (newline-count rule); a rank that
+    skips the chunk must cut it at the same byte, also when the chunk ends exactly on a record's last newline (where
+    a 'next header seen' rule holds the last FASTA record back).  Simulated ranks over RawChunker, G in {2, 3, 8}:
+    every record is owned exactly once and all ranks walk the same cuts."""
+    import gzip
+    from kmer_mapper_amd import reads_io as rio
+    rng = np.random.default_rng(31)
+    recs = []
+    for i in range(1500):
+        seq = bytes(rng.choice(list(b"ACGT"), size=int(rng.integers(1, 120))))
+        recs.append((b">r%d\n" % i + seq + b"\n") if fmt == "fasta" else
+                    (b"@r%d\n" % i + seq + b"\n+\n" + b"I" * len(seq) + b"\n"))
+    data = b"".join(recs)
+    pz = str(tmp_path / ("t.%s.gz" % ("fa" if fmt == "fasta" else "fq")))
+    with gzip.open(pz, "wb") as f:
+        f.write(data)
+    period = 2 if fmt == "fasta" else 4
+    # the 3-record example of the finding: a buffer that ends on a record's final newline
+    three = b"".join(recs[:3])
+    assert rio.records_cut(np.frombuffer(three, np.uint8), fmt) == len(three) == _gpu_parser_consumed(three, period)
+    if fmt == "fasta":
+        assert rio.last_record_start(np.frombuffer(three, np.uint8), fmt) < len(three)   # the rule that disagreed
+    for chunk_size in (997, 4096, len(recs[0]) + len(recs[1])):      # the last one ends chunks on record boundaries
+        for G in (2, 3, 8):
+            owned, cuts = [], []
+            for g in range(G):
+                ch = rio.RawChunker(pz, chunk_size)
+                mine, my_cuts, i = bytearray(), [], 0
+                while True:
+                    buf = ch.next_chunk()
+                    if buf is None:
+                        break
+                    if i % G == g:
+                        used = _gpu_parser_consumed(buf, period)
+                        mine += buf[:used].tobytes()
+                    else:
+                        used = rio.records_cut(buf, fmt)
+                    assert used > 0
+                    my_cuts.append(used)
+                    ch.consumed(used)
+                    i += 1
+                ch.close()
+                owned.append(bytes(mine))
+                cuts.append(my_cuts)
+            assert all(c == cuts[0] for c in cuts), (chunk_size, G)
+            assert sum(len(o) for o in owned) == len(data)
+            # interleave the owners' chunks back in stream order
+            pos, parts = [0] * G, []
+            for i, used in enumerate(cuts[0]):
+                g = i % G
+                parts.append(owned[g][pos[g]:pos[g] + used])
+                pos[g] += used
+            assert b"".join(parts) == data, (chunk_size, G)
+
+
 # ---------------------------------------------------------------- .gz input inflated on several cores
 def test_bgzf_is_inflated_member_parallel_and_plain_gzip_still_works(tmp_path):
     """BGZF (independent members with their size in the header, what bgzip writes) is inflated on a thread pool;
@@ -244,6 +316,29 @@ def test_bgzf_is_inflated_member_parallel_and_plain_gzip_still_works(tmp_path):
             ch.consumed(used)
         ch.close()
         assert bytes(out) == data
+    # a truncated plain gzip file must raise like gzip.open does, not yield partial reads
+    pt = str(tmp_path / "trunc.fq.gz")
+    whole_gz = open(pg, "rb").read()
+    for cut in (len(whole_gz) // 2, len(whole_gz) - 4):
+        open(pt, "wb").write(whole_gz[:cut])
+        with pytest.raises(EOFError):
+            with gz_io.open_gz(pt, 1) as s:
+                s.read()
+        with pytest.raises(EOFError):
+            list(rio.read_chunks(pt, 60_000))
+    # a BGZF payload of the right length but wrong content: the member's CRC32 objects
+    raw_b = bytearray(open(pb, "rb").read())
+    first = gz_io._bgzf_block_size(bytes(raw_b[:18]))
+    fixed = bytes(raw_b[:first])
+    xlen = struct.unpack_from("<H", fixed, 10)[0]
+    body = zlib.decompress(fixed[12 + xlen:-8], wbits=-15)
+    forged = bytearray(body)
+    forged[10] ^= 0x01
+    c = zlib.compressobj(6, zlib.DEFLATED, -15)
+    payload = c.compress(bytes(forged)) + c.flush()
+    member = (fixed[:16] + struct.pack("<H", 18 + len(payload) + 8 - 1) + payload + fixed[-8:])   # old CRC, same ISIZE
+    with pytest.raises(ValueError, match="CRC32"):
+        gz_io._inflate_member(member)
     with pytest.raises(ValueError):
         bad = bytearray(open(pb, "rb").read())
         bad[len(bad) // 2] ^= 0xFF                              # corrupt a member: zlib or the size check objects

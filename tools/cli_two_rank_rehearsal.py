@@ -21,18 +21,19 @@ def main():
     os.makedirs(d, exist_ok=True)
     index, genome = syn.make_index(20000, seed=5)
     bases, offs = syn.make_ragged_reads(genome, 30000, 20, 220, seed=6)
-    idx_path, fq = os.path.join(d, "index.npz"), os.path.join(d, "reads.fq")
+    idx_path, fq, fa = os.path.join(d, "index.npz"), os.path.join(d, "reads.fq"), os.path.join(d, "reads.fa")
     if rank == 0:
         index.to_file(idx_path)
         reads_io.write_fastq(fq, ReadBatch(bases, offs))
         reads_io.write_fastq(fq + ".gz", ReadBatch(bases, offs), gz=True)
+        reads_io.write_fasta(fa + ".gz", ReadBatch(bases, offs), gz=True)   # two-line FASTA through the GPU parser
     import torch.distributed as dist
     dist.init_process_group(os.environ.get("KMM_DIST_BACKEND", "gloo"))
     dist.barrier()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     ok = True
-    for path in (fq, fq + ".gz"):
-        out = os.path.join(d, "out_gz" if path.endswith(".gz") else "out")
+    for path in (fq, fq + ".gz", fa + ".gz"):
+        out = os.path.join(d, "out_" + os.path.basename(path).replace(".", "_"))
         run_argument_parser(["map", "-i", idx_path, "-f", path, "-o", out, "-c", "300000"])
         dist.barrier()
         if rank == 0:
