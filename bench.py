@@ -64,6 +64,7 @@ def main():
     ap.add_argument("--skewed", action="store_true", help="node = i mod 1000 (atomic contention)")
     ap.add_argument("--path", type=int, default=0, help="0 auto (by batch size), 1 direct fused kernel, 2 radix path")
     ap.add_argument("--part-shift", type=int, default=None)
+    ap.add_argument("--fine-bits", type=int, default=None, help="radix path: log2 fine partitions per coarse partition")
     ap.add_argument("--bucket-order-flush", action="store_true", help="radix path: flush the per-entry counts in bucket order (scattered atomics)")
     ap.add_argument("--grid-per-cu", type=int, default=None)
     ap.add_argument("--radix-grid-per-cu", type=int, default=None, help="persistent workgroups per CU of radix passes 2 and 3 (1 or 2)")
@@ -84,6 +85,10 @@ def main():
     ap.add_argument("--dist-backend", default="nccl",
                     help="nccl (= RCCL, the real multi-GPU path) or gloo (rehearsal on a 1-GPU box: all "
                          "ranks share device LOCAL_RANK %% device_count, the reduce runs on host copies)")
+    ap.add_argument("--strong", action="store_true",
+                    help="strong scaling (BASELINE configs[3]): the job is --steps x --reads reads IN TOTAL (default 10 x 10 M "
+                         "= 100 M), split evenly over the ranks; timed region = map + flush + RCCL reduce as always. "
+                         "Default (weak): every rank maps --steps batches of --reads reads.")
     ap.add_argument("--max-freq", type=int, default=1000,
                     help="max_index_lookup_frequency (-1 filters every hit: timing ablation without atomics)")
     args = ap.parse_args()
@@ -135,6 +140,8 @@ def main():
         dev.set_param("grid_per_cu", args.grid_per_cu)
     if args.part_shift is not None:
         dev.set_param("part_shift", args.part_shift)
+    if args.fine_bits is not None:
+        dev.set_param("fine_bits", args.fine_bits)
     if args.radix_grid_per_cu is not None:
         dev.set_param("radix_grid_per_cu", args.radix_grid_per_cu)
     if args.bucket_order_flush:
@@ -180,8 +187,25 @@ def main():
         del o
     log("setup done in %.1fs; %d reads/batch/GPU, %d k-mers/step/GPU" % (time.time() - t_setup, R, kmers_per_step))
 
+    # batch sizes of this rank: weak scaling = --steps full batches; strong scaling = this rank's share of the
+    # --steps x --reads reads of the whole job, cut into batches of at most --reads reads
+    if args.strong:
+        from kmer_mapper_amd.distributed import shard_range
+        lo_r, hi_r = shard_range(R * args.steps, rank, world)
+        sizes = [R] * ((hi_r - lo_r) // R) + ([(hi_r - lo_r) % R] if (hi_r - lo_r) % R else [])
+        assert not (args.records or args.operator), "--strong times the fused reads path"
+    else:
+        sizes = [R] * args.steps
+    my_kmers = sum(sizes) * max(L - k + 1, 0)
+
     def step(i):
         b = batches[i & 1]
+        if sizes[i] != R:
+            if offs is not None:
+                dev.map_reads(b[:sizes[i] * L], offs[:sizes[i] + 1], k, args.max_freq)
+            else:
+                dev.map_reads_uniform(b[:sizes[i] * L], sizes[i], L, k, args.max_freq)
+            return
         if fastq_batches is not None:
             used, n_rec = dev.map_records(fastq_batches[i & 1], fmt=kmm_lib.FORMAT_FASTQ, k=k,
                                           max_index_lookup_frequency=args.max_freq)
@@ -237,7 +261,7 @@ def main():
 
     dev.set_timing(True)
     t0 = time.perf_counter()
-    for i in range(args.steps):
+    for i in range(len(sizes)):
         step(i)
     dev.synchronize()
     t_map = time.perf_counter()
@@ -250,14 +274,21 @@ def main():
 
     elapsed = t1 - t0
     reduce_s = t1 - t_map
+    per_rank_map_ms = [round((t_map - t0) * 1e3, 3)]
     if world > 1:
-        tt = torch.tensor([elapsed, reduce_s], dtype=torch.float64,
-                          device=dev_t if args.dist_backend == "nccl" else "cpu")
+        cdev = dev_t if args.dist_backend == "nccl" else "cpu"
+        tt = torch.tensor([elapsed, reduce_s], dtype=torch.float64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed, reduce_s = tt[0].item(), tt[1].item()
-
-    total_kmers = kmers_per_step * args.steps * world
+        mine = torch.tensor([(t_map - t0) * 1e3, float(my_kmers)], dtype=torch.float64, device=cdev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank_map_ms = [round(t[0].item(), 3) for t in every]
+        total_kmers = int(sum(t[1].item() for t in every))
+    else:
+        total_kmers = my_kmers
     hits = int(counts.to(torch.int64).bitwise_and(0xFFFFFFFF).sum().item()) if rank == 0 else 0
+    hbm_free, hbm_total = torch.cuda.mem_get_info(dev_t)
 
     result = None
     if rank == 0:
@@ -270,7 +301,7 @@ def main():
             used = [n for n in RX_KERNELS if timing[n][1]]
             launches = timing["k_rx_p1"][1]                      # one pipeline (one launch of every kernel) per step
             avg_kernel_s = sum(timing[n][0] for n in used) / max(launches, 1) / 1e3
-            kmers_per_launch = kmers_per_step * args.steps / max(launches, 1)
+            kmers_per_launch = my_kmers / max(launches, 1)
             per_kernel = {}
             for n in used:
                 t_s = timing[n][0] / max(launches, 1) / 1e3
@@ -284,7 +315,7 @@ def main():
         else:
             kernel_ms, launches = timing[dom]
             avg_kernel_s = kernel_ms / 1e3 / max(launches, 1)
-            kmers_per_launch = kmers_per_step * args.steps / max(launches, 1)
+            kmers_per_launch = my_kmers / max(launches, 1)
             b_alg = B_ALG[dom]
         achieved = kmers_per_launch * b_alg / avg_kernel_s / 1e9
         traffic = None
@@ -338,7 +369,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if args.strong else "weak",
             "vs_baseline": None,
             "dtype": "u64",
             "data": "synthetic",
@@ -350,10 +381,21 @@ def main():
                                "operator kmm_map_kmers on pre-extracted k-mers" if args.operator else
                                "fused kmm_map_reads" + ("" if args.general_path else "_uniform")),
                 "kmers_per_step_per_gpu": kmers_per_step,
+                "reads_in_hbm_when_timed": True, "h2d_in_timed_region": False,
+                "job": ("strong scaling: %d reads in total split over %d rank(s), batches of <= %d reads"
+                        % (R * args.steps, world, R)) if args.strong else
+                       ("weak scaling: every rank maps %d batches of %d reads" % (args.steps, R)),
+                "batches_this_rank": len(sizes),
+                "per_rank_map_ms": per_rank_map_ms,
+                "flush_ms_total": round(timing["k_rx_flush"][0], 3),
                 "hit_rate": round(hits / max(total_kmers, 1), 4),
                 "nodes": "skewed(mod 1000)" if args.skewed else "uniform",
                 "path": {0: "auto", 1: "direct", 2: "radix"}[args.path],
                 "path_taken": "radix" if per_kernel else "direct",
+                "hbm_in_use_GB": round((hbm_total - hbm_free) / 1e9, 1),
+                "index_views": {"radix_GB": round(dev.get_param("radix_view_bytes") / 1e9, 2),
+                                "direct_GB": round(dev.get_param("direct_view_bytes") / 1e9, 2),
+                                "direct_resident": bool(dev.get_param("direct_view_resident"))},
                 "radix_fine_partitions": dev.get_param("n_partitions"),
                 "radix_coarse_partitions": dev.get_param("n_coarse_partitions"),
                 "occupancy_filter": bool(dev.get_param("occupancy_filter")),
@@ -362,7 +404,7 @@ def main():
                 "final_reduce_ms": round(reduce_s * 1e3, 3) if world > 1 else 0.0,
                 "parallelism": "reads sharded by batch over %d GPU(s), index replicated, one RCCL sum (%s)"
                                % (world, "kmm_comm_reduce_counts" if own_comm or world == 1 else "torch.distributed"),
-                "kernel_ms_per_step": {n: round(t[0] / args.steps, 3) for n, t in timing.items() if t[1]},
+                "kernel_ms_per_step": {n: round(t[0] / max(len(sizes), 1), 3) for n, t in timing.items() if t[1]},
             },
             "roofline": {
                 "bound": "hbm",
@@ -381,26 +423,33 @@ def main():
             },
         }
 
-    # ---- PCIe-inclusive rate: the same steps with the reads in pinned host memory, staged by every call ----
+    # ---- SURVEY 8(d)'s map-phase figure: the SAME steps with the reads in pinned host memory, staged by every call
+    # (double-buffered on a copy stream).  `value` above times reads that are already resident in HBM (the bench
+    # contract); this one includes the read H2D and is bound by the PCIe link (~50 GB/s of read bytes per GPU).
     if rank == 0 and world == 1 and not args.no_h2d_leg and not (args.records or args.operator or args.general_path):
         host_batches = [b.cpu().pin_memory() for b in batches]
-        n_h = min(args.steps, 4)
         dev.map_reads_uniform(host_batches[0], R, L, k, args.max_freq)      # warm the staging buffers
         dev.synchronize()
         th0 = time.perf_counter()
-        for i in range(n_h):
-            dev.map_reads_uniform(host_batches[i & 1], R, L, k, args.max_freq)
+        for i in range(len(sizes)):
+            dev.map_reads_uniform(host_batches[i & 1][:sizes[i] * L], sizes[i], L, k, args.max_freq)
         dev.synchronize()
         th = time.perf_counter() - th0
-        result["value_incl_h2d"] = round(kmers_per_step * n_h / th / 1e6, 1)
+        v_h2d = my_kmers / th / 1e6
+        result["value_incl_h2d"] = round(v_h2d, 1)
+        result["config"]["value_incl_h2d"] = round(v_h2d, 1)
         result["config"]["h2d_leg"] = ("%d steps with the batch in pinned host memory, copied to HBM by every call "
                                        "(double-buffered staging on a copy stream): %.1f GB/s of read bytes over PCIe"
-                                       % (n_h, R * L * n_h / th / 1e9))
+                                       % (len(sizes), sum(sizes) * L / th / 1e9))
+        result["roofline"]["frac_incl_h2d"] = round(v_h2d * 1e6 * B_ALG_PER_KMER / 1e9 / HBM_PEAK_GBPS, 4)
+        result["roofline"]["note"] = ("frac prices the HBM-resident pipeline (sum of the kernels' average durations); "
+                                      "frac_incl_h2d the whole map phase with read staging over PCIe included (wall clock)")
         del host_batches
 
     # ---- CPU baseline + parity on a bounded sample (rank 0, N=1 only) ---------------------------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle        # checker / reported baseline only
+        oracle_flags = oracle.use_native_build()      # -O3 -march=native, built on the box that runs it (setup.py:10-15)
         n_s = min(args.cpu_sample_reads, R)
         sample = batches[0][: n_s * L].cpu().numpy()
         s_offs = np.arange(n_s + 1, dtype=np.int64) * L
@@ -425,8 +474,8 @@ def main():
             "cores": n_threads,
             "kind": "port",
             "sample": "first %d reads of batch 0 (%d k-mers, %.1f s wall); oracle/kmm_oracle.c "
-                      "oracle_map_reads, gcc -O3, %d pthreads, private count vectors summed"
-                      % (n_s, n_k, tc, n_threads),
+                      "oracle_map_reads, gcc %s, %d pthreads, private count vectors summed"
+                      % (n_s, n_k, tc, oracle_flags, n_threads),
         }
         # BASELINE.md section 3 also promises "all physical cores": every core this process may run on,
         # capped so that the private count vectors (4 B x nodes per thread) stay within 32 GB
@@ -435,8 +484,12 @@ def main():
             ta0 = time.perf_counter()
             expect_all, _ = oracle.map_reads(index, mx, sample, s_offs, k, n_threads=n_all)
             ta = time.perf_counter() - ta0
-            result["cpu_baseline"]["all_cores"] = {"value": round(n_k / ta / 1e6, 2), "cores": n_all,
-                                                   "wall_s": round(ta, 1)}
+            result["cpu_baseline"]["all_cores"] = {
+                "value": round(n_k / ta / 1e6, 2), "cores": n_all, "wall_s": round(ta, 1),
+                "note": "same structure as the reference's pool (one private count vector per worker, summed): with "
+                        "%d-byte vectors more workers are not faster; `best` is the faster of the two legs"
+                        % (4 * (mx + 1))}
+            result["cpu_baseline"]["best"] = max(result["cpu_baseline"]["value"], round(n_k / ta / 1e6, 2))
             parity = parity and bool(np.array_equal(expect_all, expect))
         result["cpu_baseline"]["available_cores"] = avail
         result["speedup_vs_cpu_16_threads"] = round(result["value"] / max(result["cpu_baseline"]["value"], 1e-9), 1)

@@ -45,6 +45,9 @@ extern "C" {
 #define KMM_ERR_INVALID_BASE (-4)  /* a read byte is not a nucleotide under the lookup table     */
 #define KMM_ERR_NOMEM (-5)
 #define KMM_ERR_MALFORMED (-6)     /* raw FASTA/FASTQ chunk does not have the expected line structure */
+#define KMM_ERR_INTERNAL (-7)      /* self-check of the radix path failed (k-mers emitted by pass 1 != gathered by
+                                      pass 2 != probed by pass 3): counts are NOT returned; sticky until
+                                      kmm_reset_counts */
 
 #define KMM_MAX_K 31               /* a k-mer is packed 2 bits/base into a uint64; bionumpy's
                                       get_kmers (util.py:72) is used with k <= 31                */

@@ -20,6 +20,7 @@ KMM_ERR_INDEX = -3
 KMM_ERR_INVALID_BASE = -4
 KMM_ERR_NOMEM = -5
 KMM_ERR_MALFORMED = -6
+KMM_ERR_INTERNAL = -7
 FORMAT_FASTA2, FORMAT_FASTQ = 2, 4
 
 # kernel ids of kmm_get_timing (include/kmm.h)

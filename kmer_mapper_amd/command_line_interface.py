@@ -74,8 +74,10 @@ def map_cpu(args, kmer_index, chunk_sequence):
 
 
 def map_gpu(index, chunks, k, hash_map_size=0, map_reverse_complements=False,
-            max_index_lookup_frequency=1000, device=0, rank=0, world_size=1):
-    """command_line_interface.py:59-79 on the HIP engine: chunks -> fused kmm_map_reads calls."""
+            max_index_lookup_frequency=1000, device=0, rank=0, world_size=1, before_fetch=None):
+    """command_line_interface.py:59-79 on the HIP engine: chunks -> fused kmm_map_reads calls.
+    before_fetch(dev): called with the open handle after the last chunk and before the counts are copied to the
+    host (the multi-rank reduce runs there, on the device)."""
     max_node_id = index.max_node_id() if hasattr(index, "max_node_id") else int(np.max(index._nodes))
     dev = DeviceIndex.from_index(index, max_node_id, device=device)
     t_start = time.perf_counter()
@@ -95,6 +97,8 @@ def map_gpu(index, chunks, k, hash_map_size=0, map_reverse_complements=False,
             n_kmers += chunk.n_kmers(k)
             logging.debug("GPU: chunk %d (%d reads) submitted in %.5f sec", i, len(chunk),
                           time.perf_counter() - t0)
+        if before_fetch is not None:
+            before_fetch(dev)
         node_counts = dev.get_node_counts()
     finally:
         dev.close()
@@ -105,7 +109,7 @@ def map_gpu(index, chunks, k, hash_map_size=0, map_reverse_complements=False,
 
 
 def map_gpu_raw(index, path, chunk_size, fmt, k, map_reverse_complements=False,
-                max_index_lookup_frequency=1000, device=0, rank=0, world_size=1):
+                max_index_lookup_frequency=1000, device=0, rank=0, world_size=1, before_fetch=None):
     """Same job as map_gpu, but the FASTQ / two-line FASTA records are parsed ON THE GPU
     (kmm_map_records): the host only reads (and for .gz inflates) raw bytes."""
     max_node_id = index.max_node_id() if hasattr(index, "max_node_id") else int(np.max(index._nodes))
@@ -140,8 +144,10 @@ def map_gpu_raw(index, path, chunk_size, fmt, k, map_reverse_complements=False,
             n_bytes += used
             chunker.consumed(used)
             i += 1
-        node_counts = dev.get_node_counts()
         n_lookups, n_hits = dev.get_stats()
+        if before_fetch is not None:
+            before_fetch(dev)
+        node_counts = dev.get_node_counts()
     finally:
         chunker.close()
         dev.close()
@@ -177,11 +183,31 @@ def map_bnp(args):
     backend = os.environ.get("KMM_DIST_BACKEND", "nccl")      # "gloo": rehearsal of the N>1 flow on one GPU
     if world > 1 and backend == "gloo":
         device = local_rank % max(_lib.device_count(), 1)
+    before_fetch = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        from .distributed import init_rccl_comm, reduce_node_counts
+        if not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if backend == "nccl" and torch.cuda.is_available():
+                torch.cuda.set_device(local_rank)
+                dist.init_process_group("nccl")
+            else:
+                dist.init_process_group("gloo")
+        if dist.get_backend() == "nccl":
+            # the additive reduce of command_line_interface.py:124-130 as ONE RCCL sum on the device, in place on the
+            # handle's count vector (kmm_comm_reduce_counts); torch.distributed only carries the 128-byte communicator id
+            def before_fetch(dev):
+                t0 = time.perf_counter()
+                init_rccl_comm(dev)
+                dev.comm_reduce_counts(root=0)
+                logging.info("Rank %d: RCCL reduce of the node counts on the device: %.5f sec", rank, time.perf_counter() - t0)
     revcomp = bool(getattr(args, "map_reverse_complements", False))
     fmt, gpu_parsable = sniff_format(args.reads)
     if gpu_parsable and not getattr(args, "host_parser", False):
         node_counts = map_gpu_raw(kmer_index, args.reads, args.chunk_size, fmt, k, revcomp, max_freq,
-                                  device=device, rank=rank, world_size=world)
+                                  device=device, rank=rank, world_size=world, before_fetch=before_fetch)
     else:
         logging.info("Using the host FASTA/FASTQ parser")
         seekable = not str(args.reads).endswith(".gz")
@@ -195,20 +221,13 @@ def map_bnp(args):
             chunks = read_chunks(args.reads, min_chunk_size=args.chunk_size)
         chunks = prefetch(chunks)
         node_counts = map_gpu(kmer_index, chunks, k, getattr(args, "gpu_hash_map_size", 0), revcomp,
-                              max_freq, device=device, rank=rank, world_size=world)
+                              max_freq, device=device, rank=rank, world_size=world, before_fetch=before_fetch)
 
     if world > 1:
-        import torch
-        import torch.distributed as dist
-        from .distributed import reduce_node_counts
-        if not dist.is_initialized():
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            dist.init_process_group(backend if torch.cuda.is_available() else "gloo")
-        t = torch.from_numpy(node_counts.view(np.int32).copy())
-        if dist.get_backend() == "nccl":
-            t = t.cuda(local_rank)
-        reduce_node_counts(t, dst=0)
-        node_counts = t.cpu().numpy().view(np.uint32)
+        if before_fetch is None:        # gloo rehearsal on a 1-GPU box: the sum runs on the host copies
+            t = torch.from_numpy(node_counts.view(np.int32).copy())
+            reduce_node_counts(t, dst=0)
+            node_counts = t.numpy().view(np.uint32)
         if rank != 0:
             return node_counts
 

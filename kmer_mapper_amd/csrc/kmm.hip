@@ -155,6 +155,12 @@ struct kmm_index {
     int occ_shift = 0;                 // log2(bitmap bits per bucket)
     uint32_t bloom_words = 0;          // != 0: occ is a word-blocked Bloom filter
     bool wide = false;                 // 32-byte buckets (chosen when the index is too large for the bitmap)
+    bool direct_deferred = false;      // the direct view (buckets, entries) is packed from the radix view on first use
+    size_t direct_bytes = 0;           // HBM bytes of the direct view (resident or not yet)
+    size_t occ_bytes_plan = 0;         // size of the direct view's pre-filter (0: none)
+    int rx_why_not = 0;                // why the radix path is unavailable: 0 it is available, 1 modulo >= 2^31, 2 more
+                                       // than 512 x 512 slices / slices too dense for LDS, 3 out of memory, 4 the
+                                       // buckets of the index overlap (sum of bucket sizes > n_entries)
     uint32_t *counts = nullptr;
     uint32_t *own_counts_buf = nullptr;
     uint8_t *lut_default = nullptr;
@@ -171,7 +177,7 @@ struct kmm_index {
     // path selection / radix path state (kmm_radix.hpp)
     int path = 0;         // 0 auto, 1 direct, 2 radix
     int grid_per_cu = 64; // upper bound on workgroups per CU of the grid-stride fused kernel
-    bool rx_ok = false;   // the index fits the radix path's fan-out (<= 256 x 256 fine partitions)
+    bool rx_ok = false;   // the index fits the radix path's fan-out (<= 512 x 512 fine partitions)
     int rx_w = 12, rx_f2 = 0; // log2 buckets per fine partition, log2 fine partitions per coarse one
     uint32_t rx_PF = 1, rx_F1 = 1, rx_F2 = 1;
     bool rx_flush_sorted = true; // "radix_sorted_flush": use the node-ordered entry list for the flush
@@ -186,6 +192,7 @@ struct kmm_index {
     uint32_t *rx_pnodes = nullptr, *rx_porig = nullptr, *rx_ecnt = nullptr, *rx_ecnt_acc = nullptr;
     uint32_t *rx_norder = nullptr, *rx_nnode = nullptr; // entries in node order (k_rx_flush_sorted); absent if memory is short
     bool ecnt_dirty = false;  // rx_ecnt holds hits that are not in `counts` yet
+    bool rx_unchecked = false; // radix passes have run since the conservation counters were last compared (drain)
     DevBuf rx_buf1, rx_buf2, rx_meta;
     // deferred device-side error, sticky until kmm_reset_counts
     int sticky_rc = KMM_OK;
@@ -252,6 +259,40 @@ struct ScopedTimer {
 };
 
 int rx_flush(kmm_index *ix);
+int ensure_direct(kmm_index *ix);
+constexpr size_t KMM_STAT_BYTES = (size_t)KMM_STAT_SHARDS * KMM_STAT_STRIDE * 8;
+
+// Self-check of the radix path at every synchronising call: every k-mer pass 1 emitted must have been gathered by
+// pass 2 and probed by pass 3 (or dropped by pass 2's empty-bucket filter).  The three passes count independently
+// (per-lane registers -> one sharded atomic per wavefront at kernel end), so a work item that is handed out twice, skipped, or
+// seen differently by the wavefronts of one workgroup (the round-2 race) shows up here instead of as
+// silently wrong counts.  Called with both streams drained.
+int rx_check_conservation(kmm_index *ix)
+{
+    if (!ix->rx_unchecked)
+        return KMM_OK;
+    ix->rx_unchecked = false;
+    static thread_local std::vector<unsigned long long> st;
+    st.resize(KMM_STAT_BYTES / 8);
+    HIPCHK(hipMemcpy(st.data(), ix->stats, KMM_STAT_BYTES, hipMemcpyDeviceToHost));
+    unsigned long long p1 = 0, p2 = 0, p3 = 0, dropped = 0;
+    for (int i = 0; i < KMM_STAT_SHARDS; ++i) {
+        const unsigned long long *sh = st.data() + (size_t)i * KMM_STAT_STRIDE;
+        p1 += sh[KMM_STAT_RX_P1];
+        p2 += sh[2];
+        p3 += sh[3];
+        dropped += sh[KMM_STAT_RX_DROPPED];
+    }
+    if (p1 == p2 && p2 == p3 + dropped)
+        return KMM_OK;
+    const int rc = fail(KMM_ERR_INTERNAL, "radix path self-check failed: pass 1 emitted %llu k-mers, pass 2 gathered %llu, "
+                        "pass 3 probed %llu (+ %llu dropped as absent) since the counters were last reset: the node counts "
+                        "are invalid until kmm_reset_counts [latest map call #%llu on this handle]",
+                        p1, p2, p3, dropped, (unsigned long long)ix->map_calls);
+    ix->sticky_rc = rc;
+    ix->sticky_msg = g_err;
+    return rc;
+}
 
 // Drain the streams and surface deferred device-side errors (invalid bases, malformed records, bad offsets).
 // The reference raises before any count of the offending chunk is added (bionumpy's encoder, util.py:72); here
@@ -264,6 +305,7 @@ int drain(kmm_index *ix)
     HIPCHK(hipStreamSynchronize(ix->stream));
     if (ix->sticky_rc != KMM_OK)
         return fail(ix->sticky_rc, "%s", ix->sticky_msg.c_str());
+    KMMCHK(rx_check_conservation(ix));
     unsigned long long bad[3] = {NO_BAD, NO_BAD, NO_BAD};
     HIPCHK(hipMemcpy(bad, ix->first_bad, sizeof bad, hipMemcpyDeviceToHost));
     if (bad[0] != NO_BAD || bad[1] != NO_BAD || bad[2] != NO_BAD) {
@@ -377,7 +419,6 @@ int resolve_lut(kmm_index *ix, Stage &s, const uint8_t *lut, const uint8_t **dev
     return stage_in<uint8_t>(ix, s.lut, lut, 256, dev, staged);
 }
 
-constexpr size_t KMM_STAT_BYTES = (size_t)KMM_STAT_SHARDS * KMM_STAT_STRIDE * 8;
 // Layout choice by index size (profiles/r01/partitioned_path_ablation.md, ms per 1.2e9 k-mers, same box):
 //   16-byte buckets + L2 bitmap vs 32-byte buckets without: 10 M entries 20.2 / 24.4, 15 M 21.4 / 26.3,
 //   20 M 23.6 / 27.9, 40 M (10 MB bitmap) 28.7 / 30.3, 100 M (25 MB bitmap) 34.0 / 31.7.
@@ -389,18 +430,22 @@ constexpr size_t KMM_OCC_SWEET_BYTES = (size_t)5 << 20; // bitmap size that stil
 constexpr int TILE_S = 4;
 constexpr int TILE_T = 256 * TILE_S;
 
-// Fan-out of the radix path for 2^w buckets per fine partition: F1 coarse x F2 fine partitions.
-bool rx_configure(kmm_index *ix, int w)
+// Fan-out of the radix path for 2^w buckets per fine partition: F1 coarse x F2 fine partitions, each at most `maxf`
+// (<= RX_MAXF = 512: 512 x 512 slices of 8192 buckets cover every modulo the index format's int32 tables allow,
+// mapper.pyx:22-23,31-32).  f2_force >= 0 (experiments, KMM_RX_F2): that many fine-partition bits.
+bool rx_configure(kmm_index *ix, int w, int maxf = RX_MAXF, int f2_force = -1)
 {
     if (w < 0 || w > 13 || ix->modulo >= (1ull << 31)) // (pass 1 divides with a 32-bit remainder)
         return false;
     const uint64_t PF = (ix->modulo + (1ull << w) - 1) >> w;
-    if (PF > (uint64_t)RX_MAXF * RX_MAXF)
+    if (PF > (uint64_t)maxf * maxf)
         return false;
     int lg = 0;
     while ((1ull << lg) < PF)
         ++lg;
     int f2 = (lg + 1) / 2;
+    if (f2_force >= 0)
+        f2 = f2_force;
     // the packed form (kmm_radix.hpp) keeps floor(q / modulo) above w + f2 hash bits: it must fit for EVERY
     // 64-bit q (callers may hand over arbitrary uint64 values), else give the quotient more room
     const uint64_t max_quo = ~0ull / ix->modulo;
@@ -410,6 +455,8 @@ bool rx_configure(kmm_index *ix, int w)
     if (!fits(w + f2))
         return false;
     const uint64_t F2 = 1ull << f2, F1 = (PF + F2 - 1) / F2;
+    if (F2 > (uint64_t)maxf || F1 > (uint64_t)maxf)
+        return false;
     ix->rx_w = w;
     ix->rx_f2 = f2;
     ix->rx_PF = (uint32_t)PF;
@@ -487,7 +534,7 @@ int launch_rx(kmm_index *ix, const ReadsView &rv, const uint64_t *kmers_in, int6
         KMMCHK(tm.begin(ix, KMM_KERNEL_RX_SCAN));
         hipLaunchKernelGGL(k_rx_colsum, dim3(chunks), dim3(256), 0, ix->stream, rx);
         hipLaunchKernelGGL(k_rx_chunkscan, dim3(F1), dim3(256), 0, ix->stream, rx, chunks);
-        hipLaunchKernelGGL(k_rx_tables, dim3(1), dim3(256), 0, ix->stream, rx);
+        hipLaunchKernelGGL(k_rx_tables, dim3(1), dim3(512), 0, ix->stream, rx);
         hipLaunchKernelGGL(k_rx_colscan, dim3(chunks), dim3(256), 0, ix->stream, rx);
         HIPCHK(hipGetLastError());
         KMMCHK(tm.end());
@@ -496,7 +543,7 @@ int launch_rx(kmm_index *ix, const ReadsView &rv, const uint64_t *kmers_in, int6
         HIPCHK(hipGetLastError());
         KMMCHK(tm.end());
         KMMCHK(tm.begin(ix, KMM_KERNEL_RX_SCAN));
-        hipLaunchKernelGGL(k_rx_tr2, dim3((unsigned)((max_items + 63) / 64)), dim3(256), 0, ix->stream, rx);
+        hipLaunchKernelGGL(k_rx_tr2, dim3((unsigned)((max_items + RX_TR2 - 1) / RX_TR2)), dim3(256), 0, ix->stream, rx);
         HIPCHK(hipGetLastError());
         KMMCHK(tm.end());
         KMMCHK(tm.begin(ix, KMM_KERNEL_RX_P3));
@@ -513,6 +560,7 @@ int launch_rx(kmm_index *ix, const ReadsView &rv, const uint64_t *kmers_in, int6
         HIPCHK(hipGetLastError());
         KMMCHK(tm.end());
         ix->ecnt_dirty = true;
+        ix->rx_unchecked = true;
     }
     return KMM_OK;
 }
@@ -542,13 +590,14 @@ int rx_flush(kmm_index *ix)
 template <int MODE>
 int launch_map_reads(kmm_index *ix, const ReadsView &rv, int k, int max_freq, int also_rc)
 {
-    const IndexView iv = view_of(ix);
     const int64_t n_tiles = (rv.total + TILE_T - 1) / TILE_T;
     // records mode: pass 1's front end (line numbering of raw file bytes) costs more than the direct kernel hides
     // behind its gathers (profiles/r02/README.md: 34 vs 45 G k-mers/s at the 10 M index), so raw chunks take the
     // radix path only when it is forced
     const bool radix = MODE == MODE_RECORDS ? (ix->rx_ok && (ix->path == 2 || ix->rx_ecnt_acc)) : use_radix(ix, rv.total);
     if (!radix) {
+        KMMCHK(ensure_direct(ix));
+        const IndexView iv = view_of(ix); // (the direct view may have been packed just now)
         ScopedTimer tm;
         KMMCHK(tm.begin(ix, KMM_KERNEL_MAP_READS));
         // large launches: persistent workgroups + dynamic tile queue; small ones: static schedule
@@ -600,6 +649,68 @@ int scan_exclusive(const uint32_t *in, uint32_t *out, uint64_t n, std::vector<De
     hipLaunchKernelGGL(k_scan_add, dim3((unsigned)g), dim3(256), 0, stream, out, (const uint32_t *)pre.p, n);
     HIPCHK(hipGetLastError());
     return KMM_OK;
+}
+
+// The direct view (kmm_probe.hpp): bucket records + 16-byte entries (+ the L2 pre-filter for small indexes), packed
+// from the caller's arrays at creation or from the radix view's bucket-ordered copy later.  Synchronous.
+template <typename Src>
+int direct_build(kmm_index *ix, const Src &src, int64_t n_entries, size_t occ_bytes, uint32_t *d_err)
+{
+    const uint64_t M = ix->modulo;
+    const size_t nb = sizeof(uint4) * (size_t)M * (ix->wide ? 2 : 1), ne = sizeof(uint4) * (size_t)(n_entries > 0 ? n_entries : 1);
+    hipError_t e = hipMalloc(&ix->buckets, nb);
+    if (e == hipSuccess) e = hipMalloc(&ix->entries, ne);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        if (ix->buckets) { (void)hipFree(ix->buckets); ix->buckets = nullptr; }
+        return fail(e == hipErrorOutOfMemory ? KMM_ERR_NOMEM : KMM_ERR_HIP, "direct view of the index (%zu + %zu bytes): %s",
+                    nb, ne, hipGetErrorString(e));
+    }
+    if (ix->wide)
+        hipLaunchKernelGGL((k_pack_buckets_wide<Src>), dim3(grid_for(ix, (int64_t)((M + 255) / 256), 16)), dim3(256), 0,
+                           ix->stream, src, M, n_entries, ix->max_node_id, ix->buckets, d_err);
+    else
+        hipLaunchKernelGGL((k_pack_buckets<Src>), dim3(grid_for(ix, (int64_t)((M + 255) / 256), 16)), dim3(256), 0,
+                           ix->stream, src, M, n_entries, ix->max_node_id, ix->buckets, d_err);
+    if (n_entries > 0)
+        hipLaunchKernelGGL((k_pack_entries<Src>), dim3(grid_for(ix, (n_entries + 255) / 256, 16)), dim3(256), 0, ix->stream,
+                           src, n_entries, ix->max_node_id, ix->entries, d_err);
+    e = hipGetLastError();
+    // occupancy bitmap / Bloom filter (16-byte layout only), built from the k-mers while they are here
+    if (e == hipSuccess && occ_bytes) {
+        e = hipMalloc(&ix->occ, occ_bytes);
+        if (e == hipSuccess) e = hipMemsetAsync(ix->occ, 0, occ_bytes, ix->stream);
+        if (e == hipSuccess && n_entries > 0) {
+            if (ix->bloom_words)
+                hipLaunchKernelGGL(k_build_bloom, dim3(grid_for(ix, (n_entries + 255) / 256, 16)), dim3(256), 0, ix->stream,
+                                   src.kmers, n_entries, ix->bloom_words, ix->occ);
+            else
+                hipLaunchKernelGGL(k_build_occ, dim3(grid_for(ix, (n_entries + 255) / 256, 16)), dim3(256), 0, ix->stream,
+                                   src.kmers, n_entries, M, ix->magic, ix->occ_shift, ix->occ);
+            e = hipGetLastError();
+        }
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ix->stream);
+    if (e != hipSuccess)
+        return fail(KMM_ERR_HIP, "index repack: %s", hipGetErrorString(e));
+    return KMM_OK;
+}
+
+// Called by every entry point that needs the direct view (small batches, kmm_in_index).
+int ensure_direct(kmm_index *ix)
+{
+    if (ix->buckets || !ix->direct_deferred)
+        return KMM_OK;
+    DevBuf d_err;
+    KMMCHK(ensure(d_err, 4));
+    HIPCHK(hipMemsetAsync(d_err.p, 0, 4, ix->stream));
+    IdxRx src;
+    src.pstart = ix->rx_pstart; src.kmers = ix->rx_pkeys_raw; src.nodes = ix->rx_pnodes; src.freqs = ix->rx_pfreq;
+    const int rc = direct_build(ix, src, (int64_t)ix->rx_S, ix->occ_bytes_plan, (uint32_t *)d_err.p);
+    release(d_err);
+    if (rc == KMM_OK)
+        ix->direct_deferred = false;
+    return rc;
 }
 
 int check_k(int k)
@@ -721,22 +832,37 @@ static int rx_build(kmm_index *ix, const int32_t *h2i, const int32_t *nk, const 
                     const int32_t *nodes, const uint16_t *freqs)
 {
     const uint64_t M = ix->modulo;
-    if (M + 1 > 0xFFFFFFFFull)
-        return KMM_OK; // no radix path; the direct path serves every batch
+    ix->rx_why_not = 1;
+    if (M >= (1ull << 31))
+        return KMM_OK; // beyond the index format's int32 tables: no radix path; the direct path serves every batch
     DevBuf sizes;
     std::vector<DevBuf> scratch(2 * SCAN_MAX_LEVELS);
     int rc = KMM_OK;
     hipError_t e = hipSuccess;
+    bool overlap = false;
     do {
         if ((rc = ensure(sizes, (size_t)(M + 1) * 4))) break;
         if ((e = hipMalloc(&ix->rx_pstart, (size_t)(M + 1) * 4))) break;
         hipLaunchKernelGGL(k_rx_bucket_sizes, dim3(grid_for(ix, (int64_t)((M + 256) / 256), 16)), dim3(256), 0,
                            ix->stream, h2i, nk, M, ix->n_entries, (uint32_t *)sizes.p);
+        // an index whose buckets overlap (sum of the bucket sizes > n_entries: legal for the reference's loop, which only
+        // follows (start, count) per bucket) has no bucket-ordered copy of bounded size, and a 32-bit prefix could
+        // wrap: such an index is served by the direct path alone
+        unsigned long long sum64 = 0;
+        if ((e = hipMemsetAsync(ix->queue, 0, sizeof(unsigned long long), ix->stream))) break;
+        hipLaunchKernelGGL(k_sum_u32, dim3(grid_for(ix, (int64_t)((M + 256) / 256), 8)), dim3(256), 0, ix->stream,
+                           (const uint32_t *)sizes.p, M + 1, ix->queue);
+        if ((e = hipMemcpyAsync(&sum64, ix->queue, 8, hipMemcpyDeviceToHost, ix->stream))) break;
+        if ((e = hipStreamSynchronize(ix->stream))) break;
+        if (sum64 > (unsigned long long)ix->n_entries) {
+            overlap = true;
+            break;
+        }
         if ((rc = scan_exclusive((const uint32_t *)sizes.p, ix->rx_pstart, M + 1, scratch, 0, ix->stream))) break;
         uint32_t total = 0;
         if ((e = hipMemcpyAsync(&total, ix->rx_pstart + M, 4, hipMemcpyDeviceToHost, ix->stream))) break;
         if ((e = hipStreamSynchronize(ix->stream))) break;
-        ix->rx_S = total; // < 2^32: a sum of validated bucket sizes may exceed n_entries only if buckets overlap
+        ix->rx_S = total; // = sum64 <= n_entries < 2^31
         const size_t S = total ? total : 1;
         if ((e = hipMalloc(&ix->rx_pkeys, S * 8))) break;
         if ((e = hipMalloc(&ix->rx_pkeys_raw, S * 8))) break;
@@ -790,10 +916,31 @@ static int rx_build(kmm_index *ix, const int32_t *h2i, const int32_t *nk, const 
     release(sizes);
     for (DevBuf &b : scratch)
         release(b);
-    if (rc != KMM_OK)
-        return rc;
-    if (e != hipSuccess)
-        return fail(e == hipErrorOutOfMemory ? KMM_ERR_NOMEM : KMM_ERR_HIP, "radix index build: %s", hipGetErrorString(e));
+    if (rc != KMM_OK || e != hipSuccess || overlap) {
+        // the radix view is optional: without the memory for it (or for an index with overlapping buckets) the
+        // direct path serves every batch; any other failure is an error
+        const bool nomem = rc == KMM_ERR_NOMEM || e == hipErrorOutOfMemory;
+        (void)hipGetLastError();
+        for (void **q : {(void **)&ix->rx_pstart, (void **)&ix->rx_pkeys, (void **)&ix->rx_pkeys_raw, (void **)&ix->rx_pfreq,
+                         (void **)&ix->rx_pnodes, (void **)&ix->rx_porig, (void **)&ix->rx_ecnt, (void **)&ix->rx_norder,
+                         (void **)&ix->rx_nnode}) {
+            if (*q)
+                (void)hipFree(*q);
+            *q = nullptr;
+        }
+        ix->rx_S = 0;
+        ix->rx_ok = false;
+        if (overlap || nomem) {
+            ix->rx_why_not = overlap ? 4 : 3;
+            if (getenv("KMM_VERBOSE"))
+                fprintf(stderr, "libkmm: radix view not built (%s): every batch takes the direct path\n",
+                        overlap ? "the buckets of the index overlap" : "out of HBM");
+            return KMM_OK;
+        }
+        if (rc != KMM_OK)
+            return rc;
+        return fail(KMM_ERR_HIP, "radix index build: %s", hipGetErrorString(e));
+    }
     // 2^w buckets per fine partition: as many as keep a slice's entries (load factor x 2^w) well inside the LDS key
     // capacity; fewer when the table is dense.  The fan-out must fit 256 x 256 fine partitions.
     int w = 12;
@@ -803,11 +950,27 @@ static int rx_build(kmm_index *ix, const int32_t *h2i, const int32_t *nk, const 
         while (w > 0 && ((double)ix->rx_S / (double)M * (double)(1u << w) * 1.3 + 64.0 > (double)RX_ECAP ||
                          (1ull << w) > M))
             --w;
-    ix->rx_ok = rx_configure(ix, w);
-    // more than 256 x 256 slices of 4096 buckets: slices of 8192 (one workgroup of pass 3 per CU) if their entries fit
-    if (!ix->rx_ok && w == 12 && !getenv("KMM_RX_W") &&
-        (double)ix->rx_S / (double)M * 8192.0 * 1.3 + 64.0 <= (double)RX_ECAP_BIG)
-        ix->rx_ok = rx_configure(ix, 13);
+    // Fan-out, in order of preference (runs between the passes get shorter, then pass 3 loses its second workgroup
+    // per CU): up to 256 x 256 slices of 2^w buckets; 256 x 256 slices of 8192 buckets whose entries fit 4096 keys
+    // (16-bit LDS directory, two workgroups of pass 3 per CU); up to 512 x 512 slices of 4096 buckets; slices of 8192
+    // buckets with up to 8192 keys (one workgroup of pass 3 per CU), 256 x 256, then 512 x 512: every modulo below
+    // 2^31 is covered as long as the load factor lets a slice's entries fit LDS.
+    const int f2_force = getenv("KMM_RX_F2") ? atoi(getenv("KMM_RX_F2")) : -1; // experiments: fine-partition bits
+    const double load = (double)ix->rx_S / (double)M;
+    const bool fits13_small = load * 8192.0 * 1.3 + 64.0 <= (double)RX_ECAP;
+    const bool fits13 = load * 8192.0 * 1.3 + 64.0 <= (double)RX_ECAP_BIG;
+    ix->rx_ok = rx_configure(ix, w, f2_force >= 0 ? RX_MAXF : 256, f2_force);
+    if (!ix->rx_ok && w == 12 && !getenv("KMM_RX_W")) {
+        ix->rx_ok = (fits13_small && rx_configure(ix, 13, 256)) || rx_configure(ix, 12, RX_MAXF) ||
+                    (fits13 && (rx_configure(ix, 13, 256) || rx_configure(ix, 13, RX_MAXF)));
+    } else if (!ix->rx_ok) {
+        ix->rx_ok = rx_configure(ix, w, RX_MAXF);
+    }
+    ix->rx_why_not = ix->rx_ok ? 0 : 2;
+    if (getenv("KMM_VERBOSE"))
+        fprintf(stderr, "libkmm: modulo %llu, %llu entries: radix path %s (2^%d buckets per slice, %u x %u partitions)\n",
+                (unsigned long long)M, (unsigned long long)ix->rx_S, ix->rx_ok ? "available" : "NOT available: slices too "
+                "dense for LDS or more than 512 x 512 of them", ix->rx_w, ix->rx_F1, ix->rx_F2);
     if (ix->rx_ok)
         KMMCHK(rx_repack_keys(ix));
     // auto: the radix path streams the whole directory + key arrays once per batch (4 B x modulo + 14 B x entries),
@@ -875,8 +1038,6 @@ static int index_create_impl(kmm_index *ix, const int32_t *h2i, const int32_t *n
     ix->wide = !with_occ;
     if (const char *env = getenv("KMM_WIDE_BUCKETS")) // experiments: force the bucket layout (0 / 1)
         ix->wide = atoi(env) != 0;
-    HIPCHK(hipMalloc(&ix->buckets, sizeof(uint4) * (size_t)M * (ix->wide ? 2 : 1)));
-    HIPCHK(hipMalloc(&ix->entries, sizeof(uint4) * (size_t)(N > 0 ? N : 1)));
     HIPCHK(hipMalloc(&ix->own_counts_buf, sizeof(uint32_t) * (size_t)(ix->max_node_id + 1)));
     ix->counts = ix->own_counts_buf;
     HIPCHK(hipMemsetAsync(ix->counts, 0, sizeof(uint32_t) * (size_t)(ix->max_node_id + 1), ix->stream));
@@ -891,7 +1052,7 @@ static int index_create_impl(kmm_index *ix, const int32_t *h2i, const int32_t *n
     unsigned long long nb[3] = {NO_BAD, NO_BAD, NO_BAD};
     HIPCHK(hipMemcpy(ix->first_bad, nb, sizeof nb, hipMemcpyHostToDevice));
 
-    // raw arrays -> HBM (temporary), repack + validate on the GPU
+    // raw arrays -> HBM (temporary); validate, build the radix view, and the direct view now or on first use
     DevBuf d_h2i, d_nk, d_km, d_nd, d_fr, d_err;
     bool staged = false;
     const int32_t *p_h2i = nullptr, *p_nk = nullptr, *p_nd = nullptr;
@@ -913,41 +1074,34 @@ static int index_create_impl(kmm_index *ix, const int32_t *h2i, const int32_t *n
             rc = fail(KMM_ERR_HIP, "index upload: %s", hipGetErrorString(e));
     }
     uint32_t err = 0;
-    if (rc == KMM_OK) {
-        if (ix->wide)
-            hipLaunchKernelGGL(k_pack_buckets_wide, dim3(grid_for(ix, (int64_t)((M + 255) / 256), 16)),
-                               dim3(256), 0, ix->stream, p_h2i, p_nk, p_km, p_nd, p_fr, M, N,
-                               ix->max_node_id, ix->buckets, (uint32_t *)d_err.p);
-        else
-            hipLaunchKernelGGL(k_pack_buckets, dim3(grid_for(ix, (int64_t)((M + 255) / 256), 16)),
-                               dim3(256), 0, ix->stream, p_h2i, p_nk, p_km, p_nd, p_fr, M, N,
-                               ix->max_node_id, ix->buckets, (uint32_t *)d_err.p);
-        if (N > 0)
-            hipLaunchKernelGGL(k_pack_entries, dim3(grid_for(ix, (N + 255) / 256, 16)), dim3(256),
-                               0, ix->stream, p_km, p_nd, p_fr, N, ix->max_node_id, ix->entries,
-                               (uint32_t *)d_err.p);
+    if (rc == KMM_OK) { // what the reference never checks (mapper.pyx:17 disables bounds checks)
+        hipLaunchKernelGGL(k_validate_index, dim3(grid_for(ix, (int64_t)((M + 255) / 256), 16)), dim3(256), 0, ix->stream,
+                           p_h2i, p_nk, p_nd, M, N, ix->max_node_id, (uint32_t *)d_err.p);
         hipError_t e = hipGetLastError();
-        // occupancy bitmap (16-byte layout only), built from the raw k-mers while they are still here
-        if (e == hipSuccess && with_occ) {
-            e = hipMalloc(&ix->occ, occ_bytes);
-            if (e == hipSuccess) e = hipMemsetAsync(ix->occ, 0, occ_bytes, ix->stream);
-            if (e == hipSuccess && N > 0) {
-                if (ix->bloom_words)
-                    hipLaunchKernelGGL(k_build_bloom, dim3(grid_for(ix, (N + 255) / 256, 16)), dim3(256), 0,
-                                       ix->stream, p_km, N, ix->bloom_words, ix->occ);
-                else
-                    hipLaunchKernelGGL(k_build_occ, dim3(grid_for(ix, (N + 255) / 256, 16)), dim3(256), 0, ix->stream,
-                                       p_km, N, M, ix->magic, ix->occ_shift, ix->occ);
-                e = hipGetLastError();
-            }
-        }
         if (e == hipSuccess) e = hipStreamSynchronize(ix->stream);
         if (e == hipSuccess) e = hipMemcpy(&err, d_err.p, 4, hipMemcpyDeviceToHost);
         if (e != hipSuccess)
-            rc = fail(KMM_ERR_HIP, "index repack: %s", hipGetErrorString(e));
+            rc = fail(KMM_ERR_HIP, "index validation: %s", hipGetErrorString(e));
     }
     if (rc == KMM_OK && !err)
         rc = rx_build(ix, p_h2i, p_nk, p_km, p_nd, p_fr);
+    // HBM budget: an index whose direct view is large (a 10^9-k-mer index: 64 GB of wide buckets + 16 GB of entries
+    // beside the 46 GB radix view) keeps only the radix view resident; the direct view is packed from it when the
+    // first small batch (or kmm_in_index) needs it.  Small indexes pack both now.
+    size_t eager_max = (size_t)16 << 30;
+    if (const char *env = getenv("KMM_DIRECT_EAGER_BYTES")) // tests / experiments
+        eager_max = (size_t)strtoull(env, nullptr, 10);
+    ix->direct_bytes = sizeof(uint4) * ((size_t)M * (ix->wide ? 2 : 1) + (size_t)(N > 0 ? N : 1));
+    if (rc == KMM_OK && !err) {
+        ix->occ_bytes_plan = with_occ ? occ_bytes : 0;
+        if (ix->rx_ok && ix->direct_bytes > eager_max) {
+            ix->direct_deferred = true;
+        } else {
+            IdxRaw src;
+            src.h2i = p_h2i; src.nk = p_nk; src.kmers = p_km; src.nodes = p_nd; src.freqs = p_fr;
+            rc = direct_build(ix, src, N, with_occ ? occ_bytes : 0, (uint32_t *)d_err.p);
+        }
+    }
     release(d_h2i); release(d_nk); release(d_km); release(d_nd); release(d_fr); release(d_err);
     if (rc != KMM_OK)
         return rc;
@@ -1020,6 +1174,8 @@ int kmm_reset_counts(kmm_index_t *ix)
         unsigned long long nb[3] = {NO_BAD, NO_BAD, NO_BAD};
         HIPCHK(hipStreamSynchronize(ix->stream));
         HIPCHK(hipMemcpy(ix->first_bad, nb, sizeof nb, hipMemcpyHostToDevice));
+        if (ix->sticky_rc == KMM_ERR_INTERNAL) // the conservation counters restart with the counts
+            HIPCHK(hipMemset(ix->stats, 0, KMM_STAT_BYTES));
         ix->sticky_rc = KMM_OK;
         ix->sticky_msg.clear();
     }
@@ -1253,6 +1409,7 @@ int kmm_map_kmers(kmm_index_t *ix, const uint64_t *kmers, int64_t n, int max_fre
         return stage_release(ix, s, staged);
     }
     constexpr int U = 8;
+    KMMCHK(ensure_direct(ix));
     ScopedTimer tm;
     KMMCHK(tm.begin(ix, KMM_KERNEL_MAP_KMERS));
     {
@@ -1459,6 +1616,7 @@ int kmm_in_index(kmm_index_t *ix, const uint64_t *kmers, int64_t n, uint8_t *out
     if (n == 0)
         return KMM_OK;
     HIPCHK(hipSetDevice(ix->device));
+    KMMCHK(ensure_direct(ix));
     Stage &s = next_stage(ix);
     KMMCHK(stage_acquire(ix, s));
     bool staged = false;
@@ -1825,17 +1983,26 @@ int kmm_set_param(kmm_index_t *ix, const char *name, int64_t value)
         if (value < 0 || value > 2)
             return fail(KMM_ERR_INVALID_ARG, "path must be 0 (auto), 1 (direct) or 2 (radix)");
         if (value == 2 && !ix->rx_ok)
-            return fail(KMM_ERR_INVALID_ARG, "the radix path is not available for this index (modulo %llu needs more "
-                        "than 256 x 256 fine partitions)", (unsigned long long)ix->modulo);
+            return fail(KMM_ERR_INVALID_ARG, "the radix path is not available for this index (modulo %llu: needs modulo < 2^31 "
+                        "and slices whose entries fit LDS)", (unsigned long long)ix->modulo);
         ix->path = (int)value;
     } else if (!strcmp(name, "part_shift")) {
         if (!rx_configure(ix, (int)value))
-            return fail(KMM_ERR_INVALID_ARG, "part_shift %lld: needs 0 <= shift <= 13, at most 256 x 256 fine partitions "
+            return fail(KMM_ERR_INVALID_ARG, "part_shift %lld: needs 0 <= shift <= 13, at most 512 x 512 fine partitions "
                         "and 2^shift small enough for the quotient of a 64-bit k-mer by the modulo to fit beside "
                         "the hash bits", (long long)value);
         ix->rx_ok = ix->rx_pstart != nullptr;
         if (ix->rx_ok) {
             KMMCHK(rx_flush(ix)); // nothing of the old layout may be pending
+            KMMCHK(rx_repack_keys(ix));
+        }
+    } else if (!strcmp(name, "fine_bits")) {
+        // experiments: split the current slice width's fan-out as F2 = 2^value fine partitions per coarse partition
+        if (value < 0 || value > 9 || !rx_configure(ix, ix->rx_w, RX_MAXF, (int)value))
+            return fail(KMM_ERR_INVALID_ARG, "fine_bits %lld: both fan-outs must stay within 512", (long long)value);
+        ix->rx_ok = ix->rx_pstart != nullptr;
+        if (ix->rx_ok) {
+            KMMCHK(rx_flush(ix));
             KMMCHK(rx_repack_keys(ix));
         }
     } else if (!strcmp(name, "radix_min_units")) {
@@ -1873,6 +2040,14 @@ int kmm_set_param(kmm_index_t *ix, const char *name, int64_t value)
         ix->dyn_chunk = (int)value;
     } else if (!strcmp(name, "occupancy_filter")) {
         ix->use_occ = value != 0;
+    } else if (!strcmp(name, "debug_skew_p2_counter")) {
+        // test hook of the conservation self-check: adds `value` to the device-side "gathered by pass 2" counter, as a
+        // doubly processed work item would; the next synchronising call must fail with KMM_ERR_INTERNAL
+        unsigned long long v = 0;
+        HIPCHK(hipMemcpy(&v, ix->stats + 2, 8, hipMemcpyDeviceToHost));
+        v += (unsigned long long)value;
+        HIPCHK(hipMemcpy(ix->stats + 2, &v, 8, hipMemcpyHostToDevice));
+        ix->rx_unchecked = true;
 
     } else {
         return fail(KMM_ERR_INVALID_ARG, "unknown parameter '%s'", name);
@@ -1896,11 +2071,23 @@ int kmm_get_param(kmm_index_t *ix, const char *name, int64_t *value)
         *value = (ix->rx_flush_sorted && ix->rx_norder) ? 1 : 0;
     else if (!strcmp(name, "radix_available"))
         *value = ix->rx_ok ? 1 : 0;
+    else if (!strcmp(name, "radix_unavailable_reason")) // 0 available, 1 modulo >= 2^31, 2 slices, 3 memory, 4 overlapping buckets
+        *value = ix->rx_ok ? 0 : ix->rx_why_not;
+    else if (!strcmp(name, "direct_view_resident"))
+        *value = ix->buckets ? 1 : 0;
+    else if (!strcmp(name, "direct_view_bytes"))
+        *value = (int64_t)ix->direct_bytes;
+    else if (!strcmp(name, "radix_view_bytes"))
+        *value = ix->rx_pstart ? (int64_t)((ix->modulo + 1) * 4 + (ix->rx_S ? ix->rx_S : 1) * (8 + 8 + 2 + 4 + 4 + 4 + (ix->rx_norder ? 8 : 0)))
+                               : 0;
+    else if (!strcmp(name, "n_fine_per_coarse"))
+        *value = ix->rx_ok ? ix->rx_F2 : 0;
     else if (!strcmp(name, "count_kmers"))
         *value = ix->rx_ecnt_acc ? 1 : 0;
     else if (!strcmp(name, "n_coarse_partitions"))
         *value = ix->rx_ok ? ix->rx_F1 : 0;
-    else if (!strcmp(name, "radix_p2_kmers") || !strcmp(name, "radix_p3_kmers") || !strncmp(name, "stats_slot_", 11)) {
+    else if (!strcmp(name, "radix_p2_kmers") || !strcmp(name, "radix_p3_kmers") || !strcmp(name, "radix_p2_dropped") ||
+             !strncmp(name, "stats_slot_", 11)) {
         // conservation check of the radix path: k-mers gathered by pass 2 / probed by pass 3 since the last
         // kmm_get_stats(reset): both must equal the lookups pass 1 emitted
         HIPCHK(hipSetDevice(ix->device));
@@ -1908,7 +2095,8 @@ int kmm_get_param(kmm_index_t *ix, const char *name, int64_t *value)
         std::vector<unsigned long long> st(KMM_STAT_BYTES / 8);
         HIPCHK(hipMemcpy(st.data(), ix->stats, KMM_STAT_BYTES, hipMemcpyDeviceToHost));
         // ("stats_slot_<n>": raw counter n of the statistics block; slots 4.. are only written by diagnostic builds)
-        const int slot = name[0] == 's' ? atoi(name + 11) : name[7] == '2' ? 2 : 3;
+        const int slot = name[0] == 's' ? atoi(name + 11) : !strcmp(name, "radix_p2_dropped") ? KMM_STAT_RX_DROPPED
+                                                          : name[7] == '2' ? 2 : 3;
         if (slot < 0 || slot >= KMM_STAT_STRIDE)
             return fail(KMM_ERR_INVALID_ARG, "unknown parameter '%s'", name);
         unsigned long long t = 0;

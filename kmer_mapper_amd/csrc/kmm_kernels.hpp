@@ -278,30 +278,72 @@ __global__ void k_in_index(const uint64_t *__restrict__ kmers, int64_t n, IndexV
 // ------------------------------------------------------------------------------------------------
 // Index repack (on the GPU, at load).  Also the validation the reference does not do.
 // err bit 0: bucket outside [0, n_entries); bit 1: node outside [0, max_node_id].
+// The direct view is packed either from the caller's arrays (IdxRaw: at kmm_index_create, small indexes) or later,
+// on the first batch that takes the direct path, from the radix view's bucket-ordered copy (IdxRx: large indexes
+// keep ONE view resident until the other is needed — HBM budget).
 // ------------------------------------------------------------------------------------------------
-__global__ void k_pack_buckets(const int32_t *__restrict__ h2i, const int32_t *__restrict__ nk,
-                               const uint64_t *__restrict__ kmers, const int32_t *__restrict__ nodes,
-                               const uint16_t *__restrict__ freqs, uint64_t modulo,
-                               int64_t n_entries, int64_t max_node_id, uint4 *__restrict__ buckets,
-                               uint32_t *err)
+struct IdxRaw {
+    const int32_t *h2i, *nk;
+    const uint64_t *kmers;
+    const int32_t *nodes;
+    const uint16_t *freqs;
+    __device__ __forceinline__ int64_t count(uint64_t h) const { return nk[h]; }
+    __device__ __forceinline__ int64_t start(uint64_t h) const { return h2i[h]; }
+    __device__ __forceinline__ int64_t node(int64_t l) const { return nodes[l]; }
+};
+
+struct IdxRx { // entries in bucket order: validated and clamped when the radix view was built
+    const uint32_t *pstart;
+    const uint64_t *kmers;
+    const uint32_t *nodes;
+    const uint16_t *freqs;
+    __device__ __forceinline__ int64_t count(uint64_t h) const { return (int64_t)(pstart[h + 1] - pstart[h]); }
+    __device__ __forceinline__ int64_t start(uint64_t h) const { return pstart[h]; }
+    __device__ __forceinline__ int64_t node(int64_t l) const { return nodes[l]; }
+};
+
+// validation only (the direct view of a large index is packed later, the errors are reported at creation)
+__global__ void k_validate_index(const int32_t *__restrict__ h2i, const int32_t *__restrict__ nk,
+                                 const int32_t *__restrict__ nodes, uint64_t modulo, int64_t n_entries,
+                                 int64_t max_node_id, uint32_t *err)
+{
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (uint64_t)gridDim.x * blockDim.x;
+    uint32_t e = 0;
+    for (uint64_t h = gid; h < modulo; h += stride) {
+        const int32_t c = nk[h], s = h2i[h];
+        if (c > 0 && (s < 0 || (int64_t)s + c > n_entries))
+            e |= 1u;
+    }
+    for (uint64_t l = gid; l < (uint64_t)n_entries; l += stride) {
+        const int32_t nd = nodes[l];
+        if (nd < 0 || (int64_t)nd > max_node_id)
+            e |= 2u;
+    }
+    if (e)
+        atomicOr(err, e);
+}
+
+template <typename Src>
+__global__ void k_pack_buckets(Src src, uint64_t modulo, int64_t n_entries, int64_t max_node_id,
+                               uint4 *__restrict__ buckets, uint32_t *err)
 {
     for (uint64_t h = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; h < modulo;
          h += (uint64_t)gridDim.x * blockDim.x) {
-        const int32_t c = nk[h], s = h2i[h];
+        const int64_t c = src.count(h), s = src.start(h);
         uint4 b = make_uint4(0u, 0u, 0u, 0u);
         if (c > 0) { // c <= 0: `for j in range(n_local_hits)` runs zero times (mapper.pyx:58)
-            if (s < 0 || (int64_t)s + c > n_entries) {
+            if (s < 0 || s + c > n_entries) {
                 atomicOr(err, 1u);
             } else if (c == 1) {
-                const uint64_t km = kmers[s];
-                int32_t nd = nodes[s];
-                if (nd < 0 || (int64_t)nd > max_node_id)
-                    nd = 0; // reported by k_pack_entries
+                const uint64_t km = src.kmers[s];
+                int64_t nd = src.node(s);
+                if (nd < 0 || nd > max_node_id)
+                    nd = 0; // reported by k_pack_entries / k_validate_index
                 b = make_uint4((uint32_t)km, (uint32_t)(km >> 32), (uint32_t)nd,
-                               ((uint32_t)freqs[s] << 16) | 1u);
+                               ((uint32_t)src.freqs[s] << 16) | 1u);
             } else if (c <= 3) {
-                const uint32_t f0 = kmer_fp16(kmers[s]), f1 = kmer_fp16(kmers[s + 1]);
-                const uint32_t f2 = c > 2 ? kmer_fp16(kmers[s + 2]) : 0u;
+                const uint32_t f0 = kmer_fp16(src.kmers[s]), f1 = kmer_fp16(src.kmers[s + 1]);
+                const uint32_t f2 = c > 2 ? kmer_fp16(src.kmers[s + 2]) : 0u;
                 b = make_uint4((uint32_t)s, (uint32_t)c, f0 | (f1 << 16), (f2 << 16) | 4u | 2u);
             } else {
                 b = make_uint4((uint32_t)s, (uint32_t)c, 0u, 2u);
@@ -312,26 +354,25 @@ __global__ void k_pack_buckets(const int32_t *__restrict__ h2i, const int32_t *_
 }
 
 // Wide layout: 32-byte bucket = halves A (2h) and B (2h+1), up to two entries inline.
-__global__ void k_pack_buckets_wide(const int32_t *__restrict__ h2i, const int32_t *__restrict__ nk,
-                                    const uint64_t *__restrict__ kmers, const int32_t *__restrict__ nodes,
-                                    const uint16_t *__restrict__ freqs, uint64_t modulo, int64_t n_entries,
-                                    int64_t max_node_id, uint4 *__restrict__ buckets, uint32_t *err)
+template <typename Src>
+__global__ void k_pack_buckets_wide(Src src, uint64_t modulo, int64_t n_entries, int64_t max_node_id,
+                                    uint4 *__restrict__ buckets, uint32_t *err)
 {
     for (uint64_t h = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; h < modulo;
          h += (uint64_t)gridDim.x * blockDim.x) {
-        const int32_t c = nk[h], s = h2i[h];
+        const int64_t c = src.count(h), s = src.start(h);
         uint4 a = make_uint4(0u, 0u, 0u, 0u), b = make_uint4(0u, 0u, 0u, 0u);
         if (c > 0) {
-            if (s < 0 || (int64_t)s + c > n_entries) {
+            if (s < 0 || s + c > n_entries) {
                 atomicOr(err, 1u);
             } else if (c <= 2) {
-                for (int j = 0; j < c; ++j) {
-                    const uint64_t km = kmers[s + j];
-                    int32_t nd = nodes[s + j];
-                    if (nd < 0 || (int64_t)nd > max_node_id)
-                        nd = 0; // reported by k_pack_entries
+                for (int j = 0; j < (int)c; ++j) {
+                    const uint64_t km = src.kmers[s + j];
+                    int64_t nd = src.node(s + j);
+                    if (nd < 0 || nd > max_node_id)
+                        nd = 0; // reported by k_pack_entries / k_validate_index
                     const uint4 e = make_uint4((uint32_t)km, (uint32_t)(km >> 32), (uint32_t)nd,
-                                               ((uint32_t)freqs[s + j] << 16) | (uint32_t)c);
+                                               ((uint32_t)src.freqs[s + j] << 16) | (uint32_t)c);
                     if (j == 0)
                         a = e;
                     else
@@ -346,19 +387,18 @@ __global__ void k_pack_buckets_wide(const int32_t *__restrict__ h2i, const int32
     }
 }
 
-__global__ void k_pack_entries(const uint64_t *__restrict__ kmers, const int32_t *__restrict__ nodes,
-                               const uint16_t *__restrict__ freqs, int64_t n, int64_t max_node_id,
-                               uint4 *__restrict__ entries, uint32_t *err)
+template <typename Src>
+__global__ void k_pack_entries(Src src, int64_t n, int64_t max_node_id, uint4 *__restrict__ entries, uint32_t *err)
 {
     for (int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; l < n;
          l += (int64_t)gridDim.x * blockDim.x) {
-        uint64_t km = kmers[l];
-        int32_t nd = nodes[l];
-        if (nd < 0 || (int64_t)nd > max_node_id) {
+        uint64_t km = src.kmers[l];
+        int64_t nd = src.node(l);
+        if (nd < 0 || nd > max_node_id) {
             atomicOr(err, 2u);
             nd = 0;
         }
-        entries[l] = make_uint4((uint32_t)km, (uint32_t)(km >> 32), (uint32_t)nd, (uint32_t)freqs[l]);
+        entries[l] = make_uint4((uint32_t)km, (uint32_t)(km >> 32), (uint32_t)nd, (uint32_t)src.freqs[l]);
     }
 }
 

@@ -141,7 +141,10 @@ __device__ __forceinline__ uint32_t kmer_fp16(uint64_t q)
 // slot when the workgroup retires.  uint32 wrap-around is preserved (sums of sums mod 2^32).
 // ------------------------------------------------------------------------------------------------
 constexpr int KMM_STAT_SHARDS = 256;
-constexpr int KMM_STAT_STRIDE = 16; // unsigned long longs = 128 bytes between shards
+constexpr int KMM_STAT_STRIDE = 32; // unsigned long longs = 256 bytes between shards
+// slots: [0] k-mer lookups, [1] hits, [2] k-mers gathered by radix pass 2, [3] probed by radix pass 3, [4..15] phase
+// timers of diagnostic builds, [16] k-mers emitted by radix pass 1, [17] dropped by pass 2's empty-bucket filter
+constexpr int KMM_STAT_RX_P1 = 16, KMM_STAT_RX_DROPPED = 17;
 constexpr int AGG_LOG_SLOTS = 11;
 constexpr int AGG_SLOTS = 1 << AGG_LOG_SLOTS;
 constexpr uint32_t AGG_EMPTY = 0xFFFFFFFFu; // node ids are < 2^31

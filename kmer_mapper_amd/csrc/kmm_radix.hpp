@@ -51,7 +51,7 @@ constexpr int RX_B = 8192;            // positions per pass-1 block = k-mer capa
                                       // 256-thread half of the workgroup owns 4096 of them (flat reads: one tile of
                                       // 16 windows per lane; records mode: four tiles of 4 windows per lane)
 constexpr int RX_KPT = RX_B / RX_NT;  // 16 k-mers per thread
-constexpr int RX_MAXF = 256;          // largest fan-out of one pass
+constexpr int RX_MAXF = 512;          // largest fan-out of one pass (512 x 512 slices of 8192 buckets = every modulo < 2^32)
 #ifndef RX_CHV
 #define RX_CHV 512
 #endif
@@ -140,12 +140,21 @@ __device__ __forceinline__ uint64_t rx_pack(const IndexView &iv, int sh, uint64_
     return (quo << sh) | (uint64_t)(h & ((1u << sh) - 1u));
 }
 
-// Exclusive scan of s_in[0..n) (n <= 256) into s_out[0..n], s_out[n] = total, by a RX_NT-thread workgroup.
+// Exclusive scan of s_in[0..n) (n <= 512) into s_out[0..n], s_out[n] = total, by a RX_NT-thread workgroup.  Lane l of
+// wavefront v < 4 owns the counters 128 v + 2 l and 128 v + 2 l + 1 (one 8-byte LDS read; s_in is 8-byte aligned).
 // Call after a barrier that completes s_in; ends with a barrier.  ONEBAR: the wavefront that scans counters
-// [64 w, 64 w + 64) sums the counters before them itself (DPP reductions) instead of waiting at a second barrier for
+// [128 v, 128 v + 128) sums the counters before them itself (DPP reductions) instead of waiting at a second barrier for
 // the other wavefronts' totals: pass 1 2.91 -> 2.80 ms, pass 2 3.89 -> 3.96 ms (so pass 2 keeps the exchange).
 // (Letting EVERY wavefront scan all the counters for itself — no barrier at all — measured slower: pass 1 3.58 vs
 // 3.20 ms; so did the one-barrier form while the reductions still went through ds_bpermute: 3.78.)
+__device__ __forceinline__ uint2 rx_pair(const uint32_t *s_in, int c0, int n)
+{
+    // counters at and beyond n are not part of the scan (the spare counters behind them are never cleared)
+    const uint2 p = *reinterpret_cast<const uint2 *>(s_in + c0);
+    return make_uint2(c0 < n ? p.x : 0u, c0 + 1 < n ? p.y : 0u);
+}
+
+// n <= 256: one counter per lane of wavefronts 0..3 (the form the passes were tuned with)
 template <bool ONEBAR>
 __device__ __forceinline__ uint32_t rx_scan256(const uint32_t *s_in, uint32_t *s_out, int n, uint32_t *s_wave)
 {
@@ -181,6 +190,62 @@ __device__ __forceinline__ uint32_t rx_scan256(const uint32_t *s_in, uint32_t *s
         for (int x = 0; x < wave; ++x)
             base += s_wave[x];
         s_out[tid] = base + inc - v;
+    }
+    if (tid == 0)
+        s_out[n] = total;
+    __syncthreads();
+    return total;
+}
+
+template <bool ONEBAR>
+__device__ __forceinline__ uint32_t rx_scan512(const uint32_t *s_in, uint32_t *s_out, int n, uint32_t *s_wave)
+{
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (ONEBAR) {
+    (void)s_wave;
+    if (wave < 4) {
+        const int c0 = wave * 128 + lane * 2;
+        const uint2 p = rx_pair(s_in, c0, n);
+        const uint32_t v = p.x + p.y;
+        const uint32_t inc = wave_scan_incl(v);
+        uint32_t before = 0;
+        for (int x = 0; x < wave; ++x) {
+            const uint2 t = rx_pair(s_in, x * 128 + lane * 2, n);
+            before += (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_incl(t.x + t.y), 63);
+        }
+        const uint32_t ex = before + inc - v;
+        if (c0 < n)
+            s_out[c0] = ex;
+        if (c0 + 1 < n)
+            s_out[c0 + 1] = ex + p.x;
+        if (tid == 255)
+            s_out[n] = before + inc; // wavefront 3 has seen every counter
+    }
+    __syncthreads();
+    return s_out[n];
+    }
+    uint2 p = make_uint2(0u, 0u);
+    uint32_t v = 0, inc = 0;
+    const int c0 = wave * 128 + lane * 2;
+    if (wave < 4) {
+        p = rx_pair(s_in, c0, n);
+        v = p.x + p.y;
+        inc = wave_scan_incl(v);
+        if (lane == 63)
+            s_wave[wave] = inc;
+    }
+    __syncthreads();
+    const uint32_t total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    if (wave < 4) {
+        uint32_t base = 0;
+        for (int x = 0; x < wave; ++x)
+            base += s_wave[x];
+        const uint32_t ex = base + inc - v;
+        if (c0 < n)
+            s_out[c0] = ex;
+        if (c0 + 1 < n)
+            s_out[c0 + 1] = ex + p.x;
     }
     if (tid == 0)
         s_out[n] = total;
@@ -269,9 +334,11 @@ __device__ __forceinline__ void rx_sort_emit(uint64_t (&q)[RX_KPT], PrepFn prep,
     __syncthreads();
     RX_PT(2); // keys + ranks
     mid();
-    const uint32_t total = rx_scan256<ONEBAR>(s_cnt, s_base, F, s_wave);
+    const uint32_t total = F <= 256 ? rx_scan256<ONEBAR>(s_cnt, s_base, F, s_wave) : rx_scan512<ONEBAR>(s_cnt, s_base, F, s_wave);
     if (tid <= F)
         dir_row[tid] = (uint16_t)s_base[tid];
+    if (F == RX_NT && tid == 0) // (fan-out 512: one more entry than threads)
+        dir_row[RX_NT] = (uint16_t)s_base[RX_NT];
     // (one slot after the other: reading all 16 run starts first and then writing — 16 overlapping LDS round trips —
     // measured SLOWER, pass 1 4.41 vs 3.62 ms, pass 2 4.75 vs 4.30 ms)
 #ifndef RX_PLACE_BATCH
@@ -292,6 +359,8 @@ __device__ __forceinline__ void rx_sort_emit(uint64_t (&q)[RX_KPT], PrepFn prep,
     RX_PT(3); // scan + placement
     if (tid <= F)
         s_cnt[tid] = 0; // for the next call (every wavefront's scan has read the counts: they lie before the barrier)
+    if (F == RX_NT && tid == 0)
+        s_cnt[RX_NT] = 0;
     const uint4 *s4 = reinterpret_cast<const uint4 *>(sbuf);
     uint4 *o4 = reinterpret_cast<uint4 *>(out);
     for (uint32_t i = tid; i < (total + 1) / 2; i += RX_NT) {
@@ -363,7 +432,7 @@ __device__ __forceinline__ uint32_t rx_n_pieces(uint32_t len, uint64_t src)
 
 template <int LPR, bool LINECUT>
 __device__ __forceinline__ void rx_list_subruns(uint32_t pre, uint32_t len, uint64_t src, uint32_t dst, uint32_t win,
-                                                uint64_t *sub_src, uint32_t *sub_meta)
+                                                uint32_t *sub_src, uint32_t *sub_meta)
 {
     const uint32_t off = LINECUT ? (uint32_t)src & (uint32_t)(LPR - 1) : 0u;
     const uint32_t nsub = rx_n_pieces<LPR, LINECUT>(len, src);
@@ -374,7 +443,7 @@ __device__ __forceinline__ void rx_list_subruns(uint32_t pre, uint32_t len, uint
         const uint32_t a = p ? 0u : off;
         const uint32_t done = p ? p * LPR - off : 0u; // k-mers of the run before this piece
         const uint32_t n = len - done < (uint32_t)LPR - a ? len - done : (uint32_t)LPR - a;
-        sub_src[j - win] = src - off + (uint64_t)p * LPR;
+        sub_src[j - win] = (uint32_t)(src - off) + p * LPR; // element offsets of a sub-batch's buffers fit 32 bits (launch_rx)
         sub_meta[j - win] = ((dst + done) << 12) | (a << 6) | n;
     }
 }
@@ -382,12 +451,12 @@ __device__ __forceinline__ void rx_list_subruns(uint32_t pre, uint32_t len, uint
 // The copiers read the list in batches of STEP sub-runs without checking for its end: entries [n, n rounded up to
 // STEP) are cleared (0 k-mers from offset 0) before the barrier that publishes the list.  STEP divides RX_SUBCAP.
 template <int STEP>
-__device__ __forceinline__ void rx_pad_list(uint32_t n, uint64_t *sub_src, uint32_t *sub_meta)
+__device__ __forceinline__ void rx_pad_list(uint32_t n, uint32_t *sub_src, uint32_t *sub_meta)
 {
     static_assert(RX_SUBCAP % STEP == 0, "a padded list must fit the window");
     const uint32_t n_pad = (n + STEP - 1) / STEP * STEP;
     for (uint32_t i = n + threadIdx.x; i < n_pad; i += RX_NT) {
-        sub_src[i] = 0ull;
+        sub_src[i] = 0u;
         sub_meta[i] = 0u;
     }
 }
@@ -423,7 +492,8 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p1(ReadsView rv, const uint64_t
     constexpr int R = RX_KPT / S;                  // tiles per half-workgroup per block
     __shared__ TileSmem<S> sm[2];
     __shared__ uint64_t sbuf[RX_B];
-    __shared__ uint32_t s_cnt[RX_MAXF + 1 + 64], s_base[RX_MAXF + 1], s_wave[4];
+    __shared__ __attribute__((aligned(8))) uint32_t s_cnt[RX_MAXF + 2 + 64];
+    __shared__ uint32_t s_base[RX_MAXF + 1], s_wave[4];
     const int tid = threadIdx.x, half = tid >> 8, ltid = tid & 255;
     TileConst tc;
     tc.kmask = 0; tc.bmask = 0; tc.aligned = false;
@@ -445,6 +515,8 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p1(ReadsView rv, const uint64_t
     TileRaw pw[R];
     if (tid <= F1)
         s_cnt[tid] = 0; // (rx_sort_emit)
+    if (tid == 0)
+        s_cnt[RX_NT] = 0;
     __syncthreads(); // also: the code table is in LDS
     for (uint32_t sb = blockIdx.x; sb < n_src; sb += gridDim.x) {
         uint64_t q[RX_KPT];
@@ -518,6 +590,7 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p1(ReadsView rv, const uint64_t
     RX_PT_END(iv, 10);
 #endif
     rx_stat_add(iv, 0, lookups);
+    rx_stat_add(iv, KMM_STAT_RX_P1, lookups); // conservation check (drain): = gathered by pass 2 = probed by pass 3 (+ dropped)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -525,28 +598,28 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p1(ReadsView rv, const uint64_t
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_rx_colsum(RxView rx)
 {
-    const uint32_t c = threadIdx.x, F1 = rx.F1;
-    if (c >= F1)
-        return;
+    const uint32_t F1 = rx.F1;
     const uint32_t b0 = blockIdx.x * RX_CH;
     const uint32_t b1 = b0 + RX_CH < rx.NB ? b0 + RX_CH : rx.NB;
     const size_t ld = F1 + 1;
-    const uint16_t *p = rx.start1 + (size_t)b0 * ld + c;
-    uint32_t sum = 0, b = b0;
-    for (; b + 8 <= b1; b += 8, p += 8 * ld) { // independent loads first: the loop is latency-bound
-        uint32_t lo[8], hi[8];
+    for (uint32_t c = threadIdx.x; c < F1; c += 256) {
+        const uint16_t *p = rx.start1 + (size_t)b0 * ld + c;
+        uint32_t sum = 0, b = b0;
+        for (; b + 8 <= b1; b += 8, p += 8 * ld) { // independent loads first: the loop is latency-bound
+            uint32_t lo[8], hi[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            lo[u] = p[u * ld];
-            hi[u] = p[u * ld + 1];
+            for (int u = 0; u < 8; ++u) {
+                lo[u] = p[u * ld];
+                hi[u] = p[u * ld + 1];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                sum += hi[u] - lo[u];
         }
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-            sum += hi[u] - lo[u];
+        for (; b < b1; ++b, p += ld)
+            sum += (uint32_t)p[1] - (uint32_t)p[0];
+        rx.csum[(size_t)blockIdx.x * F1 + c] = sum;
     }
-    for (; b < b1; ++b, p += ld)
-        sum += (uint32_t)p[1] - (uint32_t)p[0];
-    rx.csum[(size_t)blockIdx.x * F1 + c] = sum;
 }
 
 // exclusive prefix of one value per thread over a 256-thread workgroup; *total gets the sum
@@ -586,17 +659,36 @@ __global__ void __launch_bounds__(256) k_rx_chunkscan(RxView rx, uint32_t n_chun
     }
 }
 
-// One workgroup: the item table (items of RX_B k-mers per coarse partition) and the pass-3 row table.
-__global__ void __launch_bounds__(256) k_rx_tables(RxView rx)
+// exclusive prefix of one value per thread over a 512-thread workgroup; *total gets the sum
+__device__ __forceinline__ uint32_t scan512_excl(uint32_t v, uint32_t *s_wave8, uint32_t *total)
 {
-    __shared__ uint32_t s_wave4[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t inc = wave_scan_incl(v);
+    __syncthreads(); // s_wave8 may still be read by the previous call
+    if (lane == 63)
+        s_wave8[wave] = inc;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+    for (int x = 0; x < 8; ++x) {
+        base += x < wave ? s_wave8[x] : 0u;
+        tot += s_wave8[x];
+    }
+    *total = tot;
+    return base + inc - v;
+}
+
+// One workgroup: the item table (items of RX_B k-mers per coarse partition) and the pass-3 row table.
+__global__ void __launch_bounds__(512) k_rx_tables(RxView rx)
+{
+    static_assert(RX_MAXF <= 512, "one thread per coarse partition");
+    __shared__ uint32_t s_wave8[8];
     const uint32_t c = threadIdx.x, F1 = rx.F1;
     const uint32_t run = c < F1 ? rx.T1[c] : 0u;
     const uint32_t n_items = c < F1 ? (run + RX_B - 1) / RX_B : 0u;
     const uint32_t rows = (n_items + RX_IC - 1) / RX_IC;
     uint32_t tot_items, tot_rows;
-    const uint32_t ib = scan256_excl(n_items, s_wave4, &tot_items);
-    const uint32_t wb = scan256_excl(rows, s_wave4, &tot_rows);
+    const uint32_t ib = scan512_excl(n_items, s_wave8, &tot_items);
+    const uint32_t wb = scan512_excl(rows, s_wave8, &tot_rows);
     uint32_t jmax = n_items;
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) {
@@ -605,16 +697,16 @@ __global__ void __launch_bounds__(256) k_rx_tables(RxView rx)
     }
     __syncthreads();
     if ((threadIdx.x & 63) == 0)
-        s_wave4[threadIdx.x >> 6] = jmax;
+        s_wave8[threadIdx.x >> 6] = jmax;
     __syncthreads();
     if (c < F1) {
         rx.item_base[c] = ib;
         rx.work_base[c] = wb;
     }
     if (c == 0) {
-        uint32_t m = s_wave4[0];
-        for (int x = 1; x < 4; ++x)
-            m = s_wave4[x] > m ? s_wave4[x] : m;
+        uint32_t m = s_wave8[0];
+        for (int x = 1; x < 8; ++x)
+            m = s_wave8[x] > m ? s_wave8[x] : m;
         rx.item_base[F1] = tot_items;
         rx.work_base[F1] = tot_rows;
         rx.ctrl[0] = tot_items;
@@ -628,16 +720,19 @@ __global__ void __launch_bounds__(256) k_rx_tables(RxView rx)
 // consecutive values are written as one 128-byte (P1T) / 64-byte (S1T) piece.
 __global__ void __launch_bounds__(256) k_rx_colscan(RxView rx)
 {
-    constexpr int TB = 32;
-    __shared__ uint32_t tP[RX_MAXF][TB + 1];
-    __shared__ uint16_t tS[RX_MAXF][TB + 2];
-    const uint32_t c = threadIdx.x, F1 = rx.F1, NB = rx.NB;
+    constexpr int TB = 32, CW = 256; // blocks per tile; coarse partitions per sweep (F1 > 256: two sweeps)
+    __shared__ uint32_t tP[CW][TB + 1];
+    __shared__ uint16_t tS[CW][TB + 2];
+    const uint32_t F1 = rx.F1, NB = rx.NB;
     const uint32_t b0 = blockIdx.x * RX_CH;
     const uint32_t b1 = b0 + RX_CH < NB ? b0 + RX_CH : NB;
-    uint32_t run = c < F1 ? rx.csum[(size_t)blockIdx.x * F1 + c] : 0u;
-    const uint32_t ib = c < F1 ? rx.item_base[c] : 0u;
     const size_t ld = F1 + 1;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (uint32_t cb = 0; cb < F1; cb += CW) {
+    const uint32_t c = cb + threadIdx.x;
+    const uint32_t nc = F1 - cb < (uint32_t)CW ? F1 - cb : (uint32_t)CW;
+    uint32_t run = c < F1 ? rx.csum[(size_t)blockIdx.x * F1 + c] : 0u;
+    const uint32_t ib = c < F1 ? rx.item_base[c] : 0u;
     for (uint32_t t0 = b0; t0 < b1; t0 += TB) {
         const uint32_t nb = b1 - t0 < (uint32_t)TB ? b1 - t0 : (uint32_t)TB;
         if (c < F1) {
@@ -651,8 +746,8 @@ __global__ void __launch_bounds__(256) k_rx_colscan(RxView rx)
 #pragma unroll
             for (int u = 0; u < TB; ++u) {
                 const uint32_t cnt = hi[u] - lo[u];
-                tP[c][u] = run;
-                tS[c][u] = (uint16_t)lo[u];
+                tP[threadIdx.x][u] = run;
+                tS[threadIdx.x][u] = (uint16_t)lo[u];
                 if (cnt) { // items whose first k-mer lies in this run
                     uint32_t m = (run + RX_B - 1) / RX_B;
                     while ((uint64_t)m * RX_B < (uint64_t)run + cnt) {
@@ -666,32 +761,34 @@ __global__ void __launch_bounds__(256) k_rx_colscan(RxView rx)
         __syncthreads();
         // two partitions per wavefront instruction, 32 consecutive blocks each
         const uint32_t bi = lane & 31;
-        for (uint32_t cc = wave * 2 + (lane >> 5); cc < F1; cc += 8) {
+        for (uint32_t cc = wave * 2 + (lane >> 5); cc < nc; cc += 8) {
             if (bi < nb) {
-                rx.P1T[(size_t)cc * (NB + 1) + t0 + bi] = tP[cc][bi];
-                rx.S1T[(size_t)cc * NB + t0 + bi] = tS[cc][bi];
+                rx.P1T[(size_t)(cb + cc) * (NB + 1) + t0 + bi] = tP[cc][bi];
+                rx.S1T[(size_t)(cb + cc) * NB + t0 + bi] = tS[cc][bi];
             }
         }
         __syncthreads();
     }
+    }
 }
 
-// start2 [item][F2 + 1] -> start2T [F2 + 1][max_items], 64 items per workgroup through an LDS tile
+// start2 [item][F2 + 1] -> start2T [F2 + 1][max_items], RX_TR2 items per workgroup through an LDS tile
+constexpr int RX_TR2 = 32;
 __global__ void __launch_bounds__(256) k_rx_tr2(RxView rx)
 {
-    __shared__ uint16_t tile[64][RX_MAXF + 2];
+    __shared__ uint16_t tile[RX_TR2][RX_MAXF + 2];
     const uint32_t n_items = rx.ctrl[0], cols = rx.F2 + 1;
-    const uint32_t i0 = blockIdx.x * 64;
+    const uint32_t i0 = blockIdx.x * RX_TR2;
     if (i0 >= n_items)
         return;
-    const uint32_t ni = n_items - i0 < 64u ? n_items - i0 : 64u;
+    const uint32_t ni = n_items - i0 < (uint32_t)RX_TR2 ? n_items - i0 : (uint32_t)RX_TR2;
     for (uint32_t e = threadIdx.x; e < ni * cols; e += 256)
         tile[e / cols][e % cols] = rx.start2[(size_t)i0 * cols + e];
     __syncthreads();
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane < ni)
-        for (uint32_t col = wave; col < cols; col += 4)
-            rx.start2T[(size_t)col * rx.max_items + i0 + lane] = tile[lane][col];
+    const uint32_t it = threadIdx.x % RX_TR2, c0 = threadIdx.x / RX_TR2;
+    if (it < ni)
+        for (uint32_t col = c0; col < cols; col += 256 / RX_TR2)
+            rx.start2T[(size_t)col * rx.max_items + i0 + it] = tile[it][col];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -700,9 +797,10 @@ __global__ void __launch_bounds__(256) k_rx_tr2(RxView rx)
 __global__ void __launch_bounds__(RX_NT, 4) k_rx_p2(IndexView iv, RxView rx)
 {
     __shared__ uint64_t sbuf[RX_B];
-    __shared__ uint64_t sub_src[RX_SUBCAP];
+    __shared__ uint32_t sub_src[RX_SUBCAP];
     __shared__ uint32_t sub_meta[RX_SUBCAP], s_wave8[2][RX_NT / 64];
-    __shared__ uint32_t s_cnt[RX_MAXF + 1 + 64], s_base[RX_MAXF + 1], s_wave[4];
+    __shared__ __attribute__((aligned(8))) uint32_t s_cnt[RX_MAXF + 2 + 64];
+    __shared__ uint32_t s_base[RX_MAXF + 1], s_wave[4];
     __shared__ uint32_t s_idx;
     const int tid = threadIdx.x, grp = tid / RX_LPR, lg = tid % RX_LPR;
     const uint32_t NB = rx.NB;
@@ -716,6 +814,8 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p2(IndexView iv, RxView rx)
     const uint32_t home = rx_xcc_id();
     if (tid <= F2)
         s_cnt[tid] = 0; // (rx_sort_emit; the barriers of the first index broadcast lie before the first use)
+    if (tid == 0)
+        s_cnt[RX_NT] = 0;
     // An item's description (uniform) and this thread's run descriptor of its first round.  Both are loaded while
     // the PREVIOUS item is being sorted: the two dependent round trips (item table, then run descriptors) would
     // otherwise stand at the head of every item (measured: 27 % of the pass).
@@ -805,8 +905,8 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p2(IndexView iv, RxView rx)
                     rx_pad_list<RX_NG * RX_U2>(nw, sub_src, sub_meta);
                     __syncthreads();
                     for (uint32_t j0 = grp; j0 < nw; j0 += RX_NG * RX_U2) {
-                        uint64_t x[RX_U2], so[RX_U2];
-                        uint32_t meta[RX_U2];
+                        uint64_t x[RX_U2];
+                        uint32_t meta[RX_U2], so[RX_U2];
 #pragma unroll
                         for (int u = 0; u < RX_U2; ++u) {
                             meta[u] = sub_meta[j0 + u * RX_NG];
@@ -817,7 +917,7 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p2(IndexView iv, RxView rx)
 #pragma unroll
                         for (int u = 0; u < RX_U2; ++u) {
                             const uint32_t rel = (uint32_t)lg - ((meta[u] >> 6) & 63u);
-                            x[u] = rel < (meta[u] & 63u) ? RX_LOAD2(rx.buf1 + so[u] + lg) : 0ull;
+                            x[u] = rel < (meta[u] & 63u) ? RX_LOAD2(rx.buf1 + ((size_t)so[u] + lg)) : 0ull;
                         }
 #pragma unroll
                         for (int u = 0; u < RX_U2; ++u) {
@@ -893,7 +993,7 @@ __global__ void __launch_bounds__(RX_NT, WPS) k_rx_p3(IndexView iv, RxView rx, i
     __shared__ DirT sdir[WMAX + 1]; // bucket b of the slice holds entries [sdir[b], sdir[b + 1]) - e0
     __shared__ uint64_t skeys[ECAP];
     __shared__ uint32_t scnt[ECAP];
-    __shared__ uint64_t sub_src[RX_SUBCAP];
+    __shared__ uint32_t sub_src[RX_SUBCAP];
     __shared__ uint32_t sub_meta[RX_SUBCAP];
     __shared__ uint32_t s_wb[RX_MAXF + 1], s_wave8[2][RX_NT / 64];
     __shared__ uint32_t s_idx;
@@ -1060,8 +1160,8 @@ __global__ void __launch_bounds__(RX_NT, WPS) k_rx_p3(IndexView iv, RxView rx, i
                 for (uint32_t j0 = grp; j0 < nw; j0 += RX_NG3 * RX_U) {
                     // list entries first, then the loads, nothing conditional in between: the RX_U loads of a lane
                     // leave back to back (a lane outside its piece re-reads the piece's first k-mer)
-                    uint64_t x[RX_U], so[RX_U];
-                    uint32_t rel[RX_U], n[RX_U]; // lane's position inside the piece, k-mers of the piece
+                    uint64_t x[RX_U];
+                    uint32_t so[RX_U], rel[RX_U], n[RX_U]; // piece start; lane's position inside the piece, k-mers of the piece
 #pragma unroll
                     for (int u = 0; u < RX_U; ++u) {
                         const uint32_t m = sub_meta[j0 + u * RX_NG3];
@@ -1071,7 +1171,7 @@ __global__ void __launch_bounds__(RX_NT, WPS) k_rx_p3(IndexView iv, RxView rx, i
                     }
 #pragma unroll
                     for (int u = 0; u < RX_U; ++u)
-                        x[u] = RX_LOAD3(rx.buf2 + so[u] + (rel[u] < n[u] ? (uint32_t)lg : (uint32_t)lg - rel[u]));
+                        x[u] = RX_LOAD3(rx.buf2 + ((size_t)so[u] + (rel[u] < n[u] ? (uint32_t)lg : (uint32_t)lg - rel[u])));
                     // probe (mapper.pyx:53-69 on the LDS slice), RX_G3 k-mers side by side so that their LDS round
                     // trips overlap: all bucket bounds; then entry j of every bucket, j = 0, 1, ... (a lane whose
                     // bucket has no entry j reads key 0 and ignores it) — nothing conditional between the reads
@@ -1287,6 +1387,19 @@ __global__ void k_rx_bucket_sizes(const int32_t *__restrict__ h2i, const int32_t
         }
         out[h] = c;
     }
+}
+
+// 64-bit sum of n uint32 values (one atomic per wavefront)
+__global__ void __launch_bounds__(256) k_sum_u32(const uint32_t *__restrict__ v, uint64_t n, unsigned long long *out)
+{
+    unsigned long long s = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256)
+        s += v[i];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1)
+        s += __shfl_xor(s, d);
+    if ((threadIdx.x & 63) == 0 && s)
+        atomicAdd(out, s);
 }
 
 __global__ void k_rx_pack(const int32_t *__restrict__ h2i, const uint64_t *__restrict__ kmers,

@@ -44,13 +44,39 @@ def pack_kmers_at(codes, positions, k):
     return out
 
 
+def pack_kmers_strided(codes, n, stride, k):
+    """pack_kmers_at(codes, arange(n) * stride, k) without the index arrays: k strided sweeps (a 3e8-k-mer index
+    in seconds instead of minutes)."""
+    out = np.zeros(n, dtype=np.uint64)
+    tmp = np.empty(n, dtype=np.uint64)
+    for j in range(k):
+        np.copyto(tmp, codes[j:j + (n - 1) * stride + 1:stride], casting="unsafe")
+        tmp <<= np.uint64(2 * j)
+        out |= tmp
+    return out
+
+
+def pack_kmers_strided_torch(codes, n, stride, k, device=0):
+    """Same integers as pack_kmers_strided, packed on the GPU with torch (setup of >= 5e7-k-mer test indexes)."""
+    import torch
+    g = torch.from_numpy(codes).to("cuda:%d" % device)
+    out = torch.zeros(n, dtype=torch.int64, device=g.device)          # k <= 31: 62 bits, no sign involved
+    for j in range(k):
+        out |= g[j:j + (n - 1) * stride + 1:stride].to(torch.int64) << (2 * j)
+    res = out.cpu().numpy().view(np.uint64)
+    del g, out
+    return res
+
+
 def make_index(n_kmers, k=31, seed=1, skewed=False, plant=True, modulo=None, gpu_builder=False, device=0):
     """Returns (KmerIndex, genome codes).  gpu_builder: build the index arrays with kmm_build_index
     (bit-identical to the numpy construction, much faster for 1e8 entries)."""
     N = int(n_kmers)
     genome = make_genome(4 * N + k, seed)
-    pos = np.arange(N, dtype=np.int64) * 4
-    kmers = pack_kmers_at(genome, pos, k)
+    if gpu_builder and N >= 50_000_000:
+        kmers = pack_kmers_strided_torch(genome, N, 4, k, device)
+    else:
+        kmers = pack_kmers_strided(genome, N, 4, k)
     nodes = (np.arange(N, dtype=np.int64) % 1000) if skewed else np.arange(N, dtype=np.int64)
     n_nodes = 1000 if skewed else N
     if plant and N >= 8:

@@ -6,9 +6,12 @@
  * baseline.  The product path (kmer_mapper_amd/) never links, loads or calls it.
  *
  * Pinning status (see DESIGN.md "Oracle"):
- *   - lookup half  (oracle_map_kmers, oracle_in_index): pinned by the reference's own known-answer
- *     vector (reference tests/test_gpucounter.py:41-48) and by the outputs of the unmodified
- *     compiled reference recorded in SURVEY.md §8c (tests/golden/reference_vectors.json).
+ *   - lookup half  (oracle_map_kmers, oracle_in_index): pinned by the two known-answer vectors the reference's own
+ *     tests hold (tests/test_gpucounter.py:41-48 and tests/test_mapping.py:33-40; data in
+ *     tests/golden/reference_vectors.json).  The other vectors of that file (hash collision, multi-node k-mer,
+ *     frequency filter) are transcriptions of numbers in SURVEY.md section 8c prose and are NOT pins: they are
+ *     regression vectors; for those cases the restatement rests on its line-by-line correspondence with
+ *     mapper.pyx:53-69.
  *   - extraction half (oracle_extract_kmers): the arithmetic lives in bionumpy, which is not in
  *     the reference tree nor installed here -> PARITY UNPINNED at that boundary; it follows the
  *     call shape of kmer_mapper/util.py:71-75, the N->A rule of command_line_interface.py:41 and

@@ -31,6 +31,37 @@ def build(force=False):
     return _SO
 
 
+def _cpu_signature():
+    """Short hash of this host's CPU flags: a -march=native build is only ever loaded on the CPU it was built for."""
+    import hashlib
+    try:
+        with open("/proc/cpuinfo") as f:
+            flags = next((ln for ln in f if ln.startswith("flags")), "")
+    except OSError:
+        flags = ""
+    return hashlib.sha1(flags.encode()).hexdigest()[:10]
+
+
+_native = None          # path of the -march=native build in use, or None (portable build)
+
+
+def use_native_build():
+    """BASELINE.md section 3 / reference setup.py:10-15 compile with -O3 -march=native: build such a copy ON THIS HOST
+    (gcc, seconds) and use it from now on; the portable -O3 build stays the fallback when gcc refuses.  Returns the
+    flags in use.  Call before the first lib()."""
+    global _native, _lib
+    so = os.path.join(_HERE, "libkmm_oracle_native_%s.so" % _cpu_signature())
+    src = os.path.join(_HERE, "kmm_oracle.c")
+    try:
+        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+            subprocess.check_call(["gcc", "-O3", "-march=native", "-fPIC", "-std=c11", "-pthread", "-shared", "-o", so, src,
+                                   "-lpthread"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        _native, _lib = so, None
+        return "-O3 -march=native (built on this host)"
+    except Exception:
+        return "-O3 (portable build; -march=native failed here)"
+
+
 _lib = None
 
 
@@ -38,7 +69,7 @@ def lib():
     global _lib
     if _lib is None:
         build()
-        L = ctypes.CDLL(_SO)
+        L = ctypes.CDLL(_native or _SO)
         L.oracle_map_kmers.argtypes = [_P, _P, _c.c_uint64, _P, _P, _P, _P, _c.c_int64, _c.c_int, _P]
         L.oracle_map_kmers.restype = None
         L.oracle_in_index.argtypes = [_P, _P, _c.c_uint64, _P, _P, _c.c_int64, _P]

@@ -105,3 +105,104 @@ def test_customary_large_modulo_uses_8192_bucket_slices(kmm, oracle):
             dev.map_reads_uniform(bases, 300_000, 150, 31)
             assert np.array_equal(dev.get_node_counts(), expect), path
         assert dev.get_param("radix_p3_kmers") == n
+
+
+def test_modulo_above_2_pow_29_takes_the_radix_path(kmm, oracle):
+    """a table with more than 256 x 256 slices of 8192 buckets (modulo > 2^29; the reference's int32
+    tables allow every modulo below 2^31, mapper.pyx:22-23,31-32,53-56) used to fall off the radix path.  3e8 entries,
+    modulo ~6e8: the fan-out goes beyond 256 per pass; a full 10 M-read batch through direct == radix == auto,
+    conservation counters, and a 200 k-read sample against the oracle.  The direct view of an index this size
+    (24 GB) is only packed when the first direct-path batch asks for it."""
+    import torch
+    from kmer_mapper_amd import synthetic as syn
+    R, L, k = 10_000_000, 150, 31
+    index, genome = syn.make_index(300_000_000, k=k, seed=1, gpu_builder=True)
+    assert index._modulo > 2 ** 29
+    mx = index.max_node_id()
+    g_ascii = torch.from_numpy(syn.ACGT[genome]).cuda()
+    reads = syn.make_reads_torch(g_ascii, R, L, seed=1001)
+    del g_ascii, genome
+    torch.cuda.synchronize()
+    n_kmers = R * (L - k + 1)
+    with kmm.DeviceIndex.from_index(index, mx) as dev:
+        assert dev.get_param("radix_available") == 1 and dev.get_param("radix_unavailable_reason") == 0
+        assert max(dev.get_param("n_coarse_partitions"), dev.get_param("n_fine_per_coarse")) > 256
+        assert dev.get_param("direct_view_resident") == 0          # HBM budget: one view until the other is needed
+        res = {}
+        for name, path in (("radix", 2), ("auto", 0), ("direct", 1)):
+            dev.reset()
+            dev.set_param("path", path)
+            dev.map_reads_uniform(reads, R, L, k)
+            res[name] = dev.get_node_counts()
+            if path != 1:
+                assert dev.get_param("radix_p2_kmers") == n_kmers, name
+                assert dev.get_param("radix_p3_kmers") + dev.get_param("radix_p2_dropped") == n_kmers, name
+            else:
+                assert dev.get_param("direct_view_resident") == 1
+            assert dev.get_stats(reset=True)[0] == n_kmers, name
+        assert np.array_equal(res["radix"], res["direct"]) and np.array_equal(res["auto"], res["direct"])
+        hits = int(res["direct"].astype(np.uint64).sum())
+        assert 0.15 < hits / n_kmers < 0.25
+        n_s = 200_000
+        sample = reads[:n_s * L].cpu().numpy()
+        s_offs = np.arange(n_s + 1, dtype=np.int64) * L
+        expect, n = oracle.map_reads(index, mx, sample, s_offs, k, n_threads=8)
+        assert n == n_s * (L - k + 1)
+        for path in (1, 2):
+            dev.reset()
+            dev.set_param("path", path)
+            dev.map_reads_uniform(reads[:n_s * L], n_s, L, k)
+            assert np.array_equal(dev.get_node_counts(), expect), path
+        km = kmm.extract_kmers(sample[:20_000 * L], s_offs[:20_001], k)
+        assert np.array_equal(dev.in_index(km), oracle.in_index(index, km))
+
+
+def test_direct_view_is_packed_on_first_use_when_deferred(kmm, oracle, monkeypatch):
+    """HBM budget of large indexes: with the direct view deferred (forced here on a small index) the radix path
+    works without it, the first direct-path batch / kmm_in_index packs it from the radix view's bucket-ordered
+    copy, and every result equals the oracle's (also with the L2 pre-filter rebuilt from that copy)."""
+    from kmer_mapper_amd import synthetic as syn
+    monkeypatch.setenv("KMM_DIRECT_EAGER_BYTES", "0")
+    for n_index, modulo in ((30_000, None), (200_000, 452_930_477)):     # Bloom-filter layout; wide layout
+        index, genome = syn.make_index(n_index, k=31, seed=71, modulo=modulo, gpu_builder=True)
+        mx = index.max_node_id()
+        bases, offs = syn.make_ragged_reads(genome, 20_000, 0, 250, seed=72)
+        expect, n = oracle.map_reads(index, mx, bases, offs, 31, n_threads=4)
+        km = oracle.extract(bases, offs, 31)
+        with kmm.DeviceIndex.from_index(index, mx) as dev:
+            assert dev.get_param("direct_view_resident") == 0
+            dev.set_param("path", 2)
+            dev.map_reads(bases, offs, 31)
+            assert np.array_equal(dev.get_node_counts(), expect)
+            assert dev.get_param("direct_view_resident") == 0
+            assert np.array_equal(dev.in_index(km[:50_000]), oracle.in_index(index, km[:50_000]))
+            assert dev.get_param("direct_view_resident") == 1
+            dev.reset()
+            dev.set_param("path", 1)
+            dev.map_reads(bases, offs, 31)
+            assert np.array_equal(dev.get_node_counts(), expect)
+            dev.reset()
+            dev.map_kmers(km)
+            assert np.array_equal(dev.get_node_counts(), expect)
+
+
+def test_overlapping_buckets_are_served_by_the_direct_path(kmm, oracle):
+    """The reference's loop only follows (hashes_to_index[h], n_kmers[h]) (mapper.pyx:55-58): two buckets may share
+    entries.  Such an index has no bucket-ordered copy of bounded size, so the radix view is not built (reason 4) and
+    the direct path answers — same counts as the oracle."""
+    import types
+    from kmer_mapper_amd import synthetic as syn
+    index, genome = syn.make_index(5_000, k=31, seed=91)
+    h2i, nk = index._hashes_to_index.copy(), index._n_kmers.copy()
+    empty = np.flatnonzero(nk == 0)[:200]
+    full = np.flatnonzero(nk > 0)[:200]
+    h2i[empty], nk[empty] = h2i[full], nk[full]        # 200 empty buckets alias 200 occupied ones (never matched: wrong hash)
+    dup = types.SimpleNamespace(_hashes_to_index=h2i, _n_kmers=nk, _nodes=index._nodes, _kmers=index._kmers,
+                                _frequencies=index._frequencies, _modulo=index._modulo)
+    mx = index.max_node_id()
+    bases, offs = syn.make_reads(genome, 5_000, 150, seed=92)
+    expect, _ = oracle.map_reads(dup, mx, bases, offs, 31, n_threads=2)
+    with kmm.DeviceIndex.from_index(dup, mx) as dev:
+        assert dev.get_param("radix_available") == 0 and dev.get_param("radix_unavailable_reason") == 4
+        dev.map_reads(bases, offs, 31)
+        assert np.array_equal(dev.get_node_counts(), expect)

@@ -279,3 +279,29 @@ def test_uniform_reads_of_any_length(kmm, syn, oracle, read_len):
             dev.reset()
             dev.map_reads_uniform(bases, n_reads, read_len, 31)
             assert np.array_equal(dev.get_node_counts(), expect), path
+
+
+def test_conservation_self_check_is_armed_in_production(kmm, syn, oracle):
+    """Every synchronising call compares the k-mers emitted by pass 1, gathered by pass 2 and probed by pass 3 (+ those
+    pass 2 dropped as absent) and refuses to return counts when they differ (KMM_ERR_INTERNAL, sticky until
+    kmm_reset_counts) — the tripwire for a work item processed twice (the round-2 race).  The
+    mismatch is forced through the debug parameter; the normal run before and after it passes the check."""
+    from kmer_mapper_amd._lib import KmmError
+    index, genome = syn.make_index(30000, seed=811)
+    mx = index.max_node_id()
+    bases, offs = syn.make_reads(genome, 20000, 150, seed=812)
+    expect, n = oracle.map_reads(index, mx, bases, offs, 31, n_threads=4)
+    with kmm.DeviceIndex.from_index(index, mx) as dev:
+        dev.set_param("path", 2)
+        dev.map_reads(bases, offs, 31)
+        assert np.array_equal(dev.get_node_counts(), expect)          # check passes on a normal run
+        dev.map_reads(bases, offs, 31)
+        dev.set_param("debug_skew_p2_counter", 1024)                  # "one item gathered twice"
+        with pytest.raises(KmmError, match="self-check failed"):
+            dev.get_node_counts()
+        with pytest.raises(KmmError, match="self-check failed"):     # sticky: no counts until the reset
+            dev.synchronize()
+        dev.reset()
+        dev.map_reads(bases, offs, 31)
+        assert np.array_equal(dev.get_node_counts(), expect)
+        assert dev.get_param("radix_p2_kmers") == n == dev.get_param("radix_p3_kmers") + dev.get_param("radix_p2_dropped")
