@@ -59,6 +59,9 @@ def main():
     ap.add_argument("--index-kmers", type=int, default=None, help="overrides --config's index size")
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--numpy-builder", action="store_true", help="build the synthetic index with numpy instead of kmm_build_index")
+    ap.add_argument("--torch-index", action="store_true",
+                    help="generate and build the synthetic index on the GPU (synthetic.make_index_torch; default above "
+                         "3e8 k-mers: BASELINE configs[4]'s 1e9-k-mer index takes minutes on the host)")
     ap.add_argument("--modulo", type=int, default=None, help="hash-table size (default: smallest prime >= 2N)")
     ap.add_argument("-k", "--kmer-size", type=int, default=31)
     ap.add_argument("--skewed", action="store_true", help="node = i mod 1000 (atomic contention)")
@@ -123,12 +126,20 @@ def main():
 
     k, L, R = args.kmer_size, args.read_len, args.reads
     t_setup = time.time()
-    index, genome = syn.make_index(args.index_kmers, k=k, seed=1, skewed=args.skewed, modulo=args.modulo,
-                                   gpu_builder=not args.numpy_builder, device=local_rank)   # untimed setup; identical arrays
+    torch_index = args.torch_index or args.index_kmers > 300_000_000
+    if torch_index:
+        assert not args.skewed
+        index, g_ascii = syn.make_index_torch(args.index_kmers, k=k, seed=1, modulo=args.modulo, device=local_rank)
+    else:
+        index, genome = syn.make_index(args.index_kmers, k=k, seed=1, skewed=args.skewed, modulo=args.modulo,
+                                       gpu_builder=not args.numpy_builder, device=local_rank)   # untimed setup; identical arrays
     mx = index.max_node_id()
-    log("index: %d entries, modulo %d, max_node_id %d (%.1fs)"
-        % (len(index._kmers), index._modulo, mx, time.time() - t_setup))
+    n_entries, modulo_used = len(index._kmers), index._modulo
+    log("index: %d entries, modulo %d, max_node_id %d (%.1fs)" % (n_entries, modulo_used, mx, time.time() - t_setup))
     dev = DeviceIndex.from_index(index, mx, device=local_rank)
+    if torch_index:          # the handle owns its own copy: keep only what the CPU leg needs (host arrays, on demand)
+        index = index.to_host() if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
+        torch.cuda.empty_cache()
     dev.set_param("path", args.path)
     if args.no_filter:
         dev.set_param("occupancy_filter", 0)
@@ -149,7 +160,8 @@ def main():
     counts = torch.zeros(mx + 1, dtype=torch.int32, device=dev_t)    # uint32 bits; wrap-add == int32 add
     dev.bind_counts(counts)
 
-    g_ascii = torch.from_numpy(syn.ACGT[genome]).to(dev_t)
+    if not torch_index:
+        g_ascii = torch.from_numpy(syn.ACGT[genome]).to(dev_t)
     batches = [syn.make_reads_torch(g_ascii, R, L, seed=1000 * (rank + 1) + b) for b in range(2)]
     offs = None
     if args.general_path:
@@ -354,7 +366,9 @@ def main():
                     break
             except Exception:
                 traffic = None
-        if args.index_kmers == 100_000_000 and R == 10_000_000:
+        if args.index_kmers == 1_000_000_000:
+            cfg_label = "configs[4]'s index on one GPU (1 B-k-mer index resident in HBM)"
+        elif args.index_kmers == 100_000_000 and R == 10_000_000:
             cfg_label = "configs[2] (100 M reads as batches of 10 M, 100 M-k-mer index)"
         elif args.index_kmers == 10_000_000 and R == 10_000_000:
             cfg_label = "configs[1] (10 M reads per batch, 10 M-k-mer index)"
@@ -376,7 +390,7 @@ def main():
             "config": {
                 "workload": "%s: %d steps x %d synthetic %d bp reads per batch per GPU, k=%d, %d-k-mer index "
                             "(modulo %d, %d entries), reads resident in HBM, %s"
-                            % (cfg_label, args.steps, R, L, k, args.index_kmers, index._modulo, len(index._kmers),
+                            % (cfg_label, args.steps, R, L, k, args.index_kmers, modulo_used, n_entries,
                                "kmm_map_records on raw FASTQ chunks" if args.records else
                                "operator kmm_map_kmers on pre-extracted k-mers" if args.operator else
                                "fused kmm_map_reads" + ("" if args.general_path else "_uniform")),
@@ -457,7 +471,8 @@ def main():
             avail = len(os.sched_getaffinity(0))
         except AttributeError:
             avail = os.cpu_count() or 1
-        n_threads = min(16, avail)                         # reference CLI default -t 16
+        # reference CLI default -t 16; fewer when 16 private count vectors (4 B x nodes each) would not fit 24 GB
+        n_threads = max(1, min(16, avail, int(24e9 // (4 * (mx + 1)))))
         oracle.map_reads(index, mx, sample[: 20000 * L], s_offs[:20001], k, n_threads=n_threads)  # warm
         tc0 = time.perf_counter()
         expect, n_k = oracle.map_reads(index, mx, sample, s_offs, k, n_threads=n_threads)

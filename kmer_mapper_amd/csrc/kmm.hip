@@ -484,7 +484,10 @@ int launch_rx(kmm_index *ix, const ReadsView &rv, const uint64_t *kmers_in, int6
     const int64_t units = MODE == MODE_KMERS ? n_in : rv.total;
     const int64_t n_src_total = (units + RX_B - 1) / RX_B;
     const uint32_t X = also_rc ? 2u : 1u;
-    const int64_t max_src = (((int64_t)1 << 31) / RX_B) / X; // < 2^31 k-mers per sub-batch: 32-bit prefixes
+    const int64_t cap_src = (((int64_t)1 << 31) / RX_B) / X; // < 2^31 k-mers per sub-batch: 32-bit prefixes
+    // sub-batches of equal size (every one of them streams the index slices once: no small last one)
+    const int64_t n_sub = (n_src_total + cap_src - 1) / cap_src;
+    const int64_t max_src = n_sub ? (n_src_total + n_sub - 1) / n_sub : cap_src;
     const uint32_t F1 = ix->rx_F1, F2 = ix->rx_F2;
     for (int64_t s0 = 0; s0 < n_src_total; s0 += max_src) {
         const uint32_t n_src = (uint32_t)(n_src_total - s0 < max_src ? n_src_total - s0 : max_src);

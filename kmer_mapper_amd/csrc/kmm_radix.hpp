@@ -301,12 +301,13 @@ struct RxNoHook {
 // non-temporal copy-out), one after the placement.  ENDBAR = false leaves out the one after the copy-out:
 // the caller then guarantees a barrier of its own before sbuf is written again and before the next call's ranking
 // (which needs the counters this call clears during its copy-out).
-template <int RB, bool ENDBAR, bool ONEBAR, typename PrepFn, typename MidFn = RxNoHook>
-__device__ __forceinline__ void rx_sort_emit(uint64_t (&q)[RX_KPT], PrepFn prep, int F, uint64_t *sbuf,
+template <int RB, bool ENDBAR, bool ONEBAR, int NT = RX_NT, typename PrepFn, typename MidFn = RxNoHook>
+__device__ __forceinline__ void rx_sort_emit(uint64_t (&q)[RX_B / NT], PrepFn prep, int F, uint64_t *sbuf,
                                              uint32_t *s_cnt, uint32_t *s_base, uint32_t *s_wave,
                                              uint64_t *__restrict__ out, uint16_t *__restrict__ dir_row,
                                              unsigned long long *pt_acc = nullptr, MidFn mid = MidFn())
 {
+    constexpr int KPT = RX_B / NT; // k-mers per thread
     const int tid = threadIdx.x;
     (void)pt_acc;
     // s_cnt[0..F] is zero on entry: cleared by the caller before its first call (followed by a barrier) and by every
@@ -314,9 +315,9 @@ __device__ __forceinline__ void rx_sort_emit(uint64_t (&q)[RX_KPT], PrepFn prep,
     // rank inside the key's run: one returning LDS atomic per k-mer, RB in flight before the first result is
     // consumed; RB at a time also bounds the registers
     // the key computation (pass 1: a 64-bit division by the modulo) holds at once
-    uint32_t cr[RX_KPT]; // key << 16 | rank
+    uint32_t cr[KPT]; // key << 16 | rank
 #pragma unroll
-    for (int h = 0; h < RX_KPT; h += RB) {
+    for (int h = 0; h < KPT; h += RB) {
         uint32_t ck[RB], rk[RB];
 #pragma unroll
         for (int i = 0; i < RB; ++i)
@@ -337,15 +338,15 @@ __device__ __forceinline__ void rx_sort_emit(uint64_t (&q)[RX_KPT], PrepFn prep,
     const uint32_t total = F <= 256 ? rx_scan256<ONEBAR>(s_cnt, s_base, F, s_wave) : rx_scan512<ONEBAR>(s_cnt, s_base, F, s_wave);
     if (tid <= F)
         dir_row[tid] = (uint16_t)s_base[tid];
-    if (F == RX_NT && tid == 0) // (fan-out 512: one more entry than threads)
-        dir_row[RX_NT] = (uint16_t)s_base[RX_NT];
+    if (NT == RX_MAXF && F == NT && tid == 0) // (fan-out 512 on 512 threads: one more entry than threads)
+        dir_row[NT] = (uint16_t)s_base[NT];
     // (one slot after the other: reading all 16 run starts first and then writing — 16 overlapping LDS round trips —
     // measured SLOWER, pass 1 4.41 vs 3.62 ms, pass 2 4.75 vs 4.30 ms)
 #ifndef RX_PLACE_BATCH
 #define RX_PLACE_BATCH 1
 #endif
 #pragma unroll
-    for (int h = 0; h < RX_KPT; h += RX_PLACE_BATCH) {
+    for (int h = 0; h < KPT; h += RX_PLACE_BATCH) {
         uint32_t pos[RX_PLACE_BATCH];
 #pragma unroll
         for (int i = 0; i < RX_PLACE_BATCH; ++i)
@@ -359,11 +360,11 @@ __device__ __forceinline__ void rx_sort_emit(uint64_t (&q)[RX_KPT], PrepFn prep,
     RX_PT(3); // scan + placement
     if (tid <= F)
         s_cnt[tid] = 0; // for the next call (every wavefront's scan has read the counts: they lie before the barrier)
-    if (F == RX_NT && tid == 0)
-        s_cnt[RX_NT] = 0;
+    if (NT == RX_MAXF && F == NT && tid == 0)
+        s_cnt[NT] = 0;
     const uint4 *s4 = reinterpret_cast<const uint4 *>(sbuf);
     uint4 *o4 = reinterpret_cast<uint4 *>(out);
-    for (uint32_t i = tid; i < (total + 1) / 2; i += RX_NT) {
+    for (uint32_t i = tid; i < (total + 1) / 2; i += NT) {
         if (ONEBAR) { // (pass 1) streamed out past L2: the directory rows the scan kernels read next stay there
             typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
             const uint4 v = s4[i];

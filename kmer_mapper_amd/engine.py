@@ -255,6 +255,24 @@ def extract_kmers(bases, read_offsets, k, lut=None, device=0, out=None):
     return out
 
 
+def build_index_device(kmers, nodes, modulo, device=0):
+    """kmm_build_index on torch DEVICE tensors (kmers int64/uint64 bit patterns, nodes int32), outputs left on the
+    device: (hashes_to_index int32[M], n_kmers int32[M], kmers int64[n], nodes int32[n], frequencies uint16[n]).
+    For indexes too large to round-trip through host memory quickly (a 10^9-k-mer index is 30 GB of arrays)."""
+    import torch
+    n, M = kmers.numel(), int(modulo)
+    assert kmers.is_cuda and nodes.is_cuda and nodes.dtype == torch.int32 and kmers.element_size() == 8
+    dev = kmers.device
+    h2i = torch.empty(M, dtype=torch.int32, device=dev)
+    nk = torch.empty(M, dtype=torch.int32, device=dev)
+    ko = torch.empty(n, dtype=torch.int64, device=dev)
+    no = torch.empty(n, dtype=torch.int32, device=dev)
+    fo = torch.empty(n, dtype=torch.uint16, device=dev)
+    p = lambda t: _P(t.data_ptr())
+    _lib.check(_lib.lib().kmm_build_index(int(device), p(kmers), p(nodes), n, M, p(h2i), p(nk), p(ko), p(no), p(fo)))
+    return h2i, nk, ko, no, fo
+
+
 def build_index(kmers, nodes, modulo, device=0):
     """GPU counterpart of graph_kmer_index's KmerIndex.from_flat_kmers (tests/test_mapping.py:36-38):
     returns (hashes_to_index int32[M], n_kmers int32[M], kmers uint64[n], nodes int32[n],

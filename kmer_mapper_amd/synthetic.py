@@ -158,3 +158,65 @@ def make_reads_torch(genome_ascii_dev, n_reads, read_len=150, seed=2, sub_rate=0
         rd = torch.where(low, rd | 0x20, rd)
         out[r0:r1] = rd
     return out.reshape(-1)
+
+
+class DeviceSyntheticIndex:
+    """A synthetic Kmer Index whose five arrays live in HBM as torch tensors (duck-typed like the reference's index
+    object, mapper.pyx:22-29: DeviceIndex.from_index takes it as it is).  to_host() gives the numpy KmerIndex the
+    CPU oracle needs."""
+
+    def __init__(self, h2i, nk, kmers, nodes, freqs, modulo, max_node):
+        self._hashes_to_index, self._n_kmers, self._kmers, self._nodes, self._frequencies = h2i, nk, kmers, nodes, freqs
+        self._modulo = int(modulo)
+        self._max_node = int(max_node)
+
+    def max_node_id(self):
+        return self._max_node
+
+    def to_host(self):
+        c = lambda t: t.cpu().numpy()
+        return KmerIndex(c(self._hashes_to_index), c(self._n_kmers), c(self._nodes), c(self._kmers).view(np.uint64),
+                         self._modulo, c(self._frequencies))
+
+
+def make_index_torch(n_kmers, k=31, seed=1, modulo=None, device=0, plant=True):
+    """make_index's data model (genome of 4 N + k uniform bases, the k-mers at positions 4 i under node i, 0.1 % of them
+    duplicated under 1-2 further nodes, one k-mer planted 1500 times) generated AND built on the GPU — torch's generator,
+    so the values differ from make_index's numpy stream; for index sizes whose host-side generation would take
+    minutes (BASELINE configs[4]: 10^9 k-mers).  Returns (DeviceSyntheticIndex, genome ASCII uint8 tensor on the device)."""
+    import torch
+    from .engine import build_index_device
+    N = int(n_kmers)
+    dev = torch.device("cuda", device)
+    g = torch.Generator(device=dev)
+    g.manual_seed(int(seed))
+    genome = torch.empty(4 * N + k, dtype=torch.uint8, device=dev)
+    step = 1 << 28
+    for a in range(0, genome.numel(), step):
+        b = min(genome.numel(), a + step)
+        genome[a:b] = torch.randint(0, 4, (b - a,), generator=g, device=dev, dtype=torch.uint8)
+    kmers = torch.zeros(N, dtype=torch.int64, device=dev)
+    for j in range(k):
+        kmers |= genome[j:j + (N - 1) * 4 + 1:4].to(torch.int64) << (2 * j)
+    nodes = torch.arange(N, dtype=torch.int32, device=dev)
+    if plant and N >= 8:
+        n_dup = max(1, N // 1000)
+        dup = torch.randint(0, N, (n_dup,), generator=g, device=dev)
+        reps = torch.randint(1, 3, (n_dup,), generator=g, device=dev)
+        dup_k = torch.repeat_interleave(kmers[dup], reps)
+        dup_n = torch.randint(0, N, (dup_k.numel(),), generator=g, device=dev, dtype=torch.int32)
+        hot = kmers[int(torch.randint(0, N, (1,), generator=g, device=dev).item())]
+        hot_k = hot.repeat(1500)
+        hot_n = torch.randint(0, N, (1500,), generator=g, device=dev, dtype=torch.int32)
+        kmers = torch.cat([kmers, dup_k, hot_k])
+        nodes = torch.cat([nodes, dup_n, hot_n])
+    if modulo is None:
+        modulo = next_prime(2 * N)
+    h2i, nk, ko, no, fo = build_index_device(kmers, nodes, modulo, device=device)
+    del kmers, nodes
+    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+    for a in range(0, genome.numel(), step):          # codes -> ASCII in place
+        b = min(genome.numel(), a + step)
+        genome[a:b] = lut[genome[a:b].long()]
+    torch.cuda.synchronize(dev)
+    return DeviceSyntheticIndex(h2i, nk, ko, no, fo, modulo, N - 1), genome
