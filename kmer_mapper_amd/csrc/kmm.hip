@@ -191,6 +191,8 @@ struct kmm_index {
     uint16_t *rx_pfreq = nullptr;
     uint32_t *rx_pnodes = nullptr, *rx_porig = nullptr, *rx_ecnt = nullptr, *rx_ecnt_acc = nullptr;
     uint32_t *rx_norder = nullptr, *rx_nnode = nullptr; // entries in node order (k_rx_flush_sorted); absent if memory is short
+    uint32_t *rx_occ = nullptr;   // bit h = bucket h holds an entry: pass 2's empty-bucket filter (k_rx_p2f); optional
+    bool rx_filter = true;        // "radix_filter": use the filtering pass 2 whenever a coarse partition's bitmap fits LDS
     bool ecnt_dirty = false;  // rx_ecnt holds hits that are not in `counts` yet
     bool rx_unchecked = false; // radix passes have run since the conservation counters were last compared (drain)
     DevBuf rx_buf1, rx_buf2, rx_meta;
@@ -444,6 +446,14 @@ bool rx_configure(kmm_index *ix, int w, int maxf = RX_MAXF, int f2_force = -1)
     while ((1ull << lg) < PF)
         ++lg;
     int f2 = (lg + 1) / 2;
+    bool for_filter = false;
+    // pass 2's empty-bucket filter needs coarse partitions of at most 2^19 buckets (64 KB of LDS bitmap): take fewer
+    // fine-partition bits — more, smaller coarse partitions — when pass 1's fan-out stays within 512
+    if (ix->rx_filter && w + f2 > P2F_LOGBITS && P2F_LOGBITS - w >= 0 &&
+        ((PF + (1ull << (P2F_LOGBITS - w)) - 1) >> (P2F_LOGBITS - w)) <= (uint64_t)RX_MAXF) {
+        f2 = P2F_LOGBITS - w;
+        for_filter = true;
+    }
     if (f2_force >= 0)
         f2 = f2_force;
     // the packed form (kmm_radix.hpp) keeps floor(q / modulo) above w + f2 hash bits: it must fit for EVERY
@@ -455,7 +465,7 @@ bool rx_configure(kmm_index *ix, int w, int maxf = RX_MAXF, int f2_force = -1)
     if (!fits(w + f2))
         return false;
     const uint64_t F2 = 1ull << f2, F1 = (PF + F2 - 1) / F2;
-    if (F2 > (uint64_t)maxf || F1 > (uint64_t)maxf)
+    if (F2 > (uint64_t)maxf || F1 > (uint64_t)(for_filter ? RX_MAXF : maxf))
         return false;
     ix->rx_w = w;
     ix->rx_f2 = f2;
@@ -463,6 +473,14 @@ bool rx_configure(kmm_index *ix, int w, int maxf = RX_MAXF, int f2_force = -1)
     ix->rx_F1 = (uint32_t)F1;
     ix->rx_F2 = (uint32_t)F2;
     return true;
+}
+
+// Pass 2 filters k-mers of empty buckets (k_rx_p2f) when a coarse partition's bitmap fits its 64 KB of LDS and its
+// first bucket starts a bitmap word.
+bool rx_filter_active(const kmm_index *ix)
+{
+    const int sh = ix->rx_w + ix->rx_f2;
+    return ix->rx_filter && ix->rx_occ && sh >= 5 && sh <= P2F_LOGBITS;
 }
 
 bool use_radix(const kmm_index *ix, int64_t units)
@@ -497,6 +515,7 @@ int launch_rx(kmm_index *ix, const ReadsView &rv, const uint64_t *kmers_in, int6
         RxView rx;
         memset(&rx, 0, sizeof rx);
         rx.pstart = ix->rx_pstart; rx.pkeys = ix->rx_pkeys; rx.pfreq = ix->rx_pfreq; rx.ecnt = ix->rx_ecnt;
+        rx.occ = ix->rx_occ;
         rx.w = ix->rx_w; rx.f2 = ix->rx_f2; rx.PF = ix->rx_PF; rx.F1 = F1; rx.F2 = F2;
         rx.NB = NB; rx.max_items = (uint32_t)max_items;
         size_t off = 0;
@@ -542,7 +561,10 @@ int launch_rx(kmm_index *ix, const ReadsView &rv, const uint64_t *kmers_in, int6
         HIPCHK(hipGetLastError());
         KMMCHK(tm.end());
         KMMCHK(tm.begin(ix, KMM_KERNEL_RX_P2));
-        hipLaunchKernelGGL(k_rx_p2, dim3(ix->n_cu * ix->rx_grid_per_cu), dim3(RX_NT), 0, ix->stream, iv, rx);
+        if (rx_filter_active(ix)) // the coarse partition's occupancy bitmap fits LDS: drop k-mers of empty buckets here
+            hipLaunchKernelGGL(k_rx_p2f, dim3(ix->n_cu), dim3(P2F_NT), 0, ix->stream, iv, rx);
+        else
+            hipLaunchKernelGGL(k_rx_p2, dim3(ix->n_cu * ix->rx_grid_per_cu), dim3(RX_NT), 0, ix->stream, iv, rx);
         HIPCHK(hipGetLastError());
         KMMCHK(tm.end());
         KMMCHK(tm.begin(ix, KMM_KERNEL_RX_SCAN));
@@ -771,7 +793,8 @@ void kmm_index_destroy(kmm_index_t *ix)
     release(ix->rx_buf1);
     release(ix->rx_buf2);
     for (void *q : {(void *)ix->rx_pstart, (void *)ix->rx_pkeys, (void *)ix->rx_pkeys_raw, (void *)ix->rx_pfreq, (void *)ix->rx_pnodes,
-                    (void *)ix->rx_porig, (void *)ix->rx_ecnt, (void *)ix->rx_ecnt_acc, (void *)ix->rx_norder, (void *)ix->rx_nnode})
+                    (void *)ix->rx_porig, (void *)ix->rx_ecnt, (void *)ix->rx_ecnt_acc, (void *)ix->rx_norder, (void *)ix->rx_nnode,
+                    (void *)ix->rx_occ})
         if (q)
             (void)hipFree(q);
     for (auto &ev : ix->ev_used) {
@@ -835,6 +858,8 @@ static int rx_build(kmm_index *ix, const int32_t *h2i, const int32_t *nk, const 
                     const int32_t *nodes, const uint16_t *freqs)
 {
     const uint64_t M = ix->modulo;
+    if (const char *env = getenv("KMM_RX_FILTER")) // experiments: 0 = plain pass 2 and the fan-out chosen without the filter
+        ix->rx_filter = atoi(env) != 0;
     ix->rx_why_not = 1;
     if (M >= (1ull << 31))
         return KMM_OK; // beyond the index format's int32 tables: no radix path; the direct path serves every batch
@@ -866,6 +891,18 @@ static int rx_build(kmm_index *ix, const int32_t *h2i, const int32_t *nk, const 
         if ((e = hipMemcpyAsync(&total, ix->rx_pstart + M, 4, hipMemcpyDeviceToHost, ix->stream))) break;
         if ((e = hipStreamSynchronize(ix->stream))) break;
         ix->rx_S = total; // = sum64 <= n_entries < 2^31
+        {   // occupancy bitmap for pass 2's empty-bucket filter, padded by one coarse partition's worth of words
+            // (k_rx_p2f loads whole partitions); optional: without the memory for it the plain pass 2 runs
+            const size_t occ_words = (size_t)((M + 31) / 32) + ((size_t)1 << (P2F_LOGBITS - 5));
+            if (hipMalloc(&ix->rx_occ, occ_words * 4) == hipSuccess) {
+                if ((e = hipMemsetAsync(ix->rx_occ, 0, occ_words * 4, ix->stream))) break;
+                hipLaunchKernelGGL(k_rx_build_occ, dim3(grid_for(ix, (int64_t)((M / 32 + 256) / 256), 16)), dim3(256), 0, ix->stream,
+                                   ix->rx_pstart, M, ix->rx_occ);
+            } else {
+                (void)hipGetLastError();
+                ix->rx_occ = nullptr;
+            }
+        }
         const size_t S = total ? total : 1;
         if ((e = hipMalloc(&ix->rx_pkeys, S * 8))) break;
         if ((e = hipMalloc(&ix->rx_pkeys_raw, S * 8))) break;
@@ -926,7 +963,7 @@ static int rx_build(kmm_index *ix, const int32_t *h2i, const int32_t *nk, const 
         (void)hipGetLastError();
         for (void **q : {(void **)&ix->rx_pstart, (void **)&ix->rx_pkeys, (void **)&ix->rx_pkeys_raw, (void **)&ix->rx_pfreq,
                          (void **)&ix->rx_pnodes, (void **)&ix->rx_porig, (void **)&ix->rx_ecnt, (void **)&ix->rx_norder,
-                         (void **)&ix->rx_nnode}) {
+                         (void **)&ix->rx_nnode, (void **)&ix->rx_occ}) {
             if (*q)
                 (void)hipFree(*q);
             *q = nullptr;
@@ -1999,6 +2036,14 @@ int kmm_set_param(kmm_index_t *ix, const char *name, int64_t value)
             KMMCHK(rx_flush(ix)); // nothing of the old layout may be pending
             KMMCHK(rx_repack_keys(ix));
         }
+    } else if (!strcmp(name, "radix_filter")) {
+        // 1 (default): pass 2 drops the k-mers of empty buckets where a coarse partition's bitmap fits LDS (the
+        // fan-out is chosen for it); 0: the plain pass 2
+        ix->rx_filter = value != 0;
+        if (ix->rx_pstart && rx_configure(ix, ix->rx_w)) {
+            KMMCHK(rx_flush(ix));
+            KMMCHK(rx_repack_keys(ix));
+        }
     } else if (!strcmp(name, "fine_bits")) {
         // experiments: split the current slice width's fan-out as F2 = 2^value fine partitions per coarse partition
         if (value < 0 || value > 9 || !rx_configure(ix, ix->rx_w, RX_MAXF, (int)value))
@@ -2083,6 +2128,8 @@ int kmm_get_param(kmm_index_t *ix, const char *name, int64_t *value)
     else if (!strcmp(name, "radix_view_bytes"))
         *value = ix->rx_pstart ? (int64_t)((ix->modulo + 1) * 4 + (ix->rx_S ? ix->rx_S : 1) * (8 + 8 + 2 + 4 + 4 + 4 + (ix->rx_norder ? 8 : 0)))
                                : 0;
+    else if (!strcmp(name, "radix_filter"))
+        *value = (ix->rx_ok && rx_filter_active(ix)) ? 1 : 0;
     else if (!strcmp(name, "n_fine_per_coarse"))
         *value = ix->rx_ok ? ix->rx_F2 : 0;
     else if (!strcmp(name, "count_kmers"))

@@ -111,6 +111,7 @@ struct RxView {
     const uint64_t *pkeys;  // [S] entry k-mers in bucket order, in the packed form the passes carry (rx_pack)
     const uint16_t *pfreq;  // [S]
     uint32_t *ecnt;         // [S] per-entry hit counts not yet added to the node counts
+    const uint32_t *occ;    // bit h = bucket h holds an entry (padded by one coarse partition's worth of words), or null
     int w, f2;              // sh = w + f2: hash bits below the coarse partition number
     uint32_t PF, F1, F2;
     // batch side
@@ -301,7 +302,7 @@ struct RxNoHook {
 // non-temporal copy-out), one after the placement.  ENDBAR = false leaves out the one after the copy-out:
 // the caller then guarantees a barrier of its own before sbuf is written again and before the next call's ranking
 // (which needs the counters this call clears during its copy-out).
-template <int RB, bool ENDBAR, bool ONEBAR, int NT = RX_NT, typename PrepFn, typename MidFn = RxNoHook>
+template <int RB, bool ENDBAR, bool ONEBAR, int NT = RX_NT, bool NTSTORE = ONEBAR, typename PrepFn, typename MidFn = RxNoHook>
 __device__ __forceinline__ void rx_sort_emit(uint64_t (&q)[RX_B / NT], PrepFn prep, int F, uint64_t *sbuf,
                                              uint32_t *s_cnt, uint32_t *s_base, uint32_t *s_wave,
                                              uint64_t *__restrict__ out, uint16_t *__restrict__ dir_row,
@@ -365,7 +366,7 @@ __device__ __forceinline__ void rx_sort_emit(uint64_t (&q)[RX_B / NT], PrepFn pr
     const uint4 *s4 = reinterpret_cast<const uint4 *>(sbuf);
     uint4 *o4 = reinterpret_cast<uint4 *>(out);
     for (uint32_t i = tid; i < (total + 1) / 2; i += NT) {
-        if (ONEBAR) { // (pass 1) streamed out past L2: the directory rows the scan kernels read next stay there
+        if (NTSTORE) { // (pass 1) streamed out past L2: the directory rows the scan kernels read next stay there
             typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
             const uint4 v = s4[i];
             const u32x4_t w = {v.x, v.y, v.z, v.w};
@@ -984,6 +985,278 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p2(IndexView iv, RxView rx)
 }
 
 // ------------------------------------------------------------------------------------------------
+// pass 2 with the empty-bucket filter (k_rx_p2f)
+// ------------------------------------------------------------------------------------------------
+// 80 % of the k-mers of a read set are not in the index, and at load factor 0.5 three fifths of those fall into an
+// EMPTY bucket.  Pass 2 is the first place where a k-mer's bucket range is narrow enough to test that from LDS: a
+// coarse partition of 2^19 buckets has a 64 KB occupancy bitmap.  A k-mer whose bucket is empty cannot match
+// anything (mapper.pyx:55-58: n_local_hits == 0), so it is dropped here instead of being written by pass 2 and read
+// again by pass 3 (16 B of HBM traffic each).  The bitmap leaves no room for a second workgroup per CU (measured:
+// the plain pass 2 with one 512-thread workgroup per CU takes 5.96 ms instead of 4.05), so this kernel is built
+// differently from k_rx_p2:
+//   * ONE workgroup of 1024 threads per CU; the memory phase of item j + 1 overlaps the LDS phase of item j inside
+//     the workgroup: the k-mers of the next item are requested (8 per thread, into registers) BEFORE the current
+//     item is sorted, and are consumed (tested against the bitmap, the survivors appended to the sort buffer) after;
+//   * gather by k-mer, not by run: thread t takes the item's k-mers t, t + 1024, ...; the run a k-mer lies in is
+//     found by a 10-step binary search in an LDS table of the item's run starts (all 8 searches of a thread
+//     interleaved); consecutive lanes read consecutive k-mers, every lane of every load instruction is used
+//     whatever the run length (piece lists: 52 % at 17-k-mer runs), no list is built, scanned or padded;
+//   * a work unit = P2F_K consecutive items of one coarse partition: one bitmap load per unit.
+// Output: item slot as in k_rx_p2 (one output item per input item), holding the survivors only.
+constexpr int P2F_NT = 1024;
+constexpr int P2F_KPT = RX_B / P2F_NT;   // 8 k-mers per thread and item
+constexpr int P2F_K = 16;                // items per work unit
+constexpr int P2F_LOGBITS = 19;          // buckets per coarse partition the LDS bitmap covers: 2^19 (64 KB)
+
+__global__ void __launch_bounds__(P2F_NT) k_rx_p2f(IndexView iv, RxView rx)
+{
+    __shared__ uint32_t s_bits[(1 << P2F_LOGBITS) / 32];
+    __shared__ uint64_t sbuf[RX_B];
+    __shared__ uint32_t t_vs[P2F_NT + 1]; // run table of the item being requested: where run t starts in the
+    __shared__ uint16_t t_st[P2F_NT];     // coarse partition's virtual array; where it starts inside its block
+    __shared__ uint16_t t_aux[RX_B / 64 + 1]; // run (table index) of the item's k-mers 0, 64, 128, ...: a wavefront's 64
+    __shared__ uint32_t t_last;               // consecutive k-mers lie between two of them; run of the last covered k-mer
+    __shared__ __attribute__((aligned(8))) uint32_t s_cnt[RX_MAXF + 2 + 64];
+    __shared__ uint32_t s_base[RX_MAXF + 1], s_wave[4];
+    __shared__ uint32_t s_b0[P2F_K];
+    __shared__ uint32_t s_idx, s_m;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const uint32_t NB = rx.NB;
+    const size_t buf1_elems = (size_t)NB * RX_B;
+    const int F2 = (int)rx.F2, w = rx.w;
+    const uint32_t bmask = (1u << (rx.w + rx.f2)) - 1u;          // bucket inside the coarse partition
+    const uint32_t nwords = ((uint32_t)F2 << w) / 32u;           // bitmap words of one coarse partition (<= 16384)
+    const uint32_t spare = rx_spare_key();
+    uint32_t gathered = 0, dropped = 0; // conservation check: gathered = pass 1's lookups = pass 3's probes + dropped
+    const uint32_t cs = (rx.F1 + 7u) / 8u;
+    const uint32_t limit = ((rx.ctrl[2] + P2F_K - 1u) / P2F_K) * cs; // units of the largest coarse partition x cs
+    const uint32_t home = rx_xcc_id();
+    if (tid <= F2)
+        s_cnt[tid] = 0; // (rx_sort_emit)
+    if (tid == 0)
+        s_m = 0;
+    RX_PT_DECL;
+
+    struct RunDesc {
+        uint32_t vs, ve, st;
+    };
+    for (uint32_t turn = 0; turn < 8u; ++turn) {
+    const uint32_t sub = (home + turn) & 7u;
+    for (;;) {
+        if (tid == 0)
+            s_idx = rx_pop(rx.queue, sub, limit);
+        __syncthreads();
+        const uint32_t idx = s_idx;
+        __syncthreads(); // every wavefront has read s_idx before it is written again (the round-2 race)
+        if (idx >= limit)
+            break;
+        const uint32_t cu = idx / cs, cc = sub * cs + idx % cs;
+        if (cc >= rx.F1)
+            continue; // F1 is no multiple of 8
+        const uint32_t ib = rx.item_base[cc], n_items_c = rx.item_base[cc + 1] - ib;
+        if (cu * P2F_K >= n_items_c)
+            continue; // partition sizes differ
+        const uint32_t j0 = cu * P2F_K;
+        const uint32_t n_it = n_items_c - j0 < (uint32_t)P2F_K ? n_items_c - j0 : (uint32_t)P2F_K;
+        const uint32_t Tc = rx.T1[cc];
+        const uint32_t *P = rx.P1T + (size_t)cc * (NB + 1);
+        const uint16_t *S = rx.S1T + (size_t)cc * NB;
+        // unit prologue: first blocks of the unit's items, the coarse partition's bitmap
+        if ((uint32_t)tid < n_it)
+            s_b0[tid] = rx.item_desc[ib + j0 + tid].x;
+        {
+            const uint4 *src = reinterpret_cast<const uint4 *>(rx.occ + (size_t)cc * nwords);
+            uint4 *dst = reinterpret_cast<uint4 *>(s_bits);
+            for (uint32_t i = tid; i < nwords / 4u; i += P2F_NT)
+                dst[i] = src[i];
+            for (uint32_t i = (nwords & ~3u) + tid; i < nwords; i += P2F_NT) // (tiny tables)
+                s_bits[i] = rx.occ[(size_t)cc * nwords + i];
+        }
+        __syncthreads();
+
+        auto load_desc = [&](uint32_t bb) {
+            RunDesc r;
+            const uint32_t b = bb + tid;
+            r.vs = 0xFFFFFFFFu; r.ve = 0xFFFFFFFFu; r.st = 0;
+            if (b < NB) {
+                r.vs = P[b];
+                r.ve = P[b + 1];
+                r.st = S[b];
+            }
+            return r;
+        };
+        // Table of the runs [bb, bb + 1024) for the item [lo, hi).  Besides its own row every thread marks the run of
+        // each k-mer lo + 64 a that lies in its run (t_aux), and of the item's last covered k-mer (t_last): the search of
+        // a wavefront's 64 consecutive k-mers then starts from two table indices a few runs apart instead of 0 .. 1023.
+        auto put_table = [&](const RunDesc &r, uint32_t lo, uint32_t hi) {
+            t_vs[tid] = r.vs;
+            t_st[tid] = (uint16_t)r.st;
+            if (tid == P2F_NT - 1) {
+                t_vs[P2F_NT] = r.ve; // virtual position the table covers up to (all ones: to the partition's end)
+                if (r.ve < hi)
+                    t_last = P2F_NT - 1;
+            }
+            const uint32_t from = r.vs > lo ? r.vs : lo, to = r.ve < hi ? r.ve : hi;
+            if (r.vs != 0xFFFFFFFFu && from < to) {
+                for (uint32_t a = (from - lo + 63u) >> 6; lo + (a << 6) < to; ++a)
+                    t_aux[a] = (uint16_t)tid;
+                if (to == hi)
+                    t_last = (uint32_t)tid;
+            }
+        };
+        // request the k-mers [lo + e] of the item, e = u * 1024 + tid < n, whose position lies in [c_lo, c_hi): the
+        // run of each by binary search over the table (block bb + t holds the virtual range [t_vs[t], t_vs[t + 1]))
+        auto issue = [&](uint32_t bb, uint32_t lo, uint32_t n, uint32_t c_lo, uint32_t c_hi, uint64_t (&x)[P2F_KPT]) {
+            uint32_t v[P2F_KPT], pos[P2F_KPT], p1[P2F_KPT], vmask = 0, len_max = 0;
+            const uint32_t c_end = lo + n < c_hi ? lo + n : c_hi; // positions this table serves: [c_lo, c_end)
+            const uint32_t last = t_last;
+#pragma unroll
+            for (int u = 0; u < P2F_KPT; ++u) {
+                const uint32_t e = (uint32_t)u * P2F_NT + tid;
+                const uint32_t e0 = e & ~63u, pa = lo + e0; // the wavefront's first k-mer of this slot (uniform)
+                v[u] = lo + e;
+                if (e < n && v[u] >= c_lo && v[u] < c_hi)
+                    vmask |= 1u << u;
+                // the run lies between the runs of k-mer e0 and of k-mer e0 + 64 (or the last covered one)
+                pos[u] = (pa >= c_lo && pa < c_end) ? t_aux[e0 >> 6] : 0u;
+                p1[u] = pa + 64u < c_end ? t_aux[(e0 >> 6) + 1u] : last;
+                const uint32_t len = pa < c_end && p1[u] > pos[u] ? p1[u] - pos[u] : 0u;
+                len_max = len > len_max ? len : len_max;
+            }
+            // uniform over the wavefront: the widest of the 8 ranges decides the number of steps (typically 2-3)
+            len_max = (uint32_t)__builtin_amdgcn_readfirstlane((int)len_max);
+            for (uint32_t stp = len_max ? 1u << (31 - __builtin_clz(len_max)) : 0u; stp >= 1u; stp >>= 1) {
+#pragma unroll
+                for (int u = 0; u < P2F_KPT; ++u) {
+                    const uint32_t cand = pos[u] + stp;
+                    const uint32_t cc2 = cand <= p1[u] ? cand : p1[u]; // (stays inside the table)
+                    pos[u] = (cand <= p1[u] && t_vs[cc2] <= v[u]) ? cand : pos[u];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < P2F_KPT; ++u) {
+                x[u] = 0;
+                if ((vmask >> u) & 1u) {
+                    size_t src = (size_t)(bb + pos[u]) * RX_B + t_st[pos[u]] + (v[u] - t_vs[pos[u]]);
+                    src = src < buf1_elems ? src : buf1_elems - 1; // never leave pass 1's output, whatever the table says
+                    x[u] = RX_LOAD2(rx.buf1 + src);
+                }
+            }
+            return vmask;
+        };
+        // test the requested k-mers against the bitmap and append the survivors to the sort buffer (one LDS atomic
+        // per wavefront: the lanes' survivor counts are prefix-summed with DPP additions)
+        auto consume = [&](const uint64_t (&x)[P2F_KPT], uint32_t vmask) {
+            uint32_t pass = 0;
+#pragma unroll
+            for (int u = 0; u < P2F_KPT; ++u) {
+                const uint32_t bit = (uint32_t)x[u] & bmask; // packed form: the hash bits below the coarse partition number
+                const uint32_t word = s_bits[bit >> 5];
+                pass |= (((vmask >> u) & (word >> (bit & 31u))) & 1u) << u;
+            }
+            gathered += (uint32_t)__popc(vmask);
+            dropped += (uint32_t)(__popc(vmask) - __popc(pass));
+            const uint32_t c = (uint32_t)__popc(pass);
+            const uint32_t inc = wave_scan_incl(c);
+            uint32_t base = 0;
+            if (lane == 63)
+                base = inc ? atomicAdd(&s_m, inc) : 0u;
+            base = (uint32_t)__builtin_amdgcn_readlane((int)base, 63);
+            uint32_t off = base + inc - c;
+#pragma unroll
+            for (int u = 0; u < P2F_KPT; ++u)
+                if ((pass >> u) & 1u)
+                    sbuf[off++] = x[u];
+        };
+
+        // prime the pipeline: item 0's table and requests, item 1's run descriptors
+        uint64_t x[P2F_KPT];
+        uint32_t b0 = s_b0[0];
+        RunDesc rd = load_desc(b0);
+        {
+            const uint32_t lo0 = j0 * RX_B;
+            put_table(rd, lo0, Tc - lo0 < (uint32_t)RX_B ? Tc : lo0 + RX_B);
+        }
+        __syncthreads();
+        uint32_t cover = t_vs[P2F_NT];
+        uint32_t vmask;
+        {
+            const uint32_t lo0 = j0 * RX_B;
+            const uint32_t n0 = Tc - lo0 < (uint32_t)RX_B ? Tc - lo0 : (uint32_t)RX_B;
+            vmask = issue(b0, lo0, n0, lo0, cover, x);
+        }
+        __syncthreads(); // every wavefront has finished its searches before item 1's table is written (in the loop the
+                         // sort's barriers lie in between; without this one a stale table entry above a k-mer's position
+                         // made `v - t_vs[pos]` wrap and the request left the buffer: memory fault, first GPU run)
+        if (n_it > 1u)
+            rd = load_desc(s_b0[1]);
+        for (uint32_t j = 0; j < n_it; ++j) {
+            const uint32_t item = ib + j0 + j;
+            const uint32_t lo = (j0 + j) * RX_B;
+            const uint32_t n = Tc - lo < (uint32_t)RX_B ? Tc - lo : (uint32_t)RX_B, hi = lo + n;
+            // (C) item j's k-mers have arrived: filter, append the survivors
+            consume(x, vmask);
+            if (cover < hi) { // (rare: an item of more than 1024 runs, tiny runs only) the rest, table by table
+                uint32_t bb = b0 + P2F_NT;
+                while (cover < hi) {
+                    __syncthreads(); // the table's last readers are done
+                    const RunDesc r2 = load_desc(bb);
+                    put_table(r2, lo, hi);
+                    __syncthreads();
+                    const uint32_t cover2 = t_vs[P2F_NT];
+                    uint64_t x2[P2F_KPT];
+                    const uint32_t vm2 = issue(bb, lo, n, cover, cover2, x2);
+                    consume(x2, vm2);
+                    cover = cover2;
+                    bb += P2F_NT;
+                }
+                __syncthreads(); // ... before the next item's table is written
+            }
+            // (D) the next item: table, then its requests — they travel while item j is sorted
+            if (j + 1u < n_it) {
+                const uint32_t lo1 = lo + RX_B;
+                put_table(rd, lo1, Tc - lo1 < (uint32_t)RX_B ? Tc : lo1 + RX_B);
+            }
+            __syncthreads(); // survivors complete in the sort buffer; the table is published
+            if (j + 1u < n_it) {
+                b0 = s_b0[j + 1u];
+                cover = t_vs[P2F_NT];
+                const uint32_t lo1 = lo + RX_B;
+                const uint32_t n1 = Tc - lo1 < (uint32_t)RX_B ? Tc - lo1 : (uint32_t)RX_B;
+                vmask = issue(b0, lo1, n1, lo1, cover, x);
+                if (j + 2u < n_it)
+                    rd = load_desc(s_b0[j + 2u]);
+            }
+            // (B) sort item j's survivors by fine partition and write them out
+            const uint32_t m = s_m;
+            uint64_t q[P2F_KPT];
+            uint32_t valid = 0;
+#pragma unroll
+            for (int i = 0; i < P2F_KPT; ++i) {
+                const uint32_t e = (uint32_t)i * P2F_NT + tid;
+                q[i] = 0;
+                if (e < m) {
+                    q[i] = sbuf[e];
+                    valid |= 1u << i;
+                }
+            }
+            auto fine = [&](int i) {
+                return ((valid >> i) & 1u) ? ((uint32_t)(q[i] >> w) & (uint32_t)(F2 - 1)) : spare;
+            };
+            auto mid = [&]() {
+                if (tid == 0)
+                    s_m = 0; // (every wavefront has read it: the ranking's barrier lies in between)
+            };
+            rx_sort_emit<P2F_KPT, true, true, P2F_NT, false>(q, fine, F2, sbuf, s_cnt, s_base, s_wave, rx.buf2 + (size_t)item * RX_B,
+                                                       rx.start2 + (size_t)item * (F2 + 1) RX_PT_ARG2, mid);
+        }
+    }
+    }
+    rx_stat_add(iv, 2, gathered);
+    rx_stat_add(iv, KMM_STAT_RX_DROPPED, dropped);
+}
+
+// ------------------------------------------------------------------------------------------------
 // pass 3
 // ------------------------------------------------------------------------------------------------
 // DirT: type of the LDS directory; uint16_t (half the LDS: 8192-bucket slices with two workgroups per CU) only when
@@ -1387,6 +1660,22 @@ __global__ void k_rx_bucket_sizes(const int32_t *__restrict__ h2i, const int32_t
                 c = (uint32_t)n;
         }
         out[h] = c;
+    }
+}
+
+// occupancy bitmap of the bucket directory: bit h = bucket h holds an entry (the array is zeroed first)
+__global__ void __launch_bounds__(256) k_rx_build_occ(const uint32_t *__restrict__ pstart, uint64_t modulo, uint32_t *__restrict__ occ)
+{
+    for (uint64_t wd = (uint64_t)blockIdx.x * 256 + threadIdx.x; wd * 32 < modulo; wd += (uint64_t)gridDim.x * 256) {
+        uint32_t bits = 0;
+        const uint64_t h0 = wd * 32;
+        uint32_t prev = pstart[h0];
+        for (uint32_t i = 0; i < 32 && h0 + i < modulo; ++i) {
+            const uint32_t nx = pstart[h0 + i + 1];
+            bits |= (nx > prev ? 1u : 0u) << i;
+            prev = nx;
+        }
+        occ[wd] = bits;
     }
 }
 

@@ -41,7 +41,8 @@ def test_radix_equals_oracle_at_every_slice_width(kmm, syn, oracle, shift, revco
         assert np.array_equal(dev.get_node_counts(), expect)
         lookups = (2 if revcomp else 1) * n
         # conservation through the passes: every k-mer pass 1 emits is gathered once by pass 2 and probed once by pass 3
-        assert dev.get_param("radix_p2_kmers") == lookups and dev.get_param("radix_p3_kmers") == lookups
+        assert dev.get_param("radix_p2_kmers") == lookups
+        assert dev.get_param("radix_p3_kmers") + dev.get_param("radix_p2_dropped") == lookups   # dropped: empty-bucket filter
         assert dev.get_stats(reset=True) == (lookups, int(expect.sum()))
         dev.reset()
         dev.map_kmers(km, also_revcomp=revcomp, k=31)          # operator entry point through the same passes
@@ -137,7 +138,7 @@ def test_slices_of_8192_buckets(kmm, syn, oracle, n_entries):
         dev.set_param("path", 2)
         dev.map_reads(bases, offs, 31, also_revcomp=True)
         assert np.array_equal(dev.get_node_counts(), expect)
-        assert dev.get_param("radix_p3_kmers") == 2 * n
+        assert dev.get_param("radix_p3_kmers") + dev.get_param("radix_p2_dropped") == 2 * n
 
 
 def test_per_kmer_counting_mode(kmm, syn, oracle):
