@@ -32,6 +32,7 @@
 #ifndef KMM_H
 #define KMM_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -161,7 +162,10 @@ int kmm_map_reads_uniform(kmm_index_t *idx, const uint8_t *bases, int64_t n_read
  * caller prepends the remaining raw[consumed:] to the next chunk; at end of file the last line must end
  * with a newline) and in *n_records the number of reads mapped.  '\r' before '\n' is tolerated.
  * The call returns once the chunk is staged and scanned (so *consumed is valid and the host buffer is
- * free); the mapping kernels run asynchronously like every other map call.  n_bytes <= 2^30.
+ * free); the mapping kernels run asynchronously like every other map call.  Chunks of any size: beyond 2^30
+ * bytes the library maps the chunk piece by piece (each piece starts at the end of the previous one's last
+ * complete record).  Large chunks let the batch reach the radix path: kmer_mapper map accumulates file chunks up
+ * to kmm_get_param("radix_min_units") positions per call.
  * A line that should start a record ('@' / '>') or the FASTQ '+' line but does not (e.g. multi-line
  * FASTA) makes the next synchronising call fail with KMM_ERR_MALFORMED.
  */
@@ -170,6 +174,14 @@ int kmm_map_reads_uniform(kmm_index_t *idx, const uint8_t *bases, int64_t n_read
 int kmm_map_records(kmm_index_t *idx, const uint8_t *raw, int64_t n_bytes, int format, int k,
                     int max_index_lookup_frequency, int also_revcomp, const uint8_t *lut,
                     int64_t *consumed, int64_t *n_records);
+
+/*
+ * kmm_host_alloc / kmm_host_free — page-locked host memory (hipHostMalloc) for the caller's read buffers: the
+ * staging copy of a map call then runs at the PCIe link's rate (~50 GB/s) instead of the pageable path's.  The
+ * reference keeps its chunks in POSIX shared memory (command_line_interface.py:110); this is the GPU counterpart.
+ */
+int kmm_host_alloc(size_t bytes, void **out);
+int kmm_host_free(void *p);
 
 /*
  * kmm_extract_kmers — replaces get_kmer_hashes_from_chunk_sequence (util.py:71-75) as an

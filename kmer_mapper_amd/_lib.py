@@ -36,6 +36,8 @@ SIGNATURES = {
     "kmm_version": (_c.c_char_p, []),
     "kmm_last_error": (_c.c_char_p, []),
     "kmm_device_count": (_c.c_int, [_P]),
+    "kmm_host_alloc": (_c.c_int, [_c.c_size_t, _P]),
+    "kmm_host_free": (_c.c_int, [_P]),
     "kmm_index_create": (_c.c_int, [_P, _P, _c.c_uint64, _P, _P, _P, _c.c_int64, _c.c_int64,
                                     _c.c_int, _P]),
     "kmm_index_destroy": (None, [_P]),

@@ -118,7 +118,22 @@ def map_gpu_raw(index, path, chunk_size, fmt, k, map_reverse_complements=False,
     byte_range = rank_byte_range(path, fmt, rank, world_size) if (world_size > 1 and seekable) else None
     if byte_range is not None:
         logging.info("Rank %d of %d maps bytes [%d, %d) of %s", rank, world_size, byte_range[0], byte_range[1], path)
-    chunker = RawChunker(path, chunk_size, byte_range)
+    # GPU batches: the reference maps chunk by chunk (-c bytes, command_line_interface.py:109-111,169); here the chunks
+    # of a large file are accumulated until one map call holds enough positions for the radix path (raw chunks take it
+    # from 2 x radix_min_units bytes on, for indexes beyond the direct path's L2 pre-filter), at most 2 GiB per call.
+    batch_bytes = int(chunk_size)
+    try:
+        n_file = os.stat(path).st_size * (6.5 if not seekable else 1)
+    except OSError:
+        n_file = 0
+    if dev.get_param("radix_available") and dev.get_param("wide_buckets") and not os.environ.get("KMM_CLI_NO_BATCHING"):
+        want = min(int(2.2 * dev.get_param("radix_min_units")), 2 << 30)
+        share = n_file / max(world_size, 1)
+        if share >= want > batch_bytes:
+            # equal batches, none below the threshold (a small last batch would take the direct path)
+            batch_bytes = min(int(share / int(share // want)) + (1 << 20), 2 << 30) if seekable else want
+            logging.info("Chunks of %d bytes are accumulated into GPU batches of %d bytes (radix path)", chunk_size, batch_bytes)
+    chunker = RawChunker(path, batch_bytes, byte_range, pinned=True)
     owns = (lambda i: True) if (world_size == 1 or seekable) else (lambda i: chunk_owner(i, world_size) == rank)
     kfmt = _lib.FORMAT_FASTQ if fmt == "fastq" else _lib.FORMAT_FASTA2
     t_start = time.perf_counter()
@@ -145,6 +160,7 @@ def map_gpu_raw(index, path, chunk_size, fmt, k, map_reverse_complements=False,
             chunker.consumed(used)
             i += 1
         n_lookups, n_hits = dev.get_stats()
+        n_radix, n_direct = dev.get_param("radix_batches"), dev.get_param("direct_batches")
         if before_fetch is not None:
             before_fetch(dev)
         node_counts = dev.get_node_counts()
@@ -156,6 +172,8 @@ def map_gpu_raw(index, path, chunk_size, fmt, k, map_reverse_complements=False,
     logging.info("Mapped %d reads from %d bytes (%.1f MB/s, GPU record parser): %d k-mer lookups "
                  "(%.1f M/s), %d index hits" % (n_reads, n_bytes, n_bytes / max(dt, 1e-9) / 1e6, n_lookups,
                                                   n_lookups / max(dt, 1e-9) / 1e6, n_hits))
+    logging.info("path_taken: %s (%d batches on the radix path, %d on the direct path)"
+                 % ("radix" if n_radix and not n_direct else "direct" if n_direct and not n_radix else "mixed", n_radix, n_direct))
     return node_counts
 
 

@@ -200,6 +200,7 @@ struct kmm_index {
     int sticky_rc = KMM_OK;
     std::string sticky_msg;
     uint64_t map_calls = 0;   // sequence number of map calls on this handle (error reports name the call)
+    uint64_t n_radix_batches = 0, n_direct_batches = 0; // which path the batches took ("radix_batches" / "direct_batches")
     ncclComm_t comm = nullptr; // multi-process communicator of this handle (kmm_comm_init_rank)
     int comm_rank = -1, comm_size = 0;
     // timing
@@ -587,6 +588,7 @@ int launch_rx(kmm_index *ix, const ReadsView &rv, const uint64_t *kmers_in, int6
         ix->ecnt_dirty = true;
         ix->rx_unchecked = true;
     }
+    ix->n_radix_batches++;
     return KMM_OK;
 }
 
@@ -619,9 +621,15 @@ int launch_map_reads(kmm_index *ix, const ReadsView &rv, int k, int max_freq, in
     // records mode: pass 1's front end (line numbering of raw file bytes) costs more than the direct kernel hides
     // behind its gathers (profiles/r02/README.md: 34 vs 45 G k-mers/s at the 10 M index), so raw chunks take the
     // radix path only when it is forced
-    const bool radix = MODE == MODE_RECORDS ? (ix->rx_ok && (ix->path == 2 || ix->rx_ecnt_acc)) : use_radix(ix, rv.total);
+    // ... or for a large batch against an index too large for the direct path's L2 pre-filter (wide buckets: the direct
+    // kernel then runs at the 55 G requests/s random-access ceiling, ~38 G k-mers/s at the 100 M index, and the radix
+    // path's slower front end still wins)
+    const bool radix = MODE == MODE_RECORDS ? (ix->rx_ok && ix->path != 1 && (ix->path == 2 || ix->rx_ecnt_acc ||
+                                                                               (ix->wide && rv.total >= 2 * ix->rx_min_units)))
+                                            : use_radix(ix, rv.total);
     if (!radix) {
         KMMCHK(ensure_direct(ix));
+        ix->n_direct_batches++;
         const IndexView iv = view_of(ix); // (the direct view may have been packed just now)
         ScopedTimer tm;
         KMMCHK(tm.begin(ix, KMM_KERNEL_MAP_READS));
@@ -755,6 +763,28 @@ extern "C" {
 const char *kmm_version(void) { return "kmm 0.3.0 (gfx950)"; }
 
 const char *kmm_last_error(void) { return g_err.c_str(); }
+
+int kmm_host_alloc(size_t bytes, void **out)
+{
+    if (!out || bytes == 0)
+        return fail(KMM_ERR_INVALID_ARG, "out is NULL or bytes is 0");
+    *out = nullptr;
+    hipError_t e = hipHostMalloc(out, bytes, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        *out = nullptr;
+        return fail(e == hipErrorOutOfMemory ? KMM_ERR_NOMEM : KMM_ERR_HIP, "hipHostMalloc(%zu bytes) -> %s", bytes,
+                    hipGetErrorString(e));
+    }
+    return KMM_OK;
+}
+
+int kmm_host_free(void *p)
+{
+    if (p)
+        HIPCHK(hipHostFree(p));
+    return KMM_OK;
+}
 
 int kmm_device_count(int *n_devices)
 {
@@ -1450,6 +1480,7 @@ int kmm_map_kmers(kmm_index_t *ix, const uint64_t *kmers, int64_t n, int max_fre
     }
     constexpr int U = 8;
     KMMCHK(ensure_direct(ix));
+    ix->n_direct_batches++;
     ScopedTimer tm;
     KMMCHK(tm.begin(ix, KMM_KERNEL_MAP_KMERS));
     {
@@ -1584,27 +1615,14 @@ int kmm_map_reads_uniform(kmm_index_t *ix, const uint8_t *bases, int64_t n_reads
     return map_reads_common(ix, bases, nullptr, n_reads, read_len, k, max_freq, also_revcomp, lut);
 }
 
-int kmm_map_records(kmm_index_t *ix, const uint8_t *raw, int64_t n_bytes, int format, int k,
-                    int max_freq, int also_revcomp, const uint8_t *lut, int64_t *consumed,
-                    int64_t *n_records)
+// One piece of at most 2^30 bytes (the newline census is a two-level scan over 1024 x 1024 tiles of 1024 bytes).
+static int map_records_piece(kmm_index_t *ix, const uint8_t *raw, int64_t n_bytes, int format, int k,
+                             int max_freq, int also_revcomp, const uint8_t *lut, int64_t *consumed,
+                             int64_t *n_records)
 {
     static_assert(TILE_T == 1024, "records mode counts newlines per 1024-byte tile");
-    if (!ix)
-        return fail(KMM_ERR_INVALID_ARG, "idx is NULL");
-    KMMCHK(check_k(k));
-    if (format != KMM_FORMAT_FASTQ && format != KMM_FORMAT_FASTA2)
-        return fail(KMM_ERR_INVALID_ARG, "format must be KMM_FORMAT_FASTQ (4) or KMM_FORMAT_FASTA2 (2)");
-    if (n_bytes < 0 || n_bytes > ((int64_t)1 << 30))
-        return fail(KMM_ERR_INVALID_ARG, "n_bytes outside [0, 2^30]: cut the file into smaller chunks");
-    if (consumed)
-        *consumed = 0;
-    if (n_records)
-        *n_records = 0;
-    if (n_bytes == 0)
-        return KMM_OK;
-    if (!raw)
-        return fail(KMM_ERR_INVALID_ARG, "raw is NULL");
-    HIPCHK(hipSetDevice(ix->device));
+    *consumed = 0;
+    *n_records = 0;
     Stage &s = next_stage(ix);
     KMMCHK(stage_acquire(ix, s));
     ix->map_calls++;
@@ -1630,10 +1648,8 @@ int kmm_map_records(kmm_index_t *ix, const uint8_t *raw, int64_t n_bytes, int fo
     int64_t out[3] = {0, 0, 0};
     HIPCHK(hipMemcpyAsync(out, d_out, sizeof out, hipMemcpyDeviceToHost, ix->copy_stream));
     HIPCHK(hipStreamSynchronize(ix->copy_stream)); // the borrowed host buffer is free from here on
-    if (consumed)
-        *consumed = out[0];
-    if (n_records)
-        *n_records = out[1];
+    *consumed = out[0];
+    *n_records = out[1];
     if (out[0] > 0) {
         rv.total = out[0];
         rv.first_bad = ix->first_bad;
@@ -1645,6 +1661,46 @@ int kmm_map_records(kmm_index_t *ix, const uint8_t *raw, int64_t n_bytes, int fo
         KMMCHK(launch_map_reads<MODE_RECORDS>(ix, rv, k, max_freq, also_revcomp ? 1 : 0));
     }
     return stage_release(ix, s, false);
+}
+
+int kmm_map_records(kmm_index_t *ix, const uint8_t *raw, int64_t n_bytes, int format, int k,
+                    int max_freq, int also_revcomp, const uint8_t *lut, int64_t *consumed,
+                    int64_t *n_records)
+{
+    if (!ix)
+        return fail(KMM_ERR_INVALID_ARG, "idx is NULL");
+    KMMCHK(check_k(k));
+    if (format != KMM_FORMAT_FASTQ && format != KMM_FORMAT_FASTA2)
+        return fail(KMM_ERR_INVALID_ARG, "format must be KMM_FORMAT_FASTQ (4) or KMM_FORMAT_FASTA2 (2)");
+    if (n_bytes < 0)
+        return fail(KMM_ERR_INVALID_ARG, "n_bytes negative");
+    if (consumed)
+        *consumed = 0;
+    if (n_records)
+        *n_records = 0;
+    if (n_bytes == 0)
+        return KMM_OK;
+    if (!raw)
+        return fail(KMM_ERR_INVALID_ARG, "raw is NULL");
+    HIPCHK(hipSetDevice(ix->device));
+    // chunks beyond 2^30 bytes are mapped piece by piece: every piece starts where the previous one's last complete
+    // record ended, so the pieces cut the chunk exactly as one census over all of it would
+    const int64_t piece_max = (int64_t)1 << 30;
+    int64_t off = 0, recs = 0;
+    while (off < n_bytes) {
+        const int64_t len = n_bytes - off < piece_max ? n_bytes - off : piece_max;
+        int64_t used = 0, nr = 0;
+        KMMCHK(map_records_piece(ix, raw + off, len, format, k, max_freq, also_revcomp, lut, &used, &nr));
+        off += used;
+        recs += nr;
+        if (used == 0 || len < piece_max)
+            break; // no complete record left in reach / the last piece
+    }
+    if (consumed)
+        *consumed = off;
+    if (n_records)
+        *n_records = recs;
+    return KMM_OK;
 }
 
 int kmm_in_index(kmm_index_t *ix, const uint64_t *kmers, int64_t n, uint8_t *out)
@@ -2119,6 +2175,10 @@ int kmm_get_param(kmm_index_t *ix, const char *name, int64_t *value)
         *value = (ix->rx_flush_sorted && ix->rx_norder) ? 1 : 0;
     else if (!strcmp(name, "radix_available"))
         *value = ix->rx_ok ? 1 : 0;
+    else if (!strcmp(name, "radix_batches"))
+        *value = (int64_t)ix->n_radix_batches;
+    else if (!strcmp(name, "direct_batches"))
+        *value = (int64_t)ix->n_direct_batches;
     else if (!strcmp(name, "radix_unavailable_reason")) // 0 available, 1 modulo >= 2^31, 2 slices, 3 memory, 4 overlapping buckets
         *value = ix->rx_ok ? 0 : ix->rx_why_not;
     else if (!strcmp(name, "direct_view_resident"))

@@ -1,6 +1,7 @@
 // kmm_radix.hpp — part of libkmm (MI355X / gfx950); included by kmm.hip inside its anonymous namespace.
 // Radix path: two block-local partition passes by hash range, then a probe of LDS-resident index slices.
 #pragma once
+#include <type_traits>
 
 // ------------------------------------------------------------------------------------------------
 // Why.  A probe that goes to HBM costs one 64-byte fabric request per k-mer and MI355X serves ~55 G
@@ -302,12 +303,16 @@ struct RxNoHook {
 // non-temporal copy-out), one after the placement.  ENDBAR = false leaves out the one after the copy-out:
 // the caller then guarantees a barrier of its own before sbuf is written again and before the next call's ranking
 // (which needs the counters this call clears during its copy-out).
-template <int RB, bool ENDBAR, bool ONEBAR, int NT = RX_NT, bool NTSTORE = ONEBAR, typename PrepFn, typename MidFn = RxNoHook>
+template <int RB, bool ENDBAR, bool ONEBAR, int NT = RX_NT, bool NTSTORE = ONEBAR, bool DUMMY = false, typename PrepFn,
+          typename MidFn = RxNoHook>
 __device__ __forceinline__ void rx_sort_emit(uint64_t (&q)[RX_B / NT], PrepFn prep, int F, uint64_t *sbuf,
                                              uint32_t *s_cnt, uint32_t *s_base, uint32_t *s_wave,
                                              uint64_t *__restrict__ out, uint16_t *__restrict__ dir_row,
-                                             unsigned long long *pt_acc = nullptr, MidFn mid = MidFn())
+                                             unsigned long long *pt_acc = nullptr, MidFn mid = MidFn(),
+                                             int n_slots = RX_B / NT)
 {
+    // n_slots (uniform): only the slots [0, n_slots) of q can hold a k-mer (a caller whose k-mers are packed towards
+    // the low slots skips the ranking and placement of the rest: k_rx_p2f after its filter)
     constexpr int KPT = RX_B / NT; // k-mers per thread
     const int tid = threadIdx.x;
     (void)pt_acc;
@@ -319,6 +324,12 @@ __device__ __forceinline__ void rx_sort_emit(uint64_t (&q)[RX_B / NT], PrepFn pr
     uint32_t cr[KPT]; // key << 16 | rank
 #pragma unroll
     for (int h = 0; h < KPT; h += RB) {
+        if (h >= n_slots) {
+#pragma unroll
+            for (int i = 0; i < RB; ++i)
+                cr[h + i] = 0xFFFF0000u; // key beyond every fan-out: not placed
+            continue;
+        }
         uint32_t ck[RB], rk[RB];
 #pragma unroll
         for (int i = 0; i < RB; ++i)
@@ -348,14 +359,20 @@ __device__ __forceinline__ void rx_sort_emit(uint64_t (&q)[RX_B / NT], PrepFn pr
 #endif
 #pragma unroll
     for (int h = 0; h < KPT; h += RX_PLACE_BATCH) {
+        if (h >= n_slots)
+            break;
         uint32_t pos[RX_PLACE_BATCH];
 #pragma unroll
         for (int i = 0; i < RX_PLACE_BATCH; ++i)
             pos[i] = s_base[cr[h + i] >> 16] + (cr[h + i] & 0xFFFFu);
 #pragma unroll
-        for (int i = 0; i < RX_PLACE_BATCH; ++i)
-            if ((cr[h + i] >> 16) < (uint32_t)F)
+        for (int i = 0; i < RX_PLACE_BATCH; ++i) {
+            if (DUMMY) { // branch-free: a slot without a k-mer is written to the lane's dummy element behind the buffer
+                sbuf[(cr[h + i] >> 16) < (uint32_t)F ? pos[i] : (uint32_t)RX_B + (threadIdx.x & 63)] = q[h + i];
+            } else if ((cr[h + i] >> 16) < (uint32_t)F) {
                 sbuf[pos[i]] = q[h + i];
+            }
+        }
     }
     __syncthreads();
     RX_PT(3); // scan + placement
@@ -1005,24 +1022,34 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p2(IndexView iv, RxView rx)
 // Output: item slot as in k_rx_p2 (one output item per input item), holding the survivors only.
 constexpr int P2F_NT = 1024;
 constexpr int P2F_KPT = RX_B / P2F_NT;   // 8 k-mers per thread and item
-constexpr int P2F_K = 16;                // items per work unit
+#ifndef P2F_KV
+#define P2F_KV 16
+#endif
+constexpr int P2F_K = P2F_KV;            // items per work unit
 constexpr int P2F_LOGBITS = 19;          // buckets per coarse partition the LDS bitmap covers: 2^19 (64 KB)
+#ifndef P2F_AUX
+#define P2F_AUX 1                        // search between the runs of the wavefront's first and last k-mer (else 0 .. 1023)
+#endif
+#ifndef P2F_ONEBAR
+#define P2F_ONEBAR 1                     // one-barrier counter scan in the sort
+#endif
 
 __global__ void __launch_bounds__(P2F_NT) k_rx_p2f(IndexView iv, RxView rx)
 {
     __shared__ uint32_t s_bits[(1 << P2F_LOGBITS) / 32];
-    __shared__ uint64_t sbuf[RX_B];
+    __shared__ uint64_t sbuf[RX_B + 64];  // (+ one dummy element per lane: branch-free placement)
     __shared__ uint32_t t_vs[P2F_NT + 1]; // run table of the item being requested: where run t starts in the
-    __shared__ uint16_t t_st[P2F_NT];     // coarse partition's virtual array; where it starts inside its block
+    __shared__ uint32_t t_off[P2F_NT];    // coarse partition's virtual array; t_off[t] + v = where k-mer v of run t lies
+                                          // in pass 1's output, relative to the table's first block
     __shared__ uint16_t t_aux[RX_B / 64 + 1]; // run (table index) of the item's k-mers 0, 64, 128, ...: a wavefront's 64
     __shared__ uint32_t t_last;               // consecutive k-mers lie between two of them; run of the last covered k-mer
     __shared__ __attribute__((aligned(8))) uint32_t s_cnt[RX_MAXF + 2 + 64];
     __shared__ uint32_t s_base[RX_MAXF + 1], s_wave[4];
     __shared__ uint32_t s_b0[P2F_K];
-    __shared__ uint32_t s_idx, s_m;
+    __shared__ uint32_t s_idx;
     const int tid = threadIdx.x, lane = tid & 63;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t NB = rx.NB;
-    const size_t buf1_elems = (size_t)NB * RX_B;
     const int F2 = (int)rx.F2, w = rx.w;
     const uint32_t bmask = (1u << (rx.w + rx.f2)) - 1u;          // bucket inside the coarse partition
     const uint32_t nwords = ((uint32_t)F2 << w) / 32u;           // bitmap words of one coarse partition (<= 16384)
@@ -1033,8 +1060,6 @@ __global__ void __launch_bounds__(P2F_NT) k_rx_p2f(IndexView iv, RxView rx)
     const uint32_t home = rx_xcc_id();
     if (tid <= F2)
         s_cnt[tid] = 0; // (rx_sort_emit)
-    if (tid == 0)
-        s_m = 0;
     RX_PT_DECL;
 
     struct RunDesc {
@@ -1074,6 +1099,11 @@ __global__ void __launch_bounds__(P2F_NT) k_rx_p2f(IndexView iv, RxView rx)
         }
         __syncthreads();
 
+        auto item_lo = [&](uint32_t j) { return (j0 + j) * (uint32_t)RX_B; };
+        auto item_n = [&](uint32_t j) {
+            const uint32_t lo = (j0 + j) * (uint32_t)RX_B;
+            return Tc - lo < (uint32_t)RX_B ? Tc - lo : (uint32_t)RX_B;
+        };
         auto load_desc = [&](uint32_t bb) {
             RunDesc r;
             const uint32_t b = bb + tid;
@@ -1090,7 +1120,7 @@ __global__ void __launch_bounds__(P2F_NT) k_rx_p2f(IndexView iv, RxView rx)
         // a wavefront's 64 consecutive k-mers then starts from two table indices a few runs apart instead of 0 .. 1023.
         auto put_table = [&](const RunDesc &r, uint32_t lo, uint32_t hi) {
             t_vs[tid] = r.vs;
-            t_st[tid] = (uint16_t)r.st;
+            t_off[tid] = (uint32_t)tid * RX_B + r.st - r.vs; // (modulo 2^32: the sum with v is < 1025 x 8192)
             if (tid == P2F_NT - 1) {
                 t_vs[P2F_NT] = r.ve; // virtual position the table covers up to (all ones: to the partition's end)
                 if (r.ve < hi)
@@ -1104,154 +1134,142 @@ __global__ void __launch_bounds__(P2F_NT) k_rx_p2f(IndexView iv, RxView rx)
                     t_last = (uint32_t)tid;
             }
         };
-        // request the k-mers [lo + e] of the item, e = u * 1024 + tid < n, whose position lies in [c_lo, c_hi): the
-        // run of each by binary search over the table (block bb + t holds the virtual range [t_vs[t], t_vs[t + 1]))
-        auto issue = [&](uint32_t bb, uint32_t lo, uint32_t n, uint32_t c_lo, uint32_t c_hi, uint64_t (&x)[P2F_KPT]) {
-            uint32_t v[P2F_KPT], pos[P2F_KPT], p1[P2F_KPT], vmask = 0, len_max = 0;
+        // Request the k-mers lo + e of the item whose position lies in [c_lo, c_hi) (the part of the item the table
+        // [bb, bb + 1024) covers).  Wavefront y holds the positions e = (8 y + u) 64 + lane, u = 0 .. 7: eight runs of 64
+        // consecutive k-mers.  The run of each k-mer by binary search between the runs of its 64-block's first k-mer
+        // and of the next block's (t_aux; the nine values a wavefront needs come from ONE LDS read and readlane).
+        // Every load is issued unconditionally, with its element index clamped into pass 1's output: no exec-mask
+        // bookkeeping (a slot outside [c_lo, c_hi) holds garbage and no bit of the returned mask).  MERGE: slots
+        // outside the range keep what an earlier table left in them.
+        auto fill = [&](auto merge_tag, uint32_t bb, uint32_t lo, uint32_t n, uint32_t c_lo, uint32_t c_hi,
+                        uint64_t (&x)[P2F_KPT]) {
+            constexpr bool MERGE = decltype(merge_tag)::value;
             const uint32_t c_end = lo + n < c_hi ? lo + n : c_hi; // positions this table serves: [c_lo, c_end)
-            const uint32_t last = t_last;
+            const uint32_t a0 = wave * 8u;
+            uint32_t av = 0;
+            {
+                const uint32_t pa = lo + ((a0 + (uint32_t)lane) << 6);
+                const uint32_t ia = a0 + ((uint32_t)lane <= 8u ? (uint32_t)lane : 8u);
+                const uint32_t aux = t_aux[ia];
+                av = pa < c_lo ? 0u : (pa < c_end ? aux : t_last);
+            }
+            uint32_t A[P2F_KPT + 1];
+#pragma unroll
+            for (int i = 0; i <= P2F_KPT; ++i)
+                A[i] = (uint32_t)__builtin_amdgcn_readlane((int)av, i);
+            uint32_t v[P2F_KPT], pos[P2F_KPT], vmask = 0, len_max = 0;
 #pragma unroll
             for (int u = 0; u < P2F_KPT; ++u) {
-                const uint32_t e = (uint32_t)u * P2F_NT + tid;
-                const uint32_t e0 = e & ~63u, pa = lo + e0; // the wavefront's first k-mer of this slot (uniform)
+                const uint32_t e = ((a0 + (uint32_t)u) << 6) + (uint32_t)lane;
                 v[u] = lo + e;
-                if (e < n && v[u] >= c_lo && v[u] < c_hi)
-                    vmask |= 1u << u;
-                // the run lies between the runs of k-mer e0 and of k-mer e0 + 64 (or the last covered one)
-                pos[u] = (pa >= c_lo && pa < c_end) ? t_aux[e0 >> 6] : 0u;
-                p1[u] = pa + 64u < c_end ? t_aux[(e0 >> 6) + 1u] : last;
-                const uint32_t len = pa < c_end && p1[u] > pos[u] ? p1[u] - pos[u] : 0u;
+                vmask |= (e < n && v[u] >= c_lo && v[u] < c_hi ? 1u : 0u) << u;
+                pos[u] = A[u];
+                const uint32_t len = A[u + 1] > A[u] ? A[u + 1] - A[u] : 0u;
                 len_max = len > len_max ? len : len_max;
             }
-            // uniform over the wavefront: the widest of the 8 ranges decides the number of steps (typically 2-3)
-            len_max = (uint32_t)__builtin_amdgcn_readfirstlane((int)len_max);
             for (uint32_t stp = len_max ? 1u << (31 - __builtin_clz(len_max)) : 0u; stp >= 1u; stp >>= 1) {
 #pragma unroll
                 for (int u = 0; u < P2F_KPT; ++u) {
                     const uint32_t cand = pos[u] + stp;
-                    const uint32_t cc2 = cand <= p1[u] ? cand : p1[u]; // (stays inside the table)
-                    pos[u] = (cand <= p1[u] && t_vs[cc2] <= v[u]) ? cand : pos[u];
+                    const uint32_t t = t_vs[cand <= A[u + 1] ? cand : A[u + 1]]; // (stays inside the table)
+                    pos[u] = (cand <= A[u + 1] && t <= v[u]) ? cand : pos[u];
                 }
             }
+            const uint64_t *base = rx.buf1 + (size_t)bb * RX_B;
+            const size_t left = (size_t)NB * RX_B - (size_t)bb * RX_B; // elements of pass 1's output from block bb on
+            const uint32_t lim = left > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)left - 1u;
 #pragma unroll
             for (int u = 0; u < P2F_KPT; ++u) {
-                x[u] = 0;
-                if ((vmask >> u) & 1u) {
-                    size_t src = (size_t)(bb + pos[u]) * RX_B + t_st[pos[u]] + (v[u] - t_vs[pos[u]]);
-                    src = src < buf1_elems ? src : buf1_elems - 1; // never leave pass 1's output, whatever the table says
-                    x[u] = RX_LOAD2(rx.buf1 + src);
-                }
+                uint32_t el = t_off[pos[u]] + v[u];
+                el = el < lim ? el : lim; // never leave pass 1's output, whatever the table says
+                const uint64_t y = RX_LOAD2(base + el);
+                x[u] = (!MERGE || ((vmask >> u) & 1u)) ? y : x[u];
             }
             return vmask;
         };
-        // test the requested k-mers against the bitmap and append the survivors to the sort buffer (one LDS atomic
-        // per wavefront: the lanes' survivor counts are prefix-summed with DPP additions)
-        auto consume = [&](const uint64_t (&x)[P2F_KPT], uint32_t vmask) {
+
+        // One item: xa holds its k-mers (mask vma); the next item's are requested into xb while this one is sorted.
+        uint32_t cover = 0, b0 = 0;
+        RunDesc rd;
+        rd.vs = rd.ve = 0xFFFFFFFFu; rd.st = 0;
+        // rounds beyond the first 1024 runs of item j (rare: tiny runs): table by table, into the same slots
+        auto more_rounds = [&](uint32_t j, uint64_t (&x)[P2F_KPT], uint32_t &vm) {
+            const uint32_t lo = item_lo(j), n = item_n(j), hi = lo + n;
+            uint32_t bb = b0 + P2F_NT;
+            while (cover < hi) { // (uniform)
+                __syncthreads(); // the table's last readers are done
+                const RunDesc r2 = load_desc(bb);
+                put_table(r2, lo, hi);
+                __syncthreads();
+                const uint32_t cover2 = t_vs[P2F_NT];
+                vm |= fill(std::true_type(), bb, lo, n, cover, cover2, x);
+                cover = cover2;
+                bb += P2F_NT;
+            }
+            __syncthreads(); // ... and of this table, before the next item's is written
+        };
+        auto process = [&](uint32_t j, uint64_t (&xa)[P2F_KPT], uint32_t vma, uint64_t (&xb)[P2F_KPT], uint32_t &vmb) {
+            const uint32_t item = ib + j0 + j;
+            const bool has_next = j + 1u < n_it;
+            RX_PT(0);
+            if (has_next)
+                put_table(rd, item_lo(j + 1u), item_lo(j + 1u) + item_n(j + 1u));
+            // item j's k-mers against the bitmap (waits for them): key = fine partition, or the lane's spare counter
             uint32_t pass = 0;
 #pragma unroll
             for (int u = 0; u < P2F_KPT; ++u) {
-                const uint32_t bit = (uint32_t)x[u] & bmask; // packed form: the hash bits below the coarse partition number
+                const uint32_t bit = (uint32_t)xa[u] & bmask; // packed form: the hash bits below the coarse partition number
                 const uint32_t word = s_bits[bit >> 5];
-                pass |= (((vmask >> u) & (word >> (bit & 31u))) & 1u) << u;
+                pass |= (((vma >> u) & (word >> (bit & 31u))) & 1u) << u;
             }
-            gathered += (uint32_t)__popc(vmask);
-            dropped += (uint32_t)(__popc(vmask) - __popc(pass));
-            const uint32_t c = (uint32_t)__popc(pass);
-            const uint32_t inc = wave_scan_incl(c);
-            uint32_t base = 0;
-            if (lane == 63)
-                base = inc ? atomicAdd(&s_m, inc) : 0u;
-            base = (uint32_t)__builtin_amdgcn_readlane((int)base, 63);
-            uint32_t off = base + inc - c;
-#pragma unroll
-            for (int u = 0; u < P2F_KPT; ++u)
-                if ((pass >> u) & 1u)
-                    sbuf[off++] = x[u];
-        };
-
-        // prime the pipeline: item 0's table and requests, item 1's run descriptors
-        uint64_t x[P2F_KPT];
-        uint32_t b0 = s_b0[0];
-        RunDesc rd = load_desc(b0);
-        {
-            const uint32_t lo0 = j0 * RX_B;
-            put_table(rd, lo0, Tc - lo0 < (uint32_t)RX_B ? Tc : lo0 + RX_B);
-        }
-        __syncthreads();
-        uint32_t cover = t_vs[P2F_NT];
-        uint32_t vmask;
-        {
-            const uint32_t lo0 = j0 * RX_B;
-            const uint32_t n0 = Tc - lo0 < (uint32_t)RX_B ? Tc - lo0 : (uint32_t)RX_B;
-            vmask = issue(b0, lo0, n0, lo0, cover, x);
-        }
-        __syncthreads(); // every wavefront has finished its searches before item 1's table is written (in the loop the
-                         // sort's barriers lie in between; without this one a stale table entry above a k-mer's position
-                         // made `v - t_vs[pos]` wrap and the request left the buffer: memory fault, first GPU run)
-        if (n_it > 1u)
-            rd = load_desc(s_b0[1]);
-        for (uint32_t j = 0; j < n_it; ++j) {
-            const uint32_t item = ib + j0 + j;
-            const uint32_t lo = (j0 + j) * RX_B;
-            const uint32_t n = Tc - lo < (uint32_t)RX_B ? Tc - lo : (uint32_t)RX_B, hi = lo + n;
-            // (C) item j's k-mers have arrived: filter, append the survivors
-            consume(x, vmask);
-            if (cover < hi) { // (rare: an item of more than 1024 runs, tiny runs only) the rest, table by table
-                uint32_t bb = b0 + P2F_NT;
-                while (cover < hi) {
-                    __syncthreads(); // the table's last readers are done
-                    const RunDesc r2 = load_desc(bb);
-                    put_table(r2, lo, hi);
-                    __syncthreads();
-                    const uint32_t cover2 = t_vs[P2F_NT];
-                    uint64_t x2[P2F_KPT];
-                    const uint32_t vm2 = issue(bb, lo, n, cover, cover2, x2);
-                    consume(x2, vm2);
-                    cover = cover2;
-                    bb += P2F_NT;
-                }
-                __syncthreads(); // ... before the next item's table is written
-            }
-            // (D) the next item: table, then its requests — they travel while item j is sorted
-            if (j + 1u < n_it) {
-                const uint32_t lo1 = lo + RX_B;
-                put_table(rd, lo1, Tc - lo1 < (uint32_t)RX_B ? Tc : lo1 + RX_B);
-            }
-            __syncthreads(); // survivors complete in the sort buffer; the table is published
-            if (j + 1u < n_it) {
+            gathered += (uint32_t)__popc(vma);
+            dropped += (uint32_t)(__popc(vma) - __popc(pass));
+            RX_PT(5); // waiting for the requests + filter
+            __syncthreads(); // the next item's table is published
+            if (has_next) {
                 b0 = s_b0[j + 1u];
                 cover = t_vs[P2F_NT];
-                const uint32_t lo1 = lo + RX_B;
-                const uint32_t n1 = Tc - lo1 < (uint32_t)RX_B ? Tc - lo1 : (uint32_t)RX_B;
-                vmask = issue(b0, lo1, n1, lo1, cover, x);
+                vmb = fill(std::false_type(), b0, item_lo(j + 1u), item_n(j + 1u), item_lo(j + 1u), cover, xb);
                 if (j + 2u < n_it)
                     rd = load_desc(s_b0[j + 2u]);
             }
-            // (B) sort item j's survivors by fine partition and write them out
-            const uint32_t m = s_m;
-            uint64_t q[P2F_KPT];
-            uint32_t valid = 0;
-#pragma unroll
-            for (int i = 0; i < P2F_KPT; ++i) {
-                const uint32_t e = (uint32_t)i * P2F_NT + tid;
-                q[i] = 0;
-                if (e < m) {
-                    q[i] = sbuf[e];
-                    valid |= 1u << i;
-                }
-            }
+            RX_PT(1); // table + search + requests
             auto fine = [&](int i) {
-                return ((valid >> i) & 1u) ? ((uint32_t)(q[i] >> w) & (uint32_t)(F2 - 1)) : spare;
+                return ((pass >> i) & 1u) ? ((uint32_t)(xa[i] >> w) & (uint32_t)(F2 - 1)) : spare;
             };
-            auto mid = [&]() {
-                if (tid == 0)
-                    s_m = 0; // (every wavefront has read it: the ranking's barrier lies in between)
-            };
-            rx_sort_emit<P2F_KPT, true, true, P2F_NT, false>(q, fine, F2, sbuf, s_cnt, s_base, s_wave, rx.buf2 + (size_t)item * RX_B,
-                                                       rx.start2 + (size_t)item * (F2 + 1) RX_PT_ARG2, mid);
+            rx_sort_emit<P2F_KPT, true, P2F_ONEBAR != 0, P2F_NT, false, true>(
+                xa, fine, F2, sbuf, s_cnt, s_base, s_wave, rx.buf2 + (size_t)item * RX_B,
+                rx.start2 + (size_t)item * (F2 + 1) RX_PT_ARG2);
+            if (has_next && cover < item_lo(j + 1u) + item_n(j + 1u))
+                more_rounds(j + 1u, xb, vmb); // (after the sort's closing barrier: the table is free)
+        };
+
+        // prime the pipeline: item 0's table and requests, item 1's run descriptors
+        uint64_t x0[P2F_KPT], x1[P2F_KPT];
+        uint32_t vm0 = 0, vm1 = 0;
+        b0 = s_b0[0];
+        rd = load_desc(b0);
+        put_table(rd, item_lo(0), item_lo(0) + item_n(0));
+        __syncthreads();
+        cover = t_vs[P2F_NT];
+        vm0 = fill(std::false_type(), b0, item_lo(0), item_n(0), item_lo(0), cover, x0);
+        __syncthreads(); // every wavefront has finished its searches before the next table is written (in the loop the
+                         // sort's barriers lie in between; without this one a stale table entry above a k-mer's position
+                         // made the offset wrap and the request left the buffer: memory fault, first GPU run)
+        if (cover < item_lo(0) + item_n(0))
+            more_rounds(0, x0, vm0);
+        if (n_it > 1u)
+            rd = load_desc(s_b0[1]);
+        for (uint32_t j = 0; j < n_it; j += 2u) {
+            process(j, x0, vm0, x1, vm1);
+            if (j + 1u < n_it)
+                process(j + 1u, x1, vm1, x0, vm0);
         }
     }
     }
+#ifndef RX_PT_P1
+    RX_PT_END(iv, 10);
+#endif
     rx_stat_add(iv, 2, gathered);
     rx_stat_add(iv, KMM_STAT_RX_DROPPED, dropped);
 }

@@ -359,12 +359,23 @@ class RawChunker:
     """Feeds successive raw file chunks of ~chunk_size bytes to a consumer that reports how many
     bytes it used (the end of the last complete record); the unused tail is carried over."""
 
-    def __init__(self, path, chunk_size, byte_range=None):
+    def __init__(self, path, chunk_size, byte_range=None, pinned=False):
         """byte_range = (lo, hi): only that part of an uncompressed file (both ends record starts,
-        rank_byte_range)."""
+        rank_byte_range).  pinned: the buffer is page-locked host memory (kmm_host_alloc), so the staging copy of
+        kmm_map_records runs at the PCIe link's rate."""
         self.f = _open(path)
         self.chunk_size = int(chunk_size)
-        self.buf = np.empty(self.chunk_size + (1 << 20), dtype=np.uint8)
+        self._pinned = None
+        n = self.chunk_size + (1 << 20)
+        if pinned:
+            import ctypes
+            from . import _lib
+            p = ctypes.c_void_p()
+            _lib.check(_lib.lib().kmm_host_alloc(n, ctypes.byref(p)))
+            self._pinned = p
+            self.buf = np.frombuffer((ctypes.c_uint8 * n).from_address(p.value), dtype=np.uint8)
+        else:
+            self.buf = np.empty(n, dtype=np.uint8)
         self.fill = 0
         self.eof = False
         self.left = None
@@ -404,3 +415,8 @@ class RawChunker:
 
     def close(self):
         self.f.close()
+        if self._pinned is not None:
+            from . import _lib
+            self.buf = np.empty(0, dtype=np.uint8)          # drop the view before the memory goes away
+            _lib.lib().kmm_host_free(self._pinned)
+            self._pinned = None

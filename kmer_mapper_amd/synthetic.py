@@ -162,8 +162,8 @@ def make_reads_torch(genome_ascii_dev, n_reads, read_len=150, seed=2, sub_rate=0
 
 class DeviceSyntheticIndex:
     """A synthetic Kmer Index whose five arrays live in HBM as torch tensors (duck-typed like the reference's index
-    object, mapper.pyx:22-29: DeviceIndex.from_index takes it as it is).  to_host() gives the numpy KmerIndex the
-    CPU oracle needs."""
+    object, mapper.pyx:22-29: DeviceIndex.from_index takes it as it is).  to_host() gives the numpy KmerIndex a
+    host-side checker needs."""
 
     def __init__(self, h2i, nk, kmers, nodes, freqs, modulo, max_node):
         self._hashes_to_index, self._n_kmers, self._kmers, self._nodes, self._frequencies = h2i, nk, kmers, nodes, freqs

@@ -31,6 +31,9 @@ with DeviceIndex.from_index(index, mx) as dev:
     p1 = "ptp1" in os.environ.get("KMM_LIB_PATH", "")
     names3 = ["wait item", "slice load", "scan+list", "stream+probe", "flush", "-"]
     names2 = ["wait item", "descriptors+scan", "keys+ranks", "scan+place", "copy-out", "list+gather"]
+    if dev.get_param("radix_filter"):      # k_rx_p2f's phases
+        names2 = ["unit prologue / loop top", "table + search + requests", "keys+ranks", "scan+place", "copy-out",
+                  "wait for requests + filter + compaction"]
     names1 = ["front end", "-", "keys+ranks (division)", "scan+place", "copy-out", "-"]
     for title, base, names in (("pass 3", 4, names3), ("pass 1" if p1 else "pass 2", 10, names1 if p1 else names2)):
         tot = sum(s[base:base + 6]) or 1
