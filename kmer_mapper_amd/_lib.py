@@ -71,7 +71,7 @@ SIGNATURES = {
 def build(force=False, verbose=False):
     """Compile csrc/kmm.hip for gfx950 into kmer_mapper_amd/libkmm.so (cross-compiles on CPU)."""
     csrc = os.path.dirname(SRC)
-    deps = [os.path.join(INCLUDE, "kmm.h")] + [os.path.join(csrc, f) for f in os.listdir(csrc)]
+    deps = [os.path.join(INCLUDE, "kmm.h")] + [os.path.join(csrc, f) for f in os.listdir(csrc) if f != "kmm_io.cpp"]
     if (not force and os.path.exists(SO_PATH)
             and os.path.getmtime(SO_PATH) >= max(os.path.getmtime(d) for d in deps)):
         return SO_PATH
@@ -81,6 +81,8 @@ def build(force=False, verbose=False):
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    from . import _io
+    _io.build(force=True)               # the host-side reader library (g++), same build step
     return SO_PATH
 
 

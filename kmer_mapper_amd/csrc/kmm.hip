@@ -517,6 +517,7 @@ int launch_rx(kmm_index *ix, const ReadsView &rv, const uint64_t *kmers_in, int6
         memset(&rx, 0, sizeof rx);
         rx.pstart = ix->rx_pstart; rx.pkeys = ix->rx_pkeys; rx.pfreq = ix->rx_pfreq; rx.ecnt = ix->rx_ecnt;
         rx.occ = ix->rx_occ;
+        rx.p2f_k = NB / 2048u < 4u ? 4u : (NB / 2048u > (uint32_t)P2F_KMAX ? (uint32_t)P2F_KMAX : NB / 2048u);
         rx.w = ix->rx_w; rx.f2 = ix->rx_f2; rx.PF = ix->rx_PF; rx.F1 = F1; rx.F2 = F2;
         rx.NB = NB; rx.max_items = (uint32_t)max_items;
         size_t off = 0;

@@ -113,6 +113,8 @@ struct RxView {
     const uint16_t *pfreq;  // [S]
     uint32_t *ecnt;         // [S] per-entry hit counts not yet added to the node counts
     const uint32_t *occ;    // bit h = bucket h holds an entry (padded by one coarse partition's worth of words), or null
+    uint32_t p2f_k;         // k_rx_p2f: items per work unit (one bitmap load, one pipeline fill: 16 / 32 / 64 items measured
+                            // 4.47 / 4.40 / 4.36 ms at configs[2]); fewer for small batches, so that every CU gets units
     int w, f2;              // sh = w + f2: hash bits below the coarse partition number
     uint32_t PF, F1, F2;
     // batch side
@@ -1022,10 +1024,7 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p2(IndexView iv, RxView rx)
 // Output: item slot as in k_rx_p2 (one output item per input item), holding the survivors only.
 constexpr int P2F_NT = 1024;
 constexpr int P2F_KPT = RX_B / P2F_NT;   // 8 k-mers per thread and item
-#ifndef P2F_KV
-#define P2F_KV 16
-#endif
-constexpr int P2F_K = P2F_KV;            // items per work unit
+constexpr int P2F_KMAX = 64;             // most items per work unit (rx.p2f_k: chosen per batch, launch_rx)
 constexpr int P2F_LOGBITS = 19;          // buckets per coarse partition the LDS bitmap covers: 2^19 (64 KB)
 #ifndef P2F_AUX
 #define P2F_AUX 1                        // search between the runs of the wavefront's first and last k-mer (else 0 .. 1023)
@@ -1045,7 +1044,7 @@ __global__ void __launch_bounds__(P2F_NT) k_rx_p2f(IndexView iv, RxView rx)
     __shared__ uint32_t t_last;               // consecutive k-mers lie between two of them; run of the last covered k-mer
     __shared__ __attribute__((aligned(8))) uint32_t s_cnt[RX_MAXF + 2 + 64];
     __shared__ uint32_t s_base[RX_MAXF + 1], s_wave[4];
-    __shared__ uint32_t s_b0[P2F_K];
+    __shared__ uint32_t s_b0[P2F_KMAX];
     __shared__ uint32_t s_idx;
     const int tid = threadIdx.x, lane = tid & 63;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1056,6 +1055,7 @@ __global__ void __launch_bounds__(P2F_NT) k_rx_p2f(IndexView iv, RxView rx)
     const uint32_t spare = rx_spare_key();
     uint32_t gathered = 0, dropped = 0; // conservation check: gathered = pass 1's lookups = pass 3's probes + dropped
     const uint32_t cs = (rx.F1 + 7u) / 8u;
+    const uint32_t P2F_K = rx.p2f_k;
     const uint32_t limit = ((rx.ctrl[2] + P2F_K - 1u) / P2F_K) * cs; // units of the largest coarse partition x cs
     const uint32_t home = rx_xcc_id();
     if (tid <= F2)
@@ -1082,7 +1082,7 @@ __global__ void __launch_bounds__(P2F_NT) k_rx_p2f(IndexView iv, RxView rx)
         if (cu * P2F_K >= n_items_c)
             continue; // partition sizes differ
         const uint32_t j0 = cu * P2F_K;
-        const uint32_t n_it = n_items_c - j0 < (uint32_t)P2F_K ? n_items_c - j0 : (uint32_t)P2F_K;
+        const uint32_t n_it = n_items_c - j0 < P2F_K ? n_items_c - j0 : P2F_K;
         const uint32_t Tc = rx.T1[cc];
         const uint32_t *P = rx.P1T + (size_t)cc * (NB + 1);
         const uint16_t *S = rx.S1T + (size_t)cc * NB;

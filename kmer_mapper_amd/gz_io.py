@@ -160,9 +160,16 @@ def _gzip_pieces(path, piece=1 << 24):
                     raw = b""
 
 
-def open_gz(path, n_threads=None):
+def open_gz(path, n_threads=None, native=None):
     """Forward-only inflated byte stream of a .gz file; BGZF files use up to n_threads cores (default: the cores
-    this process may run on, at most 16 — the reference CLI's -t default)."""
+    this process may run on, at most 16 — the reference CLI's -t default).  With libkmm_io.so built (the default)
+    the native reader does the work — members inflated by C++ threads straight into the caller's buffer; native=False
+    or KMM_IO_PYTHON=1 selects the pure-Python reader below."""
+    from . import _io
+    if native is None:
+        native = _io.available()
+    if native:
+        return _io.NativeStream(path, n_threads)
     if n_threads is None:
         try:
             n_threads = len(os.sched_getaffinity(0))

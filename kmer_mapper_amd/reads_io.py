@@ -23,6 +23,9 @@ def _open(path):
     if str(path).endswith(".gz"):
         from .gz_io import open_gz
         return open_gz(path)            # BGZF members are inflated on several cores, plain gzip on one
+    from . import _io
+    if _io.available():
+        return _io.NativeStream(path)   # parallel pread into the caller's (pinned) buffer
     return open(path, "rb", buffering=0)
 
 

@@ -31,6 +31,18 @@ def test_library_exports_every_declared_symbol():
     assert L.kmm_version().startswith(b"kmm ")
 
 
+def test_reader_library_exports_every_declared_symbol():
+    """include/kmm_io.h (host-side reader library, g++): same rule as kmm.h."""
+    from kmer_mapper_amd import _io
+    _io.build()
+    text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "kmm_io.h")).read(), flags=re.S)
+    syms = sorted(set(re.findall(r"\b(kmm_io_[a-z_0-9]+)\s*\(", text)))
+    L = _io.lib()
+    for s in syms:
+        assert hasattr(L, s), "libkmm_io.so does not export %s" % s
+    assert set(syms) == set(_io.SIGNATURES), "ctypes table and kmm_io.h disagree"
+
+
 def test_no_gpu_fails_loudly_not_silently():
     if _lib.device_count() > 0:
         pytest.skip("a GPU is present")

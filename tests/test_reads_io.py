@@ -1,9 +1,12 @@
 """CPU tests of the chunked FASTA/FASTQ(+gz) reader."""
+import os
 import struct
 import zlib
 
 import numpy as np
 import pytest
+
+ROOT_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 from kmer_mapper_amd import reads_io
 from kmer_mapper_amd import synthetic as syn
@@ -345,3 +348,81 @@ def test_bgzf_is_inflated_member_parallel_and_plain_gzip_still_works(tmp_path):
         open(pb, "wb").write(bad)
         with gz_io.open_gz(pb, 4) as s:
             s.read()
+
+
+# ---------------------------------------------------------------- native reader (libkmm_io.so)
+def test_native_reader_equals_python_reader_on_every_kind_of_file(tmp_path):
+    """libkmm_io.so (C++ threads; libdeflate or zlib) against the pure-Python readers and the raw file: BGZF (members
+    inflated in parallel straight into the caller's buffer, also when the buffer is smaller than one member), a plain
+    gzip stream, concatenated gzip members, an uncompressed file with seek; zlib engine too (KMM_IO_NO_LIBDEFLATE is
+    read when the library is first used, so that leg runs in a child process)."""
+    import gzip
+    import subprocess
+    import sys
+    from kmer_mapper_amd import _io, gz_io, reads_io as rio
+    _io.build()
+    rng = np.random.default_rng(41)
+    p = str(tmp_path / "t.fq")
+    _random_fastq(p, 6000, rng)
+    data = open(p, "rb").read()
+    pb, pg, pm = str(tmp_path / "b.fq.gz"), str(tmp_path / "g.fq.gz"), str(tmp_path / "m.fq.gz")
+    gz_io.write_bgzf(pb, data, block=30_000)
+    with gzip.open(pg, "wb") as f:
+        f.write(data)
+    with open(pm, "wb") as f:
+        f.write(gzip.compress(data[:len(data) // 3]) + gzip.compress(data[len(data) // 3:]))
+    for path, kind in ((pb, 1), (pg, 2), (pm, 2), (p, 0)):
+        for nt in (1, 5):
+            for piece in (7, 4093, 70_001, 1 << 20):          # (7 and 4093: smaller than a BGZF member)
+                with _io.NativeStream(path, nt) as s:
+                    assert s.kind == kind
+                    got = bytearray()
+                    while True:
+                        b = s.read(piece)
+                        if not b:
+                            break
+                        got += b
+                        if piece == 7 and len(got) > 3000:
+                            got += s.read()
+                            break
+                assert bytes(got) == data, (path, nt, piece)
+    with _io.NativeStream(p, 3) as s:                          # byte ranges of ranks: seek on a plain file
+        s.seek(12345)
+        assert s.read(1000) == data[12345:13345]
+    # the RawChunker the CLI uses, over the native reader, gives the file back
+    for path in (pb, pg, p):
+        ch = rio.RawChunker(path, 90_000)
+        out = bytearray()
+        while True:
+            buf = ch.next_chunk()
+            if buf is None:
+                break
+            used = rio.records_cut(buf, "fastq")
+            out += buf[:used].tobytes()
+            ch.consumed(used)
+        ch.close()
+        assert bytes(out) == data
+    # errors: truncated BGZF, truncated gzip stream, corrupt member
+    bad = str(tmp_path / "bad.gz")
+    raw_b = open(pb, "rb").read()
+    open(bad, "wb").write(raw_b[:len(raw_b) // 2])
+    with pytest.raises(EOFError):
+        with _io.NativeStream(bad, 2) as s:
+            s.read()
+    raw_g = open(pg, "rb").read()
+    open(bad, "wb").write(raw_g[:len(raw_g) - 5])
+    with pytest.raises(EOFError):
+        with _io.NativeStream(bad, 2) as s:
+            s.read()
+    flip = bytearray(raw_b)
+    flip[len(flip) // 3] ^= 0x5A
+    open(bad, "wb").write(flip)
+    with pytest.raises((ValueError, EOFError)):
+        with _io.NativeStream(bad, 2) as s:
+            s.read()
+    # the zlib engine gives the same bytes
+    code = ("import sys; sys.path.insert(0, %r); from kmer_mapper_amd import _io; assert _io.lib().kmm_io_engine() == 0; "
+            "s = _io.NativeStream(%r, 3); d = s.read(); s.close(); sys.stdout.buffer.write(d)" % (ROOT_DIR, pb))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, KMM_IO_NO_LIBDEFLATE="1"), capture_output=True)
+    assert r.returncode == 0, r.stderr[-500:]
+    assert r.stdout == data
