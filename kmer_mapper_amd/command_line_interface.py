@@ -112,8 +112,10 @@ def map_gpu_raw(index, path, chunk_size, fmt, k, map_reverse_complements=False,
                 max_index_lookup_frequency=1000, device=0, rank=0, world_size=1, before_fetch=None):
     """Same job as map_gpu, but the FASTQ / two-line FASTA records are parsed ON THE GPU
     (kmm_map_records): the host only reads (and for .gz inflates) raw bytes."""
+    t_index = time.perf_counter()
     max_node_id = index.max_node_id() if hasattr(index, "max_node_id") else int(np.max(index._nodes))
     dev = DeviceIndex.from_index(index, max_node_id, device=device)
+    logging.info("Index resident in HBM after %.3f sec (max_node_id scan + upload + repack)", time.perf_counter() - t_index)
     seekable = not str(path).endswith(".gz")
     byte_range = rank_byte_range(path, fmt, rank, world_size) if (world_size > 1 and seekable) else None
     if byte_range is not None:
@@ -165,9 +167,9 @@ def map_gpu_raw(index, path, chunk_size, fmt, k, map_reverse_complements=False,
             before_fetch(dev)
         node_counts = dev.get_node_counts()
     finally:
+        dt = time.perf_counter() - t_start
         chunker.close()
         dev.close()
-    dt = time.perf_counter() - t_start
     logging.info("Time spent only on hashing and counting hashes: %.5f" % dt)
     logging.info("Mapped %d reads from %d bytes (%.1f MB/s, GPU record parser): %d k-mer lookups "
                  "(%.1f M/s), %d index hits" % (n_reads, n_bytes, n_bytes / max(dt, 1e-9) / 1e6, n_lookups,

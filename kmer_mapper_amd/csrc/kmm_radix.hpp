@@ -1032,12 +1032,15 @@ constexpr int P2F_LOGBITS = 19;          // buckets per coarse partition the LDS
 #ifndef P2F_ONEBAR
 #define P2F_ONEBAR 1                     // one-barrier counter scan in the sort
 #endif
+#ifndef P2F_SCALAR_WALK
+#define P2F_SCALAR_WALK 1                // run of a k-mer by counting broadcast run starts (else binary search in LDS)
+#endif
 
 __global__ void __launch_bounds__(P2F_NT) k_rx_p2f(IndexView iv, RxView rx)
 {
     __shared__ uint32_t s_bits[(1 << P2F_LOGBITS) / 32];
     __shared__ uint64_t sbuf[RX_B + 64];  // (+ one dummy element per lane: branch-free placement)
-    __shared__ uint32_t t_vs[P2F_NT + 1]; // run table of the item being requested: where run t starts in the
+    __shared__ uint32_t t_vs[P2F_NT + 64]; // run table of the item being requested: where run t starts in the
     __shared__ uint32_t t_off[P2F_NT];    // coarse partition's virtual array; t_off[t] + v = where k-mer v of run t lies
                                           // in pass 1's output, relative to the table's first block
     __shared__ uint16_t t_aux[RX_B / 64 + 1]; // run (table index) of the item's k-mers 0, 64, 128, ...: a wavefront's 64
@@ -1167,6 +1170,26 @@ __global__ void __launch_bounds__(P2F_NT) k_rx_p2f(IndexView iv, RxView rx)
                 const uint32_t len = A[u + 1] > A[u] ? A[u + 1] - A[u] : 0u;
                 len_max = len > len_max ? len : len_max;
             }
+#if P2F_SCALAR_WALK
+            // The wavefront's 512 k-mers span the runs A[0] .. A[8] (about 30 of them at 17 k-mers per run).  With fewer
+            // than 64: lane t holds the start of run A[0] + t (ONE LDS read per wavefront and item); every run start a
+            // 64-block crosses is broadcast (readlane -> scalar register) and compared against the block's 64 positions:
+            // a k-mer's run = A[u] + the number of starts at or below it — two vector instructions per crossed start
+            // instead of a binary search per k-mer (seven instructions and an LDS round trip per step).  Run starts do
+            // not decrease, so empty runs count themselves in.
+            const uint32_t span = A[P2F_KPT] > A[0] ? A[P2F_KPT] - A[0] : 0u;
+            if (span < 64u) {
+                const uint32_t sv = t_vs[A[0] + (uint32_t)lane]; // (the table is padded by 64 entries)
+#pragma unroll
+                for (int u = 0; u < P2F_KPT; ++u) {
+                    for (uint32_t i = A[u] + 1u; i <= A[u + 1]; ++i) { // (uniform trip count; empty when A[u + 1] <= A[u])
+                        const uint32_t st = (uint32_t)__builtin_amdgcn_readlane((int)sv, (int)(i - A[0]));
+                        pos[u] += v[u] >= st ? 1u : 0u;
+                    }
+                }
+                len_max = 0; // (the search below has nothing left to do)
+            }
+#endif
             for (uint32_t stp = len_max ? 1u << (31 - __builtin_clz(len_max)) : 0u; stp >= 1u; stp >>= 1) {
 #pragma unroll
                 for (int u = 0; u < P2F_KPT; ++u) {
