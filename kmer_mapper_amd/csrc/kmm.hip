@@ -559,7 +559,7 @@ int launch_rx(kmm_index *ix, const ReadsView &rv, const uint64_t *kmers_in, int6
         hipLaunchKernelGGL(k_rx_colsum, dim3(chunks), dim3(256), 0, ix->stream, rx);
         hipLaunchKernelGGL(k_rx_chunkscan, dim3(F1), dim3(256), 0, ix->stream, rx, chunks);
         hipLaunchKernelGGL(k_rx_tables, dim3(1), dim3(512), 0, ix->stream, rx);
-        hipLaunchKernelGGL(k_rx_colscan, dim3(chunks), dim3(256), 0, ix->stream, rx);
+        hipLaunchKernelGGL(k_rx_colscan, dim3(chunks, (F1 + 255) / 256), dim3(256), 0, ix->stream, rx);
         HIPCHK(hipGetLastError());
         KMMCHK(tm.end());
         KMMCHK(tm.begin(ix, KMM_KERNEL_RX_P2));

@@ -54,7 +54,7 @@ constexpr int RX_B = 8192;            // positions per pass-1 block = k-mer capa
 constexpr int RX_KPT = RX_B / RX_NT;  // 16 k-mers per thread
 constexpr int RX_MAXF = 512;          // largest fan-out of one pass (512 x 512 slices of 8192 buckets = every modulo < 2^32)
 #ifndef RX_CHV
-#define RX_CHV 512
+#define RX_CHV 256
 #endif
 constexpr int RX_CH = RX_CHV;            // blocks per chunk of the directory scan
 constexpr int RX_IC = 1024;           // pass-2 items per pass-3 work item
@@ -74,6 +74,10 @@ constexpr int RX_SUBCAP = 1024;       // sub-runs (<= RX_LPR k-mers each) listed
 #define RX_LPR3 16
 #endif
 constexpr bool RX_P3_LINECUT = false;
+#ifndef RX_P3_WALK
+#define RX_P3_WALK 0                  // 1: pass 3 gathers by k-mer (run table + broadcast run starts, like k_rx_p2f) instead of
+#endif                                // piece lists — bit-exact, measured SLOWER (2.05 vs 1.94 ms at configs[2]: its runs of ~32
+                                      // k-mers fill the 16-lane pieces well; the walk's scalar loop per 64-block is serial)
 constexpr int RX_LPR_P3 = RX_LPR3;    // ... pass 3 (its runs are shorter: ~32 k-mers)
 constexpr int RX_NG3 = RX_NT / RX_LPR_P3;
 #ifndef RX_U3
@@ -741,7 +745,7 @@ __global__ void __launch_bounds__(512) k_rx_tables(RxView rx)
 // consecutive values are written as one 128-byte (P1T) / 64-byte (S1T) piece.
 __global__ void __launch_bounds__(256) k_rx_colscan(RxView rx)
 {
-    constexpr int TB = 32, CW = 256; // blocks per tile; coarse partitions per sweep (F1 > 256: two sweeps)
+    constexpr int TB = 32, CW = 256; // blocks per tile; coarse partitions per sweep (F1 > 256: two sweeps = grid.y)
     __shared__ uint32_t tP[CW][TB + 1];
     __shared__ uint16_t tS[CW][TB + 2];
     const uint32_t F1 = rx.F1, NB = rx.NB;
@@ -749,7 +753,8 @@ __global__ void __launch_bounds__(256) k_rx_colscan(RxView rx)
     const uint32_t b1 = b0 + RX_CH < NB ? b0 + RX_CH : NB;
     const size_t ld = F1 + 1;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (uint32_t cb = 0; cb < F1; cb += CW) {
+    { // (grid.y = sweeps of 256 coarse partitions: the walk is latency-bound, so the sweeps run side by side)
+    const uint32_t cb = blockIdx.y * CW;
     const uint32_t c = cb + threadIdx.x;
     const uint32_t nc = F1 - cb < (uint32_t)CW ? F1 - cb : (uint32_t)CW;
     uint32_t run = c < F1 ? rx.csum[(size_t)blockIdx.x * F1 + c] : 0u;
@@ -1308,8 +1313,13 @@ __global__ void __launch_bounds__(RX_NT, WPS) k_rx_p3(IndexView iv, RxView rx, i
     __shared__ DirT sdir[WMAX + 1]; // bucket b of the slice holds entries [sdir[b], sdir[b + 1]) - e0
     __shared__ uint64_t skeys[ECAP];
     __shared__ uint32_t scnt[ECAP];
+#if RX_P3_WALK
+    __shared__ uint32_t t_vs[RX_IC + 64 + 1]; // where run r starts in the work item's virtual array (k-mers of partition g,
+    __shared__ uint32_t t_off[RX_IC];         // item after item); t_off[r] + v = element of buf2 that holds k-mer v of run r
+#else
     __shared__ uint32_t sub_src[RX_SUBCAP];
     __shared__ uint32_t sub_meta[RX_SUBCAP];
+#endif
     __shared__ uint32_t s_wb[RX_MAXF + 1], s_wave8[2][RX_NT / 64];
     __shared__ uint32_t s_idx;
     const int tid = threadIdx.x, grp = tid / RX_LPR_P3, lg = tid % RX_LPR_P3;
@@ -1406,7 +1416,7 @@ __global__ void __launch_bounds__(RX_NT, WPS) k_rx_p3(IndexView iv, RxView rx, i
         const uint16_t *rtp = rfp + rx.max_items;
 #pragma unroll
         for (int j = 0; j < RX_IC / RX_NT; ++j) {
-            const uint32_t i = tid + j * RX_NT;
+            const uint32_t i = RX_P3_WALK ? (uint32_t)tid * (RX_IC / RX_NT) + j : tid + j * RX_NT; // (walk: adjacent runs)
             rf[j] = i < n_it ? rfp[i] : 0u;
             rt[j] = i < n_it ? rtp[i] : 0u;
         }
@@ -1445,9 +1455,105 @@ __global__ void __launch_bounds__(RX_NT, WPS) k_rx_p3(IndexView iv, RxView rx, i
                 }
             }
         };
-        // partition g's run inside every item of the chunk (RX_IC / RX_NT runs per thread, one scan for all of them),
-        // cut into sub-runs listed in LDS, RX_SUBCAP at a time
         if (sl.valid) {
+#if RX_P3_WALK
+        {
+            // Partition g's runs inside the items of the chunk form one virtual array of T k-mers (run after run).  The
+            // gather is by k-mer, as in k_rx_p2f: thread t owns the runs 2 t and 2 t + 1, one prefix sum gives every
+            // run's start; wavefront y takes the k-mers [4096 i + 512 y, + 512) of the array, finds the run of its first
+            // k-mer by a binary search (once per 512 k-mers, all lanes on the same word) and then walks the run starts:
+            // lane t holds the start of run A + t, each start that a block of 64 k-mers crosses is broadcast and
+            // compared.  No piece lists; every lane of every load is used.
+            constexpr int NR = RX_IC / RX_NT;
+            static_assert(NR == 2, "two adjacent runs per thread");
+            const uint32_t len0 = rt[0] - rf[0], len1 = rt[1] - rf[1];
+            uint32_t T;
+            const uint32_t pre = rx_scan_threads(len0 + len1, s_wave8, scan_flip, &T);
+            {
+                const uint32_t r0 = (uint32_t)tid * NR;
+                t_vs[r0] = r0 < n_it ? pre : 0xFFFFFFFFu;          // (runs beyond the chunk's items end every walk)
+                t_vs[r0 + 1] = r0 + 1u < n_it ? pre + len0 : 0xFFFFFFFFu;
+                t_off[r0] = (it0 + r0) * (uint32_t)RX_B + rf[0] - pre;                // (modulo 2^32)
+                t_off[r0 + 1] = (it0 + r0 + 1u) * (uint32_t)RX_B + rf[1] - (pre + len0);
+                if (tid < 65)
+                    t_vs[RX_IC + tid] = 0xFFFFFFFFu; // (no run starts here: ends every walk)
+            }
+            __syncthreads(); // (also orders the slice's LDS writes before the probes)
+            RX_PT(2); // scan + run table
+            const uint32_t lane = (uint32_t)tid & 63u;
+            const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane(tid >> 6);
+            const uint32_t lim = (rx.max_items - 1u) * (uint32_t)RX_B + (uint32_t)RX_B - 1u; // last element of buf2
+            for (uint32_t V0 = wv * 512u; V0 < T; V0 += (uint32_t)RX_NT * 8u) { // (uniform per wavefront)
+                uint32_t A = 0;
+#pragma unroll
+                for (int stp = RX_IC / 2; stp >= 1; stp >>= 1) // largest run with start <= V0
+                    A += t_vs[A + stp] <= V0 ? (uint32_t)stp : 0u;
+                A = (uint32_t)__builtin_amdgcn_readfirstlane((int)A);
+                uint32_t svbase = A;
+                uint32_t sv = t_vs[svbase + 1u + lane]; // starts of the runs svbase + 1 .. svbase + 64
+                uint64_t x[RX_U];
+                uint32_t vmask = 0, nxt = A + 1u; // next run start to compare against
+                static_assert(RX_U == 8, "eight blocks of 64 k-mers per wavefront and step");
+#pragma unroll
+                for (int u = 0; u < RX_U; ++u) {
+                    const uint32_t pa = V0 + 64u * (uint32_t)u, v = pa + lane;
+                    uint32_t pos = nxt - 1u;
+                    for (;;) { // every run start the block [pa, pa + 64) crosses (uniform)
+                        if (nxt - svbase > 64u) { // (more than 64 runs walked: next window of starts)
+                            svbase = nxt - 1u;
+                            sv = t_vs[svbase + 1u + lane];
+                        }
+                        const uint32_t st = (uint32_t)__builtin_amdgcn_readlane((int)sv, (int)(nxt - svbase - 1u));
+                        if (st > pa + 63u)
+                            break;
+                        pos += v >= st ? 1u : 0u;
+                        ++nxt;
+                    }
+                    vmask |= (v < T ? 1u : 0u) << u;
+                    uint32_t el = t_off[pos] + v;
+                    el = el < lim ? el : lim; // never leave pass 2's output
+                    x[u] = RX_LOAD3(rx.buf2 + el);
+                }
+                    // probe (mapper.pyx:53-69 on the LDS slice), RX_G3 k-mers side by side so that their LDS round
+                    // trips overlap: all bucket bounds; then entry j of every bucket, j = 0, 1, ... (a lane whose
+                    // bucket has no entry j reads key 0 and ignores it) — nothing conditional between the reads
+#pragma unroll
+                    for (int g0 = 0; g0 < RX_U; g0 += RX_G3) {
+                        uint32_t st[RX_G3], cn[RX_G3];
+#pragma unroll
+                        for (int i = 0; i < RX_G3; ++i) {
+                            const uint32_t hb = (uint32_t)x[g0 + i] & (W - 1u); // packed form: bucket = low w bits
+                            st[i] = sdir[hb];
+                            cn[i] = sdir[hb + 1];
+                        }
+                        uint32_t mx = 0;
+#pragma unroll
+                        for (int i = 0; i < RX_G3; ++i) {
+                            const bool act = (vmask >> (g0 + i)) & 1u;
+                            probed += act ? 1u : 0u;
+                            cn[i] = act ? cn[i] - st[i] : 0u;
+                            if (cn[i] && st[i] + cn[i] > ne) { // (rare) entries beyond the LDS copy
+                                probe_bucket_hbm(x[g0 + i], st[i], cn[i]);
+                                cn[i] = 0;
+                            }
+                            mx = cn[i] > mx ? cn[i] : mx;
+                        }
+                        for (uint32_t j = 0; j < mx; ++j) {
+                            uint64_t key[RX_G3];
+#pragma unroll
+                            for (int i = 0; i < RX_G3; ++i)
+                                key[i] = skeys[j < cn[i] ? st[i] + j : 0u];
+#pragma unroll
+                            for (int i = 0; i < RX_G3; ++i)
+                                if (j < cn[i] && key[i] == x[g0 + i])
+                                    atomicAdd(&scnt[st[i] + j], 1u);
+                        }
+                    }
+            }
+            __syncthreads();
+            RX_PT(3); // streaming + probing
+        }
+#else
         {
             constexpr int NR = RX_IC / RX_NT;
             uint32_t len[NR], np[NR], np_sum = 0;
@@ -1527,6 +1633,7 @@ __global__ void __launch_bounds__(RX_NT, WPS) k_rx_p3(IndexView iv, RxView rx, i
                 RX_PT(3); // streaming + probing
             }
         }
+#endif
         // LDS counters -> per-entry count vector (entries the frequency filter excludes carry RX_FILTERED); the last
         // window's closing barrier (or, without any window, the scan's) has completed the counters
         for (uint32_t i = tid; i < ne; i += RX_NT) {
