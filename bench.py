@@ -68,6 +68,8 @@ def main():
     ap.add_argument("--path", type=int, default=0, help="0 auto (by batch size), 1 direct fused kernel, 2 radix path")
     ap.add_argument("--part-shift", type=int, default=None)
     ap.add_argument("--fine-bits", type=int, default=None, help="radix path: log2 fine partitions per coarse partition")
+    ap.add_argument("--no-packed-tiles", action="store_true", help="radix pass 1: position-based tiles also for reads of one length")
+    ap.add_argument("--no-radix-filter", action="store_true", help="radix pass 2 without the empty-bucket filter")
     ap.add_argument("--bucket-order-flush", action="store_true", help="radix path: flush the per-entry counts in bucket order (scattered atomics)")
     ap.add_argument("--grid-per-cu", type=int, default=None)
     ap.add_argument("--radix-grid-per-cu", type=int, default=None, help="persistent workgroups per CU of radix passes 2 and 3 (1 or 2)")
@@ -151,6 +153,10 @@ def main():
         dev.set_param("grid_per_cu", args.grid_per_cu)
     if args.part_shift is not None:
         dev.set_param("part_shift", args.part_shift)
+    if args.no_radix_filter:
+        dev.set_param("radix_filter", 0)
+    if args.no_packed_tiles:
+        dev.set_param("radix_packed_tiles", 0)
     if args.fine_bits is not None:
         dev.set_param("fine_bits", args.fine_bits)
     if args.radix_grid_per_cu is not None:

@@ -193,6 +193,7 @@ struct kmm_index {
     uint32_t *rx_norder = nullptr, *rx_nnode = nullptr; // entries in node order (k_rx_flush_sorted); absent if memory is short
     uint32_t *rx_occ = nullptr;   // bit h = bucket h holds an entry: pass 2's empty-bucket filter (k_rx_p2f); optional
     bool rx_filter = true;        // "radix_filter": use the filtering pass 2 whenever a coarse partition's bitmap fits LDS
+    bool rx_packed = true;        // "radix_packed_tiles": pass 1 on reads of one length takes tiles of whole reads
     bool ecnt_dirty = false;  // rx_ecnt holds hits that are not in `counts` yet
     bool rx_unchecked = false; // radix passes have run since the conservation counters were last compared (drain)
     DevBuf rx_buf1, rx_buf2, rx_meta;
@@ -501,7 +502,9 @@ int launch_rx(kmm_index *ix, const ReadsView &rv, const uint64_t *kmers_in, int6
 {
     const IndexView iv = view_of(ix);
     const int64_t units = MODE == MODE_KMERS ? n_in : rv.total;
-    const int64_t n_src_total = (units + RX_B - 1) / RX_B;
+    // blocks of pass 1: 8192 positions, or (packed tiles) the reads of two tiles
+    const int64_t n_src_total = MODE == MODE_PACKED ? (rv.n_reads + 2 * (int64_t)rv.pk_rpt - 1) / (2 * (int64_t)rv.pk_rpt)
+                                                    : (units + RX_B - 1) / RX_B;
     const uint32_t X = also_rc ? 2u : 1u;
     const int64_t cap_src = (((int64_t)1 << 31) / RX_B) / X; // < 2^31 k-mers per sub-batch: 32-bit prefixes
     // sub-batches of equal size (every one of them streams the index slices once: no small last one)
@@ -656,6 +659,8 @@ int launch_map_reads(kmm_index *ix, const ReadsView &rv, int k, int max_freq, in
         HIPCHK(hipGetLastError());
         return tm.end();
     }
+    if (MODE == MODE_UNIFORM && rv.pk_rpt) // reads of one length: tiles of whole reads, every computed window a real k-mer
+        return launch_rx<MODE_PACKED>(ix, rv, nullptr, 0, k, max_freq, also_rc);
     return launch_rx<MODE>(ix, rv, nullptr, 0, k, max_freq, also_rc);
 }
 
@@ -1558,6 +1563,17 @@ static int map_reads_common(kmm_index_t *ix, const uint8_t *bases, const int64_t
     if (uniform_kernel) {
         rv.read_len = (uint64_t)read_len;
         rv.read_len_magic = magic_for((uint64_t)read_len);
+        // packed tiles for the radix path's pass 1 (kmm_tile.hpp): pk_lpr lanes per read, pk_S windows each
+        if (ix->rx_packed && read_len >= k && read_len - k + 1 <= 4096) {
+            const uint32_t W = (uint32_t)(read_len - k + 1), lpr = (W + 15u) / 16u, rpt = 256u / lpr;
+            if (rpt >= 1u && (uint64_t)rpt * (uint64_t)read_len <= 8176u) {
+                rv.pk_rpt = rpt;
+                rv.pk_lpr = lpr;
+                rv.pk_S = (W + lpr - 1u) / lpr;
+                rv.pk_W = W;
+                rv.pk_inv = (65536u + lpr - 1u) / lpr;
+            }
+        }
         KMMCHK(stage_copies_done(ix));
         KMMCHK(launch_map_reads<MODE_UNIFORM>(ix, rv, k, max_freq, also_revcomp ? 1 : 0));
     } else {
@@ -2093,6 +2109,8 @@ int kmm_set_param(kmm_index_t *ix, const char *name, int64_t value)
             KMMCHK(rx_flush(ix)); // nothing of the old layout may be pending
             KMMCHK(rx_repack_keys(ix));
         }
+    } else if (!strcmp(name, "radix_packed_tiles")) {
+        ix->rx_packed = value != 0;
     } else if (!strcmp(name, "radix_filter")) {
         // 1 (default): pass 2 drops the k-mers of empty buckets where a coarse partition's bitmap fits LDS (the
         // fan-out is chosen for it); 0: the plain pass 2
@@ -2191,6 +2209,8 @@ int kmm_get_param(kmm_index_t *ix, const char *name, int64_t *value)
                                : 0;
     else if (!strcmp(name, "radix_filter"))
         *value = (ix->rx_ok && rx_filter_active(ix)) ? 1 : 0;
+    else if (!strcmp(name, "radix_packed_tiles"))
+        *value = ix->rx_packed ? 1 : 0;
     else if (!strcmp(name, "n_fine_per_coarse"))
         *value = ix->rx_ok ? ix->rx_F2 : 0;
     else if (!strcmp(name, "count_kmers"))

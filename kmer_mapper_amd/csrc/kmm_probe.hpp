@@ -41,6 +41,9 @@ struct ReadsView {
     int64_t n_start_words;
     uint64_t read_len;         // uniform path
     uint64_t read_len_magic;   // floor(2^64 / read_len)
+    // packed uniform tiles (radix pass 1, kmm_tile.hpp tile_packed_*): a tile = pk_rpt whole reads, pk_lpr lanes per read
+    // with pk_S consecutive windows each — every window a lane computes is a real k-mer (0 = packed tiles not used)
+    uint32_t pk_rpt, pk_lpr, pk_S, pk_W, pk_inv;
     const uint8_t *lut;        // 256 bytes in HBM
     unsigned long long *first_bad; // [0] min position of a non-nucleotide byte, [1] of a malformed
                                    //     record line (both init ~0)
@@ -51,7 +54,7 @@ struct ReadsView {
     uint32_t header_char;      // '@' or '>'
 };
 
-enum { MODE_GENERAL = 0, MODE_UNIFORM = 1, MODE_RECORDS = 2 };
+enum { MODE_GENERAL = 0, MODE_UNIFORM = 1, MODE_RECORDS = 2, MODE_PACKED = 4 }; // (3 = MODE_KMERS, kmm_radix.hpp)
 
 // Exact x % m for any m >= 1 with one 64x64->hi multiply: q = hi64(x * floor(2^64/m)) is either
 // floor(x/m) or one less (x * (2^64/m - magic) / 2^64 < 1), so a single conditional subtract

@@ -512,10 +512,13 @@ template <int MODE, bool RC>
 __global__ void __launch_bounds__(RX_NT, 4) k_rx_p1(ReadsView rv, const uint64_t *__restrict__ kmers_in, int64_t n_in,
                                                  IndexView iv, RxView rx, int k, int64_t tile_begin, uint32_t n_src)
 {
-    constexpr int TM = MODE == MODE_KMERS ? MODE_UNIFORM : MODE;
+    constexpr bool PACKED = MODE == MODE_PACKED;   // reads of one length, tiles of whole reads (kmm_tile.hpp)
+    constexpr int TM = (MODE == MODE_KMERS || PACKED) ? MODE_UNIFORM : MODE;
     constexpr int S = TM == MODE_RECORDS ? 4 : 16; // windows per lane per tile
     constexpr int R = RX_KPT / S;                  // tiles per half-workgroup per block
-    __shared__ TileSmem<S> sm[2];
+    using Smem = typename std::conditional<PACKED, TilePackedSmem, TileSmem<S>>::type;
+    using Raw = typename std::conditional<PACKED, TilePackedRaw, TileRaw>::type;
+    __shared__ Smem sm[2];
     __shared__ uint64_t sbuf[RX_B];
     __shared__ __attribute__((aligned(8))) uint32_t s_cnt[RX_MAXF + 2 + 64];
     __shared__ uint32_t s_base[RX_MAXF + 1], s_wave[4];
@@ -537,12 +540,18 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p1(ReadsView rv, const uint64_t
 #else
     constexpr bool PREFETCH = false;
 #endif
-    TileRaw pw[R];
+    Raw pw[R];
     if (tid <= F1)
         s_cnt[tid] = 0; // (rx_sort_emit)
     if (tid == 0)
         s_cnt[RX_NT] = 0;
     __syncthreads(); // also: the code table is in LDS
+    auto load_tile = [&](int64_t tile, Raw &raw) {
+        if constexpr (PACKED)
+            tile_packed_load(rv, tile, ltid, raw);
+        else
+            tile_load_vec<S, TM>(rv, tc, tile, ltid, raw);
+    };
     for (uint32_t sb = blockIdx.x; sb < n_src; sb += gridDim.x) {
         uint64_t q[RX_KPT];
         uint32_t valid = 0;
@@ -562,15 +571,19 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p1(ReadsView rv, const uint64_t
             if (!PREFETCH || sb == blockIdx.x) {
 #pragma unroll
                 for (int r = 0; r < R; ++r)
-                    tile_load_vec<S, TM>(rv, tc, tile_begin + ((int64_t)sb * 2 + half) * R + r, ltid, pw[r]);
+                    load_tile(tile_begin + ((int64_t)sb * 2 + half) * R + r, pw[r]);
             }
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 uint64_t qq[S];
                 const int64_t tile = tile_begin + ((int64_t)sb * 2 + half) * R + r;
+                uint32_t v;
                 // (the first tile of a block needs no opening barrier: the previous block's sort lies in between)
-                const uint32_t v = r == 0 ? tile_kmers<S, TM, false>(rv, tc, tile, k, sm[half], qq, ltid, pw[r])
-                                          : tile_kmers<S, TM, true>(rv, tc, tile, k, sm[half], qq, ltid, pw[r]);
+                if constexpr (PACKED)
+                    v = tile_packed_kmers<false>(rv, tc, tile, k, sm[half], qq, ltid, pw[r]);
+                else
+                    v = r == 0 ? tile_kmers<S, TM, false>(rv, tc, tile, k, sm[half], qq, ltid, pw[r])
+                               : tile_kmers<S, TM, true>(rv, tc, tile, k, sm[half], qq, ltid, pw[r]);
 #pragma unroll
                 for (int j = 0; j < S; ++j)
                     q[r * S + j] = qq[j];
@@ -579,7 +592,7 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p1(ReadsView rv, const uint64_t
             if (PREFETCH && sb + gridDim.x < n_src) {
 #pragma unroll
                 for (int r = 0; r < R; ++r)
-                    tile_load_vec<S, TM>(rv, tc, tile_begin + ((int64_t)(sb + gridDim.x) * 2 + half) * R + r, ltid, pw[r]);
+                    load_tile(tile_begin + ((int64_t)(sb + gridDim.x) * 2 + half) * R + r, pw[r]);
             }
         }
         lookups += (uint32_t)__popc(valid) * X;

@@ -371,3 +371,117 @@ __device__ __forceinline__ uint32_t tile_kmers(const ReadsView &rv, const TileCo
 {
     return tile_kmers<S, MODE>(rv, tc, tile, k, sm, q, (int)threadIdx.x);
 }
+
+// ------------------------------------------------------------------------------------------------
+// Packed tiles for reads of one length L (radix pass 1).  A position-based tile computes a window at EVERY base
+// position and discards those that cross a read boundary: k - 1 of every L (20 % at L = 150, k = 31) go through the
+// division by the modulo and the ranking for nothing.  A packed tile is made of WHOLE reads instead: a 256-thread group
+// owns pk_rpt consecutive reads, pk_lpr lanes per read, and lane (r, s) takes the windows s * pk_S .. s * pk_S + pk_S - 1
+// of read r (pk_S = ceil(W / pk_lpr) <= 16, W = L - k + 1; the last lane of a read may hold fewer) — every window
+// a lane computes is a real k-mer, blocks of pass 1 hold ~17 % more k-mers, and there are as many fewer of them.
+// The bytes of the tile's reads (pk_rpt * L <= 8176) are staged like the flat tile's: 16-byte loads from the
+// 16-byte-aligned address below the first read, two vectors per thread at most.
+// Host side: map_reads_common sets the geometry (or pk_rpt = 0: position-based tiles) — reads shorter than 2 k or so
+// and reads longer than 4 KB keep the flat path.
+// ------------------------------------------------------------------------------------------------
+struct TilePackedSmem {
+    static constexpr int NV = 512;     // 16-base words staged per tile
+    uint32_t lut[256];
+    uint32_t codes[NV + 4];
+};
+
+struct TilePackedRaw {
+    uint32_t w[2][4];
+};
+
+__device__ __forceinline__ void tile_packed_load(const ReadsView &rv, int64_t tile, const int tid, TilePackedRaw &raw)
+{
+    const int64_t first = tile * (int64_t)rv.pk_rpt * (int64_t)rv.read_len; // byte of the tile's first read
+    const int64_t base = first & ~(int64_t)15;
+    const uint32_t nbytes = (uint32_t)(first - base) + rv.pk_rpt * (uint32_t)rv.read_len;
+    const bool aligned = (((uintptr_t)rv.bases) & 15u) == 0;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const uint32_t off = (uint32_t)(tid + h * 256) * 16u;
+        const int64_t p = base + off;
+        raw.w[h][0] = raw.w[h][1] = raw.w[h][2] = raw.w[h][3] = 0u;
+        if (off < nbytes) {
+            if (aligned && p + 16 <= rv.total) {
+                u32x4 x = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(rv.bases + p));
+                raw.w[h][0] = x[0]; raw.w[h][1] = x[1]; raw.w[h][2] = x[2]; raw.w[h][3] = x[3];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    raw.w[h][i] = tile_load_bytes4(rv, p + i * 4);
+            }
+        }
+    }
+}
+
+// Returns the lane's windows (q[0 .. pk_S)) and the mask of the real ones.  TOPBAR as in tile_kmers.
+template <bool TOPBAR>
+__device__ __forceinline__ uint32_t tile_packed_kmers(const ReadsView &rv, const TileConst &tc, int64_t tile, int k,
+                                                      TilePackedSmem &sm, uint64_t (&q)[16], const int tid,
+                                                      const TilePackedRaw &raw)
+{
+    const uint32_t L = (uint32_t)rv.read_len;
+    const int64_t first = tile * (int64_t)rv.pk_rpt * (int64_t)L;
+    const int64_t base = first & ~(int64_t)15;
+    const uint32_t delta = (uint32_t)(first - base);
+    const uint32_t nbytes = delta + rv.pk_rpt * L;
+    if (TOPBAR)
+        __syncthreads(); // every wave has finished reading the previous tile's LDS words
+    // ---- bytes -> 2-bit codes in LDS (bytes before the first read / past the chunk are staged as code 0, unflagged)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const uint32_t off = (uint32_t)(tid + h * 256) * 16u;
+        if (off < nbytes) {
+            const int64_t p = base + off;
+            uint32_t code = 0, bad = 0;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const uint32_t c = (raw.w[h][i >> 2] >> (8 * (i & 3))) & 0xFFu;
+                const uint32_t l = sm.lut[c];
+                bad |= (l == 0xFFu ? 1u : 0u) << i;
+                code |= (l & 3u) << (2 * i);
+            }
+            sm.codes[off >> 4] = code;
+            if (bad) {
+                // only bytes of the tile's own reads inside the chunk count (the tile's neighbours report their own)
+                const int64_t lo = first > p ? first - p : 0, hi = rv.total - p < (int64_t)(nbytes - off) ? rv.total - p : (int64_t)(nbytes - off);
+                uint32_t m = hi >= 16 ? 0xFFFFu : (hi > 0 ? (1u << hi) - 1u : 0u);
+                m &= lo >= 16 ? 0u : ~((1u << lo) - 1u);
+                bad &= m;
+                if (bad)
+                    atomicMin(rv.first_bad, (unsigned long long)(p + __builtin_ctz(bad)));
+            }
+        }
+    }
+    if (tid < 4) // (a lane's 16-window fetch may touch up to three words past the last staged one)
+        sm.codes[((nbytes + 15u) >> 4) + (uint32_t)tid] = 0u;
+    __syncthreads();
+    // ---- lane (r, s): windows s * S .. of read r
+    const uint32_t r = ((uint32_t)tid * rv.pk_inv) >> 16;          // tid / pk_lpr (exact for tid < 256)
+    const uint32_t s = (uint32_t)tid - r * rv.pk_lpr;
+    const uint32_t o = s * rv.pk_S;                                // first window of the lane inside its read
+    const int64_t read = tile * (int64_t)rv.pk_rpt + r;
+    uint32_t nwin = 0;
+    if (r < rv.pk_rpt && read < rv.n_reads && o < rv.pk_W)
+        nwin = rv.pk_W - o < rv.pk_S ? rv.pk_W - o : rv.pk_S;
+    const uint32_t q0 = delta + r * L + o;                         // position inside the staged bytes
+    const uint32_t wi = (r < rv.pk_rpt ? q0 : 0u) >> 4;
+    // (unlike the flat tile's lanes, which start at word boundaries, a lane may start anywhere inside a word: 16 windows
+    // of up to 31 bases from offset <= 15 need 61 bases = four words)
+    const uint32_t c0 = sm.codes[wi], c1 = sm.codes[wi + 1], c2 = sm.codes[wi + 2], c3 = sm.codes[wi + 3];
+    const int sh = (q0 & 15) * 2;
+    uint64_t lo = ((uint64_t)c1 << 32) | c0, hi = ((uint64_t)c3 << 32) | c2;
+    if (sh) {
+        lo = (lo >> sh) | (hi << (64 - sh));
+        hi >>= sh;
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+        q[j] = (j == 0 ? lo : ((lo >> (2 * j)) | (hi << (64 - 2 * j)))) & tc.kmask;
+    (void)k;
+    return nwin >= 16 ? 0xFFFFu : (1u << nwin) - 1u;
+}
