@@ -307,6 +307,11 @@ def main():
         total_kmers = my_kmers
     hits = int(counts.to(torch.int64).bitwise_and(0xFFFFFFFF).sum().item()) if rank == 0 else 0
     hbm_free, hbm_total = torch.cuda.mem_get_info(dev_t)
+    survivors = None
+    if dev.get_param("radix_filter"):
+        p2_in, p2_drop = dev.get_param("radix_p2_kmers"), dev.get_param("radix_p2_dropped")
+        if p2_in:
+            survivors = 1.0 - p2_drop / p2_in
 
     result = None
     if rank == 0:
@@ -321,12 +326,17 @@ def main():
             avg_kernel_s = sum(timing[n][0] for n in used) / max(launches, 1) / 1e3
             kmers_per_launch = my_kmers / max(launches, 1)
             per_kernel = {}
+            # with the empty-bucket filter pass 2 writes, and pass 3 reads, only the surviving fraction of the k-mers
+            stream_bytes = dict(RX_STREAM_BYTES)
+            if survivors is not None:
+                stream_bytes["k_rx_p2"] = 8.0 + 8.0 * survivors
+                stream_bytes["k_rx_p3"] = 8.0 * survivors
             for n in used:
                 t_s = timing[n][0] / max(launches, 1) / 1e3
                 per_kernel[n] = {"avg_ms": round(t_s * 1e3, 3)}
-                if n in RX_STREAM_BYTES:
-                    gbps = kmers_per_launch * RX_STREAM_BYTES[n] / t_s / 1e9
-                    per_kernel[n].update(stream_bytes_per_kmer=RX_STREAM_BYTES[n], stream_GB_per_s=round(gbps, 1),
+                if n in stream_bytes:
+                    gbps = kmers_per_launch * stream_bytes[n] / t_s / 1e9
+                    per_kernel[n].update(stream_bytes_per_kmer=round(stream_bytes[n], 2), stream_GB_per_s=round(gbps, 1),
                                          frac_of_hbm_peak=round(gbps / HBM_PEAK_GBPS, 4))
             dom = "+".join(used)
             b_alg = B_ALG_PER_KMER if not args.operator else B_ALG["k_map_kmers"]
@@ -351,7 +361,7 @@ def main():
                     if per_kernel and "per_kernel" in tj:          # measured HBM bytes of every kernel of the pipeline
                         for n, pk in per_kernel.items():
                             m = [v for kk, v in tj["per_kernel"].items()
-                                 if kk == n or (n == "k_rx_scan" and kk in ("k_rx_colsum", "k_rx_chunkscan", "k_rx_tables",
+                                 if kk == n or kk == n + "f" or (n == "k_rx_scan" and kk in ("k_rx_colsum", "k_rx_chunkscan", "k_rx_tables",
                                                                             "k_rx_colscan", "k_rx_tr2"))]
                             if m:
                                 b = sum(v["read_bytes"] + v["write_bytes"] for v in m)
@@ -416,6 +426,9 @@ def main():
                 "index_views": {"radix_GB": round(dev.get_param("radix_view_bytes") / 1e9, 2),
                                 "direct_GB": round(dev.get_param("direct_view_bytes") / 1e9, 2),
                                 "direct_resident": bool(dev.get_param("direct_view_resident"))},
+                "radix_filter": bool(dev.get_param("radix_filter")),
+                "radix_filter_survivors": None if survivors is None else round(survivors, 4),
+                "radix_packed_tiles": bool(dev.get_param("radix_packed_tiles")),
                 "radix_fine_partitions": dev.get_param("n_partitions"),
                 "radix_coarse_partitions": dev.get_param("n_coarse_partitions"),
                 "occupancy_filter": bool(dev.get_param("occupancy_filter")),

@@ -74,6 +74,10 @@ constexpr int RX_SUBCAP = 1024;       // sub-runs (<= RX_LPR k-mers each) listed
 #define RX_LPR3 16
 #endif
 constexpr bool RX_P3_LINECUT = false;
+#ifndef RX_P3_LONGQ
+#define RX_P3_LONGQ 0                 // 1: pass 3 probes entries 0 and 1 of every bucket unrolled and queues longer buckets per
+#endif                                // wavefront (instead of keeping 64 lanes in the entry loop until the wavefront's longest
+                                      // bucket is done) — bit-exact, no gain (1.96 vs 1.96 ms): the probe hides behind the stream
 #ifndef RX_P3_WALK
 #define RX_P3_WALK 0                  // 1: pass 3 gathers by k-mer (run table + broadcast run starts, like k_rx_p2f) instead of
 #endif                                // piece lists — bit-exact, measured SLOWER (2.05 vs 1.94 ms at configs[2]: its runs of ~32
@@ -1335,6 +1339,13 @@ __global__ void __launch_bounds__(RX_NT, WPS) k_rx_p3(IndexView iv, RxView rx, i
 #endif
     __shared__ uint32_t s_wb[RX_MAXF + 1], s_wave8[2][RX_NT / 64];
     __shared__ uint32_t s_idx;
+#if RX_P3_LONGQ
+    // buckets with more than two entries (3 % of the probes at load factor 0.5) are finished later, 32 at a time per
+    // wavefront, instead of keeping all 64 lanes in the entry loop until the longest bucket of the wavefront is done
+    __shared__ uint64_t wq_x[RX_NT / 64][32];
+    __shared__ uint32_t wq_m[RX_NT / 64][32];
+    uint32_t wq_n = 0; // (uniform per wavefront)
+#endif
     const int tid = threadIdx.x, grp = tid / RX_LPR_P3, lg = tid % RX_LPR_P3;
     const uint32_t n_rows = rx.ctrl[1], F1 = rx.F1, F2 = rx.F2;
     const uint32_t W = 1u << rx.w;
@@ -1468,6 +1479,21 @@ __global__ void __launch_bounds__(RX_NT, WPS) k_rx_p3(IndexView iv, RxView rx, i
                 }
             }
         };
+#if RX_P3_LONGQ
+        // entries 2 .. of the queued buckets, one bucket per lane (first entry and remaining count travel packed in 16
+        // bits each: a slice holds at most 8192 entries)
+        auto drain_long = [&]() {
+            const uint32_t ql = (uint32_t)tid & 63u;
+            if (ql < wq_n) {
+                const uint64_t q = wq_x[tid >> 6][ql];
+                const uint32_t m = wq_m[tid >> 6][ql];
+                const uint32_t b = m & 0xFFFFu, c = m >> 16;
+                for (uint32_t j = 0; j < c; ++j)
+                    if (skeys[b + j] == q)
+                        atomicAdd(&scnt[b + j], 1u);
+            }
+        };
+#endif
         if (sl.valid) {
 #if RX_P3_WALK
         {
@@ -1551,6 +1577,45 @@ __global__ void __launch_bounds__(RX_NT, WPS) k_rx_p3(IndexView iv, RxView rx, i
                             }
                             mx = cn[i] > mx ? cn[i] : mx;
                         }
+#if RX_P3_LONGQ
+                        (void)mx;
+#pragma unroll
+                        for (uint32_t j = 0; j < 2u; ++j) { // entries 0 and 1: all a bucket has, 97 times out of 100
+                            uint64_t key[RX_G3];
+#pragma unroll
+                            for (int i = 0; i < RX_G3; ++i)
+                                key[i] = skeys[j < cn[i] ? st[i] + j : 0u];
+#pragma unroll
+                            for (int i = 0; i < RX_G3; ++i)
+                                if (j < cn[i] && key[i] == x[g0 + i])
+                                    atomicAdd(&scnt[st[i] + j], 1u);
+                        }
+#pragma unroll
+                        for (int i = 0; i < RX_G3; ++i) {
+                            const bool lng = cn[i] > 2u;
+                            const unsigned long long bal = __ballot(lng);
+                            if (bal) { // (uniform)
+                                const uint32_t n_l = (uint32_t)__popcll(bal);
+                                if (wq_n + n_l > 32u) {
+                                    drain_long();
+                                    wq_n = 0;
+                                }
+                                if (n_l > 32u) { // (more long buckets than the queue holds: finished here)
+                                    if (lng)
+                                        for (uint32_t j = 2; j < cn[i]; ++j)
+                                            if (skeys[st[i] + j] == x[g0 + i])
+                                                atomicAdd(&scnt[st[i] + j], 1u);
+                                } else {
+                                    const uint32_t slot = wq_n + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+                                    if (lng) {
+                                        wq_x[tid >> 6][slot] = x[g0 + i];
+                                        wq_m[tid >> 6][slot] = (st[i] + 2u) | ((cn[i] - 2u) << 16);
+                                    }
+                                    wq_n += n_l;
+                                }
+                            }
+                        }
+#else
                         for (uint32_t j = 0; j < mx; ++j) {
                             uint64_t key[RX_G3];
 #pragma unroll
@@ -1561,6 +1626,7 @@ __global__ void __launch_bounds__(RX_NT, WPS) k_rx_p3(IndexView iv, RxView rx, i
                                 if (j < cn[i] && key[i] == x[g0 + i])
                                     atomicAdd(&scnt[st[i] + j], 1u);
                         }
+#endif
                     }
             }
             __syncthreads();
@@ -1630,6 +1696,45 @@ __global__ void __launch_bounds__(RX_NT, WPS) k_rx_p3(IndexView iv, RxView rx, i
                             }
                             mx = cn[i] > mx ? cn[i] : mx;
                         }
+#if RX_P3_LONGQ
+                        (void)mx;
+#pragma unroll
+                        for (uint32_t j = 0; j < 2u; ++j) { // entries 0 and 1: all a bucket has, 97 times out of 100
+                            uint64_t key[RX_G3];
+#pragma unroll
+                            for (int i = 0; i < RX_G3; ++i)
+                                key[i] = skeys[j < cn[i] ? st[i] + j : 0u];
+#pragma unroll
+                            for (int i = 0; i < RX_G3; ++i)
+                                if (j < cn[i] && key[i] == x[g0 + i])
+                                    atomicAdd(&scnt[st[i] + j], 1u);
+                        }
+#pragma unroll
+                        for (int i = 0; i < RX_G3; ++i) {
+                            const bool lng = cn[i] > 2u;
+                            const unsigned long long bal = __ballot(lng);
+                            if (bal) { // (uniform)
+                                const uint32_t n_l = (uint32_t)__popcll(bal);
+                                if (wq_n + n_l > 32u) {
+                                    drain_long();
+                                    wq_n = 0;
+                                }
+                                if (n_l > 32u) { // (more long buckets than the queue holds: finished here)
+                                    if (lng)
+                                        for (uint32_t j = 2; j < cn[i]; ++j)
+                                            if (skeys[st[i] + j] == x[g0 + i])
+                                                atomicAdd(&scnt[st[i] + j], 1u);
+                                } else {
+                                    const uint32_t slot = wq_n + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+                                    if (lng) {
+                                        wq_x[tid >> 6][slot] = x[g0 + i];
+                                        wq_m[tid >> 6][slot] = (st[i] + 2u) | ((cn[i] - 2u) << 16);
+                                    }
+                                    wq_n += n_l;
+                                }
+                            }
+                        }
+#else
                         for (uint32_t j = 0; j < mx; ++j) {
                             uint64_t key[RX_G3];
 #pragma unroll
@@ -1640,12 +1745,18 @@ __global__ void __launch_bounds__(RX_NT, WPS) k_rx_p3(IndexView iv, RxView rx, i
                                 if (j < cn[i] && key[i] == x[g0 + i])
                                     atomicAdd(&scnt[st[i] + j], 1u);
                         }
+#endif
                     }
                 }
                 __syncthreads();
                 RX_PT(3); // streaming + probing
             }
         }
+#endif
+#if RX_P3_LONGQ
+        drain_long(); // what is left of the wavefronts' queues, before the counters are read
+        wq_n = 0;
+        __syncthreads();
 #endif
         // LDS counters -> per-entry count vector (entries the frequency filter excludes carry RX_FILTERED); the last
         // window's closing barrier (or, without any window, the scan's) has completed the counters

@@ -16,4 +16,5 @@ rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TC
 rocprofv3 --pmc TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $out/wrsize -- python3 bench.py $common "$@" > /dev/null 2> $out/wrsize.err || exit 1
 # keep only the CSVs that are read afterwards (the merge back is capped at 64 MiB)
 find $out -name "*_agent_info.csv" -delete
+find $out -name "*kernel_trace.csv" -size +8M -delete
 ls $out/stats/*/ | head
