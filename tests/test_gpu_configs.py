@@ -207,3 +207,49 @@ def test_overlapping_buckets_are_served_by_the_direct_path(kmm, oracle):
         assert dev.get_param("radix_available") == 0 and dev.get_param("radix_unavailable_reason") == 4
         dev.map_reads(bases, offs, 31)
         assert np.array_equal(dev.get_node_counts(), expect)
+
+
+def test_cli_accumulates_chunks_into_radix_batches_and_records_beyond_2_pow_30(kmm, tmp_path, caplog):
+    """`kmer_mapper map` with the reference's default -c (2.5 MB chunks,
+    command_line_interface.py:169) accumulates its chunks into GPU batches large enough for the radix path
+    (`path_taken: radix` in the log) and gives the counts of one big uniform map call; kmm_map_records takes a raw
+    chunk beyond 2^30 bytes (mapped piece by piece inside the library)."""
+    import argparse
+    import logging
+    import torch
+    from kmer_mapper_amd import synthetic as syn
+    from kmer_mapper_amd.command_line_interface import map_bnp
+    from kmer_mapper_amd import _lib
+    R, L, k = 4_000_000, 150, 31
+    index, genome = syn.make_index(100_000_000, k=k, seed=1, gpu_builder=True)
+    mx = index.max_node_id()
+    g_ascii = torch.from_numpy(syn.ACGT[genome]).cuda()
+    reads = syn.make_reads_torch(g_ascii, R, L, seed=77)
+    del g_ascii, genome
+    rec_len = 4 + L + 3 + L + 1                                     # "@rd\n" seq "\n+\n" qual "\n" = 308 bytes
+    rec = torch.empty((R, rec_len), dtype=torch.uint8, device="cuda")
+    rec[:, 0:4] = torch.tensor(list(b"@rd\n"), dtype=torch.uint8, device="cuda")
+    rec[:, 4:4 + L] = reads.view(R, L)
+    rec[:, 4 + L:4 + L + 3] = torch.tensor(list(b"\n+\n"), dtype=torch.uint8, device="cuda")
+    rec[:, 4 + L + 3:4 + L + 3 + L] = ord("F")
+    rec[:, -1] = 10
+    raw = rec.reshape(-1)                                           # 1.23 GB of FASTQ > 2^30
+    assert raw.numel() > 2 ** 30
+    with kmm.DeviceIndex.from_index(index, mx) as dev:
+        dev.map_reads_uniform(reads, R, L, k)
+        expect = dev.get_node_counts()
+        dev.reset()
+        used, n_rec = dev.map_records(raw, raw.numel(), _lib.FORMAT_FASTQ, k)
+        assert (used, n_rec) == (raw.numel(), R)
+        assert np.array_equal(dev.get_node_counts(), expect)
+    fq = str(tmp_path / "reads.fq")
+    raw.cpu().numpy().tofile(fq)
+    del raw, rec, reads
+    args = argparse.Namespace(kmer_index=index, index_bundle=None, reads=fq, kmer_size=k, n_threads=16, chunk_size=2_500_000,
+                              output_file=None, debug=None, max_hits_per_kmer=1000, gpu=True, gpu_hash_map_size=0,
+                              map_reverse_complements=False, apply_max_hits_per_kmer=False, host_parser=False, device=0)
+    with caplog.at_level(logging.INFO):
+        got = map_bnp(args)
+    assert np.array_equal(got, expect)
+    log = caplog.text
+    assert "are accumulated into GPU batches" in log and "path_taken: radix" in log, log[-600:]
