@@ -258,6 +258,17 @@ int kmm_get_kmer_counts(kmm_index_t *idx, uint32_t *out);
  *   "radix_sorted_flush" 1 (default) = per-entry counts are added to the node counts through the node-ordered entry
  *                      list (built when an index has fewer than 8 entries per node on average); 0 = in bucket order
  *   "count_kmers"      1 = per-k-mer counting mode (see kmm_get_kmer_counts)
+ *   "radix_filter"     1 (default) = pass 2 drops the k-mers whose bucket is empty (they cannot match: mapper.pyx:55-58)
+ *                      wherever a coarse partition's occupancy bitmap fits 64 KB of LDS; the fan-out is chosen for it
+ *   "radix_packed_tiles" 1 (default) = pass 1 on reads of one length works on tiles of whole reads (no windows across
+ *                      read boundaries are computed)
+ *   "fine_bits"        experiments: log2 fine partitions per coarse partition of the radix path
+ * Read-only (kmm_get_param): "radix_available", "radix_unavailable_reason" (0 available, 1 modulo >= 2^31, 2 slices too
+ *   dense for LDS, 3 out of memory, 4 the index's buckets overlap), "n_partitions", "n_coarse_partitions",
+ *   "n_fine_per_coarse", "radix_p2_kmers" / "radix_p3_kmers" / "radix_p2_dropped" (the conservation counters every
+ *   synchronising call compares: KMM_ERR_INTERNAL), "radix_batches" / "direct_batches" (which path the map calls took),
+ *   "radix_view_bytes" / "direct_view_bytes" / "direct_view_resident" (HBM budget: the direct view of an index beyond
+ *   16 GiB of it is packed on first use), "wide_buckets", "occupancy_filter", "bloom_filter_bytes".
  * Unknown names return KMM_ERR_INVALID_ARG.
  */
 int kmm_set_param(kmm_index_t *idx, const char *name, int64_t value);
