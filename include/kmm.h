@@ -171,6 +171,12 @@ int kmm_map_reads_uniform(kmm_index_t *idx, const uint8_t *bases, int64_t n_read
  */
 #define KMM_FORMAT_FASTA2 2
 #define KMM_FORMAT_FASTQ 4
+/* Multi-line FASTA (sequences wrapped over several lines; `bnp.open` reads those too): the chunk is unwrapped into
+ * two-line FASTA on the GPU first.  A record is only known to be complete once the NEXT header line has been seen, so
+ * *consumed stops at the start of the chunk's last header line — unless the caller ORs KMM_FORMAT_LAST_CHUNK into
+ * `format` (the chunk ends the file: everything is consumed). */
+#define KMM_FORMAT_FASTA 1
+#define KMM_FORMAT_LAST_CHUNK 0x100
 int kmm_map_records(kmm_index_t *idx, const uint8_t *raw, int64_t n_bytes, int format, int k,
                     int max_index_lookup_frequency, int also_revcomp, const uint8_t *lut,
                     int64_t *consumed, int64_t *n_records);

@@ -22,6 +22,7 @@ KMM_ERR_NOMEM = -5
 KMM_ERR_MALFORMED = -6
 KMM_ERR_INTERNAL = -7
 FORMAT_FASTA2, FORMAT_FASTQ = 2, 4
+FORMAT_FASTA, FORMAT_LAST_CHUNK = 1, 0x100      # multi-line FASTA (unwrapped on the GPU); flag: the chunk ends the file
 
 # kernel ids of kmm_get_timing (include/kmm.h)
 (KERNEL_MAP_READS, KERNEL_MAP_KMERS, KERNEL_RX_P1, KERNEL_RX_SCAN, KERNEL_RX_P2, KERNEL_RX_P3,

@@ -137,7 +137,8 @@ def map_gpu_raw(index, path, chunk_size, fmt, k, map_reverse_complements=False,
             logging.info("Chunks of %d bytes are accumulated into GPU batches of %d bytes (radix path)", chunk_size, batch_bytes)
     chunker = RawChunker(path, batch_bytes, byte_range, pinned=True)
     owns = (lambda i: True) if (world_size == 1 or seekable) else (lambda i: chunk_owner(i, world_size) == rank)
-    kfmt = _lib.FORMAT_FASTQ if fmt == "fastq" else _lib.FORMAT_FASTA2
+    # FASTQ and two-line FASTA are parsed as they are; FASTA with wrapped sequence lines is unwrapped on the GPU first
+    kfmt = {"fastq": _lib.FORMAT_FASTQ, "fasta": _lib.FORMAT_FASTA2, "fasta_ml": _lib.FORMAT_FASTA}[fmt]
     t_start = time.perf_counter()
     n_reads = n_bytes = 0
     try:
@@ -146,12 +147,13 @@ def map_gpu_raw(index, path, chunk_size, fmt, k, map_reverse_complements=False,
             buf = chunker.next_chunk()
             if buf is None:
                 break
+            last = _lib.FORMAT_LAST_CHUNK if (fmt == "fasta_ml" and chunker.eof) else 0
             if owns(i):
-                used, n_rec = dev.map_records(buf, buf.shape[0], kfmt, k, max_index_lookup_frequency,
+                used, n_rec = dev.map_records(buf, buf.shape[0], kfmt | last, k, max_index_lookup_frequency,
                                               also_revcomp=map_reverse_complements)
             else:   # a chunk of a shared .gz stream that another rank maps: only its record boundary is needed,
                     # cut by the SAME rule as the GPU parser's `consumed` (newline count), at end of input too
-                used, n_rec = records_cut(buf, fmt), 0
+                used, n_rec = records_cut(buf, fmt, chunker.eof), 0
             if used == 0:
                 if chunker.eof:
                     raise ValueError("trailing bytes at end of %s do not form a complete record" % path)
@@ -224,8 +226,10 @@ def map_bnp(args):
                 dev.comm_reduce_counts(root=0)
                 logging.info("Rank %d: RCCL reduce of the node counts on the device: %.5f sec", rank, time.perf_counter() - t0)
     revcomp = bool(getattr(args, "map_reverse_complements", False))
-    fmt, gpu_parsable = sniff_format(args.reads)
-    if gpu_parsable and not getattr(args, "host_parser", False):
+    fmt, two_line = sniff_format(args.reads)
+    if not getattr(args, "host_parser", False):
+        if fmt == "fasta" and not two_line:
+            fmt = "fasta_ml"           # wrapped sequence lines: unwrapped on the GPU (KMM_FORMAT_FASTA)
         node_counts = map_gpu_raw(kmer_index, args.reads, args.chunk_size, fmt, k, revcomp, max_freq,
                                   device=device, rank=rank, world_size=world, before_fetch=before_fetch)
     else:

@@ -1680,6 +1680,77 @@ static int map_records_piece(kmm_index_t *ix, const uint8_t *raw, int64_t n_byte
     return stage_release(ix, s, false);
 }
 
+// One piece of a multi-line FASTA chunk: unwrapped on the device into two-line FASTA (kmm_records.hpp k_ml_*), then
+// mapped like one.  Only whole records are taken: up to the start of the chunk's last header line, or all of it when
+// the caller says the chunk ends the file.
+static int map_multiline_piece(kmm_index_t *ix, const uint8_t *raw, int64_t n_bytes, bool last, int k, int max_freq,
+                               int also_revcomp, const uint8_t *lut, int64_t *consumed, int64_t *n_records)
+{
+    *consumed = 0;
+    *n_records = 0;
+    Stage &s = next_stage(ix);
+    KMMCHK(stage_acquire(ix, s));
+    bool staged = false;
+    const uint8_t *d_raw = nullptr;
+    KMMCHK(stage_in<uint8_t>(ix, s.bases, raw, (size_t)n_bytes, &d_raw, &staged));
+    const int64_t n_tiles = (n_bytes + 1023) / 1024;
+    const int n_super = (int)((n_tiles + 1023) / 1024);
+    KMMCHK(ensure(s.tile_first, (size_t)n_super * 1024 * 4));
+    KMMCHK(ensure(s.offsets, (size_t)n_super * 4 + 64));
+    KMMCHK(ensure(s.start_bits, (size_t)n_tiles * 8 + 64));
+    KMMCHK(ensure(s.kmers, (size_t)n_bytes + 16));
+    uint32_t *tile_cnt = (uint32_t *)s.tile_first.p;
+    uint32_t *super_tot = (uint32_t *)s.offsets.p;
+    uint8_t *cells = (uint8_t *)s.offsets.p + (((size_t)n_super * 4 + 15) & ~(size_t)15);
+    uint32_t *d_total = (uint32_t *)cells;                       // kept bytes of the whole chunk
+    int *d_last_header = (int *)(cells + 8);                     // start of the last header line (-1: none)
+    unsigned long long *d_out_len = (unsigned long long *)(cells + 16);
+    int32_t *tile_last = (int32_t *)s.start_bits.p, *tile_prev = tile_last + n_tiles;
+    uint8_t *unwrapped = (uint8_t *)s.kmers.p;
+    hipStream_t cs = ix->copy_stream;
+    HIPCHK(hipMemsetAsync(tile_cnt, 0, (size_t)n_super * 1024 * 4, cs));
+    HIPCHK(hipMemsetAsync(d_last_header, 0xFF, 4, cs));
+    const dim3 g4((unsigned)((n_tiles + 3) / 4));
+    hipLaunchKernelGGL(k_ml_tile_last, g4, dim3(256), 0, cs, d_raw, n_bytes, n_tiles, tile_last);
+    hipLaunchKernelGGL(k_ml_scan, dim3(1), dim3(1024), 0, cs, tile_last, n_tiles, tile_prev);
+    hipLaunchKernelGGL(k_ml_flags, g4, dim3(256), 0, cs, d_raw, n_bytes, n_tiles, tile_prev, tile_cnt, d_last_header);
+    hipLaunchKernelGGL(k_rec_scan1, dim3(n_super), dim3(1024), 0, cs, tile_cnt, super_tot);
+    hipLaunchKernelGGL(k_super_scan, dim3(1), dim3(1024), 0, cs, super_tot, n_super, d_total);
+    HIPCHK(hipGetLastError());
+    struct { uint32_t total; uint32_t pad; int last_header; } h = {0, 0, -1};
+    HIPCHK(hipMemcpyAsync(&h, cells, 12, hipMemcpyDeviceToHost, cs));
+    HIPCHK(hipStreamSynchronize(cs)); // (the borrowed host buffer is free from here on)
+    const int64_t limit = last ? n_bytes : (h.last_header > 0 ? (int64_t)h.last_header : 0);
+    int64_t out_len = 0;
+    if (limit > 0) {
+        unsigned long long ol = h.total;
+        if (limit < n_bytes) {
+            HIPCHK(hipMemsetAsync(d_out_len, 0, 8, cs));
+        }
+        hipLaunchKernelGGL(k_ml_scatter, g4, dim3(256), 0, cs, d_raw, n_bytes, limit, n_tiles, tile_prev, tile_cnt, super_tot,
+                           unwrapped, d_out_len);
+        HIPCHK(hipGetLastError());
+        if (limit < n_bytes) {
+            HIPCHK(hipMemcpyAsync(&ol, d_out_len, 8, hipMemcpyDeviceToHost, cs));
+            HIPCHK(hipStreamSynchronize(cs));
+        }
+        out_len = (int64_t)ol;
+    }
+    int rc = KMM_OK;
+    if (out_len > 0) {
+        // the unwrapped records, from HBM, through the two-line parser (its kernels wait for the copy stream)
+        int64_t used = 0;
+        rc = map_records_piece(ix, unwrapped, out_len, KMM_FORMAT_FASTA2, k, max_freq, also_revcomp, lut, &used, n_records);
+        if (rc == KMM_OK && used != out_len)
+            rc = fail(KMM_ERR_MALFORMED, "multi-line FASTA chunk: %lld of %lld unwrapped bytes form whole records (a record "
+                      "without a sequence line, or bytes before the first '>')", (long long)used, (long long)out_len);
+        if (rc == KMM_OK)
+            *consumed = limit;
+    }
+    const int rel = stage_release(ix, s, false); // (after the inner call's kernels: they read this stage's buffer)
+    return rc != KMM_OK ? rc : rel;
+}
+
 int kmm_map_records(kmm_index_t *ix, const uint8_t *raw, int64_t n_bytes, int format, int k,
                     int max_freq, int also_revcomp, const uint8_t *lut, int64_t *consumed,
                     int64_t *n_records)
@@ -1687,8 +1758,10 @@ int kmm_map_records(kmm_index_t *ix, const uint8_t *raw, int64_t n_bytes, int fo
     if (!ix)
         return fail(KMM_ERR_INVALID_ARG, "idx is NULL");
     KMMCHK(check_k(k));
-    if (format != KMM_FORMAT_FASTQ && format != KMM_FORMAT_FASTA2)
-        return fail(KMM_ERR_INVALID_ARG, "format must be KMM_FORMAT_FASTQ (4) or KMM_FORMAT_FASTA2 (2)");
+    const bool last_chunk = (format & KMM_FORMAT_LAST_CHUNK) != 0;
+    format &= ~KMM_FORMAT_LAST_CHUNK;
+    if (format != KMM_FORMAT_FASTQ && format != KMM_FORMAT_FASTA2 && format != KMM_FORMAT_FASTA)
+        return fail(KMM_ERR_INVALID_ARG, "format must be KMM_FORMAT_FASTQ (4), KMM_FORMAT_FASTA2 (2) or KMM_FORMAT_FASTA (1)");
     if (n_bytes < 0)
         return fail(KMM_ERR_INVALID_ARG, "n_bytes negative");
     if (consumed)
@@ -1707,7 +1780,11 @@ int kmm_map_records(kmm_index_t *ix, const uint8_t *raw, int64_t n_bytes, int fo
     while (off < n_bytes) {
         const int64_t len = n_bytes - off < piece_max ? n_bytes - off : piece_max;
         int64_t used = 0, nr = 0;
-        KMMCHK(map_records_piece(ix, raw + off, len, format, k, max_freq, also_revcomp, lut, &used, &nr));
+        if (format == KMM_FORMAT_FASTA)
+            KMMCHK(map_multiline_piece(ix, raw + off, len, last_chunk && off + len == n_bytes, k, max_freq, also_revcomp, lut,
+                                       &used, &nr));
+        else
+            KMMCHK(map_records_piece(ix, raw + off, len, format, k, max_freq, also_revcomp, lut, &used, &nr));
         off += used;
         recs += nr;
         if (used == 0 || len < piece_max)

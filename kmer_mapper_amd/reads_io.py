@@ -326,13 +326,20 @@ def last_record_start(buf, fmt):
         back *= 4
 
 
-def records_cut(buf, fmt):
+def records_cut(buf, fmt, at_eof=False):
     """Number of leading bytes of `buf` that kmm_map_records would consume: the byte after the last newline whose
     1-based count is a multiple of the record's line count (4 for FASTQ, 2 for two-line FASTA) — the rule of the GPU
     record parser (csrc/kmm_records.hpp, k_rec_scan2: target = total - total % period).  Ranks that skip a chunk of
     a shared .gz stream MUST cut it with this rule: the owner advances by the parser's `consumed`, and a rule that
     holds a FASTA record back until the next '>' has been seen (last_record_start) disagrees whenever a chunk ends
     exactly on a record's last newline — the stream positions of the ranks would drift apart."""
+    if fmt == "fasta_ml":          # multi-line FASTA: whole records end where the chunk's last header line starts
+        if at_eof:
+            return int(buf.shape[0])
+        nl = np.flatnonzero(buf == _NL)
+        starts = nl[nl + 1 < buf.shape[0]] + 1
+        hdr = starts[buf[starts] == ord(">")]
+        return int(hdr[-1]) if hdr.shape[0] else 0
     period = 4 if fmt == "fastq" else 2
     nl = np.flatnonzero(buf == _NL)
     whole = (nl.shape[0] // period) * period

@@ -365,6 +365,48 @@ def test_cli_map_end_to_end(kmm, syn, oracle, tmp_path, fmt, gz):
     assert np.array_equal(got_rc, expect_rc)
 
 
+@pytest.mark.parametrize("line_width,crlf,gz", [(60, False, False), (7, False, True), (80, True, False)])
+def test_multi_line_fasta_is_unwrapped_on_the_gpu(kmm, syn, oracle, tmp_path, line_width, crlf, gz):
+    """FASTA whose sequences are wrapped over several lines (what `bnp.open` reads too, reference
+    command_line_interface.py:102,109): kmm_map_records(KMM_FORMAT_FASTA) unwraps the chunk into two-line FASTA on
+    the GPU (k-mers span the line breaks, never the records) — chunk by chunk with the tail carried over, the last
+    chunk flagged, CRLF line ends, through `kmer_mapper map` on plain and gzipped files, against the oracle and the
+    host parser."""
+    import argparse
+    from kmer_mapper_amd import _lib, reads_io
+    from kmer_mapper_amd.command_line_interface import map_bnp
+    from kmer_mapper_amd.util import ReadBatch
+    index, genome = syn.make_index(6000, seed=141)
+    mx = index.max_node_id()
+    bases, offs = syn.make_ragged_reads(genome, 2500, 1, 400, seed=142)
+    expect, _ = oracle.map_reads(index, mx, bases, offs, 31, n_threads=4)
+    path = str(tmp_path / ("reads.fa" + (".gz" if gz else "")))
+    reads_io.write_fasta(path, ReadBatch(bases, offs), gz=gz, line_width=line_width)
+    if crlf:
+        data = open(path, "rb").read().replace(b"\n", b"\r\n")
+        open(path, "wb").write(data)
+    assert reads_io.sniff_format(path) == ("fasta", False)
+    ns = argparse.Namespace(kmer_index=index, index_bundle=None, reads=path, kmer_size=31, n_threads=16, chunk_size=30000,
+                            output_file=None, debug=None, max_hits_per_kmer=1000, gpu=True, gpu_hash_map_size=0,
+                            map_reverse_complements=False)
+    assert np.array_equal(map_bnp(ns), expect)
+    ns.host_parser = True
+    assert np.array_equal(map_bnp(ns), expect)
+    # the operator directly: one call with the last-chunk flag; without it the last record stays unconsumed
+    import gzip
+    raw = np.frombuffer((gzip.open if gz else open)(path, "rb").read(), dtype=np.uint8)
+    with kmm.DeviceIndex.from_index(index, mx) as dev:
+        used, n_rec = dev.map_records(raw, raw.shape[0], _lib.FORMAT_FASTA | _lib.FORMAT_LAST_CHUNK, 31)
+        assert (used, n_rec) == (raw.shape[0], 2500)
+        assert np.array_equal(dev.get_node_counts(), expect)
+        dev.reset()
+        used, n_rec = dev.map_records(raw, raw.shape[0], _lib.FORMAT_FASTA, 31)
+        assert n_rec == 2499 and bytes(raw[used:used + 1]) == b">" and used == reads_io.records_cut(raw, "fasta_ml")
+        used2, n2 = dev.map_records(raw[used:], raw.shape[0] - used, _lib.FORMAT_FASTA | _lib.FORMAT_LAST_CHUNK, 31)
+        assert (used2, n2) == (raw.shape[0] - used, 1)
+        assert np.array_equal(dev.get_node_counts(), expect)
+
+
 # ---------------------------------------------------------------- more edge cases
 def _flat_index(syn, kmers, nodes, modulo):
     from kmer_mapper_amd.kmer_index import KmerIndex

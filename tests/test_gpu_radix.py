@@ -306,3 +306,35 @@ def test_conservation_self_check_is_armed_in_production(kmm, syn, oracle):
         dev.map_reads(bases, offs, 31)
         assert np.array_equal(dev.get_node_counts(), expect)
         assert dev.get_param("radix_p2_kmers") == n == dev.get_param("radix_p3_kmers") + dev.get_param("radix_p2_dropped")
+
+
+@pytest.mark.parametrize("read_len", [33, 62, 101, 151, 251, 1000])
+def test_packed_tiles_equal_position_tiles_and_the_oracle(kmm, syn, oracle, read_len):
+    """Pass 1 on reads of one length takes tiles of whole reads (kmm_tile.hpp, tile_packed_*): lanes-per-read and
+    windows-per-lane geometries from one lane per read up to 61 lanes per read, tiles that start at any byte offset
+    (odd lengths), reverse complements, the last tile partly empty, and a device buffer that is not 16-byte aligned
+    (byte-wise staging) — against the position-based tiles and the oracle (reference: windows never span reads,
+    kmer_mapper/util.py:72)."""
+    import torch
+    index, genome = syn.make_index(40000, seed=391)
+    mx = index.max_node_id()
+    n_reads = max(700, 1_500_000 // read_len) + 3
+    bases, offs = syn.make_reads(genome, n_reads, read_len, seed=392)
+    for rc in (False, True):
+        expect, n = oracle.map_reads(index, mx, bases, offs, 31, also_revcomp=rc, n_threads=4)
+        with kmm.DeviceIndex.from_index(index, mx) as dev:
+            dev.set_param("path", 2)
+            assert dev.get_param("radix_packed_tiles") == 1
+            dev.map_reads_uniform(bases, n_reads, read_len, 31, also_revcomp=rc)
+            assert np.array_equal(dev.get_node_counts(), expect), ("packed", rc)
+            assert dev.get_stats(reset=True)[0] == (2 if rc else 1) * n
+            dev.reset()
+            dev.set_param("radix_packed_tiles", 0)
+            dev.map_reads_uniform(bases, n_reads, read_len, 31, also_revcomp=rc)
+            assert np.array_equal(dev.get_node_counts(), expect), ("flat", rc)
+            dev.reset()
+            dev.set_param("radix_packed_tiles", 1)
+            t = torch.empty(bases.shape[0] + 7, dtype=torch.uint8, device="cuda")
+            t[7:] = torch.from_numpy(bases).cuda()
+            dev.map_reads_uniform(t[7:], n_reads, read_len, 31, also_revcomp=rc)      # base pointer at +7 bytes
+            assert np.array_equal(dev.get_node_counts(), expect), ("unaligned", rc)
