@@ -1054,6 +1054,9 @@ constexpr int P2F_LOGBITS = 19;          // buckets per coarse partition the LDS
 #ifndef P2F_ONEBAR
 #define P2F_ONEBAR 1                     // one-barrier counter scan in the sort
 #endif
+#ifndef P2F_STARTBITS
+#define P2F_STARTBITS 1                  // run of a k-mer = run of its 64-block's first k-mer + popcount of the run-start bits
+#endif                                   // up to it (one LDS atomic OR per run, mbcnt per k-mer) instead of the walk below
 #ifndef P2F_SCALAR_WALK
 #define P2F_SCALAR_WALK 1                // run of a k-mer by counting broadcast run starts (else binary search in LDS)
 #endif
@@ -1067,6 +1070,10 @@ __global__ void __launch_bounds__(P2F_NT) k_rx_p2f(IndexView iv, RxView rx)
                                           // in pass 1's output, relative to the table's first block
     __shared__ uint16_t t_aux[RX_B / 64 + 1]; // run (table index) of the item's k-mers 0, 64, 128, ...: a wavefront's 64
     __shared__ uint32_t t_last;               // consecutive k-mers lie between two of them; run of the last covered k-mer
+#if P2F_STARTBITS
+    __shared__ uint32_t t_sbits[2][RX_B / 32]; // bit e = a run starts at the item's k-mer e (items alternate between the
+    __shared__ uint32_t t_empty[2];            // two masks); != 0: an EMPTY run starts inside the item (mask unusable)
+#endif
     __shared__ __attribute__((aligned(8))) uint32_t s_cnt[RX_MAXF + 2 + 64];
     __shared__ uint32_t s_base[RX_MAXF + 1], s_wave[4];
     __shared__ uint32_t s_b0[P2F_KMAX];
@@ -1122,6 +1129,12 @@ __global__ void __launch_bounds__(P2F_NT) k_rx_p2f(IndexView iv, RxView rx)
             for (uint32_t i = (nwords & ~3u) + tid; i < nwords; i += P2F_NT) // (tiny tables)
                 s_bits[i] = rx.occ[(size_t)cc * nwords + i];
         }
+#if P2F_STARTBITS
+        if (tid < 2 * (RX_B / 32))
+            (&t_sbits[0][0])[tid] = 0u;
+        if (tid < 2)
+            t_empty[tid] = 0u;
+#endif
         __syncthreads();
 
         auto item_lo = [&](uint32_t j) { return (j0 + j) * (uint32_t)RX_B; };
@@ -1143,7 +1156,18 @@ __global__ void __launch_bounds__(P2F_NT) k_rx_p2f(IndexView iv, RxView rx)
         // Table of the runs [bb, bb + 1024) for the item [lo, hi).  Besides its own row every thread marks the run of
         // each k-mer lo + 64 a that lies in its run (t_aux), and of the item's last covered k-mer (t_last): the search of
         // a wavefront's 64 consecutive k-mers then starts from two table indices a few runs apart instead of 0 .. 1023.
-        auto put_table = [&](const RunDesc &r, uint32_t lo, uint32_t hi) {
+        auto put_table = [&](const RunDesc &r, uint32_t lo, uint32_t hi, int mb = -1) {
+#if P2F_STARTBITS
+            // (first table of an item, mb = the item's mask: cleared two items ago, behind that item's barriers)
+            if (mb >= 0 && r.vs != 0xFFFFFFFFu && r.vs > lo && r.vs < hi) {
+                if (r.ve > r.vs)
+                    atomicOr(&t_sbits[mb][(r.vs - lo) >> 5], 1u << ((r.vs - lo) & 31u));
+                else
+                    t_empty[mb] = 1u; // two runs would share the bit
+            }
+#else
+            (void)mb;
+#endif
             t_vs[tid] = r.vs;
             t_off[tid] = (uint32_t)tid * RX_B + r.st - r.vs; // (modulo 2^32: the sum with v is < 1025 x 8192)
             if (tid == P2F_NT - 1) {
@@ -1167,7 +1191,7 @@ __global__ void __launch_bounds__(P2F_NT) k_rx_p2f(IndexView iv, RxView rx)
         // bookkeeping (a slot outside [c_lo, c_hi) holds garbage and no bit of the returned mask).  MERGE: slots
         // outside the range keep what an earlier table left in them.
         auto fill = [&](auto merge_tag, uint32_t bb, uint32_t lo, uint32_t n, uint32_t c_lo, uint32_t c_hi,
-                        uint64_t (&x)[P2F_KPT]) {
+                        uint64_t (&x)[P2F_KPT], int mb = -1) {
             constexpr bool MERGE = decltype(merge_tag)::value;
             const uint32_t c_end = lo + n < c_hi ? lo + n : c_hi; // positions this table serves: [c_lo, c_end)
             const uint32_t a0 = wave * 8u;
@@ -1192,6 +1216,26 @@ __global__ void __launch_bounds__(P2F_NT) k_rx_p2f(IndexView iv, RxView rx)
                 const uint32_t len = A[u + 1] > A[u] ? A[u + 1] - A[u] : 0u;
                 len_max = len > len_max ? len : len_max;
             }
+#if P2F_STARTBITS
+            // The item's run-start bits (first table of an item without empty runs): the run of k-mer e = the run of its
+            // 64-block's first k-mer (A[u]) + the number of runs that start at the k-mers after it up to e.  The wavefront's
+            // 512 bits are 16 words: one LDS read (lane i reads word i), two readlanes per block, mbcnt per k-mer.
+            bool by_bits = false;
+            if (!MERGE && mb >= 0 && t_empty[mb] == 0u) { // (uniform)
+                by_bits = true;
+                const uint32_t mw = t_sbits[mb][a0 * 2u + ((uint32_t)lane & 15u)];
+#pragma unroll
+                for (int u = 0; u < P2F_KPT; ++u) {
+                    const uint32_t mlo = (uint32_t)__builtin_amdgcn_readlane((int)mw, 2 * u) & ~1u; // (bit 0: counted in A[u])
+                    const uint32_t mhi = (uint32_t)__builtin_amdgcn_readlane((int)mw, 2 * u + 1);
+                    const uint32_t below = __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u));
+                    const uint32_t own = ((lane < 32 ? mlo >> lane : mhi >> (lane - 32)) & 1u);
+                    pos[u] += below + own;
+                }
+                len_max = 0;
+            }
+            if (!by_bits) {
+#endif
 #if P2F_SCALAR_WALK
             // The wavefront's 512 k-mers span the runs A[0] .. A[8] (about 30 of them at 17 k-mers per run).  With fewer
             // than 64: lane t holds the start of run A[0] + t (ONE LDS read per wavefront and item); every run start a
@@ -1210,6 +1254,9 @@ __global__ void __launch_bounds__(P2F_NT) k_rx_p2f(IndexView iv, RxView rx)
                     }
                 }
                 len_max = 0; // (the search below has nothing left to do)
+            }
+#endif
+#if P2F_STARTBITS
             }
 #endif
             for (uint32_t stp = len_max ? 1u << (31 - __builtin_clz(len_max)) : 0u; stp >= 1u; stp >>= 1) {
@@ -1257,8 +1304,16 @@ __global__ void __launch_bounds__(P2F_NT) k_rx_p2f(IndexView iv, RxView rx)
             const uint32_t item = ib + j0 + j;
             const bool has_next = j + 1u < n_it;
             RX_PT(0);
+#if P2F_STARTBITS
+            // item j's run-start mask has served (its requests were issued before the previous item's sort): cleared for
+            // item j + 2, whose bits are set one item (and its barriers) later
+            if (tid < RX_B / 32)
+                t_sbits[j & 1u][tid] = 0u;
+            if (tid == 0)
+                t_empty[j & 1u] = 0u;
+#endif
             if (has_next)
-                put_table(rd, item_lo(j + 1u), item_lo(j + 1u) + item_n(j + 1u));
+                put_table(rd, item_lo(j + 1u), item_lo(j + 1u) + item_n(j + 1u), (int)((j + 1u) & 1u));
             // item j's k-mers against the bitmap (waits for them): key = fine partition, or the lane's spare counter
             uint32_t pass = 0;
 #pragma unroll
@@ -1274,7 +1329,7 @@ __global__ void __launch_bounds__(P2F_NT) k_rx_p2f(IndexView iv, RxView rx)
             if (has_next) {
                 b0 = s_b0[j + 1u];
                 cover = t_vs[P2F_NT];
-                vmb = fill(std::false_type(), b0, item_lo(j + 1u), item_n(j + 1u), item_lo(j + 1u), cover, xb);
+                vmb = fill(std::false_type(), b0, item_lo(j + 1u), item_n(j + 1u), item_lo(j + 1u), cover, xb, (int)((j + 1u) & 1u));
                 if (j + 2u < n_it)
                     rd = load_desc(s_b0[j + 2u]);
             }
@@ -1294,10 +1349,10 @@ __global__ void __launch_bounds__(P2F_NT) k_rx_p2f(IndexView iv, RxView rx)
         uint32_t vm0 = 0, vm1 = 0;
         b0 = s_b0[0];
         rd = load_desc(b0);
-        put_table(rd, item_lo(0), item_lo(0) + item_n(0));
+        put_table(rd, item_lo(0), item_lo(0) + item_n(0), 0);
         __syncthreads();
         cover = t_vs[P2F_NT];
-        vm0 = fill(std::false_type(), b0, item_lo(0), item_n(0), item_lo(0), cover, x0);
+        vm0 = fill(std::false_type(), b0, item_lo(0), item_n(0), item_lo(0), cover, x0, 0);
         __syncthreads(); // every wavefront has finished its searches before the next table is written (in the loop the
                          // sort's barriers lie in between; without this one a stale table entry above a k-mer's position
                          // made the offset wrap and the request left the buffer: memory fault, first GPU run)
