@@ -74,14 +74,13 @@ constexpr int RX_SUBCAP = 1024;       // sub-runs (<= RX_LPR k-mers each) listed
 #define RX_LPR3 16
 #endif
 constexpr bool RX_P3_LINECUT = false;
-#ifndef RX_P3_LONGQ
-#define RX_P3_LONGQ 0                 // 1: pass 3 probes entries 0 and 1 of every bucket unrolled and queues longer buckets per
-#endif                                // wavefront (instead of keeping 64 lanes in the entry loop until the wavefront's longest
-                                      // bucket is done) — bit-exact, no gain (1.96 vs 1.96 ms): the probe hides behind the stream
-#ifndef RX_P3_WALK
-#define RX_P3_WALK 0                  // 1: pass 3 gathers by k-mer (run table + broadcast run starts, like k_rx_p2f) instead of
-#endif                                // piece lists — bit-exact, measured SLOWER (2.05 vs 1.94 ms at configs[2]: its runs of ~32
-                                      // k-mers fill the 16-lane pieces well; the walk's scalar loop per 64-block is serial)
+// (Two variants of pass 3 were measured in round 3 and removed again, both bit-exact — profiles/r03: gathering by k-mer
+// with a run table and broadcast run starts as k_rx_p2f does, 2.05 vs 1.94 ms: runs of ~32 k-mers fill the 16-lane pieces
+// well; and entries 0 and 1 of every bucket unrolled with longer buckets queued per wavefront, 1.96 vs 1.96 ms.)
+#ifndef RX_P3_PREFETCH
+#define RX_P3_PREFETCH 0              // 1: the next batch of pieces is requested before the current one is probed (two register
+                                      // sets) — bit-exact, measured SLOWER: 2.02 vs 1.91 ms (profiles/r03/ab_pass3_prefetch.txt)
+#endif
 constexpr int RX_LPR_P3 = RX_LPR3;    // ... pass 3 (its runs are shorter: ~32 k-mers)
 constexpr int RX_NG3 = RX_NT / RX_LPR_P3;
 #ifndef RX_U3
@@ -110,6 +109,13 @@ constexpr int RX_WMAX = 4096;         // buckets per fine partition (LDS directo
 constexpr int RX_ECAP = 4096;         // entries of a fine partition kept in LDS (keys + counters)
 constexpr int RX_WMAX_BIG = 8192;     // slices of indexes with more than 256 x 256 x 4096 buckets (e.g. the customary
 constexpr int RX_ECAP_BIG = 8192;     // modulo 452 930 477): 140 KB of LDS, one workgroup of pass 3 per CU
+#ifndef RX_P3_DENSE
+#define RX_P3_DENSE 0                 // 1: slices of at most RX_ECAP_DENSE entries run three workgroups of pass 3 per CU
+#endif
+#ifndef RX_P3_DENSE_WPS
+#define RX_P3_DENSE_WPS 6
+#endif
+constexpr int RX_ECAP_DENSE = 2560;
 constexpr uint32_t RX_FILTERED = 0x80000000u; // pass 3: top bit of an LDS hit counter = entry excluded by max_freq
 enum { MODE_KMERS = 3 };              // pass-1 source: a uint64 k-mer array instead of read bytes
 
@@ -1037,11 +1043,12 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p2(IndexView iv, RxView rx)
 // differently from k_rx_p2:
 //   * ONE workgroup of 1024 threads per CU; the memory phase of item j + 1 overlaps the LDS phase of item j inside
 //     the workgroup: the k-mers of the next item are requested (8 per thread, into registers) BEFORE the current
-//     item is sorted, and are consumed (tested against the bitmap, the survivors appended to the sort buffer) after;
-//   * gather by k-mer, not by run: thread t takes the item's k-mers t, t + 1024, ...; the run a k-mer lies in is
-//     found by a 10-step binary search in an LDS table of the item's run starts (all 8 searches of a thread
-//     interleaved); consecutive lanes read consecutive k-mers, every lane of every load instruction is used
-//     whatever the run length (piece lists: 52 % at 17-k-mer runs), no list is built, scanned or padded;
+//     item is sorted, and are consumed (tested against the bitmap, the survivors ranked and placed) after; three
+//     barriers per item (after ranking, scan, placement): the table of item j + 2 is built next to the scan;
+//   * gather by k-mer, not by run: wavefront y takes the item's k-mers [512 y, 512 y + 512); the run a k-mer lies in
+//     comes from a bit mask of the item's run starts (mbcnt), or a walk / binary search over the LDS table of run
+//     starts; consecutive lanes read consecutive k-mers, every lane of every load instruction is used whatever the
+//     run length (piece lists: 52 % at 17-k-mer runs), no list is built, scanned or padded;
 //   * a work unit = P2F_K consecutive items of one coarse partition: one bitmap load per unit.
 // Output: item slot as in k_rx_p2 (one output item per input item), holding the survivors only.
 constexpr int P2F_NT = 1024;
@@ -1074,7 +1081,7 @@ __global__ void __launch_bounds__(P2F_NT) k_rx_p2f(IndexView iv, RxView rx)
     __shared__ uint32_t t_sbits[2][RX_B / 32]; // bit e = a run starts at the item's k-mer e (items alternate between the
     __shared__ uint32_t t_empty[2];            // two masks); != 0: an EMPTY run starts inside the item (mask unusable)
 #endif
-    __shared__ __attribute__((aligned(8))) uint32_t s_cnt[RX_MAXF + 2 + 64];
+    __shared__ __attribute__((aligned(8))) uint32_t s_cnt2[2][RX_MAXF + 2 + 64]; // the sort's counters: items alternate
     __shared__ uint32_t s_base[RX_MAXF + 1], s_wave[4];
     __shared__ uint32_t s_b0[P2F_KMAX];
     __shared__ uint32_t s_idx;
@@ -1091,7 +1098,7 @@ __global__ void __launch_bounds__(P2F_NT) k_rx_p2f(IndexView iv, RxView rx)
     const uint32_t limit = ((rx.ctrl[2] + P2F_K - 1u) / P2F_K) * cs; // units of the largest coarse partition x cs
     const uint32_t home = rx_xcc_id();
     if (tid <= F2)
-        s_cnt[tid] = 0; // (rx_sort_emit)
+        s_cnt2[0][tid] = s_cnt2[1][tid] = 0; // (rx_sort_emit)
     RX_PT_DECL;
 
     struct RunDesc {
@@ -1300,21 +1307,19 @@ __global__ void __launch_bounds__(P2F_NT) k_rx_p2f(IndexView iv, RxView rx)
             }
             __syncthreads(); // ... and of this table, before the next item's is written
         };
+        // Three barriers per item — after the ranking, after the scan, after the placement:
+        //   top      item j's k-mers (requested one item ago) against the bitmap; item j + 1's requests from the table the
+        //            previous item's second barrier published
+        //   ranking, barrier 1
+        //   scan by wavefronts 0 .. 3 | everyone: table of item j + 2 (its descriptors were loaded one item ago), then the
+        //            descriptors of item j + 3 are requested; barrier 2 publishes counters' bases AND the table
+        //   placement, barrier 3, copy-out (+ the run-start mask item j + 1 has used is cleared for item j + 3)
+        // No closing barrier: the counters alternate between two arrays (item j + 1 ranks into the other one, this one is
+        // cleared during the copy-out and next used two barriers later), and the sort buffer is next written behind the
+        // next item's second barrier, which no wavefront passes before every wavefront has finished this copy-out.
         auto process = [&](uint32_t j, uint64_t (&xa)[P2F_KPT], uint32_t vma, uint64_t (&xb)[P2F_KPT], uint32_t &vmb) {
             const uint32_t item = ib + j0 + j;
-            const bool has_next = j + 1u < n_it;
             RX_PT(0);
-#if P2F_STARTBITS
-            // item j's run-start mask has served (its requests were issued before the previous item's sort): cleared for
-            // item j + 2, whose bits are set one item (and its barriers) later
-            if (tid < RX_B / 32)
-                t_sbits[j & 1u][tid] = 0u;
-            if (tid == 0)
-                t_empty[j & 1u] = 0u;
-#endif
-            if (has_next)
-                put_table(rd, item_lo(j + 1u), item_lo(j + 1u) + item_n(j + 1u), (int)((j + 1u) & 1u));
-            // item j's k-mers against the bitmap (waits for them): key = fine partition, or the lane's spare counter
             uint32_t pass = 0;
 #pragma unroll
             for (int u = 0; u < P2F_KPT; ++u) {
@@ -1325,41 +1330,64 @@ __global__ void __launch_bounds__(P2F_NT) k_rx_p2f(IndexView iv, RxView rx)
             gathered += (uint32_t)__popc(vma);
             dropped += (uint32_t)(__popc(vma) - __popc(pass));
             RX_PT(5); // waiting for the requests + filter
-            __syncthreads(); // the next item's table is published
-            if (has_next) {
+            if (j + 1u < n_it) {
+                const uint32_t lo1 = item_lo(j + 1u), n1 = item_n(j + 1u);
                 b0 = s_b0[j + 1u];
                 cover = t_vs[P2F_NT];
-                vmb = fill(std::false_type(), b0, item_lo(j + 1u), item_n(j + 1u), item_lo(j + 1u), cover, xb, (int)((j + 1u) & 1u));
-                if (j + 2u < n_it)
-                    rd = load_desc(s_b0[j + 2u]);
+                vmb = fill(std::false_type(), b0, lo1, n1, lo1, cover, xb, (int)((j + 1u) & 1u));
+                if (cover < lo1 + n1)
+                    more_rounds(j + 1u, xb, vmb); // (rare; own barriers; leaves the table free)
             }
-            RX_PT(1); // table + search + requests
+            RX_PT(1); // search + requests
             auto fine = [&](int i) {
                 return ((pass >> i) & 1u) ? ((uint32_t)(xa[i] >> w) & (uint32_t)(F2 - 1)) : spare;
             };
-            rx_sort_emit<P2F_KPT, true, P2F_ONEBAR != 0, P2F_NT, false, true>(
-                xa, fine, F2, sbuf, s_cnt, s_base, s_wave, rx.buf2 + (size_t)item * RX_B,
-                rx.start2 + (size_t)item * (F2 + 1) RX_PT_ARG2);
-            if (has_next && cover < item_lo(j + 1u) + item_n(j + 1u))
-                more_rounds(j + 1u, xb, vmb); // (after the sort's closing barrier: the table is free)
+            auto mid = [&]() { // between barrier 1 and the scan: every request of item j + 1 has read the table
+                if (j + 2u < n_it) {
+                    put_table(rd, item_lo(j + 2u), item_lo(j + 2u) + item_n(j + 2u), (int)(j & 1u));
+                    if (j + 3u < n_it)
+                        rd = load_desc(s_b0[j + 3u]);
+                }
+            };
+            rx_sort_emit<P2F_KPT, false, P2F_ONEBAR != 0, P2F_NT, false, true>(
+                xa, fine, F2, sbuf, s_cnt2[j & 1u], s_base, s_wave, rx.buf2 + (size_t)item * RX_B,
+                rx.start2 + (size_t)item * (F2 + 1) RX_PT_ARG2, mid);
+#if P2F_STARTBITS
+            if (tid < RX_B / 32)
+                t_sbits[(j + 1u) & 1u][tid] = 0u; // item j + 1's mask has served (its requests lie before barrier 1); item
+            if (tid == 0)                         // j + 3's bits are set behind the next item's barrier 1
+                t_empty[(j + 1u) & 1u] = 0u;
+#endif
         };
 
-        // prime the pipeline: item 0's table and requests, item 1's run descriptors
+        // prime the pipeline: item 0's table and requests, item 1's table, item 2's run descriptors
         uint64_t x0[P2F_KPT], x1[P2F_KPT];
         uint32_t vm0 = 0, vm1 = 0;
         b0 = s_b0[0];
         rd = load_desc(b0);
         put_table(rd, item_lo(0), item_lo(0) + item_n(0), 0);
+        if (n_it > 1u)
+            rd = load_desc(s_b0[1]);
         __syncthreads();
         cover = t_vs[P2F_NT];
         vm0 = fill(std::false_type(), b0, item_lo(0), item_n(0), item_lo(0), cover, x0, 0);
-        __syncthreads(); // every wavefront has finished its searches before the next table is written (in the loop the
-                         // sort's barriers lie in between; without this one a stale table entry above a k-mer's position
-                         // made the offset wrap and the request left the buffer: memory fault, first GPU run)
+        __syncthreads(); // every wavefront has finished its searches before the next table is written (without this one a
+                         // stale table entry above a k-mer's position made the offset wrap and the request left the
+                         // buffer: memory fault, first GPU run)
         if (cover < item_lo(0) + item_n(0))
             more_rounds(0, x0, vm0);
-        if (n_it > 1u)
-            rd = load_desc(s_b0[1]);
+#if P2F_STARTBITS
+        if (tid < RX_B / 32)
+            t_sbits[0][tid] = 0u; // item 0's mask has served: item 2's bits go there
+        if (tid == 0)
+            t_empty[0] = 0u;
+#endif
+        if (n_it > 1u) {
+            put_table(rd, item_lo(1), item_lo(1) + item_n(1), 1);
+            if (n_it > 2u)
+                rd = load_desc(s_b0[2]);
+        }
+        __syncthreads(); // item 1's table is published, mask 0 is clear
         for (uint32_t j = 0; j < n_it; j += 2u) {
             process(j, x0, vm0, x1, vm1);
             if (j + 1u < n_it)
@@ -1385,22 +1413,10 @@ __global__ void __launch_bounds__(RX_NT, WPS) k_rx_p3(IndexView iv, RxView rx, i
     __shared__ DirT sdir[WMAX + 1]; // bucket b of the slice holds entries [sdir[b], sdir[b + 1]) - e0
     __shared__ uint64_t skeys[ECAP];
     __shared__ uint32_t scnt[ECAP];
-#if RX_P3_WALK
-    __shared__ uint32_t t_vs[RX_IC + 64 + 1]; // where run r starts in the work item's virtual array (k-mers of partition g,
-    __shared__ uint32_t t_off[RX_IC];         // item after item); t_off[r] + v = element of buf2 that holds k-mer v of run r
-#else
     __shared__ uint32_t sub_src[RX_SUBCAP];
     __shared__ uint32_t sub_meta[RX_SUBCAP];
-#endif
     __shared__ uint32_t s_wb[RX_MAXF + 1], s_wave8[2][RX_NT / 64];
     __shared__ uint32_t s_idx;
-#if RX_P3_LONGQ
-    // buckets with more than two entries (3 % of the probes at load factor 0.5) are finished later, 32 at a time per
-    // wavefront, instead of keeping all 64 lanes in the entry loop until the longest bucket of the wavefront is done
-    __shared__ uint64_t wq_x[RX_NT / 64][32];
-    __shared__ uint32_t wq_m[RX_NT / 64][32];
-    uint32_t wq_n = 0; // (uniform per wavefront)
-#endif
     const int tid = threadIdx.x, grp = tid / RX_LPR_P3, lg = tid % RX_LPR_P3;
     const uint32_t n_rows = rx.ctrl[1], F1 = rx.F1, F2 = rx.F2;
     const uint32_t W = 1u << rx.w;
@@ -1495,7 +1511,7 @@ __global__ void __launch_bounds__(RX_NT, WPS) k_rx_p3(IndexView iv, RxView rx, i
         const uint16_t *rtp = rfp + rx.max_items;
 #pragma unroll
         for (int j = 0; j < RX_IC / RX_NT; ++j) {
-            const uint32_t i = RX_P3_WALK ? (uint32_t)tid * (RX_IC / RX_NT) + j : tid + j * RX_NT; // (walk: adjacent runs)
+            const uint32_t i = tid + j * RX_NT;
             rf[j] = i < n_it ? rfp[i] : 0u;
             rt[j] = i < n_it ? rtp[i] : 0u;
         }
@@ -1534,160 +1550,7 @@ __global__ void __launch_bounds__(RX_NT, WPS) k_rx_p3(IndexView iv, RxView rx, i
                 }
             }
         };
-#if RX_P3_LONGQ
-        // entries 2 .. of the queued buckets, one bucket per lane (first entry and remaining count travel packed in 16
-        // bits each: a slice holds at most 8192 entries)
-        auto drain_long = [&]() {
-            const uint32_t ql = (uint32_t)tid & 63u;
-            if (ql < wq_n) {
-                const uint64_t q = wq_x[tid >> 6][ql];
-                const uint32_t m = wq_m[tid >> 6][ql];
-                const uint32_t b = m & 0xFFFFu, c = m >> 16;
-                for (uint32_t j = 0; j < c; ++j)
-                    if (skeys[b + j] == q)
-                        atomicAdd(&scnt[b + j], 1u);
-            }
-        };
-#endif
         if (sl.valid) {
-#if RX_P3_WALK
-        {
-            // Partition g's runs inside the items of the chunk form one virtual array of T k-mers (run after run).  The
-            // gather is by k-mer, as in k_rx_p2f: thread t owns the runs 2 t and 2 t + 1, one prefix sum gives every
-            // run's start; wavefront y takes the k-mers [4096 i + 512 y, + 512) of the array, finds the run of its first
-            // k-mer by a binary search (once per 512 k-mers, all lanes on the same word) and then walks the run starts:
-            // lane t holds the start of run A + t, each start that a block of 64 k-mers crosses is broadcast and
-            // compared.  No piece lists; every lane of every load is used.
-            constexpr int NR = RX_IC / RX_NT;
-            static_assert(NR == 2, "two adjacent runs per thread");
-            const uint32_t len0 = rt[0] - rf[0], len1 = rt[1] - rf[1];
-            uint32_t T;
-            const uint32_t pre = rx_scan_threads(len0 + len1, s_wave8, scan_flip, &T);
-            {
-                const uint32_t r0 = (uint32_t)tid * NR;
-                t_vs[r0] = r0 < n_it ? pre : 0xFFFFFFFFu;          // (runs beyond the chunk's items end every walk)
-                t_vs[r0 + 1] = r0 + 1u < n_it ? pre + len0 : 0xFFFFFFFFu;
-                t_off[r0] = (it0 + r0) * (uint32_t)RX_B + rf[0] - pre;                // (modulo 2^32)
-                t_off[r0 + 1] = (it0 + r0 + 1u) * (uint32_t)RX_B + rf[1] - (pre + len0);
-                if (tid < 65)
-                    t_vs[RX_IC + tid] = 0xFFFFFFFFu; // (no run starts here: ends every walk)
-            }
-            __syncthreads(); // (also orders the slice's LDS writes before the probes)
-            RX_PT(2); // scan + run table
-            const uint32_t lane = (uint32_t)tid & 63u;
-            const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane(tid >> 6);
-            const uint32_t lim = (rx.max_items - 1u) * (uint32_t)RX_B + (uint32_t)RX_B - 1u; // last element of buf2
-            for (uint32_t V0 = wv * 512u; V0 < T; V0 += (uint32_t)RX_NT * 8u) { // (uniform per wavefront)
-                uint32_t A = 0;
-#pragma unroll
-                for (int stp = RX_IC / 2; stp >= 1; stp >>= 1) // largest run with start <= V0
-                    A += t_vs[A + stp] <= V0 ? (uint32_t)stp : 0u;
-                A = (uint32_t)__builtin_amdgcn_readfirstlane((int)A);
-                uint32_t svbase = A;
-                uint32_t sv = t_vs[svbase + 1u + lane]; // starts of the runs svbase + 1 .. svbase + 64
-                uint64_t x[RX_U];
-                uint32_t vmask = 0, nxt = A + 1u; // next run start to compare against
-                static_assert(RX_U == 8, "eight blocks of 64 k-mers per wavefront and step");
-#pragma unroll
-                for (int u = 0; u < RX_U; ++u) {
-                    const uint32_t pa = V0 + 64u * (uint32_t)u, v = pa + lane;
-                    uint32_t pos = nxt - 1u;
-                    for (;;) { // every run start the block [pa, pa + 64) crosses (uniform)
-                        if (nxt - svbase > 64u) { // (more than 64 runs walked: next window of starts)
-                            svbase = nxt - 1u;
-                            sv = t_vs[svbase + 1u + lane];
-                        }
-                        const uint32_t st = (uint32_t)__builtin_amdgcn_readlane((int)sv, (int)(nxt - svbase - 1u));
-                        if (st > pa + 63u)
-                            break;
-                        pos += v >= st ? 1u : 0u;
-                        ++nxt;
-                    }
-                    vmask |= (v < T ? 1u : 0u) << u;
-                    uint32_t el = t_off[pos] + v;
-                    el = el < lim ? el : lim; // never leave pass 2's output
-                    x[u] = RX_LOAD3(rx.buf2 + el);
-                }
-                    // probe (mapper.pyx:53-69 on the LDS slice), RX_G3 k-mers side by side so that their LDS round
-                    // trips overlap: all bucket bounds; then entry j of every bucket, j = 0, 1, ... (a lane whose
-                    // bucket has no entry j reads key 0 and ignores it) — nothing conditional between the reads
-#pragma unroll
-                    for (int g0 = 0; g0 < RX_U; g0 += RX_G3) {
-                        uint32_t st[RX_G3], cn[RX_G3];
-#pragma unroll
-                        for (int i = 0; i < RX_G3; ++i) {
-                            const uint32_t hb = (uint32_t)x[g0 + i] & (W - 1u); // packed form: bucket = low w bits
-                            st[i] = sdir[hb];
-                            cn[i] = sdir[hb + 1];
-                        }
-                        uint32_t mx = 0;
-#pragma unroll
-                        for (int i = 0; i < RX_G3; ++i) {
-                            const bool act = (vmask >> (g0 + i)) & 1u;
-                            probed += act ? 1u : 0u;
-                            cn[i] = act ? cn[i] - st[i] : 0u;
-                            if (cn[i] && st[i] + cn[i] > ne) { // (rare) entries beyond the LDS copy
-                                probe_bucket_hbm(x[g0 + i], st[i], cn[i]);
-                                cn[i] = 0;
-                            }
-                            mx = cn[i] > mx ? cn[i] : mx;
-                        }
-#if RX_P3_LONGQ
-                        (void)mx;
-#pragma unroll
-                        for (uint32_t j = 0; j < 2u; ++j) { // entries 0 and 1: all a bucket has, 97 times out of 100
-                            uint64_t key[RX_G3];
-#pragma unroll
-                            for (int i = 0; i < RX_G3; ++i)
-                                key[i] = skeys[j < cn[i] ? st[i] + j : 0u];
-#pragma unroll
-                            for (int i = 0; i < RX_G3; ++i)
-                                if (j < cn[i] && key[i] == x[g0 + i])
-                                    atomicAdd(&scnt[st[i] + j], 1u);
-                        }
-#pragma unroll
-                        for (int i = 0; i < RX_G3; ++i) {
-                            const bool lng = cn[i] > 2u;
-                            const unsigned long long bal = __ballot(lng);
-                            if (bal) { // (uniform)
-                                const uint32_t n_l = (uint32_t)__popcll(bal);
-                                if (wq_n + n_l > 32u) {
-                                    drain_long();
-                                    wq_n = 0;
-                                }
-                                if (n_l > 32u) { // (more long buckets than the queue holds: finished here)
-                                    if (lng)
-                                        for (uint32_t j = 2; j < cn[i]; ++j)
-                                            if (skeys[st[i] + j] == x[g0 + i])
-                                                atomicAdd(&scnt[st[i] + j], 1u);
-                                } else {
-                                    const uint32_t slot = wq_n + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-                                    if (lng) {
-                                        wq_x[tid >> 6][slot] = x[g0 + i];
-                                        wq_m[tid >> 6][slot] = (st[i] + 2u) | ((cn[i] - 2u) << 16);
-                                    }
-                                    wq_n += n_l;
-                                }
-                            }
-                        }
-#else
-                        for (uint32_t j = 0; j < mx; ++j) {
-                            uint64_t key[RX_G3];
-#pragma unroll
-                            for (int i = 0; i < RX_G3; ++i)
-                                key[i] = skeys[j < cn[i] ? st[i] + j : 0u];
-#pragma unroll
-                            for (int i = 0; i < RX_G3; ++i)
-                                if (j < cn[i] && key[i] == x[g0 + i])
-                                    atomicAdd(&scnt[st[i] + j], 1u);
-                        }
-#endif
-                    }
-            }
-            __syncthreads();
-            RX_PT(3); // streaming + probing
-        }
-#else
         {
             constexpr int NR = RX_IC / RX_NT;
             uint32_t len[NR], np[NR], np_sum = 0;
@@ -1712,11 +1575,11 @@ __global__ void __launch_bounds__(RX_NT, WPS) k_rx_p3(IndexView iv, RxView rx, i
                 rx_pad_list<RX_NG3 * RX_U>(nw, sub_src, sub_meta);
                 __syncthreads(); // (first window: also orders the slice's LDS writes before the probes)
                 RX_PT(2); // scan + sub-run list
-                for (uint32_t j0 = grp; j0 < nw; j0 += RX_NG3 * RX_U) {
-                    // list entries first, then the loads, nothing conditional in between: the RX_U loads of a lane
-                    // leave back to back (a lane outside its piece re-reads the piece's first k-mer)
-                    uint64_t x[RX_U];
-                    uint32_t so[RX_U], rel[RX_U], n[RX_U]; // piece start; lane's position inside the piece, k-mers of the piece
+                // list entries first, then the loads, nothing conditional in between: the RX_U loads of a lane leave
+                // back to back (a lane outside its piece re-reads the piece's first k-mer); returns the mask of the
+                // slots that hold a k-mer.  (The list is padded to whole batches: every lane takes every batch.)
+                auto request = [&](uint32_t j0, uint64_t (&x)[RX_U]) {
+                    uint32_t so[RX_U], rel[RX_U], n[RX_U], act = 0; // piece start; lane's position in the piece, its k-mers
 #pragma unroll
                     for (int u = 0; u < RX_U; ++u) {
                         const uint32_t m = sub_meta[j0 + u * RX_NG3];
@@ -1725,11 +1588,16 @@ __global__ void __launch_bounds__(RX_NT, WPS) k_rx_p3(IndexView iv, RxView rx, i
                         so[u] = sub_src[j0 + u * RX_NG3];
                     }
 #pragma unroll
-                    for (int u = 0; u < RX_U; ++u)
+                    for (int u = 0; u < RX_U; ++u) {
                         x[u] = RX_LOAD3(rx.buf2 + ((size_t)so[u] + (rel[u] < n[u] ? (uint32_t)lg : (uint32_t)lg - rel[u])));
-                    // probe (mapper.pyx:53-69 on the LDS slice), RX_G3 k-mers side by side so that their LDS round
-                    // trips overlap: all bucket bounds; then entry j of every bucket, j = 0, 1, ... (a lane whose
-                    // bucket has no entry j reads key 0 and ignores it) — nothing conditional between the reads
+                        act |= (rel[u] < n[u] ? 1u : 0u) << u;
+                    }
+                    return act;
+                };
+                // probe (mapper.pyx:53-69 on the LDS slice), RX_G3 k-mers side by side so that their LDS round trips
+                // overlap: all bucket bounds; then entry j of every bucket, j = 0, 1, ... (a lane whose bucket has no
+                // entry j reads key 0 and ignores it) — nothing conditional between the reads
+                auto probe = [&](const uint64_t (&x)[RX_U], uint32_t actm) {
 #pragma unroll
                     for (int g0 = 0; g0 < RX_U; g0 += RX_G3) {
                         uint32_t st[RX_G3], cn[RX_G3];
@@ -1742,7 +1610,7 @@ __global__ void __launch_bounds__(RX_NT, WPS) k_rx_p3(IndexView iv, RxView rx, i
                         uint32_t mx = 0;
 #pragma unroll
                         for (int i = 0; i < RX_G3; ++i) {
-                            const bool act = rel[g0 + i] < n[g0 + i];
+                            const bool act = (actm >> (g0 + i)) & 1u;
                             probed += act ? 1u : 0u;
                             cn[i] = act ? cn[i] - st[i] : 0u;
                             if (cn[i] && st[i] + cn[i] > ne) { // (rare) entries beyond the LDS copy
@@ -1751,45 +1619,6 @@ __global__ void __launch_bounds__(RX_NT, WPS) k_rx_p3(IndexView iv, RxView rx, i
                             }
                             mx = cn[i] > mx ? cn[i] : mx;
                         }
-#if RX_P3_LONGQ
-                        (void)mx;
-#pragma unroll
-                        for (uint32_t j = 0; j < 2u; ++j) { // entries 0 and 1: all a bucket has, 97 times out of 100
-                            uint64_t key[RX_G3];
-#pragma unroll
-                            for (int i = 0; i < RX_G3; ++i)
-                                key[i] = skeys[j < cn[i] ? st[i] + j : 0u];
-#pragma unroll
-                            for (int i = 0; i < RX_G3; ++i)
-                                if (j < cn[i] && key[i] == x[g0 + i])
-                                    atomicAdd(&scnt[st[i] + j], 1u);
-                        }
-#pragma unroll
-                        for (int i = 0; i < RX_G3; ++i) {
-                            const bool lng = cn[i] > 2u;
-                            const unsigned long long bal = __ballot(lng);
-                            if (bal) { // (uniform)
-                                const uint32_t n_l = (uint32_t)__popcll(bal);
-                                if (wq_n + n_l > 32u) {
-                                    drain_long();
-                                    wq_n = 0;
-                                }
-                                if (n_l > 32u) { // (more long buckets than the queue holds: finished here)
-                                    if (lng)
-                                        for (uint32_t j = 2; j < cn[i]; ++j)
-                                            if (skeys[st[i] + j] == x[g0 + i])
-                                                atomicAdd(&scnt[st[i] + j], 1u);
-                                } else {
-                                    const uint32_t slot = wq_n + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-                                    if (lng) {
-                                        wq_x[tid >> 6][slot] = x[g0 + i];
-                                        wq_m[tid >> 6][slot] = (st[i] + 2u) | ((cn[i] - 2u) << 16);
-                                    }
-                                    wq_n += n_l;
-                                }
-                            }
-                        }
-#else
                         for (uint32_t j = 0; j < mx; ++j) {
                             uint64_t key[RX_G3];
 #pragma unroll
@@ -1800,19 +1629,36 @@ __global__ void __launch_bounds__(RX_NT, WPS) k_rx_p3(IndexView iv, RxView rx, i
                                 if (j < cn[i] && key[i] == x[g0 + i])
                                     atomicAdd(&scnt[st[i] + j], 1u);
                         }
-#endif
                     }
+                };
+                constexpr uint32_t STEP = RX_NG3 * RX_U;
+                const uint32_t n_bat = (nw + STEP - 1u) / STEP; // (uniform)
+#if RX_P3_PREFETCH
+                // two register sets: batch i + 1 is requested before batch i is probed — the probe (dependent LDS round
+                // trips) runs under the memory latency of the next requests instead of after it
+                uint64_t xa[RX_U], xb[RX_U];
+                uint32_t ma = request(grp, xa), mb = 0;
+                for (uint32_t bi = 0; bi < n_bat; bi += 2u) {
+                    if (bi + 1u < n_bat)
+                        mb = request(grp + (bi + 1u) * STEP, xb);
+                    probe(xa, ma);
+                    if (bi + 1u >= n_bat)
+                        break;
+                    if (bi + 2u < n_bat)
+                        ma = request(grp + (bi + 2u) * STEP, xa);
+                    probe(xb, mb);
                 }
+#else
+                for (uint32_t bi = 0; bi < n_bat; ++bi) {
+                    uint64_t x[RX_U];
+                    const uint32_t m = request(grp + bi * STEP, x);
+                    probe(x, m);
+                }
+#endif
                 __syncthreads();
                 RX_PT(3); // streaming + probing
             }
         }
-#endif
-#if RX_P3_LONGQ
-        drain_long(); // what is left of the wavefronts' queues, before the counters are read
-        wq_n = 0;
-        __syncthreads();
-#endif
         // LDS counters -> per-entry count vector (entries the frequency filter excludes carry RX_FILTERED); the last
         // window's closing barrier (or, without any window, the scan's) has completed the counters
         for (uint32_t i = tid; i < ne; i += RX_NT) {
