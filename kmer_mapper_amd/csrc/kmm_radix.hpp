@@ -355,7 +355,7 @@ __device__ __forceinline__ void rx_sort_emit(uint64_t (&q)[RX_B / NT], PrepFn pr
         // instruction on one LDS address)
 #pragma unroll
         for (int i = 0; i < RB; ++i)
-            rk[i] = atomicAdd(&s_cnt[ck[i]], 1u);
+            rk[i] = atomicAdd(&s_cnt[ck[i]], 1u); // (unconditional: skipping the spare keys' atomics measured no gain)
 #pragma unroll
         for (int i = 0; i < RB; ++i)
             cr[h + i] = (ck[i] << 16) | (rk[i] & 0xFFFFu); // (a spare counter is never cleared: its rank means nothing)
@@ -373,6 +373,9 @@ __device__ __forceinline__ void rx_sort_emit(uint64_t (&q)[RX_B / NT], PrepFn pr
 #ifndef RX_PLACE_BATCH
 #define RX_PLACE_BATCH 1
 #endif
+#ifndef RX_PLACE_PRED
+#define RX_PLACE_PRED 1 // (k_rx_p2f, half of whose slots are empty after the filter: 3.70 -> 3.60 ms against the dummy slot)
+#endif
 #pragma unroll
     for (int h = 0; h < KPT; h += RX_PLACE_BATCH) {
         if (h >= n_slots)
@@ -383,7 +386,7 @@ __device__ __forceinline__ void rx_sort_emit(uint64_t (&q)[RX_B / NT], PrepFn pr
             pos[i] = s_base[cr[h + i] >> 16] + (cr[h + i] & 0xFFFFu);
 #pragma unroll
         for (int i = 0; i < RX_PLACE_BATCH; ++i) {
-            if (DUMMY) { // branch-free: a slot without a k-mer is written to the lane's dummy element behind the buffer
+            if (DUMMY && !RX_PLACE_PRED) { // branch-free: a slot without a k-mer is written to the lane's dummy element behind the buffer
                 sbuf[(cr[h + i] >> 16) < (uint32_t)F ? pos[i] : (uint32_t)RX_B + (threadIdx.x & 63)] = q[h + i];
             } else if ((cr[h + i] >> 16) < (uint32_t)F) {
                 sbuf[pos[i]] = q[h + i];
