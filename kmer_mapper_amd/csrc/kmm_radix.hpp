@@ -1216,12 +1216,17 @@ __global__ void __launch_bounds__(P2F_NT) k_rx_p2f(IndexView iv, RxView rx)
 #pragma unroll
             for (int i = 0; i <= P2F_KPT; ++i)
                 A[i] = (uint32_t)__builtin_amdgcn_readlane((int)av, i);
-            uint32_t v[P2F_KPT], pos[P2F_KPT], vmask = 0, len_max = 0;
+            uint32_t v[P2F_KPT], pos[P2F_KPT], len_max = 0;
+            // the lane's positions lo + e0 + 64 u rise with u: the ones inside [c_lo, c_end) are a window of u
+            const uint32_t e0 = (a0 << 6) + (uint32_t)lane;
+            auto n_below = [&](uint32_t bound) { // how many u in 0 .. 7 have lo + e0 + 64 u < bound
+                const int32_t c = ((int32_t)(bound - lo) - (int32_t)e0 + 63) >> 6;
+                return (uint32_t)(c < 0 ? 0 : (c > P2F_KPT ? P2F_KPT : c));
+            };
+            const uint32_t vmask = ((1u << n_below(c_end)) - 1u) & ~((1u << n_below(c_lo)) - 1u);
 #pragma unroll
             for (int u = 0; u < P2F_KPT; ++u) {
-                const uint32_t e = ((a0 + (uint32_t)u) << 6) + (uint32_t)lane;
-                v[u] = lo + e;
-                vmask |= (e < n && v[u] >= c_lo && v[u] < c_hi ? 1u : 0u) << u;
+                v[u] = lo + e0 + ((uint32_t)u << 6);
                 pos[u] = A[u];
                 const uint32_t len = A[u + 1] > A[u] ? A[u + 1] - A[u] : 0u;
                 len_max = len > len_max ? len : len_max;
@@ -1236,11 +1241,12 @@ __global__ void __launch_bounds__(P2F_NT) k_rx_p2f(IndexView iv, RxView rx)
                 const uint32_t mw = t_sbits[mb][a0 * 2u + ((uint32_t)lane & 15u)];
 #pragma unroll
                 for (int u = 0; u < P2F_KPT; ++u) {
-                    const uint32_t mlo = (uint32_t)__builtin_amdgcn_readlane((int)mw, 2 * u) & ~1u; // (bit 0: counted in A[u])
+                    // starts at the block's positions 1 .. lane (position 0's run is A[u] itself) = the bits of the mask
+                    // shifted down by one that lie below the lane
+                    const uint32_t mlo = (uint32_t)__builtin_amdgcn_readlane((int)mw, 2 * u);
                     const uint32_t mhi = (uint32_t)__builtin_amdgcn_readlane((int)mw, 2 * u + 1);
-                    const uint32_t below = __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u));
-                    const uint32_t own = ((lane < 32 ? mlo >> lane : mhi >> (lane - 32)) & 1u);
-                    pos[u] += below + own;
+                    const uint64_t m1 = (((uint64_t)mhi << 32) | mlo) >> 1;
+                    pos[u] += __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u));
                 }
                 len_max = 0;
             }
@@ -1277,14 +1283,17 @@ __global__ void __launch_bounds__(P2F_NT) k_rx_p2f(IndexView iv, RxView rx)
                     pos[u] = (cand <= A[u + 1] && t <= v[u]) ? cand : pos[u];
                 }
             }
-            const uint64_t *base = rx.buf1 + (size_t)bb * RX_B;
-            const size_t left = (size_t)NB * RX_B - (size_t)bb * RX_B; // elements of pass 1's output from block bb on
-            const uint32_t lim = left > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)left - 1u;
+            // (uniform base in scalar registers + a 32-bit byte offset per lane: no 64-bit address arithmetic per k-mer;
+            // a table's k-mers lie within 1025 blocks = 64 MB of its first block)
+            const uint32_t bbs = (uint32_t)__builtin_amdgcn_readfirstlane((int)bb);
+            const char *base = reinterpret_cast<const char *>(rx.buf1 + (size_t)bbs * RX_B);
+            const size_t left = (size_t)NB * RX_B - (size_t)bbs * RX_B; // elements of pass 1's output from block bb on
+            const uint32_t lim = left > 0x1FFFFFFFull ? 0x1FFFFFFFu : (uint32_t)left - 1u;
 #pragma unroll
             for (int u = 0; u < P2F_KPT; ++u) {
                 uint32_t el = t_off[pos[u]] + v[u];
                 el = el < lim ? el : lim; // never leave pass 1's output, whatever the table says
-                const uint64_t y = RX_LOAD2(base + el);
+                const uint64_t y = RX_LOAD2(reinterpret_cast<const uint64_t *>(base + (el << 3)));
                 x[u] = (!MERGE || ((vmask >> u) & 1u)) ? y : x[u];
             }
             return vmask;
