@@ -320,7 +320,7 @@ struct RxNoHook {
 // the caller then guarantees a barrier of its own before sbuf is written again and before the next call's ranking
 // (which needs the counters this call clears during its copy-out).
 template <int RB, bool ENDBAR, bool ONEBAR, int NT = RX_NT, bool NTSTORE = ONEBAR, bool DUMMY = false, typename PrepFn,
-          typename MidFn = RxNoHook>
+          typename MidFn = RxNoHook, bool WAVESCAN = false>
 __device__ __forceinline__ void rx_sort_emit(uint64_t (&q)[RX_B / NT], PrepFn prep, int F, uint64_t *sbuf,
                                              uint32_t *s_cnt, uint32_t *s_base, uint32_t *s_wave,
                                              uint64_t *__restrict__ out, uint16_t *__restrict__ dir_row,
@@ -363,7 +363,37 @@ __device__ __forceinline__ void rx_sort_emit(uint64_t (&q)[RX_B / NT], PrepFn pr
     __syncthreads();
     RX_PT(2); // keys + ranks
     mid();
-    const uint32_t total = F <= 256 ? rx_scan256<ONEBAR>(s_cnt, s_base, F, s_wave) : rx_scan512<ONEBAR>(s_cnt, s_base, F, s_wave);
+    uint32_t total;
+    if (WAVESCAN && F <= 128) {
+        // Fan-outs up to 128: EVERY wavefront scans the counters for itself (two per lane, six DPP additions) and keeps
+        // the bases in registers — a k-mer's base comes from lane key / 2 through the LDS crossbar (ds_bpermute) instead
+        // of an LDS table the whole workgroup would have to wait for at a barrier.
+        const int lane = tid & 63;
+        const uint2 p = rx_pair(s_cnt, lane * 2, F);
+        const uint32_t inc = wave_scan_incl(p.x + p.y);
+        const uint32_t ex0 = inc - p.x - p.y;
+        total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+        if (tid < 64) {
+            if (2 * lane <= F)
+                dir_row[2 * lane] = (uint16_t)ex0;
+            if (2 * lane + 1 <= F)
+                dir_row[2 * lane + 1] = (uint16_t)(ex0 + p.x);
+            if (lane == 63 && F == 128)
+                dir_row[128] = (uint16_t)inc;
+        }
+        const uint32_t packed = ex0 | (p.x << 16); // (both <= 8192)
+#pragma unroll
+        for (int h = 0; h < KPT; ++h) {
+            if (h >= n_slots)
+                break;
+            const uint32_t key = cr[h] >> 16;
+            const uint32_t pk = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((key >> 1) << 2), (int)packed);
+            const uint32_t pos = (pk & 0xFFFFu) + ((key & 1u) ? pk >> 16 : 0u) + (cr[h] & 0xFFFFu);
+            if (key < (uint32_t)F)
+                sbuf[pos] = q[h];
+        }
+    } else {
+    total = F <= 256 ? rx_scan256<ONEBAR>(s_cnt, s_base, F, s_wave) : rx_scan512<ONEBAR>(s_cnt, s_base, F, s_wave);
     if (tid <= F)
         dir_row[tid] = (uint16_t)s_base[tid];
     if (NT == RX_MAXF && F == NT && tid == 0) // (fan-out 512 on 512 threads: one more entry than threads)
@@ -392,6 +422,7 @@ __device__ __forceinline__ void rx_sort_emit(uint64_t (&q)[RX_B / NT], PrepFn pr
                 sbuf[pos[i]] = q[h + i];
             }
         }
+    }
     }
     __syncthreads();
     RX_PT(3); // scan + placement
@@ -1067,6 +1098,9 @@ constexpr int P2F_LOGBITS = 19;          // buckets per coarse partition the LDS
 #ifndef P2F_STARTBITS
 #define P2F_STARTBITS 1                  // run of a k-mer = run of its 64-block's first k-mer + popcount of the run-start bits
 #endif                                   // up to it (one LDS atomic OR per run, mbcnt per k-mer) instead of the walk below
+#ifndef P2F_WAVESCAN
+#define P2F_WAVESCAN 1                   // fan-outs <= 128: every wavefront scans the sort's counters itself (two barriers per item)
+#endif
 #ifndef P2F_SCALAR_WALK
 #define P2F_SCALAR_WALK 1                // run of a k-mer by counting broadcast run starts (else binary search in LDS)
 #endif
@@ -1361,7 +1395,7 @@ __global__ void __launch_bounds__(P2F_NT) k_rx_p2f(IndexView iv, RxView rx)
                         rd = load_desc(s_b0[j + 3u]);
                 }
             };
-            rx_sort_emit<P2F_KPT, false, P2F_ONEBAR != 0, P2F_NT, false, true>(
+            rx_sort_emit<P2F_KPT, false, P2F_ONEBAR != 0, P2F_NT, false, true, decltype(fine), decltype(mid), P2F_WAVESCAN != 0>(
                 xa, fine, F2, sbuf, s_cnt2[j & 1u], s_base, s_wave, rx.buf2 + (size_t)item * RX_B,
                 rx.start2 + (size_t)item * (F2 + 1) RX_PT_ARG2, mid);
 #if P2F_STARTBITS
