@@ -1366,15 +1366,18 @@ __global__ void __launch_bounds__(P2F_NT) k_rx_p2f(IndexView iv, RxView rx)
         auto process = [&](uint32_t j, uint64_t (&xa)[P2F_KPT], uint32_t vma, uint64_t (&xb)[P2F_KPT], uint32_t &vmb) {
             const uint32_t item = ib + j0 + j;
             RX_PT(0);
-            uint32_t pass = 0;
+            // item j's k-mers against the bitmap (waits for them): key = fine partition, or the lane's spare counter
+            uint32_t keys[P2F_KPT], n_ok = 0;
 #pragma unroll
             for (int u = 0; u < P2F_KPT; ++u) {
-                const uint32_t bit = (uint32_t)xa[u] & bmask; // packed form: the hash bits below the coarse partition number
-                const uint32_t word = s_bits[bit >> 5];
-                pass |= (((vma >> u) & (word >> (bit & 31u))) & 1u) << u;
+                const uint32_t xl = (uint32_t)xa[u]; // packed form: the hash bits below the coarse partition number
+                const uint32_t bit = xl & bmask;     // are the low w + f2 <= 22 bits
+                const uint32_t ok = (s_bits[bit >> 5] >> (bit & 31u)) & (vma >> u) & 1u;
+                n_ok += ok;
+                keys[u] = ok ? __builtin_amdgcn_ubfe(xl, (uint32_t)w, (uint32_t)rx.f2) : spare;
             }
             gathered += (uint32_t)__popc(vma);
-            dropped += (uint32_t)(__popc(vma) - __popc(pass));
+            dropped += (uint32_t)__popc(vma) - n_ok;
             RX_PT(5); // waiting for the requests + filter
             if (j + 1u < n_it) {
                 const uint32_t lo1 = item_lo(j + 1u), n1 = item_n(j + 1u);
@@ -1385,9 +1388,7 @@ __global__ void __launch_bounds__(P2F_NT) k_rx_p2f(IndexView iv, RxView rx)
                     more_rounds(j + 1u, xb, vmb); // (rare; own barriers; leaves the table free)
             }
             RX_PT(1); // search + requests
-            auto fine = [&](int i) {
-                return ((pass >> i) & 1u) ? ((uint32_t)(xa[i] >> w) & (uint32_t)(F2 - 1)) : spare;
-            };
+            auto fine = [&](int i) { return keys[i]; };
             auto mid = [&]() { // between barrier 1 and the scan: every request of item j + 1 has read the table
                 if (j + 2u < n_it) {
                     put_table(rd, item_lo(j + 2u), item_lo(j + 2u) + item_n(j + 2u), (int)(j & 1u));
