@@ -1460,8 +1460,7 @@ __global__ void __launch_bounds__(RX_NT, WPS) k_rx_p3(IndexView iv, RxView rx, i
     __shared__ DirT sdir[WMAX + 1]; // bucket b of the slice holds entries [sdir[b], sdir[b + 1]) - e0
     __shared__ uint64_t skeys[ECAP];
     __shared__ uint32_t scnt[ECAP];
-    __shared__ uint32_t sub_src[RX_SUBCAP];
-    __shared__ uint32_t sub_meta[RX_SUBCAP];
+    __shared__ uint32_t sub_list[RX_SUBCAP];
     __shared__ uint32_t s_wb[RX_MAXF + 1], s_wave8[2][RX_NT / 64];
     __shared__ uint32_t s_idx;
     const int tid = threadIdx.x, grp = tid / RX_LPR_P3, lg = tid % RX_LPR_P3;
@@ -1480,12 +1479,12 @@ __global__ void __launch_bounds__(RX_NT, WPS) k_rx_p3(IndexView iv, RxView rx, i
     // A work item's description (uniform): its fine partition's place in the index and its items.  It is worked
     // out — two dependent loads — while the PREVIOUS work item streams its k-mers.
     struct Slice {
-        uint32_t valid, g, e0, ne, it0, n_it;
+        uint32_t valid, g, e0, ne, it0, n_it, over;
         uint64_t h0;
     };
     auto describe = [&](uint32_t sub, uint32_t idx) {
         Slice d;
-        d.valid = 0; d.g = 0; d.e0 = 0; d.ne = 0; d.it0 = 0; d.n_it = 0; d.h0 = 0;
+        d.valid = 0; d.g = 0; d.e0 = 0; d.ne = 0; d.it0 = 0; d.n_it = 0; d.h0 = 0; d.over = 0;
         if (idx >= limit)
             return d;
         const uint32_t row = idx / gs, g = sub * gs + idx % gs;
@@ -1508,6 +1507,7 @@ __global__ void __launch_bounds__(RX_NT, WPS) k_rx_p3(IndexView iv, RxView rx, i
         d.e0 = rx.pstart[d.h0];
         const uint32_t e1 = rx.pstart[d.h0 + W < M ? d.h0 + W : M];
         d.ne = e1 - d.e0 < (uint32_t)ECAP ? e1 - d.e0 : (uint32_t)ECAP;
+        d.over = e1 - d.e0 > (uint32_t)ECAP ? 1u : 0u; // entries beyond the LDS copy: their buckets are walked in HBM
         d.it0 = rx.item_base[c] + chunk * RX_IC;
         const uint32_t it_end = rx.item_base[c + 1];
         d.n_it = it_end - d.it0 < (uint32_t)RX_IC ? it_end - d.it0 : (uint32_t)RX_IC;
@@ -1599,52 +1599,62 @@ __global__ void __launch_bounds__(RX_NT, WPS) k_rx_p3(IndexView iv, RxView rx, i
         };
         if (sl.valid) {
         {
+            // Piece list of the work item: a run of the partition inside one item is cut every RX_LPR_P3 k-mers; one
+            // word per piece = (first element, relative to the work item's first item: < 1024 x 8192) << 5 | k-mers.
             constexpr int NR = RX_IC / RX_NT;
-            uint32_t len[NR], np[NR], np_sum = 0;
-            uint64_t src[NR];
+            uint32_t len[NR], np[NR], np_sum = 0, src[NR];
 #pragma unroll
             for (int j = 0; j < NR; ++j) {
                 len[j] = rt[j] - rf[j];
-                src[j] = (uint64_t)(it0 + tid + j * RX_NT) * RX_B + rf[j];
-                np[j] = rx_n_pieces<RX_LPR_P3, RX_P3_LINECUT>(len[j], src[j]);
+                src[j] = (uint32_t)(tid + j * RX_NT) * (uint32_t)RX_B + rf[j];
+                np[j] = (len[j] + (uint32_t)RX_LPR_P3 - 1u) / (uint32_t)RX_LPR_P3;
                 np_sum += np[j];
             }
+            // (uniform base in scalar registers + a 32-bit byte offset per lane: no 64-bit address arithmetic per k-mer)
+            const char *wbase = reinterpret_cast<const char *>(rx.buf2 + (size_t)__builtin_amdgcn_readfirstlane((int)it0) * RX_B);
             uint32_t n_sub;
             const uint32_t pre = rx_scan_threads(np_sum, s_wave8, scan_flip, &n_sub);
             for (uint32_t win = 0; win < n_sub; win += RX_SUBCAP) {
                 uint32_t first = pre;
 #pragma unroll
                 for (int j = 0; j < NR; ++j) {
-                    rx_list_subruns<RX_LPR_P3, RX_P3_LINECUT>(first, len[j], src[j], 0u, win, sub_src, sub_meta);
+                    const uint32_t j0 = first > win ? first : win;
+                    const uint32_t j1 = first + np[j] < win + (uint32_t)RX_SUBCAP ? first + np[j] : win + (uint32_t)RX_SUBCAP;
+                    for (uint32_t q = j0; q < j1; ++q) {
+                        const uint32_t done = (q - first) * (uint32_t)RX_LPR_P3;
+                        const uint32_t n = len[j] - done < (uint32_t)RX_LPR_P3 ? len[j] - done : (uint32_t)RX_LPR_P3;
+                        sub_list[q - win] = ((src[j] + done) << 5) | n;
+                    }
                     first += np[j];
                 }
                 const uint32_t nw = n_sub - win < (uint32_t)RX_SUBCAP ? n_sub - win : (uint32_t)RX_SUBCAP;
-                rx_pad_list<RX_NG3 * RX_U>(nw, sub_src, sub_meta);
+                constexpr uint32_t STEP = RX_NG3 * RX_U;
+                const uint32_t n_bat = (nw + STEP - 1u) / STEP; // (uniform)
+                for (uint32_t i = nw + tid; i < n_bat * STEP; i += RX_NT)
+                    sub_list[i] = 0u; // (padding to whole batches: pieces without k-mers)
                 __syncthreads(); // (first window: also orders the slice's LDS writes before the probes)
                 RX_PT(2); // scan + sub-run list
                 // list entries first, then the loads, nothing conditional in between: the RX_U loads of a lane leave
-                // back to back (a lane outside its piece re-reads the piece's first k-mer); returns the mask of the
+                // back to back (a lane beyond its piece re-reads the piece's first k-mer); returns the mask of the
                 // slots that hold a k-mer.  (The list is padded to whole batches: every lane takes every batch.)
                 auto request = [&](uint32_t j0, uint64_t (&x)[RX_U]) {
-                    uint32_t so[RX_U], rel[RX_U], n[RX_U], act = 0; // piece start; lane's position in the piece, its k-mers
+                    uint32_t e[RX_U], act = 0;
+#pragma unroll
+                    for (int u = 0; u < RX_U; ++u)
+                        e[u] = sub_list[j0 + u * RX_NG3];
 #pragma unroll
                     for (int u = 0; u < RX_U; ++u) {
-                        const uint32_t m = sub_meta[j0 + u * RX_NG3];
-                        n[u] = m & 63u;
-                        rel[u] = (uint32_t)lg - ((m >> 6) & 63u);
-                        so[u] = sub_src[j0 + u * RX_NG3];
-                    }
-#pragma unroll
-                    for (int u = 0; u < RX_U; ++u) {
-                        x[u] = RX_LOAD3(rx.buf2 + ((size_t)so[u] + (rel[u] < n[u] ? (uint32_t)lg : (uint32_t)lg - rel[u])));
-                        act |= (rel[u] < n[u] ? 1u : 0u) << u;
+                        const bool in = (uint32_t)lg < (e[u] & 31u);
+                        x[u] = RX_LOAD3(reinterpret_cast<const uint64_t *>(wbase + (((e[u] >> 5) + (in ? (uint32_t)lg : 0u)) << 3)));
+                        act |= (in ? 1u : 0u) << u;
                     }
                     return act;
                 };
                 // probe (mapper.pyx:53-69 on the LDS slice), RX_G3 k-mers side by side so that their LDS round trips
                 // overlap: all bucket bounds; then entry j of every bucket, j = 0, 1, ... (a lane whose bucket has no
                 // entry j reads key 0 and ignores it) — nothing conditional between the reads
-                auto probe = [&](const uint64_t (&x)[RX_U], uint32_t actm) {
+                auto probe = [&](auto over_tag, const uint64_t (&x)[RX_U], uint32_t actm) {
+                    constexpr bool OVER = decltype(over_tag)::value; // (uniform per work item: the check leaves the common loop)
 #pragma unroll
                     for (int g0 = 0; g0 < RX_U; g0 += RX_G3) {
                         uint32_t st[RX_G3], cn[RX_G3];
@@ -1660,9 +1670,11 @@ __global__ void __launch_bounds__(RX_NT, WPS) k_rx_p3(IndexView iv, RxView rx, i
                             const bool act = (actm >> (g0 + i)) & 1u;
                             probed += act ? 1u : 0u;
                             cn[i] = act ? cn[i] - st[i] : 0u;
-                            if (cn[i] && st[i] + cn[i] > ne) { // (rare) entries beyond the LDS copy
-                                probe_bucket_hbm(x[g0 + i], st[i], cn[i]);
-                                cn[i] = 0;
+                            if constexpr (OVER) {
+                                if (cn[i] && st[i] + cn[i] > ne) { // (rare) entries beyond the LDS copy
+                                    probe_bucket_hbm(x[g0 + i], st[i], cn[i]);
+                                    cn[i] = 0;
+                                }
                             }
                             mx = cn[i] > mx ? cn[i] : mx;
                         }
@@ -1678,30 +1690,33 @@ __global__ void __launch_bounds__(RX_NT, WPS) k_rx_p3(IndexView iv, RxView rx, i
                         }
                     }
                 };
-                constexpr uint32_t STEP = RX_NG3 * RX_U;
-                const uint32_t n_bat = (nw + STEP - 1u) / STEP; // (uniform)
+                auto stream = [&](auto over_tag) {
 #if RX_P3_PREFETCH
-                // two register sets: batch i + 1 is requested before batch i is probed — the probe (dependent LDS round
-                // trips) runs under the memory latency of the next requests instead of after it
-                uint64_t xa[RX_U], xb[RX_U];
-                uint32_t ma = request(grp, xa), mb = 0;
-                for (uint32_t bi = 0; bi < n_bat; bi += 2u) {
-                    if (bi + 1u < n_bat)
-                        mb = request(grp + (bi + 1u) * STEP, xb);
-                    probe(xa, ma);
-                    if (bi + 1u >= n_bat)
-                        break;
-                    if (bi + 2u < n_bat)
-                        ma = request(grp + (bi + 2u) * STEP, xa);
-                    probe(xb, mb);
-                }
+                    // two register sets: batch i + 1 is requested before batch i is probed (measured slower, see above)
+                    uint64_t xa[RX_U], xb[RX_U];
+                    uint32_t ma = request(grp, xa), mb = 0;
+                    for (uint32_t bi = 0; bi < n_bat; bi += 2u) {
+                        if (bi + 1u < n_bat)
+                            mb = request(grp + (bi + 1u) * STEP, xb);
+                        probe(over_tag, xa, ma);
+                        if (bi + 1u >= n_bat)
+                            break;
+                        if (bi + 2u < n_bat)
+                            ma = request(grp + (bi + 2u) * STEP, xa);
+                        probe(over_tag, xb, mb);
+                    }
 #else
-                for (uint32_t bi = 0; bi < n_bat; ++bi) {
-                    uint64_t x[RX_U];
-                    const uint32_t m = request(grp + bi * STEP, x);
-                    probe(x, m);
-                }
+                    for (uint32_t bi = 0; bi < n_bat; ++bi) {
+                        uint64_t x[RX_U];
+                        const uint32_t m = request(grp + bi * STEP, x);
+                        probe(over_tag, x, m);
+                    }
 #endif
+                };
+                if (sl.over)
+                    stream(std::true_type());
+                else
+                    stream(std::false_type());
                 __syncthreads();
                 RX_PT(3); // streaming + probing
             }
