@@ -174,11 +174,11 @@ __device__ __forceinline__ uint2 rx_pair(const uint32_t *s_in, int c0, int n)
 
 // n <= 256: one counter per lane of wavefronts 0..3 (the form the passes were tuned with)
 template <bool ONEBAR>
-__device__ __forceinline__ uint32_t rx_scan256(const uint32_t *s_in, uint32_t *s_out, int n, uint32_t *s_wave)
+__device__ __forceinline__ uint32_t rx_scan256(const uint32_t *s_in, uint32_t *s_out, int n, uint32_t *s_wave, const int tid)
 {
     if (ONEBAR) {
     (void)s_wave;
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (wave < 4) {
         const uint32_t v = tid < n ? s_in[tid] : 0u;
@@ -196,7 +196,7 @@ __device__ __forceinline__ uint32_t rx_scan256(const uint32_t *s_in, uint32_t *s
     __syncthreads();
     return s_out[n];
     }
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = tid >> 6;
     const uint32_t v = tid < n ? s_in[tid] : 0u;
     const uint32_t inc = wave_scan_incl(v);
     if (wave < 4 && lane == 63)
@@ -216,9 +216,9 @@ __device__ __forceinline__ uint32_t rx_scan256(const uint32_t *s_in, uint32_t *s
 }
 
 template <bool ONEBAR>
-__device__ __forceinline__ uint32_t rx_scan512(const uint32_t *s_in, uint32_t *s_out, int n, uint32_t *s_wave)
+__device__ __forceinline__ uint32_t rx_scan512(const uint32_t *s_in, uint32_t *s_out, int n, uint32_t *s_wave, const int tid)
 {
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (ONEBAR) {
     (void)s_wave;
@@ -300,6 +300,17 @@ __device__ __forceinline__ uint32_t rx_scan512(const uint32_t *s_in, uint32_t *s
 #define RX_PT_END(iv, base)
 #endif
 
+// The thread index rebuilt from the wavefront's number (a scalar the kernel derives once) and the lane number the
+// hardware counts, in volatile asm: never hoisted out of the block loop, hence never kept alive across it — pass 1 had
+// its thread index spilled to scratch, and each reload behind a barrier waited for vmcnt(0): for the prefetched tile
+// and for the previous block's copy-out stores.
+__device__ __forceinline__ int rx_tid_now(int wave)
+{
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return (wave << 6) | l;
+}
+
 // Key of a slot that holds no k-mer: any value >= F; the lane's own spare counter behind the real ones.
 __device__ __forceinline__ uint32_t rx_spare_key()
 {
@@ -320,17 +331,20 @@ struct RxNoHook {
 // the caller then guarantees a barrier of its own before sbuf is written again and before the next call's ranking
 // (which needs the counters this call clears during its copy-out).
 template <int RB, bool ENDBAR, bool ONEBAR, int NT = RX_NT, bool NTSTORE = ONEBAR, bool DUMMY = false, typename PrepFn,
-          typename MidFn = RxNoHook, bool WAVESCAN = false>
+          typename MidFn = RxNoHook, bool WAVESCAN = false, bool NOWTID = false>
 __device__ __forceinline__ void rx_sort_emit(uint64_t (&q)[RX_B / NT], PrepFn prep, int F, uint64_t *sbuf,
                                              uint32_t *s_cnt, uint32_t *s_base, uint32_t *s_wave,
                                              uint64_t *__restrict__ out, uint16_t *__restrict__ dir_row,
                                              unsigned long long *pt_acc = nullptr, MidFn mid = MidFn(),
-                                             int n_slots = RX_B / NT)
+                                             int n_slots = RX_B / NT, int wave_s = -1)
 {
+    // NOWTID: the thread index is rebuilt from the wavefront's number wave_s (uniform, a scalar register) behind every
+    // barrier (rx_tid_now) instead of living in a register across the whole sort
+    auto tid_now = [&]() { return NOWTID ? rx_tid_now(wave_s) : (int)threadIdx.x; };
     // n_slots (uniform): only the slots [0, n_slots) of q can hold a k-mer (a caller whose k-mers are packed towards
     // the low slots skips the ranking and placement of the rest: k_rx_p2f after its filter)
     constexpr int KPT = RX_B / NT; // k-mers per thread
-    const int tid = threadIdx.x;
+    int tid = tid_now();
     (void)pt_acc;
     // s_cnt[0..F] is zero on entry: cleared by the caller before its first call (followed by a barrier) and by every
     // call for the next one, right after the scan has consumed the counts
@@ -393,7 +407,9 @@ __device__ __forceinline__ void rx_sort_emit(uint64_t (&q)[RX_B / NT], PrepFn pr
                 sbuf[pos] = q[h];
         }
     } else {
-    total = F <= 256 ? rx_scan256<ONEBAR>(s_cnt, s_base, F, s_wave) : rx_scan512<ONEBAR>(s_cnt, s_base, F, s_wave);
+    tid = tid_now();
+    total = F <= 256 ? rx_scan256<ONEBAR>(s_cnt, s_base, F, s_wave, tid) : rx_scan512<ONEBAR>(s_cnt, s_base, F, s_wave, tid);
+    tid = tid_now();
     if (tid <= F)
         dir_row[tid] = (uint16_t)s_base[tid];
     if (NT == RX_MAXF && F == NT && tid == 0) // (fan-out 512 on 512 threads: one more entry than threads)
@@ -426,6 +442,7 @@ __device__ __forceinline__ void rx_sort_emit(uint64_t (&q)[RX_B / NT], PrepFn pr
     }
     __syncthreads();
     RX_PT(3); // scan + placement
+    tid = tid_now();
     if (tid <= F)
         s_cnt[tid] = 0; // for the next call (every wavefront's scan has read the counts: they lie before the barrier)
     if (NT == RX_MAXF && F == NT && tid == 0)
@@ -567,6 +584,7 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p1(ReadsView rv, const uint64_t
     __shared__ __attribute__((aligned(8))) uint32_t s_cnt[RX_MAXF + 2 + 64];
     __shared__ uint32_t s_base[RX_MAXF + 1], s_wave[4];
     const int tid = threadIdx.x, half = tid >> 8, ltid = tid & 255;
+    const int wave_s = __builtin_amdgcn_readfirstlane(tid >> 6); // (rx_sort_emit rebuilds the thread index from it)
     TileConst tc;
     tc.kmask = 0; tc.bmask = 0; tc.aligned = false;
     if (MODE != MODE_KMERS) {
@@ -649,23 +667,26 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p1(ReadsView rv, const uint64_t
                 x[i] = rx_pack(iv, sh, q[i], &c);
                 return ((valid >> i) & 1u) ? c : spare;
             };
-            rx_sort_emit<RX_RB1, true, true>(x, fwd, F1, sbuf, s_cnt, s_base, s_wave, rx.buf1 + (size_t)sb * 2 * RX_B,
-                         rx.start1 + (size_t)sb * 2 * (size_t)(F1 + 1) RX_PT_ARG);
+            rx_sort_emit<RX_RB1, true, true, RX_NT, true, false, decltype(fwd), RxNoHook, false, true>(
+                x, fwd, F1, sbuf, s_cnt, s_base, s_wave, rx.buf1 + (size_t)sb * 2 * RX_B,
+                rx.start1 + (size_t)sb * 2 * (size_t)(F1 + 1) RX_PT_ARG2, RxNoHook(), RX_KPT, wave_s);
             auto rev = [&](int i) {
                 uint32_t c;
                 x[i] = rx_pack(iv, sh, revcomp(q[i], k), &c);
                 return ((valid >> i) & 1u) ? c : spare;
             };
-            rx_sort_emit<RX_RB1, MODE == MODE_KMERS, true>(x, rev, F1, sbuf, s_cnt, s_base, s_wave, rx.buf1 + ((size_t)sb * 2 + 1) * RX_B,
-                         rx.start1 + ((size_t)sb * 2 + 1) * (size_t)(F1 + 1) RX_PT_ARG);
+            rx_sort_emit<RX_RB1, MODE == MODE_KMERS, true, RX_NT, true, false, decltype(rev), RxNoHook, false, true>(
+                x, rev, F1, sbuf, s_cnt, s_base, s_wave, rx.buf1 + ((size_t)sb * 2 + 1) * RX_B,
+                rx.start1 + ((size_t)sb * 2 + 1) * (size_t)(F1 + 1) RX_PT_ARG2, RxNoHook(), RX_KPT, wave_s);
         } else {
             auto fwd = [&](int i) {
                 uint32_t c;
                 q[i] = rx_pack(iv, sh, q[i], &c);
                 return ((valid >> i) & 1u) ? c : spare;
             };
-            rx_sort_emit<RX_RB1, MODE == MODE_KMERS, true>(q, fwd, F1, sbuf, s_cnt, s_base, s_wave, rx.buf1 + (size_t)sb * RX_B,
-                         rx.start1 + (size_t)sb * (size_t)(F1 + 1) RX_PT_ARG);
+            rx_sort_emit<RX_RB1, MODE == MODE_KMERS, true, RX_NT, true, false, decltype(fwd), RxNoHook, false, true>(
+                q, fwd, F1, sbuf, s_cnt, s_base, s_wave, rx.buf1 + (size_t)sb * RX_B,
+                rx.start1 + (size_t)sb * (size_t)(F1 + 1) RX_PT_ARG2, RxNoHook(), RX_KPT, wave_s);
         }
     }
 #ifdef RX_PT_P1

@@ -63,16 +63,23 @@ struct TileRaw {
     uint32_t sbits;
 };
 
-__device__ __forceinline__ uint32_t tile_load_bytes4(const ReadsView &rv, int64_t p)
+// Byte-wise loads of a chunk's last vector / of chunks whose base address is not 16-byte aligned: a real call, kept out
+// of the callers' register budget (inlined into pass 1 its 16 addresses and bounds pushed the thread index into
+// scratch, and every reload in the block loop waited for vmcnt(0): the prefetched tile and the copy-out stores).
+__device__ __attribute__((noinline)) uint32_t tile_load_bytes4(const uint8_t *bases, int64_t total, int64_t p)
 {
     uint32_t acc = 0;
-#pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int64_t pp = p + j;
-        const uint32_t c = (pp < rv.total) ? rv.bases[pp] : 0u;
+        const uint32_t c = (pp < total) ? bases[pp] : 0u;
         acc |= c << (8 * j);
     }
     return acc;
+}
+
+__device__ __forceinline__ uint32_t tile_load_bytes4(const ReadsView &rv, int64_t p)
+{
+    return tile_load_bytes4(rv.bases, rv.total, p);
 }
 
 template <int S, int MODE>
