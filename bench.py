@@ -179,7 +179,8 @@ def main():
     if args.records:
         from kmer_mapper_amd import _lib as kmm_lib
         rec_len = 4 + L + 3 + L + 1                                   # "@rd\n" seq "\n+\n" qual "\n"
-        assert R * rec_len <= 2 ** 30, "--records needs --reads <= %d" % (2 ** 30 // rec_len)
+        # (kmm_map_records takes buffers of any size: it works through them in pieces of at most 2^30 bytes cut at
+        # record boundaries)
         fastq_batches = []
         for b in batches:
             rec = torch.empty((R, rec_len), dtype=torch.uint8, device=dev_t)

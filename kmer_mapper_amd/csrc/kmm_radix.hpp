@@ -69,7 +69,11 @@ constexpr int RX_NG = RX_NT / RX_LPR; // run copiers per workgroup
 #ifndef RX_RB2
 #define RX_RB2 8
 #endif
-constexpr int RX_SUBCAP = 1024;       // sub-runs (<= RX_LPR k-mers each) listed in LDS per window
+constexpr int RX_SUBCAP = 1024;       // sub-runs (<= RX_LPR k-mers each) listed in LDS per window (pass 2)
+#ifndef RX_SUBCAP3V
+#define RX_SUBCAP3V 3072 // (1024 runs of up to 48 k-mers in one window: configs[1] pass 3 2.40 -> 1.92 ms)
+#endif
+constexpr int RX_SUBCAP3 = RX_SUBCAP3V; // ... pass 3 (one word each)
 #ifndef RX_LPR3
 #define RX_LPR3 16
 #endif
@@ -1481,7 +1485,7 @@ __global__ void __launch_bounds__(RX_NT, WPS) k_rx_p3(IndexView iv, RxView rx, i
     __shared__ DirT sdir[WMAX + 1]; // bucket b of the slice holds entries [sdir[b], sdir[b + 1]) - e0
     __shared__ uint64_t skeys[ECAP];
     __shared__ uint32_t scnt[ECAP];
-    __shared__ uint32_t sub_list[RX_SUBCAP];
+    __shared__ uint32_t sub_list[RX_SUBCAP3];
     __shared__ uint32_t s_wb[RX_MAXF + 1], s_wave8[2][RX_NT / 64];
     __shared__ uint32_t s_idx;
     const int tid = threadIdx.x, grp = tid / RX_LPR_P3, lg = tid % RX_LPR_P3;
@@ -1635,12 +1639,12 @@ __global__ void __launch_bounds__(RX_NT, WPS) k_rx_p3(IndexView iv, RxView rx, i
             const char *wbase = reinterpret_cast<const char *>(rx.buf2 + (size_t)__builtin_amdgcn_readfirstlane((int)it0) * RX_B);
             uint32_t n_sub;
             const uint32_t pre = rx_scan_threads(np_sum, s_wave8, scan_flip, &n_sub);
-            for (uint32_t win = 0; win < n_sub; win += RX_SUBCAP) {
+            for (uint32_t win = 0; win < n_sub; win += RX_SUBCAP3) {
                 uint32_t first = pre;
 #pragma unroll
                 for (int j = 0; j < NR; ++j) {
                     const uint32_t j0 = first > win ? first : win;
-                    const uint32_t j1 = first + np[j] < win + (uint32_t)RX_SUBCAP ? first + np[j] : win + (uint32_t)RX_SUBCAP;
+                    const uint32_t j1 = first + np[j] < win + (uint32_t)RX_SUBCAP3 ? first + np[j] : win + (uint32_t)RX_SUBCAP3;
                     for (uint32_t q = j0; q < j1; ++q) {
                         const uint32_t done = (q - first) * (uint32_t)RX_LPR_P3;
                         const uint32_t n = len[j] - done < (uint32_t)RX_LPR_P3 ? len[j] - done : (uint32_t)RX_LPR_P3;
@@ -1648,8 +1652,9 @@ __global__ void __launch_bounds__(RX_NT, WPS) k_rx_p3(IndexView iv, RxView rx, i
                     }
                     first += np[j];
                 }
-                const uint32_t nw = n_sub - win < (uint32_t)RX_SUBCAP ? n_sub - win : (uint32_t)RX_SUBCAP;
+                const uint32_t nw = n_sub - win < (uint32_t)RX_SUBCAP3 ? n_sub - win : (uint32_t)RX_SUBCAP3;
                 constexpr uint32_t STEP = RX_NG3 * RX_U;
+                static_assert(RX_SUBCAP3 % STEP == 0, "a padded list must fit the window");
                 const uint32_t n_bat = (nw + STEP - 1u) / STEP; // (uniform)
                 for (uint32_t i = nw + tid; i < n_bat * STEP; i += RX_NT)
                     sub_list[i] = 0u; // (padding to whole batches: pieces without k-mers)
