@@ -265,7 +265,8 @@ int kmm_get_kmer_counts(kmm_index_t *idx, uint32_t *out);
  *                      list (built when an index has fewer than 8 entries per node on average); 0 = in bucket order
  *   "count_kmers"      1 = per-k-mer counting mode (see kmm_get_kmer_counts)
  *   "radix_filter"     1 (default) = pass 2 drops the k-mers whose bucket is empty (they cannot match: mapper.pyx:55-58)
- *                      wherever a coarse partition's occupancy bitmap fits 64 KB of LDS; the fan-out is chosen for it
+ *                      wherever a coarse partition's occupancy bitmap fits 64 KB of LDS, at one bit per bucket or — sparse
+ *                      tables — per 2 or 4 buckets ("radix_filter_buckets_per_bit", read-only); the fan-out is chosen for it
  *   "radix_packed_tiles" 1 (default) = pass 1 on reads of one length works on tiles of whole reads (no windows across
  *                      read boundaries are computed)
  *   "fine_bits"        experiments: log2 fine partitions per coarse partition of the radix path

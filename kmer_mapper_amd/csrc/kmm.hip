@@ -191,6 +191,7 @@ struct kmm_index {
     uint16_t *rx_pfreq = nullptr;
     uint32_t *rx_pnodes = nullptr, *rx_porig = nullptr, *rx_ecnt = nullptr, *rx_ecnt_acc = nullptr;
     uint32_t *rx_norder = nullptr, *rx_nnode = nullptr; // entries in node order (k_rx_flush_sorted); absent if memory is short
+    int rx_occ_shift = 0;         // k_rx_p2f folds 2^rx_occ_shift buckets into one bit of its LDS bitmap
     uint32_t *rx_occ = nullptr;   // bit h = bucket h holds an entry: pass 2's empty-bucket filter (k_rx_p2f); optional
     bool rx_filter = true;        // "radix_filter": use the filtering pass 2 whenever a coarse partition's bitmap fits LDS
     bool rx_packed = true;        // "radix_packed_tiles": pass 1 on reads of one length takes tiles of whole reads
@@ -449,15 +450,28 @@ bool rx_configure(kmm_index *ix, int w, int maxf = RX_MAXF, int f2_force = -1)
         ++lg;
     int f2 = (lg + 1) / 2;
     bool for_filter = false;
-    // pass 2's empty-bucket filter needs coarse partitions of at most 2^19 buckets (64 KB of LDS bitmap): take fewer
-    // fine-partition bits — more, smaller coarse partitions — when pass 1's fan-out stays within 512
-    if (ix->rx_filter && w + f2 > P2F_LOGBITS && P2F_LOGBITS - w >= 0 &&
-        ((PF + (1ull << (P2F_LOGBITS - w)) - 1) >> (P2F_LOGBITS - w)) <= (uint64_t)RX_MAXF) {
-        f2 = P2F_LOGBITS - w;
-        for_filter = true;
+    int occ_shift = 0;
+    // pass 2's empty-bucket filter has 2^19 bits of LDS per coarse partition: take fewer fine-partition bits — more,
+    // smaller coarse partitions — when pass 1's fan-out stays within 512; tables too large for that at one bit per
+    // bucket get one bit per 2 or 4 buckets (sparse tables such as modulo 452 930 477 with 1e8 entries still lose
+    // half of their k-mers there; at load factor 0.5 a bit per 4 buckets would pass 86 %: not taken)
+    if (ix->rx_filter && w + f2 > P2F_LOGBITS) {
+        const double load = ix->rx_S ? (double)ix->rx_S / (double)ix->modulo : 0.5;
+        for (int gs = 0; gs <= 2 && !for_filter; ++gs) {
+            const int fb = P2F_LOGBITS + gs - w;
+            if (fb < 0 || load * (double)(1 << gs) > 0.75)
+                continue;
+            if (((PF + (1ull << fb) - 1) >> fb) <= (uint64_t)RX_MAXF && fb <= 9) {
+                f2 = fb;
+                occ_shift = gs;
+                for_filter = true;
+            }
+        }
     }
-    if (f2_force >= 0)
+    if (f2_force >= 0) {
         f2 = f2_force;
+        occ_shift = w + f2 > P2F_LOGBITS ? w + f2 - P2F_LOGBITS : 0; // (rx_filter_active refuses more than 2)
+    }
     // the packed form (kmm_radix.hpp) keeps floor(q / modulo) above w + f2 hash bits: it must fit for EVERY
     // 64-bit q (callers may hand over arbitrary uint64 values), else give the quotient more room
     const uint64_t max_quo = ~0ull / ix->modulo;
@@ -471,6 +485,8 @@ bool rx_configure(kmm_index *ix, int w, int maxf = RX_MAXF, int f2_force = -1)
         return false;
     ix->rx_w = w;
     ix->rx_f2 = f2;
+    ix->rx_occ_shift = w + f2 > P2F_LOGBITS ? w + f2 - P2F_LOGBITS : 0; // (the filter's bits never outnumber its LDS)
+    (void)occ_shift;
     ix->rx_PF = (uint32_t)PF;
     ix->rx_F1 = (uint32_t)F1;
     ix->rx_F2 = (uint32_t)F2;
@@ -482,7 +498,7 @@ bool rx_configure(kmm_index *ix, int w, int maxf = RX_MAXF, int f2_force = -1)
 bool rx_filter_active(const kmm_index *ix)
 {
     const int sh = ix->rx_w + ix->rx_f2;
-    return ix->rx_filter && ix->rx_occ && sh >= 5 && sh <= P2F_LOGBITS;
+    return ix->rx_filter && ix->rx_occ && sh - ix->rx_occ_shift >= 5 && ix->rx_occ_shift <= 2;
 }
 
 bool use_radix(const kmm_index *ix, int64_t units)
@@ -520,6 +536,7 @@ int launch_rx(kmm_index *ix, const ReadsView &rv, const uint64_t *kmers_in, int6
         memset(&rx, 0, sizeof rx);
         rx.pstart = ix->rx_pstart; rx.pkeys = ix->rx_pkeys; rx.pfreq = ix->rx_pfreq; rx.ecnt = ix->rx_ecnt;
         rx.occ = ix->rx_occ;
+        rx.occ_shift = ix->rx_occ_shift;
         rx.p2f_k = NB / 2048u < 4u ? 4u : (NB / 2048u > (uint32_t)P2F_KMAX ? (uint32_t)P2F_KMAX : NB / 2048u);
         rx.w = ix->rx_w; rx.f2 = ix->rx_f2; rx.PF = ix->rx_PF; rx.F1 = F1; rx.F2 = F2;
         rx.NB = NB; rx.max_items = (uint32_t)max_items;
@@ -935,7 +952,7 @@ static int rx_build(kmm_index *ix, const int32_t *h2i, const int32_t *nk, const 
         ix->rx_S = total; // = sum64 <= n_entries < 2^31
         {   // occupancy bitmap for pass 2's empty-bucket filter, padded by one coarse partition's worth of words
             // (k_rx_p2f loads whole partitions); optional: without the memory for it the plain pass 2 runs
-            const size_t occ_words = (size_t)((M + 31) / 32) + ((size_t)1 << (P2F_LOGBITS - 5));
+            const size_t occ_words = (size_t)((M + 31) / 32) + ((size_t)1 << (P2F_LOGBITS + 2 - 5)); // (up to 4 buckets per LDS bit)
             if (hipMalloc(&ix->rx_occ, occ_words * 4) == hipSuccess) {
                 if ((e = hipMemsetAsync(ix->rx_occ, 0, occ_words * 4, ix->stream))) break;
                 hipLaunchKernelGGL(k_rx_build_occ, dim3(grid_for(ix, (int64_t)((M / 32 + 256) / 256), 16)), dim3(256), 0, ix->stream,
@@ -2292,6 +2309,8 @@ int kmm_get_param(kmm_index_t *ix, const char *name, int64_t *value)
                                : 0;
     else if (!strcmp(name, "radix_filter"))
         *value = (ix->rx_ok && rx_filter_active(ix)) ? 1 : 0;
+    else if (!strcmp(name, "radix_filter_buckets_per_bit")) // 1, 2 or 4 (0: no filter)
+        *value = (ix->rx_ok && rx_filter_active(ix)) ? (1 << ix->rx_occ_shift) : 0;
     else if (!strcmp(name, "radix_packed_tiles"))
         *value = ix->rx_packed ? 1 : 0;
     else if (!strcmp(name, "n_fine_per_coarse"))

@@ -134,6 +134,7 @@ struct RxView {
     uint32_t p2f_k;         // k_rx_p2f: items per work unit (one bitmap load, one pipeline fill: 16 / 32 / 64 items measured
                             // 4.47 / 4.40 / 4.36 ms at configs[2]); fewer for small batches, so that every CU gets units
     int w, f2;              // sh = w + f2: hash bits below the coarse partition number
+    int occ_shift;          // k_rx_p2f: one bit of its LDS bitmap covers 2^occ_shift buckets (0 .. 2)
     uint32_t PF, F1, F2;
     // batch side
     uint32_t NB;           // pass-1 output blocks of this sub-batch
@@ -1110,6 +1111,23 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p2(IndexView iv, RxView rx)
 //     run length (piece lists: 52 % at 17-k-mer runs), no list is built, scanned or padded;
 //   * a work unit = P2F_K consecutive items of one coarse partition: one bitmap load per unit.
 // Output: item slot as in k_rx_p2 (one output item per input item), holding the survivors only.
+// bit i of the result = bit 2 i | bit 2 i + 1 of x (16 bits) / = the OR of bits 4 i .. 4 i + 3 (8 bits)
+__device__ __forceinline__ uint32_t rx_fold2(uint32_t x)
+{
+    x = (x | (x >> 1)) & 0x55555555u;
+    x = (x | (x >> 1)) & 0x33333333u;
+    x = (x | (x >> 2)) & 0x0F0F0F0Fu;
+    x = (x | (x >> 4)) & 0x00FF00FFu;
+    return (x | (x >> 8)) & 0x0000FFFFu;
+}
+__device__ __forceinline__ uint32_t rx_fold4(uint32_t x)
+{
+    x = (x | (x >> 1) | (x >> 2) | (x >> 3)) & 0x11111111u;
+    x = (x | (x >> 3)) & 0x03030303u;
+    x = (x | (x >> 6)) & 0x000F000Fu;
+    return (x | (x >> 12)) & 0xFFu;
+}
+
 constexpr int P2F_NT = 1024;
 constexpr int P2F_KPT = RX_B / P2F_NT;   // 8 k-mers per thread and item
 constexpr int P2F_KMAX = 64;             // most items per work unit (rx.p2f_k: chosen per batch, launch_rx)
@@ -1152,7 +1170,9 @@ __global__ void __launch_bounds__(P2F_NT) k_rx_p2f(IndexView iv, RxView rx)
     const uint32_t NB = rx.NB;
     const int F2 = (int)rx.F2, w = rx.w;
     const uint32_t bmask = (1u << (rx.w + rx.f2)) - 1u;          // bucket inside the coarse partition
-    const uint32_t nwords = ((uint32_t)F2 << w) / 32u;           // bitmap words of one coarse partition (<= 16384)
+    const uint32_t gs = (uint32_t)rx.occ_shift;                  // buckets per bitmap bit: 2^gs (coarse partitions of
+                                                                 // up to 2^21 buckets: sparse tables such as modulo 452 930 477)
+    const uint32_t nwords = (((uint32_t)F2 << w) >> gs) / 32u;   // bitmap words of one coarse partition in LDS (<= 16384)
     const uint32_t spare = rx_spare_key();
     uint32_t gathered = 0, dropped = 0; // conservation check: gathered = pass 1's lookups = pass 3's probes + dropped
     const uint32_t cs = (rx.F1 + 7u) / 8u;
@@ -1190,13 +1210,28 @@ __global__ void __launch_bounds__(P2F_NT) k_rx_p2f(IndexView iv, RxView rx)
         // unit prologue: first blocks of the unit's items, the coarse partition's bitmap
         if ((uint32_t)tid < n_it)
             s_b0[tid] = rx.item_desc[ib + j0 + tid].x;
-        {
+        if (gs == 0) {
             const uint4 *src = reinterpret_cast<const uint4 *>(rx.occ + (size_t)cc * nwords);
             uint4 *dst = reinterpret_cast<uint4 *>(s_bits);
             for (uint32_t i = tid; i < nwords / 4u; i += P2F_NT)
                 dst[i] = src[i];
             for (uint32_t i = (nwords & ~3u) + tid; i < nwords; i += P2F_NT) // (tiny tables)
                 s_bits[i] = rx.occ[(size_t)cc * nwords + i];
+        } else {
+            // the index keeps one bit per bucket; 2 or 4 neighbouring buckets are folded into one LDS bit here
+            // (set = one of them holds an entry): 64 or 128 buckets -> one word
+            const uint32_t *src = rx.occ + (((size_t)cc * nwords) << gs);
+            for (uint32_t i = tid; i < nwords; i += P2F_NT) {
+                uint32_t o = 0;
+                if (gs == 1) {
+                    const uint2 v = *reinterpret_cast<const uint2 *>(src + 2 * (size_t)i);
+                    o = rx_fold2(v.x) | (rx_fold2(v.y) << 16);
+                } else {
+                    const uint4 v = *reinterpret_cast<const uint4 *>(src + 4 * (size_t)i);
+                    o = rx_fold4(v.x) | (rx_fold4(v.y) << 8) | (rx_fold4(v.z) << 16) | (rx_fold4(v.w) << 24);
+                }
+                s_bits[i] = o;
+            }
         }
 #if P2F_STARTBITS
         if (tid < 2 * (RX_B / 32))
@@ -1396,7 +1431,7 @@ __global__ void __launch_bounds__(P2F_NT) k_rx_p2f(IndexView iv, RxView rx)
 #pragma unroll
             for (int u = 0; u < P2F_KPT; ++u) {
                 const uint32_t xl = (uint32_t)xa[u]; // packed form: the hash bits below the coarse partition number
-                const uint32_t bit = xl & bmask;     // are the low w + f2 <= 22 bits
+                const uint32_t bit = (xl & bmask) >> gs; // are the low w + f2 <= 22 bits
                 const uint32_t ok = (s_bits[bit >> 5] >> (bit & 31u)) & (vma >> u) & 1u;
                 n_ok += ok;
                 keys[u] = ok ? __builtin_amdgcn_ubfe(xl, (uint32_t)w, (uint32_t)rx.f2) : spare;

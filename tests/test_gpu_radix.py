@@ -338,3 +338,23 @@ def test_packed_tiles_equal_position_tiles_and_the_oracle(kmm, syn, oracle, read
             t[7:] = torch.from_numpy(bases).cuda()
             dev.map_reads_uniform(t[7:], n_reads, read_len, 31, also_revcomp=rc)      # base pointer at +7 bytes
             assert np.array_equal(dev.get_node_counts(), expect), ("unaligned", rc)
+
+
+@pytest.mark.parametrize("fine_bits, per_bit", [(7, 1), (8, 2), (9, 4)])
+def test_filter_with_several_buckets_per_bit(kmm, syn, oracle, fine_bits, per_bit):
+    """Coarse partitions of 2^19, 2^20 and 2^21 buckets: pass 2 folds 1, 2 or 4 buckets of the index's occupancy bitmap
+    into one bit of its 64 KB LDS copy (sparse tables such as the customary modulo 452 930 477 keep their filter)."""
+    index, genome = syn.make_index(300000, seed=351, modulo=3000017)
+    mx = index.max_node_id()
+    bases, offs = syn.make_ragged_reads(genome, 40000, 0, 260, seed=352)
+    expect, n = oracle.map_reads(index, mx, bases, offs, 31, also_revcomp=True, n_threads=4)
+    with kmm.DeviceIndex.from_index(index, mx) as dev:
+        dev.set_param("part_shift", 12)
+        dev.set_param("fine_bits", fine_bits)
+        dev.set_param("path", 2)
+        assert dev.get_param("radix_filter_buckets_per_bit") == per_bit
+        dev.map_reads(bases, offs, 31, also_revcomp=True)
+        assert np.array_equal(dev.get_node_counts(), expect)
+        dropped = dev.get_param("radix_p2_dropped")
+        assert 0 < dropped < 2 * n
+        assert dev.get_param("radix_p3_kmers") + dropped == 2 * n
