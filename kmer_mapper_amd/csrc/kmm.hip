@@ -182,6 +182,7 @@ struct kmm_index {
     uint32_t rx_PF = 1, rx_F1 = 1, rx_F2 = 1;
     bool rx_flush_sorted = true; // "radix_sorted_flush": use the node-ordered entry list for the flush
     uint32_t rx_max_slice = 0; // most entries in one fine partition's slice (for the current part_shift)
+    bool rx_fits_small = false, rx_fits_mid = false; // all but one slice in 1000 hold at most RX_ECAP / RX_ECAP_MID entries
     int rx_grid_per_cu = 2;   // persistent workgroups of passes 2 and 3 per CU (1: leave room for another stream's kernels)
     int64_t rx_min_units = 0; // auto: batches of at least this many positions / k-mers take the radix path
     uint64_t rx_S = 0;        // entries in bucket order
@@ -536,7 +537,7 @@ int launch_rx(kmm_index *ix, const ReadsView &rv, const uint64_t *kmers_in, int6
         memset(&rx, 0, sizeof rx);
         rx.pstart = ix->rx_pstart; rx.pkeys = ix->rx_pkeys; rx.pfreq = ix->rx_pfreq; rx.ecnt = ix->rx_ecnt;
         rx.occ = ix->rx_occ;
-        rx.occ_shift = ix->rx_occ_shift;
+        rx.occ_shift = rx_filter_active(ix) ? ix->rx_occ_shift : 3; // (3: k_rx_p2f without its filter)
         rx.p2f_k = NB / 2048u < 4u ? 4u : (NB / 2048u > (uint32_t)P2F_KMAX ? (uint32_t)P2F_KMAX : NB / 2048u);
         rx.w = ix->rx_w; rx.f2 = ix->rx_f2; rx.PF = ix->rx_PF; rx.F1 = F1; rx.F2 = F2;
         rx.NB = NB; rx.max_items = (uint32_t)max_items;
@@ -583,7 +584,8 @@ int launch_rx(kmm_index *ix, const ReadsView &rv, const uint64_t *kmers_in, int6
         HIPCHK(hipGetLastError());
         KMMCHK(tm.end());
         KMMCHK(tm.begin(ix, KMM_KERNEL_RX_P2));
-        if (rx_filter_active(ix)) // the coarse partition's occupancy bitmap fits LDS: drop k-mers of empty buckets here
+        if (ix->rx_filter) // gather by k-mer; where a coarse partition's occupancy bitmap fits LDS (one bit per 1, 2 or 4
+                           // buckets) the k-mers of empty buckets are dropped here
             hipLaunchKernelGGL(k_rx_p2f, dim3(ix->n_cu), dim3(P2F_NT), 0, ix->stream, iv, rx);
         else
             hipLaunchKernelGGL(k_rx_p2, dim3(ix->n_cu * ix->rx_grid_per_cu), dim3(RX_NT), 0, ix->stream, iv, rx);
@@ -594,10 +596,14 @@ int launch_rx(kmm_index *ix, const ReadsView &rv, const uint64_t *kmers_in, int6
         HIPCHK(hipGetLastError());
         KMMCHK(tm.end());
         KMMCHK(tm.begin(ix, KMM_KERNEL_RX_P3));
-        if (ix->rx_w > 12 && ix->rx_max_slice <= (uint32_t)RX_ECAP)
+        if (ix->rx_w > 12 && ix->rx_fits_small && ix->rx_max_slice <= 65535u)
             // 8192-bucket slices whose entries all fit 4096 keys: 16-bit directory, two workgroups per CU
             hipLaunchKernelGGL((k_rx_p3<RX_WMAX_BIG, RX_ECAP, 4, uint16_t>), dim3(ix->n_cu * ix->rx_grid_per_cu), dim3(RX_NT),
                                0, ix->stream, iv, rx, max_freq);
+        else if (ix->rx_w > 12 && ix->rx_fits_mid && ix->rx_max_slice <= 65535u && !getenv("KMM_RX_NO_MID"))
+            // ... at most 4608 keys (load factor 0.5): the same with a shorter piece list
+            hipLaunchKernelGGL((k_rx_p3<RX_WMAX_BIG, RX_ECAP_MID, 4, uint16_t, 1024>), dim3(ix->n_cu * ix->rx_grid_per_cu),
+                               dim3(RX_NT), 0, ix->stream, iv, rx, max_freq);
         else if (ix->rx_w > 12)
             hipLaunchKernelGGL((k_rx_p3<RX_WMAX_BIG, RX_ECAP_BIG, 2, uint32_t>), dim3(ix->n_cu), dim3(RX_NT), 0, ix->stream,
                                iv, rx, max_freq);
@@ -664,7 +670,7 @@ int launch_map_reads(kmm_index *ix, const ReadsView &rv, int k, int max_freq, in
         const int64_t slots = (int64_t)ix->n_cu * 8;
         const bool dynamic = ix->dynamic_schedule && n_tiles >= slots * 4 * ix->dyn_chunk;
         if (dynamic)
-            HIPCHK(hipMemsetAsync(ix->queue, 0, sizeof(unsigned long long), ix->stream));
+            HIPCHK(hipMemsetAsync(ix->queue, 0, 3 * sizeof(unsigned long long), ix->stream));
         const dim3 grid(dynamic ? (unsigned)slots : (unsigned)grid_for_tiles(ix, n_tiles));
         unsigned long long *queue = dynamic ? ix->queue : nullptr;
         if (iv.occ && iv.wide)
@@ -899,14 +905,18 @@ static int rx_repack_keys(kmm_index *ix)
                            ix->stream, ix->rx_pkeys_raw, ix->rx_S, view_of(ix), ix->rx_w + ix->rx_f2, ix->rx_pkeys);
     HIPCHK(hipGetLastError());
     // most entries of one slice: decides whether pass 3 may keep a 16-bit directory (ix->queue serves as the cell)
-    HIPCHK(hipMemsetAsync(ix->queue, 0, sizeof(unsigned long long), ix->stream));
+    HIPCHK(hipMemsetAsync(ix->queue, 0, 3 * sizeof(unsigned long long), ix->stream));
     hipLaunchKernelGGL(k_rx_max_slice, dim3(grid_for(ix, (int64_t)((ix->rx_PF + 255) / 256), 16)), dim3(256), 0, ix->stream,
                        ix->rx_pstart, ix->modulo, ix->rx_w, ix->rx_PF, ix->queue);
     HIPCHK(hipGetLastError());
-    unsigned long long mx = 0;
-    HIPCHK(hipMemcpyAsync(&mx, ix->queue, sizeof mx, hipMemcpyDeviceToHost, ix->stream));
+    unsigned long long mx[3] = {0, 0, 0};
+    HIPCHK(hipMemcpyAsync(mx, ix->queue, sizeof mx, hipMemcpyDeviceToHost, ix->stream));
     HIPCHK(hipStreamSynchronize(ix->stream));
-    ix->rx_max_slice = (uint32_t)mx;
+    ix->rx_max_slice = (uint32_t)mx[0];
+    // a slice with more entries than pass 3 keeps in LDS has the buckets behind them walked in HBM: fine for the odd
+    // slice (a k-mer stored under 1500 nodes), not as the rule — at most one slice in a thousand
+    ix->rx_fits_small = mx[1] <= ix->rx_PF / 1000;
+    ix->rx_fits_mid = mx[2] <= ix->rx_PF / 1000;
     return KMM_OK;
 }
 
@@ -1142,7 +1152,7 @@ static int index_create_impl(kmm_index *ix, const int32_t *h2i, const int32_t *n
     HIPCHK(hipMemsetAsync(ix->counts, 0, sizeof(uint32_t) * (size_t)(ix->max_node_id + 1), ix->stream));
     HIPCHK(hipMalloc(&ix->lut_default, 256));
     HIPCHK(hipMalloc(&ix->first_bad, 3 * sizeof(unsigned long long)));
-    HIPCHK(hipMalloc(&ix->queue, sizeof(unsigned long long)));
+    HIPCHK(hipMalloc(&ix->queue, 4 * sizeof(unsigned long long))); // (a tile queue head; also the result cells of small reductions)
     HIPCHK(hipMalloc(&ix->stats, KMM_STAT_BYTES));
     HIPCHK(hipMemset(ix->stats, 0, KMM_STAT_BYTES));
     uint8_t lut[256];
@@ -1518,7 +1528,7 @@ int kmm_map_kmers(kmm_index_t *ix, const uint64_t *kmers, int64_t n, int max_fre
         const int64_t slots = (int64_t)ix->n_cu * 8;
         const bool dynamic = ix->dynamic_schedule && n_spans >= slots * 4 * ix->dyn_chunk;
         if (dynamic)
-            HIPCHK(hipMemsetAsync(ix->queue, 0, sizeof(unsigned long long), ix->stream));
+            HIPCHK(hipMemsetAsync(ix->queue, 0, 3 * sizeof(unsigned long long), ix->stream));
         const dim3 grid(dynamic ? (unsigned)slots : (unsigned)grid_for_tiles(ix, n_spans));
         unsigned long long *queue = dynamic ? ix->queue : nullptr;
         if (iv.occ && iv.wide)

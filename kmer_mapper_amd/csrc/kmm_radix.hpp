@@ -113,6 +113,8 @@ constexpr int RX_WMAX = 4096;         // buckets per fine partition (LDS directo
 constexpr int RX_ECAP = 4096;         // entries of a fine partition kept in LDS (keys + counters)
 constexpr int RX_WMAX_BIG = 8192;     // slices of indexes with more than 256 x 256 x 4096 buckets (e.g. the customary
 constexpr int RX_ECAP_BIG = 8192;     // modulo 452 930 477): 140 KB of LDS, one workgroup of pass 3 per CU
+constexpr int RX_ECAP_MID = 4608;     // 8192-bucket slices at load factor 0.5 (4096 +- 64 entries): 16-bit directory, 1024-piece
+                                      // list, 77 KB of LDS: two workgroups per CU (the 1 B-k-mer index)
 #ifndef RX_P3_DENSE
 #define RX_P3_DENSE 0                 // 1: slices of at most RX_ECAP_DENSE entries run three workgroups of pass 3 per CU
 #endif
@@ -1172,7 +1174,9 @@ __global__ void __launch_bounds__(P2F_NT) k_rx_p2f(IndexView iv, RxView rx)
     const uint32_t bmask = (1u << (rx.w + rx.f2)) - 1u;          // bucket inside the coarse partition
     const uint32_t gs = (uint32_t)rx.occ_shift;                  // buckets per bitmap bit: 2^gs (coarse partitions of
                                                                  // up to 2^21 buckets: sparse tables such as modulo 452 930 477)
-    const uint32_t nwords = (((uint32_t)F2 << w) >> gs) / 32u;   // bitmap words of one coarse partition in LDS (<= 16384)
+    const bool nofilt = gs > 2u;                                 // coarse partitions beyond 2^21 buckets: nothing is
+                                                                 // dropped — the kernel is still the faster pass 2
+    const uint32_t nwords = nofilt ? 0u : (((uint32_t)F2 << w) >> gs) / 32u; // bitmap words of one coarse partition in LDS (<= 16384)
     const uint32_t spare = rx_spare_key();
     uint32_t gathered = 0, dropped = 0; // conservation check: gathered = pass 1's lookups = pass 3's probes + dropped
     const uint32_t cs = (rx.F1 + 7u) / 8u;
@@ -1210,7 +1214,8 @@ __global__ void __launch_bounds__(P2F_NT) k_rx_p2f(IndexView iv, RxView rx)
         // unit prologue: first blocks of the unit's items, the coarse partition's bitmap
         if ((uint32_t)tid < n_it)
             s_b0[tid] = rx.item_desc[ib + j0 + tid].x;
-        if (gs == 0) {
+        if (nofilt) {
+        } else if (gs == 0) {
             const uint4 *src = reinterpret_cast<const uint4 *>(rx.occ + (size_t)cc * nwords);
             uint4 *dst = reinterpret_cast<uint4 *>(s_bits);
             for (uint32_t i = tid; i < nwords / 4u; i += P2F_NT)
@@ -1428,13 +1433,22 @@ __global__ void __launch_bounds__(P2F_NT) k_rx_p2f(IndexView iv, RxView rx)
             RX_PT(0);
             // item j's k-mers against the bitmap (waits for them): key = fine partition, or the lane's spare counter
             uint32_t keys[P2F_KPT], n_ok = 0;
+            if (nofilt) {
 #pragma unroll
-            for (int u = 0; u < P2F_KPT; ++u) {
-                const uint32_t xl = (uint32_t)xa[u]; // packed form: the hash bits below the coarse partition number
-                const uint32_t bit = (xl & bmask) >> gs; // are the low w + f2 <= 22 bits
-                const uint32_t ok = (s_bits[bit >> 5] >> (bit & 31u)) & (vma >> u) & 1u;
-                n_ok += ok;
-                keys[u] = ok ? __builtin_amdgcn_ubfe(xl, (uint32_t)w, (uint32_t)rx.f2) : spare;
+                for (int u = 0; u < P2F_KPT; ++u) {
+                    const uint32_t ok = (vma >> u) & 1u;
+                    n_ok += ok;
+                    keys[u] = ok ? __builtin_amdgcn_ubfe((uint32_t)xa[u], (uint32_t)w, (uint32_t)rx.f2) : spare;
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < P2F_KPT; ++u) {
+                    const uint32_t xl = (uint32_t)xa[u]; // packed form: the hash bits below the coarse partition number
+                    const uint32_t bit = (xl & bmask) >> gs; // are the low w + f2 <= 22 bits
+                    const uint32_t ok = (s_bits[bit >> 5] >> (bit & 31u)) & (vma >> u) & 1u;
+                    n_ok += ok;
+                    keys[u] = ok ? __builtin_amdgcn_ubfe(xl, (uint32_t)w, (uint32_t)rx.f2) : spare;
+                }
             }
             gathered += (uint32_t)__popc(vma);
             dropped += (uint32_t)__popc(vma) - n_ok;
@@ -1514,13 +1528,13 @@ __global__ void __launch_bounds__(P2F_NT) k_rx_p2f(IndexView iv, RxView rx)
 // ------------------------------------------------------------------------------------------------
 // DirT: type of the LDS directory; uint16_t (half the LDS: 8192-bucket slices with two workgroups per CU) only when
 // no slice of the index holds more than 65535 entries (launch_rx checks).
-template <int WMAX, int ECAP, int WPS, typename DirT>
+template <int WMAX, int ECAP, int WPS, typename DirT, int SUBCAP = RX_SUBCAP3>
 __global__ void __launch_bounds__(RX_NT, WPS) k_rx_p3(IndexView iv, RxView rx, int max_freq)
 {
     __shared__ DirT sdir[WMAX + 1]; // bucket b of the slice holds entries [sdir[b], sdir[b + 1]) - e0
     __shared__ uint64_t skeys[ECAP];
     __shared__ uint32_t scnt[ECAP];
-    __shared__ uint32_t sub_list[RX_SUBCAP3];
+    __shared__ uint32_t sub_list[SUBCAP];
     __shared__ uint32_t s_wb[RX_MAXF + 1], s_wave8[2][RX_NT / 64];
     __shared__ uint32_t s_idx;
     const int tid = threadIdx.x, grp = tid / RX_LPR_P3, lg = tid % RX_LPR_P3;
@@ -1674,12 +1688,12 @@ __global__ void __launch_bounds__(RX_NT, WPS) k_rx_p3(IndexView iv, RxView rx, i
             const char *wbase = reinterpret_cast<const char *>(rx.buf2 + (size_t)__builtin_amdgcn_readfirstlane((int)it0) * RX_B);
             uint32_t n_sub;
             const uint32_t pre = rx_scan_threads(np_sum, s_wave8, scan_flip, &n_sub);
-            for (uint32_t win = 0; win < n_sub; win += RX_SUBCAP3) {
+            for (uint32_t win = 0; win < n_sub; win += SUBCAP) {
                 uint32_t first = pre;
 #pragma unroll
                 for (int j = 0; j < NR; ++j) {
                     const uint32_t j0 = first > win ? first : win;
-                    const uint32_t j1 = first + np[j] < win + (uint32_t)RX_SUBCAP3 ? first + np[j] : win + (uint32_t)RX_SUBCAP3;
+                    const uint32_t j1 = first + np[j] < win + (uint32_t)SUBCAP ? first + np[j] : win + (uint32_t)SUBCAP;
                     for (uint32_t q = j0; q < j1; ++q) {
                         const uint32_t done = (q - first) * (uint32_t)RX_LPR_P3;
                         const uint32_t n = len[j] - done < (uint32_t)RX_LPR_P3 ? len[j] - done : (uint32_t)RX_LPR_P3;
@@ -1687,9 +1701,9 @@ __global__ void __launch_bounds__(RX_NT, WPS) k_rx_p3(IndexView iv, RxView rx, i
                     }
                     first += np[j];
                 }
-                const uint32_t nw = n_sub - win < (uint32_t)RX_SUBCAP3 ? n_sub - win : (uint32_t)RX_SUBCAP3;
+                const uint32_t nw = n_sub - win < (uint32_t)SUBCAP ? n_sub - win : (uint32_t)SUBCAP;
                 constexpr uint32_t STEP = RX_NG3 * RX_U;
-                static_assert(RX_SUBCAP3 % STEP == 0, "a padded list must fit the window");
+                static_assert(SUBCAP % STEP == 0, "a padded list must fit the window");
                 const uint32_t n_bat = (nw + STEP - 1u) / STEP; // (uniform)
                 for (uint32_t i = nw + tid; i < n_bat * STEP; i += RX_NT)
                     sub_list[i] = 0u; // (padding to whole batches: pieces without k-mers)
@@ -1909,19 +1923,30 @@ __global__ void __launch_bounds__(256) k_rx_flush_sorted(IndexView iv, const uin
 __global__ void __launch_bounds__(256) k_rx_max_slice(const uint32_t *__restrict__ pstart, uint64_t modulo, int w,
                                                       uint32_t PF, unsigned long long *out)
 {
-    uint32_t m = 0;
+    // out[0] = most entries of one slice, out[1] / out[2] = slices with more than RX_ECAP / RX_ECAP_MID entries
+    uint32_t m = 0, over = 0, over_mid = 0;
     for (uint64_t f = (uint64_t)blockIdx.x * 256 + threadIdx.x; f < PF; f += (uint64_t)gridDim.x * 256) {
         const uint64_t h0 = f << w, h1 = h0 + (1ull << w) < modulo ? h0 + (1ull << w) : modulo;
         const uint32_t c = pstart[h1] - pstart[h0];
         m = c > m ? c : m;
+        over += c > (uint32_t)RX_ECAP ? 1u : 0u;
+        over_mid += c > (uint32_t)RX_ECAP_MID ? 1u : 0u;
     }
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) {
         const uint32_t o = __shfl_xor(m, d);
         m = o > m ? o : m;
+        over += __shfl_xor(over, d);
+        over_mid += __shfl_xor(over_mid, d);
     }
-    if ((threadIdx.x & 63) == 0 && m)
-        atomicMax(out, (unsigned long long)m);
+    if ((threadIdx.x & 63) == 0) {
+        if (m)
+            atomicMax(out, (unsigned long long)m);
+        if (over)
+            atomicAdd(out + 1, (unsigned long long)over);
+        if (over_mid)
+            atomicAdd(out + 2, (unsigned long long)over_mid);
+    }
 }
 
 // raw entry k-mers (bucket order) -> packed form for the current (w, f2)
