@@ -1150,6 +1150,7 @@ constexpr int P2F_LOGBITS = 19;          // buckets per coarse partition the LDS
 #define P2F_SCALAR_WALK 1                // run of a k-mer by counting broadcast run starts (else binary search in LDS)
 #endif
 
+template <bool FILTER> // false: coarse partitions beyond 2^21 buckets (no bitmap fits) — the kernel is still the faster pass 2
 __global__ void __launch_bounds__(P2F_NT) k_rx_p2f(IndexView iv, RxView rx)
 {
     __shared__ uint32_t s_bits[(1 << P2F_LOGBITS) / 32];
@@ -1174,8 +1175,9 @@ __global__ void __launch_bounds__(P2F_NT) k_rx_p2f(IndexView iv, RxView rx)
     const uint32_t bmask = (1u << (rx.w + rx.f2)) - 1u;          // bucket inside the coarse partition
     const uint32_t gs = (uint32_t)rx.occ_shift;                  // buckets per bitmap bit: 2^gs (coarse partitions of
                                                                  // up to 2^21 buckets: sparse tables such as modulo 452 930 477)
-    const bool nofilt = gs > 2u;                                 // coarse partitions beyond 2^21 buckets: nothing is
-                                                                 // dropped — the kernel is still the faster pass 2
+    constexpr bool nofilt = !FILTER;                             // (a template parameter: as a run-time branch around the
+                                                                 // bitmap test it cost 13 % — the test's LDS reads no longer
+                                                                 // moved ahead of the requests)
     const uint32_t nwords = nofilt ? 0u : (((uint32_t)F2 << w) >> gs) / 32u; // bitmap words of one coarse partition in LDS (<= 16384)
     const uint32_t spare = rx_spare_key();
     uint32_t gathered = 0, dropped = 0; // conservation check: gathered = pass 1's lookups = pass 3's probes + dropped
