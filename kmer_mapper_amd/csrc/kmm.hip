@@ -586,10 +586,10 @@ int launch_rx(kmm_index *ix, const ReadsView &rv, const uint64_t *kmers_in, int6
         KMMCHK(tm.begin(ix, KMM_KERNEL_RX_P2));
         if (ix->rx_filter) { // gather by k-mer; where a coarse partition's occupancy bitmap fits LDS (one bit per 1, 2 or 4
                            // buckets) the k-mers of empty buckets are dropped here
-            if (rx_filter_active(ix))
-                hipLaunchKernelGGL(k_rx_p2f<true>, dim3(ix->n_cu), dim3(P2F_NT), 0, ix->stream, iv, rx);
-            else
-                hipLaunchKernelGGL(k_rx_p2f<false>, dim3(ix->n_cu), dim3(P2F_NT), 0, ix->stream, iv, rx);
+            const bool flt = rx_filter_active(ix), small = F2 <= 128;
+            auto kern = flt ? (small ? k_rx_p2f<true, true> : k_rx_p2f<true, false>)
+                            : (small ? k_rx_p2f<false, true> : k_rx_p2f<false, false>);
+            hipLaunchKernelGGL(kern, dim3(ix->n_cu), dim3(P2F_NT), 0, ix->stream, iv, rx);
         } else {
             hipLaunchKernelGGL(k_rx_p2, dim3(ix->n_cu * ix->rx_grid_per_cu), dim3(RX_NT), 0, ix->stream, iv, rx);
         }

@@ -338,7 +338,7 @@ struct RxNoHook {
 // the caller then guarantees a barrier of its own before sbuf is written again and before the next call's ranking
 // (which needs the counters this call clears during its copy-out).
 template <int RB, bool ENDBAR, bool ONEBAR, int NT = RX_NT, bool NTSTORE = ONEBAR, bool DUMMY = false, typename PrepFn,
-          typename MidFn = RxNoHook, bool WAVESCAN = false, bool NOWTID = false>
+          typename MidFn = RxNoHook, int WAVESCAN = 0, bool NOWTID = false>
 __device__ __forceinline__ void rx_sort_emit(uint64_t (&q)[RX_B / NT], PrepFn prep, int F, uint64_t *sbuf,
                                              uint32_t *s_cnt, uint32_t *s_base, uint32_t *s_wave,
                                              uint64_t *__restrict__ out, uint16_t *__restrict__ dir_row,
@@ -385,7 +385,7 @@ __device__ __forceinline__ void rx_sort_emit(uint64_t (&q)[RX_B / NT], PrepFn pr
     RX_PT(2); // keys + ranks
     mid();
     uint32_t total;
-    if (WAVESCAN && F <= 128) {
+    if (WAVESCAN == 2 || (WAVESCAN == 1 && F <= 128)) { // (2: the caller guarantees F <= 128 — no other form is compiled)
         // Fan-outs up to 128: EVERY wavefront scans the counters for itself (two per lane, six DPP additions) and keeps
         // the bases in registers — a k-mer's base comes from lane key / 2 through the LDS crossbar (ds_bpermute) instead
         // of an LDS table the whole workgroup would have to wait for at a barrier.
@@ -1150,7 +1150,9 @@ constexpr int P2F_LOGBITS = 19;          // buckets per coarse partition the LDS
 #define P2F_SCALAR_WALK 1                // run of a k-mer by counting broadcast run starts (else binary search in LDS)
 #endif
 
-template <bool FILTER> // false: coarse partitions beyond 2^21 buckets (no bitmap fits) — the kernel is still the faster pass 2
+// FILTER false: coarse partitions beyond 2^21 buckets (no bitmap fits) — the kernel is still the faster pass 2
+// FSMALL: at most 128 fine partitions (the launch knows): only the per-wavefront scan is compiled into the sort
+template <bool FILTER, bool FSMALL>
 __global__ void __launch_bounds__(P2F_NT) k_rx_p2f(IndexView iv, RxView rx)
 {
     __shared__ uint32_t s_bits[(1 << P2F_LOGBITS) / 32];
@@ -1472,7 +1474,7 @@ __global__ void __launch_bounds__(P2F_NT) k_rx_p2f(IndexView iv, RxView rx)
                         rd = load_desc(s_b0[j + 3u]);
                 }
             };
-            rx_sort_emit<P2F_KPT, false, P2F_ONEBAR != 0, P2F_NT, false, true, decltype(fine), decltype(mid), P2F_WAVESCAN != 0>(
+            rx_sort_emit<P2F_KPT, false, P2F_ONEBAR != 0, P2F_NT, false, true, decltype(fine), decltype(mid), (P2F_WAVESCAN ? (FSMALL ? 2 : 1) : 0)>(
                 xa, fine, F2, sbuf, s_cnt2[j & 1u], s_base, s_wave, rx.buf2 + (size_t)item * RX_B,
                 rx.start2 + (size_t)item * (F2 + 1) RX_PT_ARG2, mid);
 #if P2F_STARTBITS
