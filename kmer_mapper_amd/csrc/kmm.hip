@@ -611,12 +611,6 @@ int launch_rx(kmm_index *ix, const ReadsView &rv, const uint64_t *kmers_in, int6
         else if (ix->rx_w > 12)
             hipLaunchKernelGGL((k_rx_p3<RX_WMAX_BIG, RX_ECAP_BIG, 2, uint32_t>), dim3(ix->n_cu), dim3(RX_NT), 0, ix->stream,
                                iv, rx, max_freq);
-#if RX_P3_DENSE
-        else if (ix->rx_max_slice <= (uint32_t)RX_ECAP_DENSE)
-            // no slice holds more than 2560 entries (load factor 0.5: 2048 +- 45): 48 KB of LDS, three workgroups per CU
-            hipLaunchKernelGGL((k_rx_p3<RX_WMAX, RX_ECAP_DENSE, RX_P3_DENSE_WPS, uint16_t>), dim3(ix->n_cu * 3), dim3(RX_NT), 0,
-                               ix->stream, iv, rx, max_freq);
-#endif
         else
             hipLaunchKernelGGL((k_rx_p3<RX_WMAX, RX_ECAP, 4, uint32_t>), dim3(ix->n_cu * ix->rx_grid_per_cu), dim3(RX_NT), 0,
                                ix->stream, iv, rx, max_freq);

@@ -80,11 +80,9 @@ constexpr int RX_SUBCAP3 = RX_SUBCAP3V; // ... pass 3 (one word each)
 constexpr bool RX_P3_LINECUT = false;
 // (Two variants of pass 3 were measured in round 3 and removed again, both bit-exact — profiles/r03: gathering by k-mer
 // with a run table and broadcast run starts as k_rx_p2f does, 2.05 vs 1.94 ms: runs of ~32 k-mers fill the 16-lane pieces
-// well; and entries 0 and 1 of every bucket unrolled with longer buckets queued per wavefront, 1.96 vs 1.96 ms.)
-#ifndef RX_P3_PREFETCH
-#define RX_P3_PREFETCH 0              // 1: the next batch of pieces is requested before the current one is probed (two register
-                                      // sets) — bit-exact, measured SLOWER: 2.02 vs 1.91 ms (profiles/r03/ab_pass3_prefetch.txt)
-#endif
+// well; entries 0 and 1 of every bucket unrolled with longer buckets queued per wavefront, 1.96 vs 1.96 ms; the next
+// batch of pieces requested before the current one is probed (two register sets), 2.02 vs 1.91 ms; three workgroups per
+// CU for slices of at most 2560 entries (48 KB of LDS, 80 VGPRs), 1.94 vs 1.94 ms.)
 constexpr int RX_LPR_P3 = RX_LPR3;    // ... pass 3 (its runs are shorter: ~32 k-mers)
 constexpr int RX_NG3 = RX_NT / RX_LPR_P3;
 #ifndef RX_U3
@@ -115,13 +113,6 @@ constexpr int RX_WMAX_BIG = 8192;     // slices of indexes with more than 256 x 
 constexpr int RX_ECAP_BIG = 8192;     // modulo 452 930 477): 140 KB of LDS, one workgroup of pass 3 per CU
 constexpr int RX_ECAP_MID = 4608;     // 8192-bucket slices at load factor 0.5 (4096 +- 64 entries): 16-bit directory, 1024-piece
                                       // list, 77 KB of LDS: two workgroups per CU (the 1 B-k-mer index)
-#ifndef RX_P3_DENSE
-#define RX_P3_DENSE 0                 // 1: slices of at most RX_ECAP_DENSE entries run three workgroups of pass 3 per CU
-#endif
-#ifndef RX_P3_DENSE_WPS
-#define RX_P3_DENSE_WPS 6
-#endif
-constexpr int RX_ECAP_DENSE = 2560;
 constexpr uint32_t RX_FILTERED = 0x80000000u; // pass 3: top bit of an LDS hit counter = entry excluded by max_freq
 enum { MODE_KMERS = 3 };              // pass-1 source: a uint64 k-mer array instead of read bytes
 
@@ -337,7 +328,7 @@ struct RxNoHook {
 // non-temporal copy-out), one after the placement.  ENDBAR = false leaves out the one after the copy-out:
 // the caller then guarantees a barrier of its own before sbuf is written again and before the next call's ranking
 // (which needs the counters this call clears during its copy-out).
-template <int RB, bool ENDBAR, bool ONEBAR, int NT = RX_NT, bool NTSTORE = ONEBAR, bool DUMMY = false, typename PrepFn,
+template <int RB, bool ENDBAR, bool ONEBAR, int NT = RX_NT, bool NTSTORE = ONEBAR, typename PrepFn,
           typename MidFn = RxNoHook, int WAVESCAN = 0, bool NOWTID = false>
 __device__ __forceinline__ void rx_sort_emit(uint64_t (&q)[RX_B / NT], PrepFn prep, int F, uint64_t *sbuf,
                                              uint32_t *s_cnt, uint32_t *s_base, uint32_t *s_wave,
@@ -422,29 +413,15 @@ __device__ __forceinline__ void rx_sort_emit(uint64_t (&q)[RX_B / NT], PrepFn pr
     if (NT == RX_MAXF && F == NT && tid == 0) // (fan-out 512 on 512 threads: one more entry than threads)
         dir_row[NT] = (uint16_t)s_base[NT];
     // (one slot after the other: reading all 16 run starts first and then writing — 16 overlapping LDS round trips —
-    // measured SLOWER, pass 1 4.41 vs 3.62 ms, pass 2 4.75 vs 4.30 ms)
-#ifndef RX_PLACE_BATCH
-#define RX_PLACE_BATCH 1
-#endif
-#ifndef RX_PLACE_PRED
-#define RX_PLACE_PRED 1 // (k_rx_p2f, half of whose slots are empty after the filter: 3.70 -> 3.60 ms against the dummy slot)
-#endif
+    // measured SLOWER, pass 1 4.41 vs 3.62 ms, pass 2 4.75 vs 4.30 ms; a slot without a k-mer is skipped under
+    // predication: writing it to a dummy element instead measured slower in k_rx_p2f, 3.70 vs 3.60 ms)
 #pragma unroll
-    for (int h = 0; h < KPT; h += RX_PLACE_BATCH) {
+    for (int h = 0; h < KPT; ++h) {
         if (h >= n_slots)
             break;
-        uint32_t pos[RX_PLACE_BATCH];
-#pragma unroll
-        for (int i = 0; i < RX_PLACE_BATCH; ++i)
-            pos[i] = s_base[cr[h + i] >> 16] + (cr[h + i] & 0xFFFFu);
-#pragma unroll
-        for (int i = 0; i < RX_PLACE_BATCH; ++i) {
-            if (DUMMY && !RX_PLACE_PRED) { // branch-free: a slot without a k-mer is written to the lane's dummy element behind the buffer
-                sbuf[(cr[h + i] >> 16) < (uint32_t)F ? pos[i] : (uint32_t)RX_B + (threadIdx.x & 63)] = q[h + i];
-            } else if ((cr[h + i] >> 16) < (uint32_t)F) {
-                sbuf[pos[i]] = q[h + i];
-            }
-        }
+        const uint32_t pos = s_base[cr[h] >> 16] + (cr[h] & 0xFFFFu);
+        if ((cr[h] >> 16) < (uint32_t)F)
+            sbuf[pos] = q[h];
     }
     }
     __syncthreads();
@@ -674,7 +651,7 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p1(ReadsView rv, const uint64_t
                 x[i] = rx_pack(iv, sh, q[i], &c);
                 return ((valid >> i) & 1u) ? c : spare;
             };
-            rx_sort_emit<RX_RB1, true, true, RX_NT, true, false, decltype(fwd), RxNoHook, false, true>(
+            rx_sort_emit<RX_RB1, true, true, RX_NT, true, decltype(fwd), RxNoHook, 0, true>(
                 x, fwd, F1, sbuf, s_cnt, s_base, s_wave, rx.buf1 + (size_t)sb * 2 * RX_B,
                 rx.start1 + (size_t)sb * 2 * (size_t)(F1 + 1) RX_PT_ARG2, RxNoHook(), RX_KPT, wave_s);
             auto rev = [&](int i) {
@@ -682,7 +659,7 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p1(ReadsView rv, const uint64_t
                 x[i] = rx_pack(iv, sh, revcomp(q[i], k), &c);
                 return ((valid >> i) & 1u) ? c : spare;
             };
-            rx_sort_emit<RX_RB1, MODE == MODE_KMERS, true, RX_NT, true, false, decltype(rev), RxNoHook, false, true>(
+            rx_sort_emit<RX_RB1, MODE == MODE_KMERS, true, RX_NT, true, decltype(rev), RxNoHook, 0, true>(
                 x, rev, F1, sbuf, s_cnt, s_base, s_wave, rx.buf1 + ((size_t)sb * 2 + 1) * RX_B,
                 rx.start1 + ((size_t)sb * 2 + 1) * (size_t)(F1 + 1) RX_PT_ARG2, RxNoHook(), RX_KPT, wave_s);
         } else {
@@ -691,7 +668,7 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p1(ReadsView rv, const uint64_t
                 q[i] = rx_pack(iv, sh, q[i], &c);
                 return ((valid >> i) & 1u) ? c : spare;
             };
-            rx_sort_emit<RX_RB1, MODE == MODE_KMERS, true, RX_NT, true, false, decltype(fwd), RxNoHook, false, true>(
+            rx_sort_emit<RX_RB1, MODE == MODE_KMERS, true, RX_NT, true, decltype(fwd), RxNoHook, 0, true>(
                 q, fwd, F1, sbuf, s_cnt, s_base, s_wave, rx.buf1 + (size_t)sb * RX_B,
                 rx.start1 + (size_t)sb * (size_t)(F1 + 1) RX_PT_ARG2, RxNoHook(), RX_KPT, wave_s);
         }
@@ -1134,21 +1111,6 @@ constexpr int P2F_NT = 1024;
 constexpr int P2F_KPT = RX_B / P2F_NT;   // 8 k-mers per thread and item
 constexpr int P2F_KMAX = 64;             // most items per work unit (rx.p2f_k: chosen per batch, launch_rx)
 constexpr int P2F_LOGBITS = 19;          // buckets per coarse partition the LDS bitmap covers: 2^19 (64 KB)
-#ifndef P2F_AUX
-#define P2F_AUX 1                        // search between the runs of the wavefront's first and last k-mer (else 0 .. 1023)
-#endif
-#ifndef P2F_ONEBAR
-#define P2F_ONEBAR 1                     // one-barrier counter scan in the sort
-#endif
-#ifndef P2F_STARTBITS
-#define P2F_STARTBITS 1                  // run of a k-mer = run of its 64-block's first k-mer + popcount of the run-start bits
-#endif                                   // up to it (one LDS atomic OR per run, mbcnt per k-mer) instead of the walk below
-#ifndef P2F_WAVESCAN
-#define P2F_WAVESCAN 1                   // fan-outs <= 128: every wavefront scans the sort's counters itself (two barriers per item)
-#endif
-#ifndef P2F_SCALAR_WALK
-#define P2F_SCALAR_WALK 1                // run of a k-mer by counting broadcast run starts (else binary search in LDS)
-#endif
 
 // FILTER false: coarse partitions beyond 2^21 buckets (no bitmap fits) — the kernel is still the faster pass 2
 // FSMALL: at most 128 fine partitions (the launch knows): only the per-wavefront scan is compiled into the sort
@@ -1156,16 +1118,14 @@ template <bool FILTER, bool FSMALL>
 __global__ void __launch_bounds__(P2F_NT) k_rx_p2f(IndexView iv, RxView rx)
 {
     __shared__ uint32_t s_bits[(1 << P2F_LOGBITS) / 32];
-    __shared__ uint64_t sbuf[RX_B + 64];  // (+ one dummy element per lane: branch-free placement)
+    __shared__ uint64_t sbuf[RX_B];
     __shared__ uint32_t t_vs[P2F_NT + 64]; // run table of the item being requested: where run t starts in the
     __shared__ uint32_t t_off[P2F_NT];    // coarse partition's virtual array; t_off[t] + v = where k-mer v of run t lies
                                           // in pass 1's output, relative to the table's first block
     __shared__ uint16_t t_aux[RX_B / 64 + 1]; // run (table index) of the item's k-mers 0, 64, 128, ...: a wavefront's 64
     __shared__ uint32_t t_last;               // consecutive k-mers lie between two of them; run of the last covered k-mer
-#if P2F_STARTBITS
     __shared__ uint32_t t_sbits[2][RX_B / 32]; // bit e = a run starts at the item's k-mer e (items alternate between the
     __shared__ uint32_t t_empty[2];            // two masks); != 0: an EMPTY run starts inside the item (mask unusable)
-#endif
     __shared__ __attribute__((aligned(8))) uint32_t s_cnt2[2][RX_MAXF + 2 + 64]; // the sort's counters: items alternate
     __shared__ uint32_t s_base[RX_MAXF + 1], s_wave[4];
     __shared__ uint32_t s_b0[P2F_KMAX];
@@ -1242,12 +1202,10 @@ __global__ void __launch_bounds__(P2F_NT) k_rx_p2f(IndexView iv, RxView rx)
                 s_bits[i] = o;
             }
         }
-#if P2F_STARTBITS
         if (tid < 2 * (RX_B / 32))
             (&t_sbits[0][0])[tid] = 0u;
         if (tid < 2)
             t_empty[tid] = 0u;
-#endif
         __syncthreads();
 
         auto item_lo = [&](uint32_t j) { return (j0 + j) * (uint32_t)RX_B; };
@@ -1270,7 +1228,6 @@ __global__ void __launch_bounds__(P2F_NT) k_rx_p2f(IndexView iv, RxView rx)
         // each k-mer lo + 64 a that lies in its run (t_aux), and of the item's last covered k-mer (t_last): the search of
         // a wavefront's 64 consecutive k-mers then starts from two table indices a few runs apart instead of 0 .. 1023.
         auto put_table = [&](const RunDesc &r, uint32_t lo, uint32_t hi, int mb = -1) {
-#if P2F_STARTBITS
             // (first table of an item, mb = the item's mask: cleared two items ago, behind that item's barriers)
             if (mb >= 0 && r.vs != 0xFFFFFFFFu && r.vs > lo && r.vs < hi) {
                 if (r.ve > r.vs)
@@ -1278,9 +1235,6 @@ __global__ void __launch_bounds__(P2F_NT) k_rx_p2f(IndexView iv, RxView rx)
                 else
                     t_empty[mb] = 1u; // two runs would share the bit
             }
-#else
-            (void)mb;
-#endif
             t_vs[tid] = r.vs;
             t_off[tid] = (uint32_t)tid * RX_B + r.st - r.vs; // (modulo 2^32: the sum with v is < 1025 x 8192)
             if (tid == P2F_NT - 1) {
@@ -1334,7 +1288,6 @@ __global__ void __launch_bounds__(P2F_NT) k_rx_p2f(IndexView iv, RxView rx)
                 const uint32_t len = A[u + 1] > A[u] ? A[u + 1] - A[u] : 0u;
                 len_max = len > len_max ? len : len_max;
             }
-#if P2F_STARTBITS
             // The item's run-start bits (first table of an item without empty runs): the run of k-mer e = the run of its
             // 64-block's first k-mer (A[u]) + the number of runs that start at the k-mers after it up to e.  The wavefront's
             // 512 bits are 16 words: one LDS read (lane i reads word i), two readlanes per block, mbcnt per k-mer.
@@ -1354,8 +1307,6 @@ __global__ void __launch_bounds__(P2F_NT) k_rx_p2f(IndexView iv, RxView rx)
                 len_max = 0;
             }
             if (!by_bits) {
-#endif
-#if P2F_SCALAR_WALK
             // The wavefront's 512 k-mers span the runs A[0] .. A[8] (about 30 of them at 17 k-mers per run).  With fewer
             // than 64: lane t holds the start of run A[0] + t (ONE LDS read per wavefront and item); every run start a
             // 64-block crosses is broadcast (readlane -> scalar register) and compared against the block's 64 positions:
@@ -1374,10 +1325,7 @@ __global__ void __launch_bounds__(P2F_NT) k_rx_p2f(IndexView iv, RxView rx)
                 }
                 len_max = 0; // (the search below has nothing left to do)
             }
-#endif
-#if P2F_STARTBITS
             }
-#endif
             for (uint32_t stp = len_max ? 1u << (31 - __builtin_clz(len_max)) : 0u; stp >= 1u; stp >>= 1) {
 #pragma unroll
                 for (int u = 0; u < P2F_KPT; ++u) {
@@ -1474,15 +1422,13 @@ __global__ void __launch_bounds__(P2F_NT) k_rx_p2f(IndexView iv, RxView rx)
                         rd = load_desc(s_b0[j + 3u]);
                 }
             };
-            rx_sort_emit<P2F_KPT, false, P2F_ONEBAR != 0, P2F_NT, false, true, decltype(fine), decltype(mid), (P2F_WAVESCAN ? (FSMALL ? 2 : 1) : 0)>(
+            rx_sort_emit<P2F_KPT, false, true, P2F_NT, false, decltype(fine), decltype(mid), (FSMALL ? 2 : 1)>(
                 xa, fine, F2, sbuf, s_cnt2[j & 1u], s_base, s_wave, rx.buf2 + (size_t)item * RX_B,
                 rx.start2 + (size_t)item * (F2 + 1) RX_PT_ARG2, mid);
-#if P2F_STARTBITS
             if (tid < RX_B / 32)
                 t_sbits[(j + 1u) & 1u][tid] = 0u; // item j + 1's mask has served (its requests lie before barrier 1); item
             if (tid == 0)                         // j + 3's bits are set behind the next item's barrier 1
                 t_empty[(j + 1u) & 1u] = 0u;
-#endif
         };
 
         // prime the pipeline: item 0's table and requests, item 1's table, item 2's run descriptors
@@ -1501,12 +1447,10 @@ __global__ void __launch_bounds__(P2F_NT) k_rx_p2f(IndexView iv, RxView rx)
                          // buffer: memory fault, first GPU run)
         if (cover < item_lo(0) + item_n(0))
             more_rounds(0, x0, vm0);
-#if P2F_STARTBITS
         if (tid < RX_B / 32)
             t_sbits[0][tid] = 0u; // item 0's mask has served: item 2's bits go there
         if (tid == 0)
             t_empty[0] = 0u;
-#endif
         if (n_it > 1u) {
             put_table(rd, item_lo(1), item_lo(1) + item_n(1), 1);
             if (n_it > 2u)
@@ -1770,27 +1714,11 @@ __global__ void __launch_bounds__(RX_NT, WPS) k_rx_p3(IndexView iv, RxView rx, i
                     }
                 };
                 auto stream = [&](auto over_tag) {
-#if RX_P3_PREFETCH
-                    // two register sets: batch i + 1 is requested before batch i is probed (measured slower, see above)
-                    uint64_t xa[RX_U], xb[RX_U];
-                    uint32_t ma = request(grp, xa), mb = 0;
-                    for (uint32_t bi = 0; bi < n_bat; bi += 2u) {
-                        if (bi + 1u < n_bat)
-                            mb = request(grp + (bi + 1u) * STEP, xb);
-                        probe(over_tag, xa, ma);
-                        if (bi + 1u >= n_bat)
-                            break;
-                        if (bi + 2u < n_bat)
-                            ma = request(grp + (bi + 2u) * STEP, xa);
-                        probe(over_tag, xb, mb);
-                    }
-#else
                     for (uint32_t bi = 0; bi < n_bat; ++bi) {
                         uint64_t x[RX_U];
                         const uint32_t m = request(grp + bi * STEP, x);
                         probe(over_tag, x, m);
                     }
-#endif
                 };
                 if (sl.over)
                     stream(std::true_type());
