@@ -21,8 +21,10 @@
 //           k_rx_colsum / k_rx_chunkscan / k_rx_tables / k_rx_colscan   column prefix of the directory: P1T[c][block] = k-mers of
 //                     coarse partition c before that block, so that c's runs form one virtual array; it is
 //                     cut into items of 8192 k-mers (item_desc = first block, c)
-//   pass 2  k_rx_p2   item (c, j): gathers its 8192 k-mers from the runs (each ~B/F1 k-mers, contiguous),
-//                     sorts them by FINE partition inside LDS, writes the sorted item + directory row start2
+//   pass 2  k_rx_p2f  item (c, j): gathers its 8192 k-mers from the runs (each ~B/F1 k-mers, contiguous), drops those
+//                     whose bucket is empty (LDS bitmap of the coarse partition, where one fits), sorts the rest by
+//                     FINE partition inside LDS, writes the sorted item + directory row start2
+//                     (k_rx_p2: the round-2 form — piece lists, no filter; behind "radix_filter" = 0)
 //   pass 3  k_rx_p3   work item (fine partition f, up to 1024 items of its coarse partition): loads f's slice
 //                     (directory, keys) into LDS, streams f's runs from the items, probes LDS, counts hits per
 //                     entry in LDS (an entry the frequency filter of mapper.pyx:64-66 excludes carries a flag in
@@ -30,11 +32,12 @@
 //   flush   k_rx_flush_sorted / k_rx_flush  at the next synchronising call: counts[node[e]] += ecnt[e]  (mapper.pyx:68
 //                     summed per entry first — the reference's GpuCounter does exactly this, gpu_counter.py:26-37)
 //
-// What the passes are tuned against (profiles/r02/README.md): pass 1 is VALU-bound, pass 2 moves 16 B per k-mer at
-// the chip's mixed read/write rate, pass 3 streams ~256-byte runs at the rate tools/chunk_read_bench.hip gives for
-// that shape.  Work between two workgroup barriers is kept short: wavefront prefix sums use DPP additions, not
-// ds_bpermute; counters are cleared off the critical path; the next block / item is requested before the current
-// one is sorted.
+// What the passes are tuned against (profiles/r03/README.md): no pass sits on one resource (vector ALUs 45-70 % busy,
+// 4-5 TB/s of HBM traffic, LDS a third of the time); what moves them is fewer instructions per k-mer and fewer
+// workgroup barriers — wavefronts drift apart between barriers and overlap each other's LDS, VALU and memory phases.
+// Work between two barriers is kept short: wavefront prefix sums use DPP additions, not ds_bpermute; counters are
+// cleared off the critical path; the next block / item is requested before the current one is sorted; nothing in a
+// block / item loop may spill (a scratch reload waits for vmcnt(0): the prefetch and the copy-out stores).
 //
 // Between the passes a k-mer q travels as x = (q / modulo) << (w + f2) | (q % modulo) & (2^(w+f2) - 1): the
 // quotient and the hash bits BELOW the coarse partition number.  Inside a coarse partition (and so inside a
