@@ -413,6 +413,27 @@ def _flat_index(syn, kmers, nodes, modulo):
     return KmerIndex.from_flat_kmers(np.asarray(kmers, dtype=np.uint64), np.asarray(nodes, dtype=np.int64), modulo)
 
 
+def _sparse_flat_index(kmers, nodes, modulo):
+    """The reference's index layout for a few k-mers in a huge table: entries grouped by kmer % modulo,
+    hashes_to_index / n_kmers written only where a bucket is in use (np.zeros maps untouched pages lazily)."""
+    import types
+    kmers = np.asarray(kmers, dtype=np.uint64)
+    nodes = np.asarray(nodes, dtype=np.int32)
+    h = (kmers % np.uint64(modulo)).astype(np.int64)
+    order = np.argsort(h, kind="stable")
+    kmers, nodes, h = kmers[order], nodes[order], h[order]
+    h2i = np.zeros(modulo, dtype=np.int32)
+    nk = np.zeros(modulo, dtype=np.int32)
+    uh, first, cnt = np.unique(h, return_index=True, return_counts=True)
+    h2i[uh] = first.astype(np.int32)
+    nk[uh] = cnt.astype(np.int32)
+    _, inv, kc = np.unique(kmers, return_inverse=True, return_counts=True)
+    index = types.SimpleNamespace(_hashes_to_index=h2i, _n_kmers=nk, _nodes=nodes, _kmers=kmers,
+                                  _frequencies=np.minimum(kc[inv], 65535).astype(np.uint16), _modulo=int(modulo))
+    index.max_node_id = lambda: int(nodes.max())
+    return index
+
+
 @pytest.mark.parametrize("modulo", [1, 2, 64, 1009, 2 ** 20, 2147483629])
 def test_fastmod_exact_for_every_modulo_and_full_uint64_range(kmm, oracle, modulo):
     """kmers[i] % modulo (mapper.pyx:54) for k-mers over the whole uint64 range, odd moduli,
@@ -420,9 +441,12 @@ def test_fastmod_exact_for_every_modulo_and_full_uint64_range(kmm, oracle, modul
     rng = np.random.default_rng(modulo)
     idx_kmers = rng.integers(0, 2 ** 64, size=300, dtype=np.uint64)
     idx_kmers[:5] = [0, 1, 2 ** 64 - 1, 2 ** 63, modulo]
-    if modulo > 10 ** 6:                      # keep hashes_to_index small enough to build on the host
-        pytest.skip("covered by test_large_modulo_table") if modulo > 2 ** 22 else None
-    index = _flat_index(None, idx_kmers, np.arange(300), modulo)
+    if modulo > 2 ** 22:
+        # a prime just below 2^31 (the largest table the reference's int32 arrays allow, mapper.pyx:22-23): the two
+        # modulo-sized tables are zero pages apart from the 300 buckets in use, built without touching the rest
+        index = _sparse_flat_index(idx_kmers, np.arange(300), modulo)
+    else:
+        index = _flat_index(None, idx_kmers, np.arange(300), modulo)
     q = np.concatenate([idx_kmers, rng.integers(0, 2 ** 64, size=5000, dtype=np.uint64),
                         idx_kmers + np.uint64(modulo)])
     expect = oracle.map_kmers(index, 299, q)
@@ -430,6 +454,11 @@ def test_fastmod_exact_for_every_modulo_and_full_uint64_range(kmm, oracle, modul
         dev.map_kmers(q)
         assert np.array_equal(dev.get_node_counts(), expect)
         assert np.array_equal(dev.in_index(q), oracle.in_index(index, q))
+        if dev.get_param("radix_available"):      # the same division in pass 1 of the radix path
+            dev.reset()
+            dev.set_param("path", 2)
+            dev.map_kmers(q)
+            assert np.array_equal(dev.get_node_counts(), expect)
 
 
 def test_large_modulo_table(kmm, oracle):
