@@ -912,9 +912,10 @@ static int rx_repack_keys(kmm_index *ix)
     HIPCHK(hipStreamSynchronize(ix->stream));
     ix->rx_max_slice = (uint32_t)mx[0];
     // a slice with more entries than pass 3 keeps in LDS has the buckets behind them walked in HBM: fine for the odd
-    // slice (a k-mer stored under 1500 nodes), not as the rule — at most one slice in a thousand
-    ix->rx_fits_small = mx[1] <= ix->rx_PF / 1000;
-    ix->rx_fits_mid = mx[2] <= ix->rx_PF / 1000;
+    // slice (a k-mer stored under 1500 nodes), not as the rule — at most one slice in a thousand (or one slice)
+    const unsigned long long odd = ix->rx_PF / 1000 > 1 ? ix->rx_PF / 1000 : 1;
+    ix->rx_fits_small = mx[1] <= odd;
+    ix->rx_fits_mid = mx[2] <= odd;
     return KMM_OK;
 }
 
@@ -2317,6 +2318,11 @@ int kmm_get_param(kmm_index_t *ix, const char *name, int64_t *value)
                                : 0;
     else if (!strcmp(name, "radix_filter"))
         *value = (ix->rx_ok && rx_filter_active(ix)) ? 1 : 0;
+    else if (!strcmp(name, "radix_p3_keys_in_lds")) // entries of a slice pass 3 keeps in LDS (the rest is walked in HBM)
+        *value = !ix->rx_ok ? 0
+                 : ix->rx_w <= 12 ? RX_ECAP
+                 : (ix->rx_fits_small && ix->rx_max_slice <= 65535u) ? RX_ECAP
+                 : (ix->rx_fits_mid && ix->rx_max_slice <= 65535u && !getenv("KMM_RX_NO_MID")) ? RX_ECAP_MID : RX_ECAP_BIG;
     else if (!strcmp(name, "radix_filter_buckets_per_bit")) // 1, 2 or 4 (0: no filter)
         *value = (ix->rx_ok && rx_filter_active(ix)) ? (1 << ix->rx_occ_shift) : 0;
     else if (!strcmp(name, "radix_packed_tiles"))

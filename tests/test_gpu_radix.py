@@ -125,10 +125,11 @@ def test_slice_with_more_entries_than_lds_capacity(kmm, oracle):
     assert oracle.map_kmers(index, mx, q, 65535).sum() >= 7 * 6000
 
 
-@pytest.mark.parametrize("n_entries", [3000, 30000])
-def test_slices_of_8192_buckets(kmm, syn, oracle, n_entries):
+@pytest.mark.parametrize("n_entries, keys_in_lds", [(3000, 4096), (21500, 4608), (30000, 8192)])
+def test_slices_of_8192_buckets(kmm, syn, oracle, n_entries, keys_in_lds):
     """part_shift 13: a sparse table (every slice's entries fit 4096 keys: 16-bit LDS directory, two workgroups of
-    pass 3 per CU) and a dense one (8192-key slices, 32-bit directory)."""
+    pass 3 per CU), one at load factor 0.54 (4608 keys, the 1 B-k-mer index's shape) and a dense one (8192-key slices,
+    32-bit directory, one workgroup per CU)."""
     index, genome = syn.make_index(n_entries, seed=341, modulo=40009)
     mx = index.max_node_id()
     bases, offs = syn.make_ragged_reads(genome, 20000, 0, 260, seed=342)
@@ -136,6 +137,7 @@ def test_slices_of_8192_buckets(kmm, syn, oracle, n_entries):
     with kmm.DeviceIndex.from_index(index, mx) as dev:
         dev.set_param("part_shift", 13)
         dev.set_param("path", 2)
+        assert dev.get_param("radix_p3_keys_in_lds") == keys_in_lds
         dev.map_reads(bases, offs, 31, also_revcomp=True)
         assert np.array_equal(dev.get_node_counts(), expect)
         assert dev.get_param("radix_p3_kmers") + dev.get_param("radix_p2_dropped") == 2 * n
