@@ -430,3 +430,194 @@ class RawChunker:
             self.buf = np.empty(0, dtype=np.uint8)          # drop the view before the memory goes away
             _lib.lib().kmm_host_free(self._pinned)
             self._pinned = None
+
+
+class PrefetchingRawChunker:
+    """RawChunker's interface with TWO buffers and a reader thread: while the consumer (kmm_map_records: staging copy over
+    PCIe, record parser, map kernels) works on one chunk, the next one is read — and, for .gz input, inflated by the
+    native reader's threads — into the other buffer.  The unused tail of a chunk (at most one record, as a rule) is
+    copied in front of the next chunk's bytes, into head room kept for it; anything out of the ordinary (a record longer
+    than the head room, a consumer that used nothing) ends the prefetching and continues on one growing buffer exactly
+    as RawChunker does.  (`kmer_mapper map` on BGZF input: inflate and the GPU's share no longer take turns.)"""
+
+    HEAD = 4 << 20
+
+    def __init__(self, path, chunk_size, byte_range=None, pinned=False):
+        import threading
+        self.f = _open(path)
+        self.chunk_size = int(chunk_size)
+        self._pinned = []
+        self._bufs = []
+        n = self.HEAD + self.chunk_size + (1 << 20)
+        for _ in range(2):
+            if pinned:
+                import ctypes
+                from . import _lib
+                p = ctypes.c_void_p()
+                _lib.check(_lib.lib().kmm_host_alloc(n, ctypes.byref(p)))
+                self._pinned.append(p)
+                self._bufs.append(np.frombuffer((ctypes.c_uint8 * n).from_address(p.value), dtype=np.uint8))
+            else:
+                self._bufs.append(np.empty(n, dtype=np.uint8))
+        self.left = None
+        if byte_range is not None:
+            self.f.seek(byte_range[0])
+            self.left = byte_range[1] - byte_range[0]
+        self.eof = False                 # the chunk handed out last holds the input's final bytes
+        self._src_eof = False            # the reader has seen the end of the input
+        self._cur = 0                    # buffer the consumer works on
+        self._start = self.HEAD          # its first byte (head room holds the carried-over tail)
+        self._end = self.HEAD            # ... one past its last byte
+        self._next_fill = 0              # bytes the reader put into the other buffer
+        self._next_eof = False
+        self._carry = 0                  # carried-over bytes in front of the other buffer's data
+        self._fallback = None            # a plain RawChunker-like state once prefetching has ended
+        self._err = None
+        self._lock = threading.Lock()
+        self._thread = None
+        self._first = True
+        self._handed = False
+        self._start_read(self._cur)      # the very first chunk is read in the background too; next_chunk waits for it
+
+    # --- reader thread: fills buffer j from HEAD on, up to chunk_size bytes or the end of the input
+    def _read_into(self, j):
+        try:
+            buf = self._bufs[j]
+            fill, eof = 0, self._src_eof
+            while not eof and fill < self.chunk_size:
+                want = memoryview(buf)[self.HEAD + fill:self.HEAD + self.chunk_size]
+                if self.left is not None:
+                    want = want[:min(len(want), self.left)]
+                got = self.f.readinto(want) if len(want) else 0
+                if self.left is not None:
+                    self.left -= got or 0
+                if not got:
+                    eof = True
+                    break
+                fill += got
+            self._next_fill, self._next_eof = fill, eof
+            self._src_eof = eof
+        except BaseException as exc:     # noqa: BLE001 - handed to the consumer's thread
+            self._err = exc
+
+    def _start_read(self, j):
+        import threading
+        self._thread = threading.Thread(target=self._read_into, args=(j,), daemon=True)
+        self._thread.start()
+
+    def _join(self):
+        if self._thread is not None:
+            self._thread.join()
+            self._thread = None
+        if self._err is not None:
+            err, self._err = self._err, None
+            raise err
+
+    def next_chunk(self):
+        """Returns a uint8 view (valid until the next call) or None at end of input."""
+        if self._fallback is not None:
+            return self._fb_next()
+        if self._handed:                                 # asked again without consumed(): the consumer could not use
+            self._handed = False                         # the chunk (a record longer than it) and wants a longer one
+            return self._to_fallback_and_next()
+        if self._first:
+            self._first = False
+            self._join()
+            self._end = self.HEAD + self._next_fill
+            self.eof = self._next_eof
+            self._finish_tail()
+            if not self.eof:
+                self._start_read(1 - self._cur)
+        if self._end == self._start:
+            return None if self.eof else self._to_fallback_and_next()
+        self._handed = True
+        return self._bufs[self._cur][self._start:self._end]
+
+    def _finish_tail(self):
+        """A last line without its newline gets one (as RawChunker does)."""
+        if self.eof and self._end > self._start and self._bufs[self._cur][self._end - 1] != _NL:
+            self._bufs[self._cur][self._end] = _NL       # (1 MiB of slack behind chunk_size)
+            self._end += 1
+
+    def consumed(self, n):
+        if self._fallback is not None:
+            return self._fb_consumed(n)
+        self._handed = False
+        rest = (self._end - self._start) - n
+        if self.eof:                                     # nothing more will come: the rest stays in this buffer
+            self._start += n
+            return
+        if n == 0 or rest > self.HEAD:                   # out of the ordinary: continue on one growing buffer
+            self._start += n
+            self._to_fallback()
+            return
+        other = 1 - self._cur
+        if rest:
+            self._bufs[other][self.HEAD - rest:self.HEAD] = self._bufs[self._cur][self._start + n:self._end]
+        self._join()                                     # the other buffer's bytes are in
+        self._cur = other
+        self._start = self.HEAD - rest
+        self._end = self.HEAD + self._next_fill
+        self.eof = self._next_eof
+        self._finish_tail()
+        if not self.eof:
+            self._start_read(1 - self._cur)
+
+    # --- fallback: everything that is left, on one growing pageable buffer (RawChunker's loop)
+    def _to_fallback(self):
+        self._join()
+        cur = self._bufs[self._cur][self._start:self._end]
+        nxt = self._bufs[1 - self._cur][self.HEAD:self.HEAD + self._next_fill] if not self.eof else cur[:0]
+        buf = np.empty(max(2 * (len(cur) + len(nxt)), self.chunk_size + (1 << 20)), dtype=np.uint8)
+        buf[:len(cur)] = cur
+        buf[len(cur):len(cur) + len(nxt)] = nxt
+        self._fallback = {"buf": buf, "fill": len(cur) + len(nxt)}
+        self.eof = self._src_eof
+
+    def _to_fallback_and_next(self):
+        self._to_fallback()
+        return self._fb_next()
+
+    def _fb_next(self):
+        st = self._fallback
+        if self.eof and st["fill"] == 0:
+            return None
+        if st["fill"] == st["buf"].shape[0]:
+            st["buf"] = np.concatenate([st["buf"], np.empty_like(st["buf"])])
+        while not self.eof and st["fill"] < min(self.chunk_size, st["buf"].shape[0]):
+            want = memoryview(st["buf"])[st["fill"]:]
+            if self.left is not None:
+                want = want[:min(len(want), self.left)]
+            got = self.f.readinto(want) if len(want) else 0
+            if self.left is not None:
+                self.left -= got or 0
+            if not got:
+                self.eof = True
+                if st["fill"] and st["buf"][st["fill"] - 1] != _NL:
+                    if st["fill"] == st["buf"].shape[0]:
+                        st["buf"] = np.concatenate([st["buf"], np.empty(16, np.uint8)])
+                    st["buf"][st["fill"]] = _NL
+                    st["fill"] += 1
+                break
+            st["fill"] += got
+        return st["buf"][:st["fill"]] if st["fill"] else None
+
+    def _fb_consumed(self, n):
+        st = self._fallback
+        rest = st["fill"] - n
+        if rest:
+            st["buf"][:rest] = st["buf"][n:st["fill"]]
+        st["fill"] = rest
+
+    def close(self):
+        try:
+            self._join()
+        except BaseException:            # noqa: BLE001 - closing: the consumer's error (if any) is the one to report
+            pass
+        self.f.close()
+        if self._pinned:
+            from . import _lib
+            self._bufs = []
+            for p in self._pinned:
+                _lib.lib().kmm_host_free(p)
+            self._pinned = []

@@ -426,3 +426,40 @@ def test_native_reader_equals_python_reader_on_every_kind_of_file(tmp_path):
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, KMM_IO_NO_LIBDEFLATE="1"), capture_output=True)
     assert r.returncode == 0, r.stderr[-500:]
     assert r.stdout == data
+
+
+@pytest.mark.parametrize("chunk_size", [500, 4096, 100_000, 10_000_000])
+@pytest.mark.parametrize("trailing_newline", [True, False])
+def test_prefetching_chunker_hands_out_the_same_records_as_the_plain_one(tmp_path, chunk_size, trailing_newline):
+    """PrefetchingRawChunker (two buffers + a reader thread, what `kmer_mapper map` feeds the GPU parser from) and
+    RawChunker cut by the same consumer give the same byte stream: ordinary chunks, records longer than a chunk (the
+    consumer uses nothing and asks again), a last line without its newline."""
+    rng = np.random.default_rng(5)
+    recs = []
+    for i in range(2000):
+        n = int(rng.integers(20, 300))
+        seq = bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), n))
+        recs.append(b"@r%d\n" % i + seq + b"\n+\n" + b"I" * n + b"\n")
+    data = b"".join(recs)
+    path = tmp_path / "x.fq"
+    path.write_bytes(data if trailing_newline else data[:-1])
+    for cls in (reads_io.RawChunker, reads_io.PrefetchingRawChunker):
+        ch = cls(str(path), chunk_size)
+        out, calls = [], 0
+        try:
+            while True:
+                calls += 1
+                assert calls < 100_000
+                b = ch.next_chunk()
+                if b is None:
+                    break
+                used = reads_io.records_cut(b, "fastq", ch.eof)
+                if used == 0:
+                    assert not ch.eof
+                    ch.chunk_size *= 2
+                    continue
+                out.append(bytes(b[:used]))
+                ch.consumed(used)
+        finally:
+            ch.close()
+        assert b"".join(out) == data, cls.__name__
