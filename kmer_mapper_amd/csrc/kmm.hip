@@ -1081,9 +1081,18 @@ static int rx_build(kmm_index *ix, const int32_t *h2i, const int32_t *nk, const 
                 "dense for LDS or more than 512 x 512 of them", ix->rx_w, ix->rx_F1, ix->rx_F2);
     if (ix->rx_ok)
         KMMCHK(rx_repack_keys(ix));
-    // auto: the radix path streams the whole directory + key arrays once per batch (4 B x modulo + 14 B x entries),
-    // which pays off once the batch's own streams (~40 B per k-mer) dominate
-    ix->rx_min_units = (int64_t)((M * 4 + ix->rx_S * 14) / 8);
+    // auto: the radix path streams the whole directory + key arrays once per batch (4 B x modulo + 14 B x entries) and
+    // then costs ~6.5 ps per k-mer (10 ps at the 1 B-k-mer index: shorter runs); the direct kernel has no fixed cost and
+    // runs at ~60 G k-mers/s below ~1 GB of index, ~38 G above.  The batch size where the two meet
+    // (profiles/r03/path_crossover.txt: 16-20 M positions at the 10 M index, ~52 M at the 100 M index; units are
+    // base positions, 1.25 per k-mer at 150 bp):
+    {
+        const double bytes = (double)M * 4.0 + (double)ix->rx_S * 14.0;
+        const double fixed = 50e-6 + bytes / 2.6e12;
+        const double per_kmer_radix = 6.5e-12 * (1.0 + bytes / 40e9);
+        const double per_kmer_direct = 1.0 / (bytes < 1e9 ? 60e9 : 38e9);
+        ix->rx_min_units = (int64_t)(1.25 * fixed / (per_kmer_direct - per_kmer_radix));
+    }
     if (ix->rx_min_units < ((int64_t)1 << 22))
         ix->rx_min_units = (int64_t)1 << 22;
     if (const char *env = getenv("KMM_RX_MIN_UNITS"))
