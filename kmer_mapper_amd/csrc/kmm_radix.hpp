@@ -121,6 +121,8 @@ enum { MODE_KMERS = 3 };              // pass-1 source: a uint64 k-mer array ins
 
 struct RxView {
     // index side (built once at kmm_index_create)
+    const uint16_t *pstart16; // [PF << w] the same relative to the first entry of the bucket's slice (pass 3 loads half
+    const uint32_t *slice_e0; // the bytes); [PF + 1] first entry of every slice.  Null: slices beyond 65535 entries
     const uint32_t *pstart; // [modulo + 1] first entry of every bucket in bucket order (exclusive prefix of the
                             //              bucket sizes; pstart[modulo] = S): any 2^w-bucket slice is a directory
     const uint64_t *pkeys;  // [S] entry k-mers in bucket order, in the packed form the passes carry (rx_pack)
@@ -1479,10 +1481,12 @@ __global__ void __launch_bounds__(P2F_NT) k_rx_p2f(IndexView iv, RxView rx)
 // ------------------------------------------------------------------------------------------------
 // DirT: type of the LDS directory; uint16_t (half the LDS: 8192-bucket slices with two workgroups per CU) only when
 // no slice of the index holds more than 65535 entries (launch_rx checks).
-template <int WMAX, int ECAP, int WPS, typename DirT, int SUBCAP = RX_SUBCAP3>
+// P16: the slice's directory comes from rx.pstart16 (two buckets per 32-bit load, already relative to the slice).
+template <int WMAX, int ECAP, int WPS, typename DirT, int SUBCAP = RX_SUBCAP3, bool P16 = false>
 __global__ void __launch_bounds__(RX_NT, WPS) k_rx_p3(IndexView iv, RxView rx, int max_freq)
 {
-    __shared__ DirT sdir[WMAX + 1]; // bucket b of the slice holds entries [sdir[b], sdir[b + 1]) - e0
+    static_assert(!P16 || sizeof(DirT) == 2, "the 16-bit directory is copied as it is");
+    __shared__ __attribute__((aligned(4))) DirT sdir[WMAX + 2]; // bucket b of the slice holds entries [sdir[b], sdir[b + 1]) - e0
     __shared__ uint64_t skeys[ECAP];
     __shared__ uint32_t scnt[ECAP];
     __shared__ uint32_t sub_list[SUBCAP];
@@ -1504,12 +1508,12 @@ __global__ void __launch_bounds__(RX_NT, WPS) k_rx_p3(IndexView iv, RxView rx, i
     // A work item's description (uniform): its fine partition's place in the index and its items.  It is worked
     // out — two dependent loads — while the PREVIOUS work item streams its k-mers.
     struct Slice {
-        uint32_t valid, g, e0, ne, it0, n_it, over;
+        uint32_t valid, g, e0, ne, it0, n_it, over, tot;
         uint64_t h0;
     };
     auto describe = [&](uint32_t sub, uint32_t idx) {
         Slice d;
-        d.valid = 0; d.g = 0; d.e0 = 0; d.ne = 0; d.it0 = 0; d.n_it = 0; d.h0 = 0; d.over = 0;
+        d.valid = 0; d.g = 0; d.e0 = 0; d.ne = 0; d.it0 = 0; d.n_it = 0; d.h0 = 0; d.over = 0; d.tot = 0;
         if (idx >= limit)
             return d;
         const uint32_t row = idx / gs, g = sub * gs + idx % gs;
@@ -1529,8 +1533,15 @@ __global__ void __launch_bounds__(RX_NT, WPS) k_rx_p3(IndexView iv, RxView rx, i
         d.valid = 1;
         d.g = g;
         d.h0 = (uint64_t)(c * F2 + g) << rx.w;
-        d.e0 = rx.pstart[d.h0];
-        const uint32_t e1 = rx.pstart[d.h0 + W < M ? d.h0 + W : M];
+        uint32_t e1;
+        if (P16) {
+            d.e0 = rx.slice_e0[c * F2 + g];
+            e1 = rx.slice_e0[c * F2 + g + 1u];
+        } else {
+            d.e0 = rx.pstart[d.h0];
+            e1 = rx.pstart[d.h0 + W < M ? d.h0 + W : M];
+        }
+        d.tot = e1 - d.e0;
         d.ne = e1 - d.e0 < (uint32_t)ECAP ? e1 - d.e0 : (uint32_t)ECAP;
         d.over = e1 - d.e0 > (uint32_t)ECAP ? 1u : 0u; // entries beyond the LDS copy: their buckets are walked in HBM
         d.it0 = rx.item_base[c] + chunk * RX_IC;
@@ -1568,10 +1579,21 @@ __global__ void __launch_bounds__(RX_NT, WPS) k_rx_p3(IndexView iv, RxView rx, i
         uint32_t dv[WMAX / RX_NT + 1];
         uint64_t kv[ECAP / RX_NT];
         uint32_t fv[ECAP / RX_NT];
+        if (P16) { // two buckets per word (W is even from w = 1 on; w = 0: one 16-bit load by thread 0)
+            const uint32_t *p32 = reinterpret_cast<const uint32_t *>(rx.pstart16 + h0);
 #pragma unroll
-        for (int j = 0; j <= WMAX / RX_NT; ++j) {
-            const uint32_t i = tid + j * RX_NT;
-            dv[j] = i <= W ? rx.pstart[h0 + i < M ? h0 + i : M] : 0u;
+            for (int j = 0; j < WMAX / 2 / RX_NT; ++j) {
+                const uint32_t i = tid + j * RX_NT;
+                dv[j] = i < W / 2u ? p32[i] : 0u;
+            }
+            if (W < 2u)
+                dv[0] = tid == 0 ? (uint32_t)rx.pstart16[h0] : 0u;
+        } else {
+#pragma unroll
+            for (int j = 0; j <= WMAX / RX_NT; ++j) {
+                const uint32_t i = tid + j * RX_NT;
+                dv[j] = i <= W ? rx.pstart[h0 + i < M ? h0 + i : M] : 0u;
+            }
         }
 #pragma unroll
         for (int j = 0; j < ECAP / RX_NT; ++j) {
@@ -1587,11 +1609,25 @@ __global__ void __launch_bounds__(RX_NT, WPS) k_rx_p3(IndexView iv, RxView rx, i
             rf[j] = i < n_it ? rfp[i] : 0u;
             rt[j] = i < n_it ? rtp[i] : 0u;
         }
+        if (P16) {
+            uint32_t *sd32 = reinterpret_cast<uint32_t *>(sdir);
 #pragma unroll
-        for (int j = 0; j <= WMAX / RX_NT; ++j) {
-            const uint32_t i = tid + j * RX_NT;
-            if (i <= W)
-                sdir[i] = (DirT)(dv[j] - e0);
+            for (int j = 0; j < WMAX / 2 / RX_NT; ++j) {
+                const uint32_t i = tid + j * RX_NT;
+                if (i < W / 2u)
+                    sd32[i] = dv[j];
+            }
+            if (W < 2u && tid == 0)
+                sdir[0] = (DirT)dv[0];
+            if (tid == 0)
+                sdir[W] = (DirT)sl.tot; // (one past the last bucket: the slice's entries)
+        } else {
+#pragma unroll
+            for (int j = 0; j <= WMAX / RX_NT; ++j) {
+                const uint32_t i = tid + j * RX_NT;
+                if (i <= W)
+                    sdir[i] = (DirT)(dv[j] - e0);
+            }
         }
 #pragma unroll
         for (int j = 0; j < ECAP / RX_NT; ++j) {
@@ -1920,6 +1956,23 @@ __global__ void k_rx_bucket_sizes(const int32_t *__restrict__ h2i, const int32_t
 }
 
 // occupancy bitmap of the bucket directory: bit h = bucket h holds an entry (the array is zeroed first)
+// pstart16[h] = pstart[h] - pstart[first bucket of h's slice] for h < PF << w (buckets beyond the modulo: the slice's
+// entry count), slice_e0[f] = pstart[f << w] for f <= PF.  Only called when no slice holds more than 65535 entries.
+__global__ void __launch_bounds__(256) k_rx_pstart16(const uint32_t *__restrict__ pstart, uint64_t modulo, int w, uint32_t PF,
+                                                     uint16_t *__restrict__ out, uint32_t *__restrict__ slice_e0)
+{
+    const uint64_t n = (uint64_t)PF << w;
+    for (uint64_t h = (uint64_t)blockIdx.x * 256 + threadIdx.x; h < n; h += (uint64_t)gridDim.x * 256) {
+        const uint64_t f = h >> w, hs = f << w;
+        const uint32_t base = pstart[hs < modulo ? hs : modulo];
+        out[h] = (uint16_t)(pstart[h < modulo ? h : modulo] - base);
+        if (h == hs)
+            slice_e0[f] = base;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        slice_e0[PF] = pstart[modulo];
+}
+
 __global__ void __launch_bounds__(256) k_rx_build_occ(const uint32_t *__restrict__ pstart, uint64_t modulo, uint32_t *__restrict__ occ)
 {
     for (uint64_t wd = (uint64_t)blockIdx.x * 256 + threadIdx.x; wd * 32 < modulo; wd += (uint64_t)gridDim.x * 256) {
