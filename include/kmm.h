@@ -259,7 +259,9 @@ int kmm_get_kmer_counts(kmm_index_t *idx, uint32_t *out);
  *                      2 = radix path (two partition passes by hash range + probe of LDS-resident index
  *                      slices)
  *   "part_shift"       log2 of the number of hash buckets per fine partition of the radix path (0..13)
- *   "radix_min_units"  auto: smallest batch (positions / k-mers) that takes the radix path
+ *   "radix_min_units"  auto: smallest batch (positions / k-mers) that takes the radix path; default: where the two
+ *                      paths break even under a cost model fitted to measurements (~0.38 M reads of 150 bp at a
+ *                      100 M-k-mer index)
  *   "radix_grid_per_cu" persistent workgroups per CU of passes 2 and 3 (1 or 2; 2 by default)
  *   "radix_sorted_flush" 1 (default) = per-entry counts are added to the node counts through the node-ordered entry
  *                      list (built when an index has fewer than 8 entries per node on average); 0 = in bucket order
@@ -275,7 +277,8 @@ int kmm_get_kmer_counts(kmm_index_t *idx, uint32_t *out);
  *   "n_fine_per_coarse", "radix_p2_kmers" / "radix_p3_kmers" / "radix_p2_dropped" (the conservation counters every
  *   synchronising call compares: KMM_ERR_INTERNAL), "radix_batches" / "direct_batches" (which path the map calls took),
  *   "radix_view_bytes" / "direct_view_bytes" / "direct_view_resident" (HBM budget: the direct view of an index beyond
- *   16 GiB of it is packed on first use), "wide_buckets", "occupancy_filter", "bloom_filter_bytes".
+ *   16 GiB of it is packed on first use), "radix_p3_keys_in_lds" (entries of a slice pass 3 keeps in LDS: 4096, 4608 or
+ *   8192; buckets behind them are walked in HBM), "wide_buckets", "occupancy_filter", "bloom_filter_bytes".
  * Unknown names return KMM_ERR_INVALID_ARG.
  */
 int kmm_set_param(kmm_index_t *idx, const char *name, int64_t value);
