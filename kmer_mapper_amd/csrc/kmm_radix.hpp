@@ -334,13 +334,15 @@ struct RxNoHook {
 // the caller then guarantees a barrier of its own before sbuf is written again and before the next call's ranking
 // (which needs the counters this call clears during its copy-out).
 template <int RB, bool ENDBAR, bool ONEBAR, int NT = RX_NT, bool NTSTORE = ONEBAR, typename PrepFn,
-          typename MidFn = RxNoHook, int WAVESCAN = 0, bool NOWTID = false>
+          typename MidFn = RxNoHook, int WAVESCAN = 0, bool NOWTID = false, typename PostFn = RxNoHook>
 __device__ __forceinline__ void rx_sort_emit(uint64_t (&q)[RX_B / NT], PrepFn prep, int F, uint64_t *sbuf,
                                              uint32_t *s_cnt, uint32_t *s_base, uint32_t *s_wave,
                                              uint64_t *__restrict__ out, uint16_t *__restrict__ dir_row,
                                              unsigned long long *pt_acc = nullptr, MidFn mid = MidFn(),
-                                             int n_slots = RX_B / NT, int wave_s = -1)
+                                             int n_slots = RX_B / NT, int wave_s = -1, PostFn post = PostFn())
 {
+    // `post` runs after the placement, before its barrier (pass 1 stages the NEXT tile's codes there: that barrier then
+    // also publishes them and the tile's own barrier goes)
     // NOWTID: the thread index is rebuilt from the wavefront's number wave_s (uniform, a scalar register) behind every
     // barrier (rx_tid_now) instead of living in a register across the whole sort
     auto tid_now = [&]() { return NOWTID ? rx_tid_now(wave_s) : (int)threadIdx.x; };
@@ -429,6 +431,7 @@ __device__ __forceinline__ void rx_sort_emit(uint64_t (&q)[RX_B / NT], PrepFn pr
             sbuf[pos] = q[h];
     }
     }
+    post();
     __syncthreads();
     RX_PT(3); // scan + placement
     tid = tid_now();
@@ -563,6 +566,10 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p1(ReadsView rv, const uint64_t
                                                  IndexView iv, RxView rx, int k, int64_t tile_begin, uint32_t n_src)
 {
     constexpr bool PACKED = MODE == MODE_PACKED;   // reads of one length, tiles of whole reads (kmm_tile.hpp)
+#ifndef RX_P1_STAGE_EARLY
+#define RX_P1_STAGE_EARLY 1
+#endif
+    constexpr bool STAGE_EARLY = PACKED && !RC && RX_P1_STAGE_EARLY != 0; // three barriers per block instead of four
     constexpr int TM = (MODE == MODE_KMERS || PACKED) ? MODE_UNIFORM : MODE;
     constexpr int S = TM == MODE_RECORDS ? 4 : 16; // windows per lane per tile
     constexpr int R = RX_KPT / S;                  // tiles per half-workgroup per block
@@ -617,6 +624,19 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p1(ReadsView rv, const uint64_t
                 }
             }
         } else {
+            if constexpr (STAGE_EARLY) {
+                // packed tiles: this block's codes were staged in LDS behind the previous block's placement (its barrier
+                // published them); the next block's bytes are requested now and staged behind this block's placement
+                const int64_t tile = tile_begin + ((int64_t)sb * 2 + half);
+                if (sb == blockIdx.x) {
+                    load_tile(tile, pw[0]);
+                    tile_packed_stage(rv, tile, sm[half], ltid, pw[0]);
+                    __syncthreads();
+                }
+                valid = tile_packed_fetch(rv, tc, tile, sm[half], q, ltid);
+                if (sb + gridDim.x < n_src)
+                    load_tile(tile_begin + ((int64_t)(sb + gridDim.x) * 2 + half), pw[0]);
+            } else {
             // the block's staged bytes: all tiles' loads are in flight together; flat reads (one tile per half):
             // the NEXT block's bytes are requested before this block is sorted, so their latency hides behind it
             if (!PREFETCH || sb == blockIdx.x) {
@@ -644,6 +664,7 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p1(ReadsView rv, const uint64_t
 #pragma unroll
                 for (int r = 0; r < R; ++r)
                     load_tile(tile_begin + ((int64_t)(sb + gridDim.x) * 2 + half) * R + r, pw[r]);
+            }
             }
         }
         lookups += (uint32_t)__popc(valid) * X;
@@ -673,9 +694,15 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p1(ReadsView rv, const uint64_t
                 q[i] = rx_pack(iv, sh, q[i], &c);
                 return ((valid >> i) & 1u) ? c : spare;
             };
-            rx_sort_emit<RX_RB1, MODE == MODE_KMERS, true, RX_NT, true, decltype(fwd), RxNoHook, 0, true>(
+            auto post = [&]() { // behind the placement: the next block's codes into LDS (the sort's barrier publishes them)
+                if constexpr (STAGE_EARLY) {
+                    if (sb + gridDim.x < n_src)
+                        tile_packed_stage(rv, tile_begin + ((int64_t)(sb + gridDim.x) * 2 + half), sm[half], ltid, pw[0]);
+                }
+            };
+            rx_sort_emit<RX_RB1, MODE == MODE_KMERS, true, RX_NT, true, decltype(fwd), RxNoHook, 0, true, decltype(post)>(
                 q, fwd, F1, sbuf, s_cnt, s_base, s_wave, rx.buf1 + (size_t)sb * RX_B,
-                rx.start1 + (size_t)sb * (size_t)(F1 + 1) RX_PT_ARG2, RxNoHook(), RX_KPT, wave_s);
+                rx.start1 + (size_t)sb * (size_t)(F1 + 1) RX_PT_ARG2, RxNoHook(), RX_KPT, wave_s, post);
         }
     }
 #ifdef RX_PT_P1

@@ -425,20 +425,17 @@ __device__ __forceinline__ void tile_packed_load(const ReadsView &rv, int64_t ti
     }
 }
 
-// Returns the lane's windows (q[0 .. pk_S)) and the mask of the real ones.  TOPBAR as in tile_kmers.
-template <bool TOPBAR>
-__device__ __forceinline__ uint32_t tile_packed_kmers(const ReadsView &rv, const TileConst &tc, int64_t tile, int k,
-                                                      TilePackedSmem &sm, uint64_t (&q)[16], const int tid,
-                                                      const TilePackedRaw &raw)
+// Stage the tile's bytes as 2-bit codes in LDS (bytes before the first read / past the chunk are staged as code 0,
+// unflagged).  A workgroup barrier must follow before tile_packed_fetch; one must lie between the previous tile's
+// fetch and this call.
+__device__ __forceinline__ void tile_packed_stage(const ReadsView &rv, int64_t tile, TilePackedSmem &sm, const int tid,
+                                                  const TilePackedRaw &raw)
 {
     const uint32_t L = (uint32_t)rv.read_len;
     const int64_t first = tile * (int64_t)rv.pk_rpt * (int64_t)L;
     const int64_t base = first & ~(int64_t)15;
     const uint32_t delta = (uint32_t)(first - base);
     const uint32_t nbytes = delta + rv.pk_rpt * L;
-    if (TOPBAR)
-        __syncthreads(); // every wave has finished reading the previous tile's LDS words
-    // ---- bytes -> 2-bit codes in LDS (bytes before the first read / past the chunk are staged as code 0, unflagged)
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const uint32_t off = (uint32_t)(tid + h * 256) * 16u;
@@ -466,8 +463,15 @@ __device__ __forceinline__ uint32_t tile_packed_kmers(const ReadsView &rv, const
     }
     if (tid < 4) // (a lane's 16-window fetch may touch up to three words past the last staged one)
         sm.codes[((nbytes + 15u) >> 4) + (uint32_t)tid] = 0u;
-    __syncthreads();
-    // ---- lane (r, s): windows s * S .. of read r
+}
+
+// Lane (r, s): the windows s * S .. of read r from the staged codes; returns the mask of the real ones.
+__device__ __forceinline__ uint32_t tile_packed_fetch(const ReadsView &rv, const TileConst &tc, int64_t tile,
+                                                      const TilePackedSmem &sm, uint64_t (&q)[16], const int tid)
+{
+    const uint32_t L = (uint32_t)rv.read_len;
+    const int64_t first = tile * (int64_t)rv.pk_rpt * (int64_t)L;
+    const uint32_t delta = (uint32_t)(first - (first & ~(int64_t)15));
     const uint32_t r = ((uint32_t)tid * rv.pk_inv) >> 16;          // tid / pk_lpr (exact for tid < 256)
     const uint32_t s = (uint32_t)tid - r * rv.pk_lpr;
     const uint32_t o = s * rv.pk_S;                                // first window of the lane inside its read
@@ -489,6 +493,19 @@ __device__ __forceinline__ uint32_t tile_packed_kmers(const ReadsView &rv, const
 #pragma unroll
     for (int j = 0; j < 16; ++j)
         q[j] = (j == 0 ? lo : ((lo >> (2 * j)) | (hi << (64 - 2 * j)))) & tc.kmask;
-    (void)k;
     return nwin >= 16 ? 0xFFFFu : (1u << nwin) - 1u;
+}
+
+// Returns the lane's windows (q[0 .. pk_S)) and the mask of the real ones.  TOPBAR as in tile_kmers.
+template <bool TOPBAR>
+__device__ __forceinline__ uint32_t tile_packed_kmers(const ReadsView &rv, const TileConst &tc, int64_t tile, int k,
+                                                      TilePackedSmem &sm, uint64_t (&q)[16], const int tid,
+                                                      const TilePackedRaw &raw)
+{
+    (void)k;
+    if (TOPBAR)
+        __syncthreads(); // every wave has finished reading the previous tile's LDS words
+    tile_packed_stage(rv, tile, sm, tid, raw);
+    __syncthreads();
+    return tile_packed_fetch(rv, tc, tile, sm, q, tid);
 }
