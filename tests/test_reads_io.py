@@ -463,3 +463,33 @@ def test_prefetching_chunker_hands_out_the_same_records_as_the_plain_one(tmp_pat
         finally:
             ch.close()
         assert b"".join(out) == data, cls.__name__
+
+
+def test_prefetching_chunker_reports_a_truncated_gz_in_the_consumers_thread(tmp_path):
+    """The reader thread's error (gzip stream that ends early: EOFError, like gzip.open) reaches the caller of
+    next_chunk / consumed — `kmer_mapper map` must not return partial counts for a truncated reads.fq.gz."""
+    import gzip
+    rng = np.random.default_rng(9)
+    recs = []
+    for i in range(3000):
+        seq = bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), 100))
+        recs.append(b"@r%d\n" % i + seq + b"\n+\n" + b"I" * 100 + b"\n")
+    data = b"".join(recs)
+    good = tmp_path / "good.fq.gz"
+    with gzip.open(good, "wb", compresslevel=1) as f:
+        f.write(data)
+    raw = good.read_bytes()
+    bad = tmp_path / "bad.fq.gz"
+    bad.write_bytes(raw[:len(raw) * 2 // 3])
+    ch = reads_io.PrefetchingRawChunker(str(bad), 50_000)
+    with pytest.raises(EOFError):
+        try:
+            while True:
+                b = ch.next_chunk()
+                if b is None:
+                    break
+                used = reads_io.records_cut(b, "fastq", ch.eof)
+                assert used
+                ch.consumed(used)
+        finally:
+            ch.close()
