@@ -121,15 +121,15 @@ def map_gpu_raw(index, path, chunk_size, fmt, k, map_reverse_complements=False,
     if byte_range is not None:
         logging.info("Rank %d of %d maps bytes [%d, %d) of %s", rank, world_size, byte_range[0], byte_range[1], path)
     # GPU batches: the reference maps chunk by chunk (-c bytes, command_line_interface.py:109-111,169); here the chunks
-    # of a large file are accumulated until one map call holds enough positions for the radix path to run well (raw
-    # chunks take it from 2 x radix_min_units bytes on, for indexes beyond the direct path's L2 pre-filter), at most
-    # 2 GiB per call.
+    # of a large file are accumulated until one map call holds enough positions for the radix path to run well (a raw
+    # FASTQ piece takes it from 2 x radix_min_units bytes on: its sequence lines are compacted into flat reads on the
+    # device first, kmm_map_records), at most 2 GiB per call.
     batch_bytes = int(chunk_size)
     try:
         n_file = os.stat(path).st_size * (6.5 if not seekable else 1)
     except OSError:
         n_file = 0
-    if dev.get_param("radix_available") and dev.get_param("wide_buckets") and not os.environ.get("KMM_CLI_NO_BATCHING"):
+    if dev.get_param("radix_available") and not os.environ.get("KMM_CLI_NO_BATCHING"):
         # (radix_min_units is where the radix path BREAKS EVEN with the direct kernel, in base positions ~ half the
         # FASTQ bytes; a batch twelve times that runs within 20 % of the path's large-batch rate)
         want = min(max(int(12 * dev.get_param("radix_min_units")), 256 << 20), 2 << 30)
@@ -303,7 +303,8 @@ def run_argument_parser(args):
     subparser.add_argument("--apply-max-hits-per-kmer", action="store_true",
                            help="Extension: actually apply -I (the reference parses it but always uses 1000).")
     subparser.add_argument("--host-parser", action="store_true",
-                           help="Extension: parse records on the host (always used for multi-line FASTA).")
+                           help="Extension: parse records on the host instead of on the GPU (kmm_map_records; wrapped FASTA is "
+                                "unwrapped on the GPU too).")
     subparser.add_argument("--device", default=0, type=int, help="Extension: GPU ordinal (single process).")
     subparser.set_defaults(func=map_bnp)
 

@@ -127,7 +127,7 @@ void default_lut(uint8_t lut[256])
 }
 
 struct Stage {
-    DevBuf bases, offsets, tile_first, start_bits, kmers, lut;
+    DevBuf bases, offsets, tile_first, start_bits, kmers, lut, aux;
     hipEvent_t done = nullptr; // the last kernel that read this stage has finished
     bool used = false;
 };
@@ -164,6 +164,7 @@ struct kmm_index {
     uint32_t *counts = nullptr;
     uint32_t *own_counts_buf = nullptr;
     uint8_t *lut_default = nullptr;
+    uint8_t *lut_codes = nullptr;        // codes 0..3 map to themselves: flat reads compacted from raw records (k_rec_scatter)
     unsigned long long *first_bad = nullptr;
     unsigned long long *stats = nullptr;
     unsigned long long *queue = nullptr; // tile counter of the dynamic schedule
@@ -185,6 +186,7 @@ struct kmm_index {
     bool rx_fits_small = false, rx_fits_mid = false; // all but one slice in 1000 hold at most RX_ECAP / RX_ECAP_MID entries
     int rx_grid_per_cu = 2;   // persistent workgroups of passes 2 and 3 per CU (1: leave room for another stream's kernels)
     int64_t rx_min_units = 0; // auto: batches of at least this many positions / k-mers take the radix path
+    int64_t rx_sub_cap = ((int64_t)1 << 32) - 2 * RX_B; // k-mer slots per sub-batch of the radix path ("radix_sub_batch_kmers")
     uint64_t rx_S = 0;        // entries in bucket order
     uint32_t *rx_pstart = nullptr;
     uint64_t *rx_pkeys = nullptr;     // packed form for the current (w, f2)
@@ -525,11 +527,37 @@ int launch_rx(kmm_index *ix, const ReadsView &rv, const uint64_t *kmers_in, int6
     const int64_t n_src_total = MODE == MODE_PACKED ? (rv.n_reads + 2 * (int64_t)rv.pk_rpt - 1) / (2 * (int64_t)rv.pk_rpt)
                                                     : (units + RX_B - 1) / RX_B;
     const uint32_t X = also_rc ? 2u : 1u;
-    const int64_t cap_src = (((int64_t)1 << 31) / RX_B) / X; // < 2^31 k-mers per sub-batch: 32-bit prefixes
-    // sub-batches of equal size (every one of them streams the index slices once: no small last one)
-    const int64_t n_sub = (n_src_total + cap_src - 1) / cap_src;
-    const int64_t max_src = n_sub ? (n_src_total + n_sub - 1) / n_sub : cap_src;
     const uint32_t F1 = ix->rx_F1, F2 = ix->rx_F2;
+    // Sub-batches.  Every sub-batch streams the index slices once (pass 3) and pays the per-work-item costs once, so they
+    // are as large as the 32-bit prefixes allow: a coarse partition's k-mers are numbered with 32 bits and in the worst
+    // case (one k-mer repeated) ALL of a sub-batch's k-mers fall into one coarse partition, hence fewer than 2^32 k-mer
+    // slots per sub-batch (r03: 2^31; the 1 B-k-mer index streamed its 14 GB of slices twice per 28 M-read batch).  Every
+    // other offset is 64-bit or relative (to a table's first block, to a work item's first item).  Without the HBM for
+    // the buffers of that size the cap is halved (and stays halved for the handle).
+    // Sub-batches of equal size: no small last one.
+    int64_t n_sub = 1, max_src = 0;
+    for (;;) {
+        const int64_t cap_src = (ix->rx_sub_cap / RX_B) / X;
+        n_sub = (n_src_total + cap_src - 1) / cap_src;
+        max_src = n_sub ? (n_src_total + n_sub - 1) / n_sub : cap_src;
+        const size_t NBm = (size_t)max_src * X, chunks_m = (NBm + RX_CH - 1) / RX_CH, items_m = NBm + F1 + 1;
+        const size_t meta = align256(NBm * (F1 + 1) * 2) + align256((size_t)F1 * (NBm + 1) * 4) + align256((size_t)F1 * NBm * 2) +
+                            align256(chunks_m * F1 * 4) + 3 * align256((size_t)(F1 + 1) * 4) + align256(items_m * 8) +
+                            align256(items_m * (F2 + 1) * 2) + align256(items_m * (F2 + 1) * 2 + 256) + align256(64) + align256(2048);
+        int rc = ensure(ix->rx_meta, meta);
+        if (rc == KMM_OK)
+            rc = ensure(ix->rx_buf1, NBm * RX_B * 8);
+        if (rc == KMM_OK)
+            rc = ensure(ix->rx_buf2, items_m * RX_B * 8);
+        if (rc == KMM_OK)
+            break;
+        if (rc != KMM_ERR_NOMEM || ix->rx_sub_cap <= ((int64_t)1 << 28) || n_src_total <= 1)
+            return rc;
+        (void)hipGetLastError();
+        release(ix->rx_buf1);
+        release(ix->rx_buf2);
+        ix->rx_sub_cap /= 2;
+    }
     for (int64_t s0 = 0; s0 < n_src_total; s0 += max_src) {
         const uint32_t n_src = (uint32_t)(n_src_total - s0 < max_src ? n_src_total - s0 : max_src);
         const uint32_t NB = n_src * X;
@@ -663,15 +691,9 @@ template <int MODE>
 int launch_map_reads(kmm_index *ix, const ReadsView &rv, int k, int max_freq, int also_rc)
 {
     const int64_t n_tiles = (rv.total + TILE_T - 1) / TILE_T;
-    // records mode: pass 1's front end (line numbering of raw file bytes) costs more than the direct kernel hides
-    // behind its gathers (profiles/r02/README.md: 34 vs 45 G k-mers/s at the 10 M index), so raw chunks take the
-    // radix path only when it is forced
-    // ... or for a large batch against an index too large for the direct path's L2 pre-filter (wide buckets: the direct
-    // kernel then runs at the 55 G requests/s random-access ceiling, ~38 G k-mers/s at the 100 M index, and the radix
-    // path's slower front end still wins)
-    const bool radix = MODE == MODE_RECORDS ? (ix->rx_ok && ix->path != 1 && (ix->path == 2 || ix->rx_ecnt_acc ||
-                                                                               (ix->wide && rv.total >= 2 * ix->rx_min_units)))
-                                            : use_radix(ix, rv.total);
+    // raw records reach this function only for the direct path: on the radix path they are compacted into flat reads
+    // first (map_records_piece_radix)
+    const bool radix = MODE == MODE_RECORDS ? false : use_radix(ix, rv.total);
     if (!radix) {
         KMMCHK(ensure_direct(ix));
         ix->n_direct_batches++;
@@ -700,9 +722,13 @@ int launch_map_reads(kmm_index *ix, const ReadsView &rv, int k, int max_freq, in
         HIPCHK(hipGetLastError());
         return tm.end();
     }
-    if (MODE == MODE_UNIFORM && rv.pk_rpt) // reads of one length: tiles of whole reads, every computed window a real k-mer
-        return launch_rx<MODE_PACKED>(ix, rv, nullptr, 0, k, max_freq, also_rc);
-    return launch_rx<MODE>(ix, rv, nullptr, 0, k, max_freq, also_rc);
+    if constexpr (MODE == MODE_RECORDS) {
+        return fail(KMM_ERR_INTERNAL, "raw records reach the radix path as flat reads only");
+    } else {
+        if (MODE == MODE_UNIFORM && rv.pk_rpt) // reads of one length: tiles of whole reads, every computed window a real k-mer
+            return launch_rx<MODE_PACKED>(ix, rv, nullptr, 0, k, max_freq, also_rc);
+        return launch_rx<MODE>(ix, rv, nullptr, 0, k, max_freq, also_rc);
+    }
 }
 
 // Exclusive scan of n uint32 values on the device (in -> out): 1024-wide block scans, recursing on the
@@ -863,6 +889,7 @@ void kmm_index_destroy(kmm_index_t *ix)
         release(s.start_bits);
         release(s.kmers);
         release(s.lut);
+        release(s.aux);
         if (s.done)
             (void)hipEventDestroy(s.done);
     }
@@ -894,6 +921,8 @@ void kmm_index_destroy(kmm_index_t *ix)
         (void)hipFree(ix->own_counts_buf);
     if (ix->lut_default)
         (void)hipFree(ix->lut_default);
+    if (ix->lut_codes)
+        (void)hipFree(ix->lut_codes);
     if (ix->first_bad)
         (void)hipFree(ix->first_bad);
     if (ix->stats)
@@ -1203,6 +1232,10 @@ static int index_create_impl(kmm_index *ix, const int32_t *h2i, const int32_t *n
     uint8_t lut[256];
     default_lut(lut);
     HIPCHK(hipMemcpy(ix->lut_default, lut, 256, hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc(&ix->lut_codes, 256));
+    memset(lut, 0xFF, sizeof lut);
+    lut[0] = 0; lut[1] = 1; lut[2] = 2; lut[3] = 3;
+    HIPCHK(hipMemcpy(ix->lut_codes, lut, 256, hipMemcpyHostToDevice));
     unsigned long long nb[3] = {NO_BAD, NO_BAD, NO_BAD};
     HIPCHK(hipMemcpy(ix->first_bad, nb, sizeof nb, hipMemcpyHostToDevice));
 
@@ -1594,6 +1627,24 @@ int kmm_map_kmers(kmm_index_t *ix, const uint64_t *kmers, int64_t n, int max_fre
     return stage_release(ix, s, staged);
 }
 
+// Reads of one length: the uniform front end's constants and, where they apply, the packed tiles of the radix path's
+// pass 1 (kmm_tile.hpp): pk_lpr lanes per read, pk_S windows each.
+static void set_uniform_geometry(const kmm_index_t *ix, ReadsView &rv, int64_t read_len, int k)
+{
+    rv.read_len = (uint64_t)read_len;
+    rv.read_len_magic = magic_for((uint64_t)read_len);
+    if (ix->rx_packed && read_len >= k && read_len - k + 1 <= 4096) {
+        const uint32_t W = (uint32_t)(read_len - k + 1), lpr = (W + 15u) / 16u, rpt = 256u / lpr;
+        if (rpt >= 1u && (uint64_t)rpt * (uint64_t)read_len <= 8176u) {
+            rv.pk_rpt = rpt;
+            rv.pk_lpr = lpr;
+            rv.pk_S = (W + lpr - 1u) / lpr;
+            rv.pk_W = W;
+            rv.pk_inv = (65536u + lpr - 1u) / lpr;
+        }
+    }
+}
+
 static int map_reads_common(kmm_index_t *ix, const uint8_t *bases, const int64_t *read_offsets,
                             int64_t n_reads, int64_t read_len, int k, int max_freq,
                             int also_revcomp, const uint8_t *lut)
@@ -1639,19 +1690,7 @@ static int map_reads_common(kmm_index_t *ix, const uint8_t *bases, const int64_t
     // the uniform kernel's wrap-around handles one read boundary per lane: needs read_len >= S
     const bool uniform_kernel = uniform && read_len >= 16;
     if (uniform_kernel) {
-        rv.read_len = (uint64_t)read_len;
-        rv.read_len_magic = magic_for((uint64_t)read_len);
-        // packed tiles for the radix path's pass 1 (kmm_tile.hpp): pk_lpr lanes per read, pk_S windows each
-        if (ix->rx_packed && read_len >= k && read_len - k + 1 <= 4096) {
-            const uint32_t W = (uint32_t)(read_len - k + 1), lpr = (W + 15u) / 16u, rpt = 256u / lpr;
-            if (rpt >= 1u && (uint64_t)rpt * (uint64_t)read_len <= 8176u) {
-                rv.pk_rpt = rpt;
-                rv.pk_lpr = lpr;
-                rv.pk_S = (W + lpr - 1u) / lpr;
-                rv.pk_W = W;
-                rv.pk_inv = (65536u + lpr - 1u) / lpr;
-            }
-        }
+        set_uniform_geometry(ix, rv, read_len, k);
         KMMCHK(stage_copies_done(ix));
         KMMCHK(launch_map_reads<MODE_UNIFORM>(ix, rv, k, max_freq, also_revcomp ? 1 : 0));
     } else {
@@ -1710,6 +1749,88 @@ int kmm_map_reads_uniform(kmm_index_t *ix, const uint8_t *bases, int64_t n_reads
     return map_reads_common(ix, bases, nullptr, n_reads, read_len, k, max_freq, also_revcomp, lut);
 }
 
+// Raw records on the radix path: should a piece of n_bytes raw bytes take it?  (Same rule as for flat reads, on the
+// bases the piece holds at most: half of a FASTQ piece's bytes, all of a FASTA piece's.)
+static bool records_take_radix(const kmm_index_t *ix, int64_t n_bytes, int format)
+{
+    return use_radix(ix, format == KMM_FORMAT_FASTQ ? n_bytes / 2 : n_bytes);
+}
+
+// One piece on the radix path (r04): census -> the sequence bytes compacted into flat reads of 2-bit codes (one per
+// byte) + the read-start bitset (kmm_records.hpp, k_rec_count2 .. k_rec_uniform), all on the copy stream, i.e. under
+// the previous piece's map kernels; then pass 1 runs on flat reads — on packed tiles when the piece's reads have one
+// length — instead of pushing every raw byte through the records front end (22.3 ms per 10 M reads in round 3).
+static int map_records_piece_radix(kmm_index_t *ix, Stage &s, const uint8_t *d_raw, int64_t n_bytes, int format, int k,
+                                   int max_freq, int also_revcomp, const uint8_t *d_lut, int64_t *consumed, int64_t *n_records)
+{
+    const int64_t n_tiles = (n_bytes + 1023) / 1024;
+    const int n_super = (int)((n_tiles + 1023) / 1024);
+    const size_t n_pad = (size_t)n_super * 1024;
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+    const size_t o_nl = carve(n_pad * 4), o_seq = carve(n_pad * 8), o_pre = carve(n_pad * 4), o_snl = carve((size_t)n_super * 4 + 64),
+                 o_sseq = carve((size_t)n_super * 4 + 64), o_info = carve(64), o_out = carve(64);
+    KMMCHK(ensure(s.aux, off));
+    const size_t n_words = (size_t)n_bytes / 32 + 2;
+    KMMCHK(ensure(s.start_bits, n_words * 4));
+    KMMCHK(ensure(s.kmers, (size_t)n_bytes + 64));
+    uint8_t *a = (uint8_t *)s.aux.p;
+    uint32_t *tile_nl = (uint32_t *)(a + o_nl), *tile_pre = (uint32_t *)(a + o_pre), *super_nl = (uint32_t *)(a + o_snl),
+             *super_seq = (uint32_t *)(a + o_sseq);
+    unsigned long long *tile_seq = (unsigned long long *)(a + o_seq), *d_out = (unsigned long long *)(a + o_out);
+    int64_t *d_info = (int64_t *)(a + o_info);
+    uint8_t *flat = (uint8_t *)s.kmers.p;
+    uint32_t *start_bits = (uint32_t *)s.start_bits.p;
+    hipStream_t cs = ix->copy_stream;
+    const uint32_t pm = (uint32_t)format - 1u, hc = format == KMM_FORMAT_FASTQ ? (uint32_t)'@' : (uint32_t)'>';
+    const dim3 g4((unsigned)((n_tiles + 3) / 4));
+    HIPCHK(hipMemsetAsync(tile_nl, 0, n_pad * 4, cs));
+    HIPCHK(hipMemsetAsync(tile_seq, 0, n_pad * 8, cs));
+    HIPCHK(hipMemsetAsync(d_info, 0, 64 + 256, cs)); // (info and out_info: neighbours)
+    HIPCHK(hipMemsetAsync(start_bits, 0, n_words * 4, cs));
+    hipLaunchKernelGGL(k_rec_count2, g4, dim3(256), 0, cs, d_raw, n_bytes, n_tiles, tile_nl, tile_seq);
+    hipLaunchKernelGGL(k_rec_scan1, dim3(n_super), dim3(1024), 0, cs, tile_nl, super_nl);
+    hipLaunchKernelGGL(k_rec_scan2, dim3(1), dim3(1024), 0, cs, d_raw, n_bytes, n_super, tile_nl, super_nl, (uint32_t)format, d_info);
+    hipLaunchKernelGGL(k_rec_seq_scan, dim3(n_super), dim3(1024), 0, cs, tile_seq, tile_nl, super_nl, n_tiles, pm, tile_pre, super_seq);
+    hipLaunchKernelGGL(k_super_scan, dim3(1), dim3(1024), 0, cs, super_seq, n_super, (uint32_t *)(d_out + 4));
+    hipLaunchKernelGGL(k_rec_scatter, g4, dim3(256), 0, cs, d_raw, n_bytes, n_tiles, tile_nl, super_nl, tile_pre, super_seq, d_info,
+                       d_lut, pm, hc, flat, start_bits, ix->first_bad, d_out);
+    hipLaunchKernelGGL(k_rec_uniform, dim3(grid_for(ix, (int64_t)(n_words + 255) / 256, 4)), dim3(256), 0, cs, start_bits, d_info, d_out);
+    HIPCHK(hipGetLastError());
+    struct { int64_t info[8]; unsigned long long out[8]; } h;
+    static_assert(sizeof h == 128, "info and out_info are copied together");
+    memset(&h, 0, sizeof h);
+    if (o_out != o_info + 256) // (carve rounds to 256 bytes: info at o_info, out_info at o_info + 256)
+        return fail(KMM_ERR_INTERNAL, "records: scratch layout");
+    HIPCHK(hipMemcpyAsync(h.info, d_info, 64, hipMemcpyDeviceToHost, cs));
+    HIPCHK(hipMemcpyAsync(h.out, d_out, 64, hipMemcpyDeviceToHost, cs));
+    HIPCHK(hipStreamSynchronize(cs)); // the borrowed host buffer is free from here on
+    *consumed = h.info[0];
+    *n_records = h.info[1];
+    const int64_t total = (int64_t)h.out[0];
+    if (h.info[0] <= 0 || total <= 0)
+        return KMM_OK;
+    ReadsView rv;
+    memset(&rv, 0, sizeof rv);
+    rv.bases = flat;
+    rv.total = total;
+    rv.n_reads = h.info[1];
+    rv.lut = ix->lut_codes;
+    rv.first_bad = ix->first_bad;
+    const int64_t L = h.info[1] > 0 ? total / h.info[1] : 0;
+    const bool uniform = L >= 16 && L * h.info[1] == total && h.out[1] == (unsigned long long)h.info[1] && h.out[2] == 0;
+    KMMCHK(stage_copies_done(ix));
+    if (uniform) {
+        set_uniform_geometry(ix, rv, L, k);
+        if (rv.pk_rpt)
+            return launch_rx<MODE_PACKED>(ix, rv, nullptr, 0, k, max_freq, also_revcomp ? 1 : 0);
+        return launch_rx<MODE_UNIFORM>(ix, rv, nullptr, 0, k, max_freq, also_revcomp ? 1 : 0);
+    }
+    rv.start_bits = start_bits;
+    rv.n_start_words = (int64_t)n_words;
+    return launch_rx<MODE_GENERAL>(ix, rv, nullptr, 0, k, max_freq, also_revcomp ? 1 : 0);
+}
+
 // One piece of at most 2^30 bytes (the newline census is a two-level scan over 1024 x 1024 tiles of 1024 bytes).
 static int map_records_piece(kmm_index_t *ix, const uint8_t *raw, int64_t n_bytes, int format, int k,
                              int max_freq, int also_revcomp, const uint8_t *lut, int64_t *consumed,
@@ -1726,6 +1847,10 @@ static int map_records_piece(kmm_index_t *ix, const uint8_t *raw, int64_t n_byte
     memset(&rv, 0, sizeof rv);
     KMMCHK(stage_in<uint8_t>(ix, s.bases, raw, (size_t)n_bytes, &rv.bases, &staged));
     KMMCHK(resolve_lut(ix, s, lut, &rv.lut, &staged));
+    if (records_take_radix(ix, n_bytes, format)) {
+        KMMCHK(map_records_piece_radix(ix, s, rv.bases, n_bytes, format, k, max_freq, also_revcomp, rv.lut, consumed, n_records));
+        return stage_release(ix, s, false);
+    }
     const int64_t n_tiles = (n_bytes + TILE_T - 1) / TILE_T;
     const int n_super = (int)((n_tiles + 1023) / 1024);
     KMMCHK(ensure(s.tile_first, (size_t)n_super * 1024 * 4));
@@ -2285,6 +2410,11 @@ int kmm_set_param(kmm_index_t *ix, const char *name, int64_t value)
         }
     } else if (!strcmp(name, "radix_min_units")) {
         ix->rx_min_units = value;
+    } else if (!strcmp(name, "radix_sub_batch_kmers")) {
+        // k-mer slots per sub-batch of the radix path: at most 2^32 - 2 blocks (launch_rx), at least a few blocks
+        if (value < 4 * RX_B || value > ((int64_t)1 << 32) - 2 * RX_B)
+            return fail(KMM_ERR_INVALID_ARG, "radix_sub_batch_kmers outside [%d, 2^32 - %d]", 4 * RX_B, 2 * RX_B);
+        ix->rx_sub_cap = value;
     } else if (!strcmp(name, "radix_sorted_flush")) {
         ix->rx_flush_sorted = value != 0;
     } else if (!strcmp(name, "radix_grid_per_cu")) {
@@ -2345,6 +2475,8 @@ int kmm_get_param(kmm_index_t *ix, const char *name, int64_t *value)
         *value = ix->rx_min_units;
     else if (!strcmp(name, "radix_grid_per_cu"))
         *value = ix->rx_grid_per_cu;
+    else if (!strcmp(name, "radix_sub_batch_kmers"))
+        *value = ix->rx_sub_cap;
     else if (!strcmp(name, "radix_sorted_flush"))
         *value = (ix->rx_flush_sorted && ix->rx_norder) ? 1 : 0;
     else if (!strcmp(name, "radix_available"))

@@ -579,8 +579,31 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p1(ReadsView rv, const uint64_t
     __shared__ uint64_t sbuf[RX_B];
     __shared__ __attribute__((aligned(8))) uint32_t s_cnt[RX_MAXF + 2 + 64];
     __shared__ uint32_t s_base[RX_MAXF + 1], s_wave[4];
+#ifndef RX_P1_INCDIV
+#define RX_P1_INCDIV 1
+#endif
+    // Incremental division (r04).  A lane's 16 windows are consecutive: q' = (q - b) / 4 + c 4^(k-1) (b = the base that
+    // leaves, c = the one that enters).  With q = quot M + rem and t = quot mod 4:  q - b = (quot - t) M + (rem + t M - b),
+    // 4 | quot - t and 4 | q - b, hence 4 | x = rem + t M - b; b = q mod 4 = (rem + t M) mod 4, so x / 4 = (rem + t M) >> 2,
+    // and 0 <= x / 4 < M (x <= rem + 3 M < 4 M).  So (q - b) / 4 = (quot >> 2) M + ((rem + t M) >> 2) is a proper
+    // (quotient, remainder) pair; adding c 4^(k-1) = Q_c M + R_c gives rem' = x / 4 + R_c < 2 M < 2^32 (one conditional
+    // subtraction, carry into the quotient) and quot' = (quot >> 2) + Q_c + carry.  Exact for every modulo < 2^31 and
+    // every k: ONE full division (five quarter-rate multiplies) per lane and block instead of 16.  rem + t M needs 33
+    // bits: with M = Mh 2^16 + Ml, (rem + t M) >> 2 = ((rem + t Ml) >> 2) + (t Mh << 14) — 24-bit multiplies, full rate.
+    // (Q_c, R_c), c = 0..3, sit in LDS; the entering bases come from the lane's register window (bits [2 k, 2 k + 32)), so
+    // the table reads do not depend on the chain of (quot, rem).
+    // Measured (profiles/r04/ab_pass1_incremental_division.txt): packed tiles 2.268 -> 2.258 ms at configs[2], 2.297 -> 2.261 ms
+    // at configs[1] — a fifth fewer VALU issue slots buy nothing: pass 1 is not bound by its vector ALUs.  Position-based
+    // tiles (ragged reads) keep the full division: with the chain their 16 ranks spill (2.53 -> 2.86 ms).
+    constexpr bool INCDIV = RX_P1_INCDIV != 0 && !RC && MODE == MODE_PACKED;
+    __shared__ uint4 s_qr[4]; // {R_c, Q_c low, Q_c high, -}
     const int tid = threadIdx.x, half = tid >> 8, ltid = tid & 255;
     const int wave_s = __builtin_amdgcn_readfirstlane(tid >> 6); // (rx_sort_emit rebuilds the thread index from it)
+    if (INCDIV && tid < 4) {
+        uint32_t r;
+        const uint64_t qc = fastdiv_m31((uint64_t)tid << (2 * (k - 1)), (uint32_t)iv.modulo, iv.magic, &r);
+        s_qr[tid] = make_uint4(r, (uint32_t)qc, (uint32_t)(qc >> 32), 0u);
+    }
     TileConst tc;
     tc.kmask = 0; tc.bmask = 0; tc.aligned = false;
     if (MODE != MODE_KMERS) {
@@ -613,6 +636,8 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p1(ReadsView rv, const uint64_t
     for (uint32_t sb = blockIdx.x; sb < n_src; sb += gridDim.x) {
         uint64_t q[RX_KPT];
         uint32_t valid = 0;
+        TileWin win;
+        win.lo = win.hi = 0;
         if (MODE == MODE_KMERS) {
 #pragma unroll
             for (int i = 0; i < RX_KPT; ++i) {
@@ -633,7 +658,7 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p1(ReadsView rv, const uint64_t
                     tile_packed_stage(rv, tile, sm[half], ltid, pw[0]);
                     __syncthreads();
                 }
-                valid = tile_packed_fetch(rv, tc, tile, sm[half], q, ltid);
+                valid = tile_packed_fetch(rv, tc, tile, sm[half], q, ltid, &win);
                 if (sb + gridDim.x < n_src)
                     load_tile(tile_begin + ((int64_t)(sb + gridDim.x) * 2 + half), pw[0]);
             } else {
@@ -651,9 +676,9 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p1(ReadsView rv, const uint64_t
                 uint32_t v;
                 // (the first tile of a block needs no opening barrier: the previous block's sort lies in between)
                 if constexpr (PACKED)
-                    v = tile_packed_kmers<false>(rv, tc, tile, k, sm[half], qq, ltid, pw[r]);
+                    v = tile_packed_kmers<false>(rv, tc, tile, k, sm[half], qq, ltid, pw[r], &win);
                 else
-                    v = r == 0 ? tile_kmers<S, TM, false>(rv, tc, tile, k, sm[half], qq, ltid, pw[r])
+                    v = r == 0 ? tile_kmers<S, TM, false>(rv, tc, tile, k, sm[half], qq, ltid, pw[r], &win)
                                : tile_kmers<S, TM, true>(rv, tc, tile, k, sm[half], qq, ltid, pw[r]);
 #pragma unroll
                 for (int j = 0; j < S; ++j)
@@ -689,10 +714,54 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p1(ReadsView rv, const uint64_t
                 x, rev, F1, sbuf, s_cnt, s_base, s_wave, rx.buf1 + ((size_t)sb * 2 + 1) * RX_B,
                 rx.start1 + ((size_t)sb * 2 + 1) * (size_t)(F1 + 1) RX_PT_ARG2, RxNoHook(), RX_KPT, wave_s);
         } else {
+            // (quot, rem) of the lane's current window; INCDIV: slot i follows from slot i - 1 (prep is called in slot order)
+            uint32_t qlo = 0, qhi = 0, rem = 0;
+            const uint32_t M32 = (uint32_t)iv.modulo, Ml = M32 & 0xFFFFu, Mh = M32 >> 16;
+            const uint32_t nb = (uint32_t)((win.lo >> (2 * k)) | (win.hi << (64 - 2 * k))); // the bases entering windows 1, 2, ...
+            uint4 e_nx = make_uint4(0u, 0u, 0u, 0u);
             auto fwd = [&](int i) {
-                uint32_t c;
-                q[i] = rx_pack(iv, sh, q[i], &c);
-                return ((valid >> i) & 1u) ? c : spare;
+                if constexpr (INCDIV && R == 1) {
+                    const uint4 e = e_nx;
+                    if (i + 1 < RX_KPT) {
+                        // (Q_c, R_c) of the NEXT step, requested one step ahead.  The empty asm ties the request to this
+                        // step's input: without it the scheduler hoists all 15 table reads to the top (45 registers) and
+                        // the ranks of the sort spill — a scratch reload in the block loop waits for vmcnt(0).
+                        uint32_t c = (nb >> (2 * i)) & 3u;
+                        asm("" : "+v"(c) : "v"(rem));
+                        e_nx = s_qr[c];
+                    }
+                    if (i == 0) {
+                        const uint64_t quot = fastdiv_m31(win.lo & tc.kmask, M32, iv.magic, &rem);
+                        qlo = (uint32_t)quot;
+                        qhi = (uint32_t)(quot >> 32);
+                    } else {
+                        const uint32_t t = qlo & 3u;
+                        uint32_t th = __umul24(t, Mh);
+                        asm("" : "+v"(th)); // (keeps t Mh a 24-bit product: folded into t (Mh << 14) it is a quarter-rate 32-bit multiply)
+                        const uint32_t y = ((__umul24(t, Ml) + rem) >> 2) + (th << 14); // (rem + t M) >> 2 < M
+                        const uint32_t r2 = y + e.x;                                      // < 2 M < 2^32
+                        // quot = (quot >> 2) + Q_c + (r2 >= M): the carry chain by hand (the compiler builds 64-bit
+                        // register pairs for each of the two additions)
+                        uint32_t nlo, nhi; // (fresh registers: the compiler keeps every window's quotient until it packs)
+                        asm("v_alignbit_b32 %0, %3, %2, 2\n\t"
+                            "v_lshrrev_b32 %1, 2, %3\n\t"
+                            "v_cmp_le_u32 vcc, %6, %7\n\t"
+                            "v_addc_co_u32 %0, vcc, %0, %4, vcc\n\t"
+                            "v_addc_co_u32 %1, vcc, %1, %5, vcc"
+                            : "=&v"(nlo), "=&v"(nhi)
+                            : "v"(qlo), "v"(qhi), "v"(e.y), "v"(e.z), "s"(M32), "v"(r2)
+                            : "vcc");
+                        qlo = nlo;
+                        qhi = nhi;
+                        rem = r2 - M32 < r2 ? r2 - M32 : r2; // (unsigned: r2 - M32 wraps above r2 when r2 < M32)
+                    }
+                    q[i] = ((((uint64_t)qhi << 32) | qlo) << sh) | (uint64_t)(rem & ((1u << sh) - 1u));
+                    return ((valid >> i) & 1u) ? rem >> sh : spare;
+                } else {
+                    uint32_t c;
+                    q[i] = rx_pack(iv, sh, q[i], &c);
+                    return ((valid >> i) & 1u) ? c : spare;
+                }
             };
             auto post = [&]() { // behind the placement: the next block's codes into LDS (the sort's barrier publishes them)
                 if constexpr (STAGE_EARLY) {

@@ -309,3 +309,274 @@ __global__ void __launch_bounds__(256) k_ml_scatter(const uint8_t *__restrict__ 
             out[dst++] = raw[q];
     }
 }
+
+// ------------------------------------------------------------------------------------------------
+// Records -> flat reads, for the radix path (r04).  Pass 1 of the radix path took raw FASTQ through its records
+// front end (line numbering per byte, four <4>-window tiles per block) at 0.57 TB/s — ten times slower than on flat
+// reads (profiles/r03/final_entry_points.txt), and that is the path `kmer_mapper map` runs
+// (command_line_interface.py:102-111).  Now the raw chunk is COMPACTED on the device first, at line granularity: only
+// the bytes of sequence lines survive, as 2-bit codes one per byte (the lookup table — and with it the reference
+// encoder's error for a non-nucleotide, util.py:72 — is applied here, where raw byte offsets are still known), every
+// read start is marked in the bitset the ragged-read front end takes, and pass 1 then runs on flat reads (on packed
+// tiles when all reads of the chunk have one length, which k_rec_uniform checks).
+//   k_rec_count2   per 1024-byte tile: newlines + non-terminator bytes per (line inside the tile) mod 4
+//   (k_rec_scan1, k_rec_scan2: newline prefix + where the last complete record ends, as before)
+//   k_rec_seq_scan per tile: its sequence bytes (the count that belongs to the phase of its first line) -> prefix
+//   (k_super_scan)
+//   k_rec_scatter  sequence bytes before `limit` -> codes, compacted; read starts -> bitset; record structure checked
+//   k_rec_uniform  do all reads have one length?
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void rec_load16(const uint8_t *__restrict__ raw, int64_t n, int64_t p, uint32_t (&w)[4])
+{
+    if ((((uintptr_t)raw) & 15u) == 0 && p + 16 <= n) {
+        const u32x4 x = *reinterpret_cast<const u32x4 *>(raw + p);
+        w[0] = x[0]; w[1] = x[1]; w[2] = x[2]; w[3] = x[3];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            w[i] = tile_load_bytes4(raw, n, p + 4 * i);
+    }
+}
+
+// 16-bit masks of the lane's bytes: '\n', '\r'
+__device__ __forceinline__ void rec_masks(const uint32_t (&w)[4], uint32_t &nl, uint32_t &cr)
+{
+    nl = 0;
+    cr = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        nl |= flags_to_bits(bytes_equal(w[i], 10u)) << (4 * i);
+        cr |= flags_to_bits(bytes_equal(w[i], 13u)) << (4 * i);
+    }
+}
+
+// tile_cnt[t] = newlines of tile t; tile_seq[t] = four 16-bit counts: bytes that are no line terminator, by the number
+// of newlines before them inside the tile, mod 4 (bytes past the end of the chunk count nowhere).
+__global__ void __launch_bounds__(256) k_rec_count2(const uint8_t *__restrict__ raw, int64_t n, int64_t n_tiles,
+                                                    uint32_t *__restrict__ tile_cnt, unsigned long long *__restrict__ tile_seq)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); // one wavefront per tile
+    if (tile >= n_tiles)
+        return;
+    const int64_t p = tile * 1024 + lane * 16;
+    uint32_t w[4], nl, cr;
+    rec_load16(raw, n, p, w);
+    rec_masks(w, nl, cr);
+    const int64_t left = n - p;
+    const uint32_t inside = left >= 16 ? 0xFFFFu : (left > 0 ? (1u << left) - 1u : 0u);
+    nl &= inside;
+    const uint32_t c = (uint32_t)__popc(nl);
+    const uint32_t before = wave_scan_incl(c) - c; // newlines of the tile before this lane's bytes
+    // the lane's bytes fall into popc(nl) + 1 segments of one line each
+    unsigned long long acc = 0;
+    uint32_t body = inside & ~(nl | cr), rest = nl, from = 0, rel = before;
+    for (;;) {
+        const uint32_t to = rest ? (uint32_t)__builtin_ctz(rest) : 16u; // the segment's bytes: [from, to)
+        const uint32_t seg = (to >= 16u ? 0xFFFFu : (1u << to) - 1u) & ~((1u << from) - 1u);
+        acc += (unsigned long long)__popc(body & seg) << (16u * (rel & 3u));
+        if (!rest)
+            break;
+        rest &= rest - 1u;
+        from = to + 1u;
+        ++rel;
+    }
+    uint32_t cs = c;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        cs += __shfl_xor(cs, d);
+        acc += __shfl_xor(acc, d); // (no field exceeds 1024)
+    }
+    if (lane == 0) {
+        tile_cnt[tile] = cs;
+        tile_seq[tile] = acc;
+    }
+}
+
+// One workgroup per super-tile, after the newline prefix is complete: the sequence bytes of every tile — the bytes of
+// the lines with (line number mod period) == 1 — as an exclusive prefix inside the super-tile + the super-tile's total.
+__global__ void __launch_bounds__(1024) k_rec_seq_scan(const unsigned long long *__restrict__ tile_seq,
+                                                       const uint32_t *__restrict__ tile_nl, const uint32_t *__restrict__ super_nl,
+                                                       int64_t n_tiles, uint32_t period_mask, uint32_t *__restrict__ tile_pre,
+                                                       uint32_t *__restrict__ super_tot)
+{
+    __shared__ uint32_t s_a[1024];
+    const int t = threadIdx.x;
+    const int64_t tile = (int64_t)blockIdx.x * 1024 + t;
+    uint32_t c = 0;
+    if (tile < n_tiles) {
+        const uint32_t line0 = super_nl[blockIdx.x] + tile_nl[tile];
+        // a byte with r newlines before it inside the tile lies on line line0 + r: sequence iff (line0 + r) & mask == 1
+        unsigned long long f = tile_seq[tile];
+        for (uint32_t r = 0; r < 4u; ++r, f >>= 16)
+            if (((line0 + r) & period_mask) == 1u)
+                c += (uint32_t)(f & 0xFFFFu);
+    }
+    s_a[t] = c;
+    __syncthreads();
+    block_scan_1024(s_a);
+    if (tile < n_tiles)
+        tile_pre[tile] = s_a[t] - c;
+    if (t == 1023)
+        super_tot[blockIdx.x] = s_a[t];
+}
+
+// One wavefront per tile.  info = {consumed, n_records, n_lines} of k_rec_scan2 (read on the device: no host round trip
+// between the census and the scatter); out_info[0] = number of flat bases (the sequence bytes before `consumed`).
+// first_bad as in the tile front end: [0] a sequence byte without a code, [1] a record line that does not start with
+// the header character / '+' (raw byte offsets).
+__global__ void __launch_bounds__(256) k_rec_scatter(const uint8_t *__restrict__ raw, int64_t n, int64_t n_tiles,
+                                                     const uint32_t *__restrict__ tile_nl, const uint32_t *__restrict__ super_nl,
+                                                     const uint32_t *__restrict__ tile_pre, const uint32_t *__restrict__ super_pre,
+                                                     const int64_t *__restrict__ info, const uint8_t *__restrict__ lut,
+                                                     uint32_t period_mask, uint32_t header_char, uint8_t *__restrict__ flat,
+                                                     uint32_t *__restrict__ start_bits, unsigned long long *__restrict__ first_bad,
+                                                     unsigned long long *__restrict__ out_info)
+{
+    __shared__ uint32_t s_lut[256];
+    __shared__ uint32_t s_out[4][1024 / 4 + 2];
+    s_lut[threadIdx.x] = lut[threadIdx.x];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t tile = (int64_t)blockIdx.x * 4 + wv;
+    const int64_t limit = info[0];
+    if (tile >= n_tiles || tile * 1024 >= limit) // (limit > 0: the caller does not launch for a chunk without a record)
+        return;
+    const int64_t p = tile * 1024 + lane * 16;
+    uint32_t w[4], nl, cr;
+    rec_load16(raw, n, p, w);
+    rec_masks(w, nl, cr);
+    const uint64_t w01 = ((uint64_t)w[1] << 32) | w[0], w23 = ((uint64_t)w[3] << 32) | w[2];
+    auto byte_at = [&](uint32_t i) { return (uint32_t)((i < 8u ? w01 >> (8u * i) : w23 >> (8u * (i - 8u))) & 0xFFu); };
+    const int64_t left = limit - p; // bytes of this lane before the limit
+    const uint32_t inside = left >= 16 ? 0xFFFFu : (left > 0 ? (1u << left) - 1u : 0u);
+    nl &= inside;
+    const uint32_t c_nl = (uint32_t)__popc(nl);
+    const uint32_t line_lane = super_nl[tile >> 10] + tile_nl[tile] + (wave_scan_incl(c_nl) - c_nl); // line of the lane's first byte
+    // first byte of a line: preceded by '\n' (or the first byte of the chunk)
+    uint32_t prev_nl = (uint32_t)__shfl_up((int)(nl >> 15), 1) & 1u;
+    if (lane == 0)
+        prev_nl = p == 0 ? 1u : (raw[p - 1] == 10u ? 1u : 0u);
+    const uint32_t first = ((nl << 1) | prev_nl) & inside;
+    // sequence bytes, line by line (segments as in k_rec_count2)
+    uint32_t seq = 0, seq_line = 0, bad_struct = 0xFFFFFFFFu;
+    {
+        uint32_t rest = nl, from = 0, line = line_lane;
+        for (;;) {
+            const uint32_t to = rest ? (uint32_t)__builtin_ctz(rest) : 16u;
+            const uint32_t seg = (to >= 16u ? 0xFFFFu : (1u << to) - 1u) & ~((1u << from) - 1u);
+            const uint32_t phase = line & period_mask;
+            if (phase == 1u)
+                seq_line |= seg | (to < 16u ? 1u << to : 0u); // (the line's terminator included)
+            if ((first >> from) & 1u) { // the segment starts its line: the record structure is checked on that byte
+                const uint32_t ch = byte_at(from);
+                if ((phase == 0u && ch != header_char) || (phase == 2u && ch != (uint32_t)'+'))
+                    bad_struct = bad_struct < from ? bad_struct : from;
+            }
+            if (!rest)
+                break;
+            rest &= rest - 1u;
+            from = to + 1u;
+            ++line;
+        }
+        seq_line &= inside;
+        seq = seq_line & ~(nl | cr);
+    }
+    if (bad_struct != 0xFFFFFFFFu)
+        atomicMin(&first_bad[1], (unsigned long long)(p + bad_struct));
+    const uint32_t cnt = (uint32_t)__popc(seq);
+    const uint32_t pre = wave_scan_incl(cnt) - cnt;
+    const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)(pre + cnt), 63);
+    const uint64_t dst0 = (uint64_t)super_pre[tile >> 10] + tile_pre[tile]; // flat position of the tile's first sequence byte
+    // read starts: the first byte of every sequence line; and whatever follows a '\r' inside a sequence line (no window
+    // may span it: the records front end treats every '\r' as a break)
+    {
+        uint32_t marks = (first | ((cr & seq_line) << 1)) & seq_line & 0xFFFFu;
+        while (marks) {
+            const uint32_t i = (uint32_t)__builtin_ctz(marks);
+            marks &= marks - 1u;
+            const uint64_t f = dst0 + pre + (uint32_t)__popc(seq & ((1u << i) - 1u));
+            atomicOr(&start_bits[f >> 5], 1u << (f & 31u));
+        }
+        // (a '\r' in the lane's last byte: the next lane's first byte — if it is a sequence byte it gets the mark there)
+        const uint32_t cr_before = (uint32_t)__shfl_up((int)((cr & seq_line) >> 15), 1) & 1u;
+        if (lane != 0 && cr_before && (seq_line & 1u)) {
+            const uint64_t f = dst0 + pre;
+            atomicOr(&start_bits[f >> 5], 1u << (f & 31u));
+        }
+    }
+    // codes of the sequence bytes -> the wavefront's LDS row, at byte offset (dst0 & 3) + rank: LDS word j then is word
+    // (dst0 >> 2) + j of the output
+    uint8_t *row = reinterpret_cast<uint8_t *>(s_out[wv]);
+    const uint32_t mis = (uint32_t)dst0 & 3u;
+    uint32_t bad = 0xFFFFFFFFu;
+    {
+        uint32_t m = seq, o = mis + pre;
+        while (m) {
+            const uint32_t i = (uint32_t)__builtin_ctz(m);
+            m &= m - 1u;
+            const uint32_t l = s_lut[byte_at(i)];
+            if (l == 0xFFu)
+                bad = bad < i ? bad : i;
+            row[o++] = (uint8_t)(l & 3u);
+        }
+    }
+    if (bad != 0xFFFFFFFFu)
+        atomicMin(&first_bad[0], (unsigned long long)(p + bad));
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block(); // the row is written and read by this wavefront only
+    // whole words by 4-byte stores; the bytes of the first and last word that belong to this tile by byte stores (the
+    // neighbouring tiles write the rest of those words)
+    const uint32_t end = mis + tot;               // bytes [mis, end) of the row are this tile's
+    const uint32_t w_lo = mis ? 1u : 0u;          // whole words: [w_lo, w_hi)
+    const uint32_t w_hi = (end >> 2) > w_lo ? end >> 2 : w_lo;
+    uint32_t *out32 = reinterpret_cast<uint32_t *>(flat) + (dst0 >> 2);
+    for (uint32_t j = w_lo + (uint32_t)lane; j < w_hi; j += 64u)
+        out32[j] = s_out[wv][j];
+    if ((uint32_t)lane < 8u) {
+        // head bytes [mis, min(end, 4 w_lo)) by lanes 0..3, tail bytes [4 w_hi, end) by lanes 4..7
+        const uint32_t b = (uint32_t)lane < 4u ? (uint32_t)lane : (w_hi << 2) + ((uint32_t)lane - 4u);
+        const bool mine = (uint32_t)lane < 4u ? (b >= mis && b < end && b < (w_lo << 2)) : (b < end);
+        if (mine)
+            flat[(dst0 - mis) + b] = row[b];
+    }
+    // the flat length = the flat position behind the lane that holds the last byte before the limit
+    if (left >= 1 && left <= 16)
+        out_info[0] = dst0 + pre + cnt;
+}
+
+// Do all reads of the compacted chunk have one length?  info[1] = records, out_info[0] = flat bases; counts the read
+// starts below the flat length into out_info[1] and those that are no multiple of L = bases / records into out_info[2]:
+// with as many distinct starts as records, all of them multiples of L, every multiple of L is a start.
+__global__ void __launch_bounds__(256) k_rec_uniform(const uint32_t *__restrict__ start_bits, const int64_t *__restrict__ info,
+                                                     unsigned long long *__restrict__ out_info)
+{
+    const uint64_t total = out_info[0], recs = (uint64_t)info[1];
+    if (!recs || !total || total % recs)
+        return; // (out_info[1] stays 0: not uniform)
+    const uint32_t L = (uint32_t)(total / recs);
+    const uint64_t n_words = (total + 31) / 32;
+    uint32_t n_set = 0, n_off = 0;
+    for (uint64_t wd = (uint64_t)blockIdx.x * 256 + threadIdx.x; wd < n_words; wd += (uint64_t)gridDim.x * 256) {
+        uint32_t m = start_bits[wd];
+        if (wd * 32 + 32 > total)
+            m &= (1u << (total - wd * 32)) - 1u;
+        n_set += (uint32_t)__popc(m);
+        while (m) {
+            const uint64_t pos = wd * 32 + (uint32_t)__builtin_ctz(m);
+            m &= m - 1u;
+            n_off += pos % L ? 1u : 0u;
+        }
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        n_set += __shfl_xor(n_set, d);
+        n_off += __shfl_xor(n_off, d);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (n_set)
+            atomicAdd(&out_info[1], (unsigned long long)n_set);
+        if (n_off)
+            atomicAdd(&out_info[2], (unsigned long long)n_off);
+    }
+}

@@ -30,6 +30,12 @@ struct TileConst {
     bool aligned;   // bases pointer is 16-byte aligned
 };
 
+// The lane's register window behind its first position: bases 0 .. 63 in `lo`, 64 .. in `hi` (first base in the lowest
+// bits).  Callers that slide over the window themselves (radix pass 1's incremental division) take it instead of q[].
+struct TileWin {
+    uint64_t lo, hi;
+};
+
 __device__ __forceinline__ TileConst tile_const(const ReadsView &rv, int k)
 {
     TileConst c;
@@ -128,7 +134,7 @@ __device__ __forceinline__ void tile_load_vec(const ReadsView &rv, const TileCon
 template <int S, int MODE, bool TOPBAR = true>
 __device__ __forceinline__ uint32_t tile_kmers(const ReadsView &rv, const TileConst &tc, int64_t tile,
                                                int k, TileSmem<S> &sm, uint64_t (&q)[S], const int tid,
-                                               const TileRaw &raw)
+                                               const TileRaw &raw, TileWin *win = nullptr)
 {
     const uint32_t (&w)[4] = raw.w;
     constexpr bool UNIFORM = MODE == MODE_UNIFORM;
@@ -357,6 +363,10 @@ __device__ __forceinline__ uint32_t tile_kmers(const ReadsView &rv, const TileCo
             valid = inside & ~dead;
         }
     }
+    if (win) {
+        win->lo = lo;
+        win->hi = hi;
+    }
 #pragma unroll
     for (int j = 0; j < S; ++j)
         q[j] = (j == 0 ? lo : ((lo >> (2 * j)) | (hi << (64 - 2 * j)))) & tc.kmask;
@@ -467,7 +477,8 @@ __device__ __forceinline__ void tile_packed_stage(const ReadsView &rv, int64_t t
 
 // Lane (r, s): the windows s * S .. of read r from the staged codes; returns the mask of the real ones.
 __device__ __forceinline__ uint32_t tile_packed_fetch(const ReadsView &rv, const TileConst &tc, int64_t tile,
-                                                      const TilePackedSmem &sm, uint64_t (&q)[16], const int tid)
+                                                      const TilePackedSmem &sm, uint64_t (&q)[16], const int tid,
+                                                      TileWin *win = nullptr)
 {
     const uint32_t L = (uint32_t)rv.read_len;
     const int64_t first = tile * (int64_t)rv.pk_rpt * (int64_t)L;
@@ -490,6 +501,10 @@ __device__ __forceinline__ uint32_t tile_packed_fetch(const ReadsView &rv, const
         lo = (lo >> sh) | (hi << (64 - sh));
         hi >>= sh;
     }
+    if (win) {
+        win->lo = lo;
+        win->hi = hi;
+    }
 #pragma unroll
     for (int j = 0; j < 16; ++j)
         q[j] = (j == 0 ? lo : ((lo >> (2 * j)) | (hi << (64 - 2 * j)))) & tc.kmask;
@@ -500,12 +515,12 @@ __device__ __forceinline__ uint32_t tile_packed_fetch(const ReadsView &rv, const
 template <bool TOPBAR>
 __device__ __forceinline__ uint32_t tile_packed_kmers(const ReadsView &rv, const TileConst &tc, int64_t tile, int k,
                                                       TilePackedSmem &sm, uint64_t (&q)[16], const int tid,
-                                                      const TilePackedRaw &raw)
+                                                      const TilePackedRaw &raw, TileWin *win = nullptr)
 {
     (void)k;
     if (TOPBAR)
         __syncthreads(); // every wave has finished reading the previous tile's LDS words
     tile_packed_stage(rv, tile, sm, tid, raw);
     __syncthreads();
-    return tile_packed_fetch(rv, tc, tile, sm, q, tid);
+    return tile_packed_fetch(rv, tc, tile, sm, q, tid, win);
 }

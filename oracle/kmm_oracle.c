@@ -18,6 +18,10 @@
  *     the bit-order identity of tests/test_hashing.py:11-26, and is checked against hand-derived
  *     known answers.
  *
+ *   - index construction (oracle_build_index): graph_kmer_index is un-vendored -> construction UPSTREAM-UNVERIFIED;
+ *     pinned by the one index the reference's tests build (tests/test_mapping.py:33-40, modulo 21) and by the
+ *     invariants mapper.pyx:53-69 reads.
+ *
  * Every function cites the reference file:line it restates (paths relative to the reference root).
  */
 #define _POSIX_C_SOURCE 200809L /* pthread_barrier_t under -std=c11 */
@@ -292,6 +296,95 @@ int64_t oracle_map_reads(const int32_t *hashes_to_index, const int32_t *n_kmers,
     free(ws);
     free(th);
     return err ? err : total;
+}
+/* ---------------------------------------------------------------------------------------------
+ * Index construction: what `FlatKmers(hashes, nodes, ref_offsets)` -> `KmerIndex.from_flat_kmers(flat, modulo=M)` ->
+ * `convert_to_int32()` produces in tests/test_mapping.py:33-38 — graph_kmer_index is an un-vendored dependency, so
+ * the construction is [UPSTREAM-UNVERIFIED]; what IS fixed by the reference tree are the invariants its lookup loop
+ * relies on (kmer_mapper/mapper.pyx:53-69), and this function establishes exactly those:
+ *   - entries grouped by kmer % modulo, groups in ascending hash order, the entries of one group in their input
+ *     order (a stable sort by hash);
+ *   - hashes_to_index[h] = first entry of group h, n_kmers[h] = its length (0 / 0 for an empty bucket);   (:55-56)
+ *   - frequencies[l] = number of index entries whose k-mer equals kmers[l], clipped to 65535                (:64)
+ * Plain loops: a counting sort over the modulo, then per bucket the equal-key counts (quadratic in the bucket
+ * length: oracle sizes only).  Returns 0, or -1 when more than INT32_MAX entries / a node outside int32 is given.
+ * ------------------------------------------------------------------------------------------- */
+static int oracle_cmp_u64(const void *a, const void *b)
+{
+    const uint64_t x = *(const uint64_t *)a, y = *(const uint64_t *)b;
+    return x < y ? -1 : x > y;
+}
+
+int oracle_build_index(const uint64_t *kmers, const int64_t *nodes, int64_t n, uint64_t modulo,
+                       int32_t *hashes_to_index, int32_t *n_kmers, uint64_t *kmers_out, int32_t *nodes_out,
+                       uint16_t *frequencies_out)
+{
+    if (n > INT32_MAX || modulo == 0)
+        return -1;
+    memset(n_kmers, 0, (size_t)modulo * sizeof(int32_t));
+    memset(hashes_to_index, 0, (size_t)modulo * sizeof(int32_t));
+    for (int64_t i = 0; i < n; ++i) {
+        if (nodes[i] < INT32_MIN || nodes[i] > INT32_MAX)
+            return -1;
+        n_kmers[kmers[i] % modulo] += 1;
+    }
+    int32_t *cursor = (int32_t *)malloc((size_t)modulo * sizeof(int32_t));
+    if (!cursor)
+        return -2;
+    int32_t run = 0;
+    for (uint64_t h = 0; h < modulo; ++h) {
+        cursor[h] = run;
+        if (n_kmers[h])
+            hashes_to_index[h] = run;
+        run += n_kmers[h];
+    }
+    for (int64_t i = 0; i < n; ++i) { /* input order inside a bucket: stable */
+        const int32_t l = cursor[kmers[i] % modulo]++;
+        kmers_out[l] = kmers[i];
+        nodes_out[l] = (int32_t)nodes[i];
+    }
+    free(cursor);
+    uint64_t *tmp = NULL;
+    int32_t tmp_cap = 0;
+    for (uint64_t h = 0; h < modulo; ++h) {
+        const int32_t s = hashes_to_index[h], c = n_kmers[h];
+        if (c <= 64) {
+            for (int32_t a = 0; a < c; ++a) {
+                uint32_t f = 0;
+                for (int32_t b = 0; b < c; ++b) /* equal k-mers share their hash: they all lie in this bucket */
+                    f += kmers_out[s + b] == kmers_out[s + a];
+                frequencies_out[s + a] = (uint16_t)f;
+            }
+            continue;
+        }
+        /* a long bucket (one k-mer under thousands of nodes): sorted copy, the count of a key = its run's length */
+        if (c > tmp_cap) {
+            free(tmp);
+            tmp = (uint64_t *)malloc((size_t)c * sizeof(uint64_t));
+            if (!tmp)
+                return -2;
+            tmp_cap = c;
+        }
+        memcpy(tmp, kmers_out + s, (size_t)c * sizeof(uint64_t));
+        qsort(tmp, (size_t)c, sizeof(uint64_t), oracle_cmp_u64);
+        for (int32_t a = 0; a < c; ++a) {
+            const uint64_t key = kmers_out[s + a];
+            int32_t lo = 0, hi = c; /* first position with tmp[pos] >= key */
+            while (lo < hi) {
+                const int32_t mid = lo + (hi - lo) / 2;
+                if (tmp[mid] < key) lo = mid + 1; else hi = mid;
+            }
+            int32_t lo2 = lo, hi2 = c; /* first position with tmp[pos] > key */
+            while (lo2 < hi2) {
+                const int32_t mid = lo2 + (hi2 - lo2) / 2;
+                if (tmp[mid] <= key) lo2 = mid + 1; else hi2 = mid;
+            }
+            const int32_t f = lo2 - lo;
+            frequencies_out[s + a] = (uint16_t)(f > 65535 ? 65535 : f);
+        }
+    }
+    free(tmp);
+    return 0;
 }
 
 #ifdef __cplusplus

@@ -8,6 +8,8 @@ Each function mirrors one reference entry point:
   in_index   -> kmer_mapper/mapper.pyx:81-130  (in_graph_index)
   extract    -> kmer_mapper/util.py:71-75      (get_kmer_hashes_from_chunk_sequence)
   map_reads  -> kmer_mapper/command_line_interface.py:32-56 + :124-130 (map_cpu + additive reduce)
+  build_index -> tests/test_mapping.py:36-38 (FlatKmers -> KmerIndex.from_flat_kmers(modulo) -> convert_to_int32;
+                 graph_kmer_index itself is un-vendored: the invariants are those mapper.pyx:53-69 reads)
 """
 import ctypes
 import os
@@ -84,6 +86,8 @@ def lib():
                                        _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _P, _c.c_int,
                                        _c.c_int64, _P]
         L.oracle_map_reads.restype = _c.c_int64
+        L.oracle_build_index.argtypes = [_P, _P, _c.c_int64, _c.c_uint64, _P, _P, _P, _P, _P]
+        L.oracle_build_index.restype = _c.c_int
         _lib = L
     return _lib
 
@@ -172,3 +176,32 @@ def map_reads(index, max_node_id, bases, read_offsets, k, max_index_lookup_frequ
     if got < 0:
         raise ValueError("oracle_map_reads failed (%d): invalid nucleotide byte" % got)
     return counts, int(got)
+
+
+class OracleIndex:
+    """What mapper.pyx:22-29 reads of an index (duck-typed there), in the dtypes convert_to_int32 leaves."""
+
+    def __init__(self, h2i, nk, nodes, kmers, modulo, freqs):
+        self._hashes_to_index, self._n_kmers, self._nodes = h2i, nk, nodes
+        self._kmers, self._modulo, self._frequencies = kmers, int(modulo), freqs
+
+    def max_node_id(self):
+        return int(self._nodes.max()) if len(self._nodes) else 0
+
+
+def build_index(kmers, nodes, modulo):
+    """FlatKmers(kmers, nodes) -> from_flat_kmers(modulo) -> convert_to_int32 (tests/test_mapping.py:36-38)."""
+    kmers = np.ascontiguousarray(np.asarray(kmers, dtype=np.uint64))
+    nodes = np.ascontiguousarray(np.asarray(nodes, dtype=np.int64))
+    if kmers.shape != nodes.shape:
+        raise ValueError("kmers and nodes differ in length")
+    n, modulo = kmers.shape[0], int(modulo)
+    h2i = np.empty(modulo, dtype=np.int32)
+    nk = np.empty(modulo, dtype=np.int32)
+    ko = np.empty(n, dtype=np.uint64)
+    no = np.empty(n, dtype=np.int32)
+    fo = np.empty(n, dtype=np.uint16)
+    rc = lib().oracle_build_index(_ptr(kmers), _ptr(nodes), n, modulo, _ptr(h2i), _ptr(nk), _ptr(ko), _ptr(no), _ptr(fo))
+    if rc:
+        raise ValueError("oracle_build_index failed (%d)" % rc)
+    return OracleIndex(h2i, nk, no, ko, modulo, fo)

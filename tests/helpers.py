@@ -16,8 +16,11 @@ def reference_vectors():
 
 
 def index_from_vector(v):
-    return KmerIndex.from_flat_kmers(np.array(v["index_kmers"], dtype=np.uint64),
-                                     np.array(v["index_nodes"], dtype=np.int64), v["modulo"])
+    """The index of a reference vector, built by the ORACLE's builder (oracle_build_index: what
+    FlatKmers -> KmerIndex.from_flat_kmers(modulo) -> convert_to_int32 gives, reference tests/test_mapping.py:36-38)."""
+    from oracle import oracle
+    return oracle.build_index(np.array(v["index_kmers"], dtype=np.uint64),
+                              np.array(v["index_nodes"], dtype=np.int64), v["modulo"])
 
 
 def golden_small():

@@ -158,6 +158,67 @@ def test_modulo_above_2_pow_29_takes_the_radix_path(kmm, oracle):
         assert np.array_equal(dev.in_index(km), oracle.in_index(index, km))
 
 
+def test_configs4_index_on_one_gpu(kmm, oracle):
+    """BASELINE configs[4]'s index on one GPU: 10^9 k-mers, modulo 2 000 000 011 — the largest the reference's int32
+    tables allow (mapper.pyx:22-23,53-56: `_hashes_to_index`, `_n_kmers` int32, `kmers[i] % modulo`).  Index generated
+    and built on the GPU (synthetic.make_index_torch / kmm_build_index); a 12 M-read batch through the radix path
+    (477 x 512 slices of 8192 buckets; ONE sub-batch of 1.44e9 k-mers) with the conservation counters; a 200 k-read
+    sample on both paths against the oracle run on the host copy of the index; linearity over a split of the batch;
+    membership of 20 k k-mers.  Semantics: mapper.pyx:53-69."""
+    import torch
+    from kmer_mapper_amd import synthetic as syn
+    R, L, k = 12_000_000, 150, 31
+    index, g_ascii = syn.make_index_torch(1_000_000_000, k=k, seed=1)
+    assert index._modulo == 2_000_000_011
+    mx = index.max_node_id()
+    reads = syn.make_reads_torch(g_ascii, R, L, seed=1001)
+    del g_ascii
+    torch.cuda.synchronize()
+    n_kmers = R * (L - k + 1)
+    with kmm.DeviceIndex.from_index(index, mx) as dev:
+        host = index.to_host()            # the oracle's copy (host numpy arrays); the handle owns its own
+        del index
+        torch.cuda.empty_cache()
+        assert dev.get_param("radix_available") == 1 and dev.get_param("part_shift") == 13
+        assert dev.get_param("n_coarse_partitions") * dev.get_param("n_fine_per_coarse") >= dev.get_param("n_partitions") > 200_000
+        assert dev.get_param("direct_view_resident") == 0          # 80 GB: packed only when a direct batch asks for it
+        dev.set_timing(True)
+        dev.set_param("path", 2)
+        dev.map_reads_uniform(reads, R, L, k)
+        full = dev.get_node_counts()
+        assert dev.get_param("radix_p2_kmers") == n_kmers
+        assert dev.get_param("radix_p3_kmers") + dev.get_param("radix_p2_dropped") == n_kmers
+        assert dev.get_stats(reset=True)[0] == n_kmers
+        assert dev.get_timing()["k_rx_p1"][1] == 1, "1.44e9 k-mers are one sub-batch (the index slices are streamed once)"
+        hits = int(full.astype(np.uint64).sum())
+        assert 0.15 < hits / n_kmers < 0.25
+        # linearity: two unequal pieces accumulate to the same vector
+        dev.reset()
+        cut = 4_999_999
+        dev.map_reads_uniform(reads[:cut * L], cut, L, k)
+        dev.map_reads_uniform(reads[cut * L:], R - cut, L, k)
+        assert np.array_equal(dev.get_node_counts(), full)
+        del full
+        # 200 k-read sample against the oracle: radix path, then the direct path (packs the direct view on first use)
+        n_s = 200_000
+        sample = reads[:n_s * L].cpu().numpy()
+        s_offs = np.arange(n_s + 1, dtype=np.int64) * L
+        expect, n = oracle.map_reads(host, mx, sample, s_offs, k, n_threads=6)
+        assert n == n_s * (L - k + 1)
+        dev.reset()
+        dev.map_reads_uniform(reads[:n_s * L], n_s, L, k)
+        assert np.array_equal(dev.get_node_counts(), expect), "radix"
+        del reads
+        torch.cuda.empty_cache()
+        dev.reset()
+        dev.set_param("path", 1)
+        dev.map_reads_uniform(sample, n_s, L, k)
+        assert np.array_equal(dev.get_node_counts(), expect), "direct"
+        assert dev.get_param("direct_view_resident") == 1
+        km = kmm.extract_kmers(sample[:20_000 * L], s_offs[:20_001], k)
+        assert np.array_equal(dev.in_index(km), oracle.in_index(host, km))
+
+
 def test_direct_view_is_packed_on_first_use_when_deferred(kmm, oracle, monkeypatch):
     """HBM budget of large indexes: with the direct view deferred (forced here on a small index) the radix path
     works without it, the first direct-path batch / kmm_in_index packs it from the radix view's bucket-ordered

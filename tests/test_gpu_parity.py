@@ -743,8 +743,9 @@ def test_beyond_4gib_batch_int64_positions(kmm, syn, oracle):
 
 @pytest.mark.parametrize("n,modulo", [(0, 5), (1, 1), (1000, 7), (5000, 10007), (300000, 600011), (2000, 2 ** 20),
                                       (40000, 5_000_011), (3_000_000, 6_000_011)])   # 3-level scans
-def test_gpu_index_builder_equals_numpy_builder(kmm, n, modulo):
-    """kmm_build_index == KmerIndex.from_flat_kmers (stable sort by hash), array for array."""
+def test_gpu_index_builder_equals_oracle_builder(kmm, oracle, n, modulo):
+    """kmm_build_index == oracle_build_index (FlatKmers -> from_flat_kmers(modulo) -> convert_to_int32, reference
+    tests/test_mapping.py:36-38; stable sort by hash), array for array; the package's numpy builder agrees too."""
     from kmer_mapper_amd.kmer_index import KmerIndex
     rng = np.random.default_rng(n + modulo)
     kmers = rng.integers(0, 2 ** 62, size=n, dtype=np.uint64)
@@ -752,11 +753,12 @@ def test_gpu_index_builder_equals_numpy_builder(kmm, n, modulo):
         kmers[rng.integers(0, n, size=n // 5)] = kmers[rng.integers(0, n, size=n // 5)]   # duplicates
         kmers[: min(n, 1500)] = kmers[0] if n == 5000 else kmers[: min(n, 1500)]           # one long run
     nodes = rng.integers(0, 2 ** 31 - 1, size=n)
-    a = KmerIndex.from_flat_kmers(kmers, nodes, modulo)
+    a = oracle.build_index(kmers, nodes, modulo)
     b = KmerIndex.from_flat_kmers_gpu(kmers, nodes, modulo)
+    c = KmerIndex.from_flat_kmers(kmers, nodes, modulo)
     for attr in ("_hashes_to_index", "_n_kmers", "_kmers", "_nodes", "_frequencies"):
-        x, y = getattr(a, attr), getattr(b, attr)
-        assert x.dtype == y.dtype and np.array_equal(x, y), attr
+        x, y, z = getattr(a, attr), getattr(b, attr), getattr(c, attr)
+        assert x.dtype == y.dtype == z.dtype and np.array_equal(x, y) and np.array_equal(x, z), attr
     assert b._modulo == modulo
 
 
@@ -929,7 +931,7 @@ def test_index_arrays_may_live_in_hbm(kmm, syn, oracle):
         assert np.array_equal(dev.get_node_counts(), expect)
 
 
-def test_gpu_index_builder_with_huge_buckets(kmm):
+def test_gpu_index_builder_with_huge_buckets(kmm, oracle):
     """a k-mer with 100 000 hits (one bucket of 100 000+ entries) and a dense collision bucket must not cost
     O(bucket^2): buckets above 64 entries are ordered by bitonic sorts.  Result identical to the stable numpy
     construction (what from_flat_kmers does upstream, reference tests/test_mapping.py:36-38)."""
@@ -944,8 +946,52 @@ def test_gpu_index_builder_with_huge_buckets(kmm):
     perm = rng.permutation(len(kmers))
     kmers = kmers[perm]
     nodes = rng.integers(0, 1 << 20, size=len(kmers)).astype(np.int64)
-    a = KmerIndex.from_flat_kmers(kmers, nodes, modulo)
+    a = oracle.build_index(kmers, nodes, modulo)
     b = KmerIndex.from_flat_kmers_gpu(kmers, nodes, modulo)
     for name in ("_hashes_to_index", "_n_kmers", "_kmers", "_nodes", "_frequencies"):
         assert np.array_equal(getattr(a, name), getattr(b, name)), name
     assert a._frequencies.max() == 65535 and a._n_kmers.max() >= 100_000
+
+
+def test_kmer_index_file_through_the_reference_read_side(kmm, oracle, golden_dir, tmp_path):
+    """Row f-2: the committed Kmer Index .npz (upstream key set, int64 on disk [UPSTREAM-UNVERIFIED]) ->
+    KmerIndex.from_file -> convert_to_int32 -> remove_ref_offsets (kmer_mapper/util.py:56-62) -> the HIP lookup, both
+    paths, against the counts frozen in the file (oracle_map_kmers, mapper.pyx:53-69) and against the oracle itself;
+    then `kmer_mapper map -i <file>` end to end on reads that contain the file's k-mers."""
+    import os
+    from kmer_mapper_amd.kmer_index import KmerIndex
+    from kmer_mapper_amd.mapper import map_kmers_to_graph_index, in_graph_index, clear_cache
+    path = os.path.join(golden_dir, "kmer_index_small.npz")
+    d = np.load(path)
+    ix = KmerIndex.from_file(path)
+    with pytest.raises(ValueError):
+        map_kmers_to_graph_index(ix, int(d["test_max_node_id"]), d["test_query_kmers"])   # int64 tables are refused
+    ix.convert_to_int32()
+    ix.remove_ref_offsets()
+    mx, q = ix.max_node_id(), d["test_query_kmers"]
+    assert np.array_equal(map_kmers_to_graph_index(ix, mx, q), d["test_expected_counts"])
+    assert np.array_equal(map_kmers_to_graph_index(ix, mx, q, 65535), d["test_expected_counts_maxfreq_65535"])
+    assert np.array_equal(in_graph_index(ix, q), d["test_expected_in_index"])
+    clear_cache()
+    with kmm.DeviceIndex.from_index(ix, mx) as dev:
+        for p in (1, 2):
+            dev.reset()
+            dev.set_param("path", p)
+            dev.map_kmers(q)
+            assert np.array_equal(dev.get_node_counts(), d["test_expected_counts"]), p
+    # the CLI on the file: reads spelled from the index's own k-mers (k = 31, first base in the lowest bits)
+    k = 31
+    letters = np.frombuffer(b"ACGT", dtype=np.uint8)
+    reads = []
+    for km in ix._kmers[::7][:100]:
+        codes = (int(km) >> (2 * np.arange(k))) & 3
+        reads.append(letters[codes].tobytes())
+    fq = tmp_path / "r.fq"
+    fq.write_bytes(b"".join(b"@r%d\n" % i + r + b"\n+\n" + b"I" * k + b"\n" for i, r in enumerate(reads)))
+    from kmer_mapper_amd.command_line_interface import run_argument_parser
+    out = tmp_path / "counts"
+    run_argument_parser(["map", "-i", path, "-f", str(fq), "-k", str(k), "-o", str(out), "-g", "True"])
+    got = np.load(str(out) + ".npy")
+    b = np.frombuffer(b"".join(reads), dtype=np.uint8)
+    expect, _ = oracle.map_reads(ix, mx, b, np.arange(len(reads) + 1, dtype=np.int64) * k, k)
+    assert np.array_equal(got, expect) and expect.sum() > 0

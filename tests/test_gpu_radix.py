@@ -218,6 +218,88 @@ def test_radix_records_mode_and_long_reads(kmm, syn, oracle):
             assert np.array_equal(dev.get_node_counts(), expect)
 
 
+def _fastq(reads, eol=b"\n", qual=b"I"):
+    return np.frombuffer(b"".join(b"@r%d x" % i + eol + r + eol + b"+" + eol + qual * len(r) + eol for i, r in enumerate(reads)),
+                         dtype=np.uint8)
+
+
+@pytest.mark.parametrize("eol", [b"\n", b"\r\n"])
+@pytest.mark.parametrize("read_len", [150, 31, 40, 1000])
+def test_radix_records_of_one_length_take_packed_tiles(kmm, syn, oracle, eol, read_len):
+    """Raw FASTQ whose reads all have one length: the chunk is compacted into flat reads on the device
+    (k_rec_scatter), found uniform (k_rec_uniform) and mapped through pass 1's packed tiles; same counts as the
+    oracle on the reads themselves (command_line_interface.py:102-111 + mapper.pyx:53-69), for both line endings,
+    whole and cut at arbitrary bytes."""
+    from kmer_mapper_amd import _lib
+    index, genome = syn.make_index(6000, seed=371)
+    mx = index.max_node_id()
+    n_reads = 7001
+    bases, offs = syn.make_reads(genome, n_reads, read_len, seed=372)
+    expect, _ = oracle.map_reads(index, mx, bases, offs, 31)
+    raw = _fastq([bases[offs[i]:offs[i + 1]].tobytes() for i in range(n_reads)], eol, qual=b"@")
+    with kmm.DeviceIndex.from_index(index, mx) as dev:
+        dev.set_param("path", 2)
+        dev.set_param("part_shift", 6)
+        used, n_rec = dev.map_records(raw, fmt=_lib.FORMAT_FASTQ)
+        assert (used, n_rec) == (raw.shape[0], n_reads)
+        assert np.array_equal(dev.get_node_counts(), expect)
+        dev.reset()
+        pos, total = 0, 0
+        while pos < raw.shape[0]:
+            used, n_rec = dev.map_records(np.ascontiguousarray(raw[pos:pos + 333337]), fmt=_lib.FORMAT_FASTQ)
+            assert used > 0
+            pos += used
+            total += n_rec
+        assert total == n_reads
+        assert np.array_equal(dev.get_node_counts(), expect)
+        assert dev.get_param("radix_batches") >= 2 and dev.get_param("direct_batches") == 0
+
+
+def test_radix_records_edge_cases(kmm, syn, oracle):
+    """Compaction corner cases: empty sequence lines, reads shorter than k, a read that ends exactly at a 16-byte lane /
+    1024-byte tile boundary, headers and quality lines full of newline-free junk, FASTA2, and the error reports (raw
+    byte offsets, as on the direct path)."""
+    from kmer_mapper_amd import _lib
+    index, genome = syn.make_index(3000, k=5, seed=381, plant=False)
+    mx = index.max_node_id()
+    g = syn.ACGT[genome]
+    rng = np.random.default_rng(382)
+    reads, pos = [], 0
+    for i in range(4000):
+        n = int(rng.choice([0, 1, 4, 5, 6, 11, 12, 16, 27, 1020, 1024, 1019, 300]))
+        reads.append(g[pos:pos + n].tobytes())
+        pos = (pos + n + 7) % (len(g) - 2000)
+    bases = np.frombuffer(b"".join(reads), dtype=np.uint8)
+    offs = np.concatenate([[0], np.cumsum([len(r) for r in reads])]).astype(np.int64)
+    expect, _ = oracle.map_reads(index, mx, bases, offs, 5)
+    with kmm.DeviceIndex.from_index(index, mx) as dev:
+        dev.set_param("path", 2)
+        for fmt, raw in ((_lib.FORMAT_FASTQ, _fastq(reads)),
+                         (_lib.FORMAT_FASTA2, np.frombuffer(b"".join(b">h%d\n" % i + r + b"\n" for i, r in enumerate(reads)), dtype=np.uint8))):
+            dev.reset()
+            used, n_rec = dev.map_records(raw, fmt=fmt, k=5)
+            assert (used, n_rec) == (raw.shape[0], len(reads))
+            assert np.array_equal(dev.get_node_counts(), expect)
+            # the last record incomplete: left to the caller, its sequence line is not mapped
+            dev.reset()
+            used, n_rec = dev.map_records(np.ascontiguousarray(raw[:-3]), fmt=fmt, k=5)
+            assert n_rec == len(reads) - 1 and raw[used - 1] == 10
+            e2, _ = oracle.map_reads(index, mx, bases[:offs[-2]], offs[:-1], 5)
+            assert np.array_equal(dev.get_node_counts(), e2)
+        # a non-nucleotide on a sequence line: reported with its RAW byte offset
+        dev.reset()
+        dev.map_records(np.frombuffer(b"@r1\nACGTXCGTAC\n+\nIIIIIIIIII\n", dtype=np.uint8), k=5)
+        with pytest.raises(ValueError, match="offset 8"):
+            dev.get_node_counts()
+        dev.reset()
+        dev.map_records(np.frombuffer(b"@r1\nACGT\nACGT\nIIII\n", dtype=np.uint8), k=3)
+        with pytest.raises(ValueError, match="record structure"):
+            dev.get_node_counts()
+        dev.reset()
+        assert dev.map_records(np.frombuffer(b"@r1\nACGT", dtype=np.uint8), k=3) == (0, 0)
+        assert dev.get_node_counts().sum() == 0
+
+
 @pytest.mark.parametrize("modulo", [16411, 40009, 200_000_033, 452_930_477, 2_147_483_629])
 def test_division_edge_values(kmm, oracle, modulo):
     """Pass 1 divides by the modulo with a magic multiply and a 32-bit remainder (fastdiv_m31): values around every

@@ -144,3 +144,37 @@ def test_header_is_plain_c_and_demo_client_links(tmp_path):
                            "-o", exe, "-L" + libdir, "-l:libkmm.so", "-Wl,-rpath," + libdir,
                            "-Wl,-rpath,/opt/rocm/lib"])
     assert os.path.exists(exe)
+
+
+def test_kmer_index_npz_fixture_loads_like_the_reference_reads_it(oracle, golden_dir):
+    """The committed Kmer Index file (tests/golden/kmer_index_small.npz: upstream key set, int64 on disk
+    [UPSTREAM-UNVERIFIED], written by tests/golden/make_index_fixture.py from the oracle's builder) through the read
+    side the reference shows (kmer_mapper/util.py:56-62): from_file -> convert_to_int32 -> remove_ref_offsets; the
+    lookup arrays then have the dtypes mapper.pyx:22-29 binds, and the oracle's lookup on them gives the frozen counts."""
+    import os
+    from kmer_mapper_amd.kmer_index import KmerIndex
+    path = os.path.join(golden_dir, "kmer_index_small.npz")
+    d = np.load(path)
+    assert {"hashes_to_index", "n_kmers", "nodes", "ref_offsets", "kmers", "modulo", "frequencies",
+            "allele_frequencies"} <= set(d.files)
+    assert d["hashes_to_index"].dtype == np.int64 and d["nodes"].dtype == np.int64 and d["n_kmers"].dtype == np.int64
+    ix = KmerIndex.from_file(path)
+    assert ix._ref_offsets is not None and ix._allele_frequencies is not None
+    with pytest.raises(ValueError, match="dtype mismatch"):
+        oracle.map_kmers(ix, int(d["test_max_node_id"]), d["test_query_kmers"])       # int64 tables: like Cython's buffers
+    ix.convert_to_int32()
+    ix.remove_ref_offsets()
+    assert ix._ref_offsets is None
+    assert (ix._hashes_to_index.dtype, ix._n_kmers.dtype, ix._nodes.dtype, ix._kmers.dtype, ix._frequencies.dtype) == \
+        (np.int32, np.int32, np.int32, np.uint64, np.uint16)
+    mx = ix.max_node_id()
+    assert mx == int(d["test_max_node_id"]) and ix._modulo == int(d["modulo"])
+    q = d["test_query_kmers"]
+    assert np.array_equal(oracle.map_kmers(ix, mx, q), d["test_expected_counts"])
+    assert np.array_equal(oracle.map_kmers(ix, mx, q, 65535), d["test_expected_counts_maxfreq_65535"])
+    assert np.array_equal(oracle.in_index(ix, q), d["test_expected_in_index"])
+    assert d["test_expected_counts"].sum() < d["test_expected_counts_maxfreq_65535"].sum()    # the filter bites
+    # a file without the optional keys loads too (util.py:60-62 only needs the lookup arrays)
+    rebuilt = oracle.build_index(ix._kmers, ix._nodes.astype(np.int64), ix._modulo)
+    for name in ("_hashes_to_index", "_n_kmers", "_kmers", "_nodes", "_frequencies"):
+        assert np.array_equal(getattr(rebuilt, name), getattr(ix, name)), name

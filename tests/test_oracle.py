@@ -20,17 +20,68 @@ def test_lookup_reference_vectors(oracle, v):
 def test_oracle_matches_reference_test_mapping(oracle, v):
     """reference tests/test_mapping.py:33-40: four 3-mers as strings (one in mixed case) -> nodes 0..3, modulo 21;
     the lower-case query 'ccg' must resolve to node 2."""
-    from kmer_mapper_amd.kmer_index import KmerIndex
     b = batch(v["node_kmers"])
     node_kmers = oracle.extract(b.bases, b.offsets, v["k"])
     assert node_kmers.shape == (len(v["node_kmers"]),)
-    index = KmerIndex.from_flat_kmers(node_kmers, np.arange(len(node_kmers), dtype=np.int64), v["modulo"])
+    index = oracle.build_index(node_kmers, np.arange(len(node_kmers), dtype=np.int64), v["modulo"])
     q = batch([v["query"]])
     qk = oracle.extract(q.bases, q.offsets, v["k"])
     counts = oracle.map_kmers(index, v["max_node_id"], qk, v["max_index_lookup_frequency"])
     assert counts.shape == (v["max_node_id"] + 1,) and counts.sum() == 1 and counts[v["expected_node"]] == 1
     counts = oracle.map_kmers(index, v["max_node_id"], node_kmers, v["max_index_lookup_frequency"])
     assert counts[:len(node_kmers)].tolist() == v["expected_counts_of_node_kmers"] and counts.sum() == len(node_kmers)
+
+
+def test_oracle_index_builder_establishes_what_the_lookup_reads(oracle):
+    """oracle_build_index (FlatKmers -> from_flat_kmers(modulo) -> convert_to_int32, reference tests/test_mapping.py:36-38):
+    the invariants the reference's loop relies on (mapper.pyx:53-69), checked directly — entries grouped by kmer % modulo
+    in ascending hash order and input order inside a bucket, hashes_to_index / n_kmers = first entry / length of every
+    bucket (0 / 0 when empty), frequencies = occurrences of the entry's k-mer in the index clipped to uint16 — on an
+    input with hash collisions, a k-mer under many nodes (frequency > 1000: the filter of mapper.pyx:64-66) and one
+    beyond 65535 occurrences."""
+    rng = np.random.default_rng(5)
+    modulo = 1009
+    kmers = rng.integers(0, 2 ** 62, size=4000, dtype=np.uint64)
+    kmers = np.concatenate([kmers, kmers[:500], np.repeat(kmers[3], 1498), np.repeat(np.uint64(77), 70000),
+                            np.uint64(modulo) * rng.integers(1, 2 ** 40, size=300, dtype=np.uint64) + np.uint64(5)])
+    kmers = kmers[rng.permutation(len(kmers))]
+    nodes = rng.integers(0, 5000, size=len(kmers))
+    ix = oracle.build_index(kmers, nodes, modulo)
+    assert (ix._hashes_to_index.dtype, ix._n_kmers.dtype, ix._nodes.dtype, ix._kmers.dtype, ix._frequencies.dtype) == \
+        (np.int32, np.int32, np.int32, np.uint64, np.uint16)
+    h = (ix._kmers % np.uint64(modulo)).astype(np.int64)
+    assert np.all(np.diff(h) >= 0) and int(ix._n_kmers.sum()) == len(kmers)
+    for b in range(modulo):
+        s, c = int(ix._hashes_to_index[b]), int(ix._n_kmers[b])
+        assert np.all(h[s:s + c] == b) and (c > 0 or s == 0)
+        src = np.flatnonzero((kmers % np.uint64(modulo)) == np.uint64(b))       # input order inside the bucket
+        assert np.array_equal(ix._kmers[s:s + c], kmers[src]) and np.array_equal(ix._nodes[s:s + c], nodes[src])
+    uniq, cnt = np.unique(kmers, return_counts=True)
+    expect_f = np.minimum(cnt[np.searchsorted(uniq, ix._kmers)], 65535)
+    assert np.array_equal(ix._frequencies, expect_f.astype(np.uint16))
+    assert ix._frequencies.max() == 65535 and 1500 in ix._frequencies
+    # the lookup on it: every occurrence of a k-mer counts under its node unless the k-mer's frequency exceeds the limit
+    got = oracle.map_kmers(ix, 4999, uniq)
+    keep = cnt <= 1000
+    expect = np.bincount(nodes[np.isin(kmers, uniq[keep])], minlength=5000).astype(np.uint32)
+    assert np.array_equal(got, expect)
+
+
+def test_package_numpy_builder_equals_the_oracle_builder(oracle):
+    """Host logic: kmer_mapper_amd.kmer_index.KmerIndex.from_flat_kmers (numpy, the builder `kmer_mapper map` users get
+    without a GPU call) == oracle_build_index, array for array; empty input and modulo 1 included."""
+    from kmer_mapper_amd.kmer_index import KmerIndex
+    rng = np.random.default_rng(6)
+    for n, modulo in ((0, 5), (1, 1), (7, 21), (3000, 211), (50000, 100003)):
+        kmers = rng.integers(0, 2 ** 64 - 1, size=n, dtype=np.uint64)
+        if n > 10:
+            kmers[rng.integers(0, n, size=n // 4)] = kmers[rng.integers(0, n, size=n // 4)]
+        nodes = rng.integers(0, 2 ** 31 - 1, size=n)
+        a, b = oracle.build_index(kmers, nodes, modulo), KmerIndex.from_flat_kmers(kmers, nodes, modulo)
+        for name in ("_hashes_to_index", "_n_kmers", "_kmers", "_nodes", "_frequencies"):
+            x, y = getattr(a, name), getattr(b, name)
+            assert x.dtype == y.dtype and np.array_equal(x, y), (name, n, modulo)
+        assert a._modulo == b._modulo == modulo and a.max_node_id() == b.max_node_id()
 
 
 @pytest.mark.parametrize("v", reference_vectors()["extract"], ids=lambda v: v["name"])
