@@ -6,11 +6,13 @@
 
 One "step" = one pass of the hot path (kmm_map_reads_uniform: encode -> rolling 31-mer pack ->
 modulo -> bucket gather -> compare/filter -> atomic node counts) over one batch of synthetic reads
-that is already resident in HBM.  Workload at N=1 (default, --config 2): BASELINE configs[2] — 100 M
-synthetic 150 bp reads as batches of 10 M, k=31, 100 M-k-mer index (the headline config; --config 1 =
-configs[1], the 10 M-k-mer index).  With N ranks every rank maps its own 10 M-read batch per step
-(reads shard by chunk: weak scaling) against a replicated index and the per-rank uint32 count
-vectors are summed once with RCCL at the end of the job, inside the timed region.
+that is already resident in HBM.  Workload at N=1 (default, --config 2): BASELINE configs[2] — synthetic
+150 bp reads in batches of 10 M (--steps batches: 10 by default = 100 M reads), k=31, 100 M-k-mer index (the
+headline config; --config 1 = configs[1], the 10 M-k-mer index; --index-kmers 1000000000 = configs[4]'s index).
+With N ranks every rank maps its own 10 M-read batch per step (reads shard by chunk: weak scaling) against a
+replicated index and the per-rank uint32 count vectors are summed once with RCCL at the end of the job, inside the
+timed region; the same invocation then also times BASELINE configs[3] — the SAME --steps x 10 M reads split over
+the ranks (`strong`) — and the PCIe-inclusive leg on every rank at once (`value_incl_h2d`).
 
 Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for every field).
 """
@@ -54,7 +56,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", type=int, default=2, choices=(1, 2),
                     help="BASELINE.json configs[]: 2 = 100 M-k-mer index (headline, default), 1 = 10 M-k-mer index; "
-                         "both map 10 M-read batches, so 10 steps = 100 M reads")
+                         "both map 10 M-read batches (--steps of them; the default 10 steps = 100 M reads)")
     ap.add_argument("--reads", type=int, default=10_000_000, help="reads per batch per GPU")
     ap.add_argument("--index-kmers", type=int, default=None, help="overrides --config's index size")
     ap.add_argument("--read-len", type=int, default=150)
@@ -456,6 +458,79 @@ def main():
                 "per_kernel": per_kernel,
             },
         }
+
+    # ---- N > 1: the same invocation also answers BASELINE configs[3] and the PCIe question ------------------------
+    # (i) `strong`: the SAME --steps x --reads reads as ONE job split evenly over the ranks (reference
+    #     command_line_interface.py:110-130: a fixed job cut over the workers, one additive reduce), timed region = map +
+    #     flush + RCCL reduce; efficiency against the N = 1 time the weak leg measured on every rank (each rank mapped the
+    #     whole --steps x --reads job there).
+    # (ii) the staged leg on EVERY rank at once: batches in pinned host memory, copied to HBM by every call over the
+    #     rank's own PCIe link (all ranks pull from host DRAM together: 8 x ~55 GB/s).
+    def timed_job(job_sizes, get_batch):
+        counts.zero_()
+        fence()
+        dev.set_timing(True)
+        a0 = time.perf_counter()
+        for j, n_j in enumerate(job_sizes):
+            dev.map_reads_uniform(get_batch(j)[: n_j * L], n_j, L, k, args.max_freq)
+        dev.synchronize()
+        a_map = time.perf_counter()
+        if world > 1:
+            reduce_counts(counts)
+        fence()
+        a1 = time.perf_counter()
+        dev.set_timing(False)
+        tm = dev.get_timing()
+        n_k = sum(job_sizes) * max(L - k + 1, 0)
+        cdev = dev_t if (world > 1 and args.dist_backend == "nccl") else "cpu"
+        mine = torch.tensor([(a_map - a0) * 1e3, tm["k_rx_flush"][0], (a1 - a_map) * 1e3, (a1 - a0) * 1e3, float(n_k),
+                             float(sum(job_sizes))], dtype=torch.float64, device=cdev)
+        every = [mine]
+        if world > 1:
+            every = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(every, mine)
+        cols = [[round(t[c].item(), 3) for t in every] for c in range(6)]
+        return {"map_ms": cols[0], "flush_ms": cols[1], "reduce_ms": cols[2], "elapsed_ms": cols[3],
+                "kmers": int(sum(cols[4])), "reads": [int(x) for x in cols[5]]}
+
+    plain_fused = not (args.records or args.operator or args.general_path)
+    if world > 1 and plain_fused and not args.strong:
+        from kmer_mapper_amd.distributed import shard_range
+        lo_r, hi_r = shard_range(R * args.steps, rank, world)
+        s_sizes = [R] * ((hi_r - lo_r) // R) + ([(hi_r - lo_r) % R] if (hi_r - lo_r) % R else [])
+        st = timed_job(s_sizes, lambda j: batches[j & 1])
+        if rank == 0:
+            t_strong = max(st["elapsed_ms"])
+            t_n1 = sum(per_rank_map_ms) / len(per_rank_map_ms)        # weak leg: map + flush of the whole job on ONE GPU
+            result["strong"] = {
+                "workload": "BASELINE configs[3]: %d reads in total split over %d ranks (%s reads per rank), batches of <= %d"
+                            % (R * args.steps, world, "/".join(str(x) for x in sorted(set(st["reads"]))), R),
+                "value": round(st["kmers"] / (t_strong * 1e-3) / 1e6, 1), "unit": "M k-mers/s",
+                "elapsed_ms": round(t_strong, 3),
+                "per_rank_map_ms": st["map_ms"],                      # map kernels + the flush behind the last batch
+                "flush_ms": st["flush_ms"], "final_reduce_ms": round(max(st["reduce_ms"]), 3),
+                "n1_time_ms_measured_in_the_weak_leg": round(t_n1, 3),
+                "efficiency_vs_n1": round(t_n1 / (world * t_strong), 4),
+                "timed_region": "map + flush + RCCL reduce, barrier / synchronize on both sides, max over ranks",
+            }
+    if world > 1 and plain_fused and not args.no_h2d_leg:
+        host_batches = [b.cpu().pin_memory() for b in batches]
+        dev.map_reads_uniform(host_batches[0], R, L, k, args.max_freq)      # warm the staging buffers
+        dev.synchronize()
+        sg = timed_job(sizes, lambda j: host_batches[j & 1])
+        del host_batches
+        if rank == 0:
+            t_st = max(sg["elapsed_ms"])
+            v_h2d = sg["kmers"] / (t_st * 1e-3) / 1e6
+            result["value_incl_h2d"] = round(v_h2d, 1)
+            result["config"]["value_incl_h2d"] = round(v_h2d, 1)
+            result["config"]["h2d_leg"] = {
+                "what": "the weak job again with every batch in pinned host memory, copied to HBM by the call that maps it "
+                        "(double-buffered staging on a copy stream), on all %d ranks at once; reduce included" % world,
+                "per_rank_read_GB_per_s": [round(r_ * L / (m_ * 1e-3) / 1e9, 1) for r_, m_ in zip(sg["reads"], sg["map_ms"])],
+                "host_read_GB_per_s_total": round(sum(sg["reads"]) * L / (t_st * 1e-3) / 1e9, 1),
+                "elapsed_ms": round(t_st, 3)}
+            result["roofline"]["frac_incl_h2d"] = round(v_h2d * 1e6 * B_ALG_PER_KMER / 1e9 / (HBM_PEAK_GBPS * world), 4)
 
     # ---- SURVEY 8(d)'s map-phase figure: the SAME steps with the reads in pinned host memory, staged by every call
     # (double-buffered on a copy stream).  `value` above times reads that are already resident in HBM (the bench

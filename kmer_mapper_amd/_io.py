@@ -36,13 +36,27 @@ def build(force=False):
 _lib = None
 
 
+def _fresh():
+    """libkmm_io.so exists and is not older than its source (rebuilt here when it is and a compiler is at hand: an edit
+    of kmm_io.cpp alone must not leave a stale reader in use)."""
+    if not os.path.exists(SO_PATH):
+        return False
+    try:
+        if _lib is None and os.path.exists(SRC) and os.path.getmtime(SO_PATH) < os.path.getmtime(SRC):
+            build()
+    except Exception:           # no compiler on this box: the existing library is what there is
+        pass
+    return True
+
+
 def available():
-    return os.environ.get("KMM_IO_PYTHON") != "1" and os.path.exists(SO_PATH)
+    return os.environ.get("KMM_IO_PYTHON") != "1" and _fresh()
 
 
 def lib():
     global _lib
     if _lib is None:
+        _fresh()
         L = ctypes.CDLL(SO_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)

@@ -210,6 +210,11 @@ struct kmm_index {
     uint64_t n_radix_batches = 0, n_direct_batches = 0; // which path the batches took ("radix_batches" / "direct_batches")
     ncclComm_t comm = nullptr; // multi-process communicator of this handle (kmm_comm_init_rank)
     int comm_rank = -1, comm_size = 0;
+    // flush of node range s under the reduce of node range s - 1 (kmm_comm_reduce_counts): "comm_overlap_slices"
+    int comm_slices = 8;
+    hipStream_t comm_stream = nullptr;
+    std::vector<hipEvent_t> comm_events;
+    std::vector<uint64_t> flush_cuts; // entry (node order) where node range s begins, for comm_slices ranges; [slices + 1]
     // timing
     bool timing = false;
     std::vector<TimedEvent> ev_used;
@@ -896,6 +901,10 @@ void kmm_index_destroy(kmm_index_t *ix)
     release(ix->rx_meta);
     release(ix->rx_buf1);
     release(ix->rx_buf2);
+    for (hipEvent_t e : ix->comm_events)
+        (void)hipEventDestroy(e);
+    if (ix->comm_stream)
+        (void)hipStreamDestroy(ix->comm_stream);
     for (void *q : {(void *)ix->rx_pstart16, (void *)ix->rx_slice_e0, (void *)ix->rx_pstart, (void *)ix->rx_pkeys, (void *)ix->rx_pkeys_raw, (void *)ix->rx_pfreq, (void *)ix->rx_pnodes,
                     (void *)ix->rx_porig, (void *)ix->rx_ecnt, (void *)ix->rx_ecnt_acc, (void *)ix->rx_norder, (void *)ix->rx_nnode,
                     (void *)ix->rx_occ})
@@ -1454,13 +1463,66 @@ int kmm_comm_reduce_counts(kmm_index_t *ix, int root)
     if (root < -1 || root >= ix->comm_size)
         return fail(KMM_ERR_INVALID_ARG, "root %d outside [-1, %d)", root, ix->comm_size);
     HIPCHK(hipSetDevice(ix->device));
-    KMMCHK(rx_flush(ix)); // every hit mapped so far is in `counts` before it travels
     const size_t n = (size_t)ix->max_node_id + 1;
-    // uint32 addition wraps modulo 2^32 like mapper.pyx:37,68, whatever the order of the reduction
-    if (root < 0)
-        RCCLCHK(g_rccl.AllReduce(ix->counts, ix->counts, n, ncclUint32, ncclSum, ix->comm, ix->stream));
-    else
-        RCCLCHK(g_rccl.Reduce(ix->counts, ix->counts, n, ncclUint32, ncclSum, root, ix->comm, ix->stream));
+    auto reduce = [&](size_t first, size_t count, hipStream_t st) {
+        // uint32 addition wraps modulo 2^32 like mapper.pyx:37,68, whatever the order of the reduction
+        return root < 0 ? g_rccl.AllReduce(ix->counts + first, ix->counts + first, count, ncclUint32, ncclSum, ix->comm, st)
+                        : g_rccl.Reduce(ix->counts + first, ix->counts + first, count, ncclUint32, ncclSum, root, ix->comm, st);
+    };
+    // The tail of a multi-GPU job is flush (per-entry hits -> node counts: 2 ms at the 100 M index, 25 ms at 10^9 entries)
+    // + the reduce of 4 (max_node_id + 1) bytes.  With the entries listed in node order the flush of one node RANGE only
+    // writes that range of the count vector, so range s is flushed while range s - 1 travels: the ranges' reduces go to
+    // a second stream, each behind the event of its flush.  Every rank issues the same sequence of reduces.
+    const int S = ix->comm_slices;
+    if (S > 1 && ix->ecnt_dirty && ix->rx_norder && !ix->rx_ecnt_acc && ix->rx_flush_sorted && n >= (size_t)S * 1024) {
+        if (!ix->comm_stream)
+            HIPCHK(hipStreamCreateWithFlags(&ix->comm_stream, hipStreamNonBlocking));
+        while ((int)ix->comm_events.size() < S + 1) {
+            hipEvent_t e;
+            HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            ix->comm_events.push_back(e);
+        }
+        if ((int)ix->flush_cuts.size() != S + 1) { // once per handle: where the node ranges begin in the node-ordered list
+            std::vector<uint32_t> bounds(S + 1);
+            for (int t = 0; t <= S; ++t)
+                bounds[t] = (uint32_t)(n * (size_t)t / (size_t)S);
+            DevBuf d_b, d_c;
+            KMMCHK(ensure(d_b, (S + 1) * 4));
+            KMMCHK(ensure(d_c, (S + 1) * 8));
+            HIPCHK(hipMemcpyAsync(d_b.p, bounds.data(), (S + 1) * 4, hipMemcpyHostToDevice, ix->stream));
+            hipLaunchKernelGGL(k_rx_node_cuts, dim3(1), dim3(64), 0, ix->stream, ix->rx_nnode, ix->rx_S, (const uint32_t *)d_b.p, S + 1,
+                               (unsigned long long *)d_c.p);
+            HIPCHK(hipGetLastError());
+            ix->flush_cuts.assign(S + 1, 0);
+            HIPCHK(hipMemcpyAsync(ix->flush_cuts.data(), d_c.p, (S + 1) * 8, hipMemcpyDeviceToHost, ix->stream));
+            HIPCHK(hipStreamSynchronize(ix->stream));
+            release(d_b);
+            release(d_c);
+            ix->flush_cuts[0] = 0;
+            ix->flush_cuts[S] = ix->rx_S;
+        }
+        ScopedTimer tm;
+        KMMCHK(tm.begin(ix, KMM_KERNEL_RX_FLUSH));
+        for (int t = 0; t < S; ++t) {
+            const uint64_t j0 = ix->flush_cuts[t], j1 = ix->flush_cuts[t + 1];
+            if (j1 > j0)
+                hipLaunchKernelGGL(k_rx_flush_sorted, dim3(grid_for(ix, (int64_t)((j1 - j0 + 1023) / 1024), 8)), dim3(256), 0, ix->stream,
+                                   view_of(ix), ix->rx_ecnt, ix->rx_norder + j0, ix->rx_nnode + j0, j1 - j0);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipEventRecord(ix->comm_events[t], ix->stream));
+            HIPCHK(hipStreamWaitEvent(ix->comm_stream, ix->comm_events[t], 0));
+            const size_t first = n * (size_t)t / (size_t)S, end = n * (size_t)(t + 1) / (size_t)S;
+            RCCLCHK(reduce(first, end - first, ix->comm_stream));
+        }
+        HIPCHK(hipMemsetAsync(ix->rx_ecnt, 0, (size_t)ix->rx_S * 4, ix->stream));
+        KMMCHK(tm.end());
+        ix->ecnt_dirty = false;
+        HIPCHK(hipEventRecord(ix->comm_events[S], ix->comm_stream));
+        HIPCHK(hipStreamWaitEvent(ix->stream, ix->comm_events[S], 0));
+        return drain(ix);
+    }
+    KMMCHK(rx_flush(ix)); // every hit mapped so far is in `counts` before it travels
+    RCCLCHK(reduce(0, n, ix->stream));
     return drain(ix);
 }
 
@@ -1756,12 +1818,18 @@ static bool records_take_radix(const kmm_index_t *ix, int64_t n_bytes, int forma
     return use_radix(ix, format == KMM_FORMAT_FASTQ ? n_bytes / 2 : n_bytes);
 }
 
-// One piece on the radix path (r04): census -> the sequence bytes compacted into flat reads of 2-bit codes (one per
+// Raw records on the radix path (r04): census -> the sequence bytes compacted into flat reads of 2-bit codes (one per
 // byte) + the read-start bitset (kmm_records.hpp, k_rec_count2 .. k_rec_uniform), all on the copy stream, i.e. under
-// the previous piece's map kernels; then pass 1 runs on flat reads — on packed tiles when the piece's reads have one
-// length — instead of pushing every raw byte through the records front end (22.3 ms per 10 M reads in round 3).
-static int map_records_piece_radix(kmm_index_t *ix, Stage &s, const uint8_t *d_raw, int64_t n_bytes, int format, int k,
-                                   int max_freq, int also_revcomp, const uint8_t *d_lut, int64_t *consumed, int64_t *n_records)
+// the previous call's map kernels; then pass 1 runs on flat reads — on packed tiles when the reads have one length —
+// instead of pushing every raw byte through the records front end (22.3 ms per 10 M reads in round 3).
+//
+// rec_compact_piece: one piece of at most 2^30 raw bytes (the census is a two-level scan over 1024 x 1024 tiles of 1024
+// bytes), appended to the flat reads at flat position `flat_base`.  Synchronises the copy stream (the caller's host
+// buffer is free afterwards) and returns where the piece's last complete record ends, its records, the flat length
+// after it, and whether its reads have one length.
+static int rec_compact_piece(kmm_index_t *ix, Stage &s, const uint8_t *d_raw, int64_t n_bytes, int format, const uint8_t *d_lut,
+                             int64_t flat_base, uint8_t *flat, uint32_t *start_bits, int64_t *consumed, int64_t *n_records,
+                             int64_t *flat_end, int64_t *uniform_len)
 {
     const int64_t n_tiles = (n_bytes + 1023) / 1024;
     const int n_super = (int)((n_tiles + 1023) / 1024);
@@ -1769,66 +1837,131 @@ static int map_records_piece_radix(kmm_index_t *ix, Stage &s, const uint8_t *d_r
     size_t off = 0;
     auto carve = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
     const size_t o_nl = carve(n_pad * 4), o_seq = carve(n_pad * 8), o_pre = carve(n_pad * 4), o_snl = carve((size_t)n_super * 4 + 64),
-                 o_sseq = carve((size_t)n_super * 4 + 64), o_info = carve(64), o_out = carve(64);
+                 o_sseq = carve((size_t)n_super * 4 + 64), o_info = carve(256), o_out = carve(256);
     KMMCHK(ensure(s.aux, off));
-    const size_t n_words = (size_t)n_bytes / 32 + 2;
-    KMMCHK(ensure(s.start_bits, n_words * 4));
-    KMMCHK(ensure(s.kmers, (size_t)n_bytes + 64));
     uint8_t *a = (uint8_t *)s.aux.p;
     uint32_t *tile_nl = (uint32_t *)(a + o_nl), *tile_pre = (uint32_t *)(a + o_pre), *super_nl = (uint32_t *)(a + o_snl),
              *super_seq = (uint32_t *)(a + o_sseq);
     unsigned long long *tile_seq = (unsigned long long *)(a + o_seq), *d_out = (unsigned long long *)(a + o_out);
     int64_t *d_info = (int64_t *)(a + o_info);
-    uint8_t *flat = (uint8_t *)s.kmers.p;
-    uint32_t *start_bits = (uint32_t *)s.start_bits.p;
     hipStream_t cs = ix->copy_stream;
     const uint32_t pm = (uint32_t)format - 1u, hc = format == KMM_FORMAT_FASTQ ? (uint32_t)'@' : (uint32_t)'>';
     const dim3 g4((unsigned)((n_tiles + 3) / 4));
     HIPCHK(hipMemsetAsync(tile_nl, 0, n_pad * 4, cs));
     HIPCHK(hipMemsetAsync(tile_seq, 0, n_pad * 8, cs));
-    HIPCHK(hipMemsetAsync(d_info, 0, 64 + 256, cs)); // (info and out_info: neighbours)
-    HIPCHK(hipMemsetAsync(start_bits, 0, n_words * 4, cs));
+    HIPCHK(hipMemsetAsync(d_info, 0, 512, cs)); // (info and out_info: neighbours)
     hipLaunchKernelGGL(k_rec_count2, g4, dim3(256), 0, cs, d_raw, n_bytes, n_tiles, tile_nl, tile_seq);
     hipLaunchKernelGGL(k_rec_scan1, dim3(n_super), dim3(1024), 0, cs, tile_nl, super_nl);
     hipLaunchKernelGGL(k_rec_scan2, dim3(1), dim3(1024), 0, cs, d_raw, n_bytes, n_super, tile_nl, super_nl, (uint32_t)format, d_info);
     hipLaunchKernelGGL(k_rec_seq_scan, dim3(n_super), dim3(1024), 0, cs, tile_seq, tile_nl, super_nl, n_tiles, pm, tile_pre, super_seq);
-    hipLaunchKernelGGL(k_super_scan, dim3(1), dim3(1024), 0, cs, super_seq, n_super, (uint32_t *)(d_out + 4));
+    hipLaunchKernelGGL(k_super_scan, dim3(1), dim3(1024), 0, cs, super_seq, n_super, (uint32_t *)(d_out + 8));
     hipLaunchKernelGGL(k_rec_scatter, g4, dim3(256), 0, cs, d_raw, n_bytes, n_tiles, tile_nl, super_nl, tile_pre, super_seq, d_info,
-                       d_lut, pm, hc, flat, start_bits, ix->first_bad, d_out);
-    hipLaunchKernelGGL(k_rec_uniform, dim3(grid_for(ix, (int64_t)(n_words + 255) / 256, 4)), dim3(256), 0, cs, start_bits, d_info, d_out);
+                       d_lut, pm, hc, flat, (uint64_t)flat_base, start_bits, ix->first_bad, d_out);
+    hipLaunchKernelGGL(k_rec_uniform, dim3(grid_for(ix, (n_bytes / 32 + 256) / 256, 4)), dim3(256), 0, cs, start_bits,
+                       (uint64_t)flat_base, d_info, d_out);
     HIPCHK(hipGetLastError());
     struct { int64_t info[8]; unsigned long long out[8]; } h;
-    static_assert(sizeof h == 128, "info and out_info are copied together");
     memset(&h, 0, sizeof h);
-    if (o_out != o_info + 256) // (carve rounds to 256 bytes: info at o_info, out_info at o_info + 256)
-        return fail(KMM_ERR_INTERNAL, "records: scratch layout");
     HIPCHK(hipMemcpyAsync(h.info, d_info, 64, hipMemcpyDeviceToHost, cs));
     HIPCHK(hipMemcpyAsync(h.out, d_out, 64, hipMemcpyDeviceToHost, cs));
     HIPCHK(hipStreamSynchronize(cs)); // the borrowed host buffer is free from here on
     *consumed = h.info[0];
     *n_records = h.info[1];
-    const int64_t total = (int64_t)h.out[0];
-    if (h.info[0] <= 0 || total <= 0)
-        return KMM_OK;
+    *flat_end = h.info[0] > 0 ? (int64_t)h.out[0] : flat_base;
+    const int64_t piece = *flat_end - flat_base, recs = h.info[1];
+    const int64_t L = recs > 0 ? piece / recs : 0;
+    *uniform_len = (recs > 0 && L * recs == piece && h.out[1] == (unsigned long long)recs && h.out[2] == 0) ? L : 0;
+    return KMM_OK;
+}
+
+// The flat reads (codes, one per byte) through the radix path.
+static int rec_launch_flat(kmm_index_t *ix, const uint8_t *flat, int64_t total, int64_t n_reads, const uint32_t *start_bits,
+                           int64_t n_words, int64_t uniform_len, int k, int max_freq, int also_revcomp)
+{
     ReadsView rv;
     memset(&rv, 0, sizeof rv);
     rv.bases = flat;
     rv.total = total;
-    rv.n_reads = h.info[1];
+    rv.n_reads = n_reads;
     rv.lut = ix->lut_codes;
     rv.first_bad = ix->first_bad;
-    const int64_t L = h.info[1] > 0 ? total / h.info[1] : 0;
-    const bool uniform = L >= 16 && L * h.info[1] == total && h.out[1] == (unsigned long long)h.info[1] && h.out[2] == 0;
     KMMCHK(stage_copies_done(ix));
-    if (uniform) {
-        set_uniform_geometry(ix, rv, L, k);
+    if (uniform_len >= 16 && uniform_len * n_reads == total) {
+        set_uniform_geometry(ix, rv, uniform_len, k);
         if (rv.pk_rpt)
             return launch_rx<MODE_PACKED>(ix, rv, nullptr, 0, k, max_freq, also_revcomp ? 1 : 0);
         return launch_rx<MODE_UNIFORM>(ix, rv, nullptr, 0, k, max_freq, also_revcomp ? 1 : 0);
     }
     rv.start_bits = start_bits;
-    rv.n_start_words = (int64_t)n_words;
+    rv.n_start_words = n_words;
     return launch_rx<MODE_GENERAL>(ix, rv, nullptr, 0, k, max_freq, also_revcomp ? 1 : 0);
+}
+
+// One piece, compacted and mapped by itself (the unwrapped pieces of multi-line FASTA come this way).
+static int map_records_piece_radix(kmm_index_t *ix, Stage &s, const uint8_t *d_raw, int64_t n_bytes, int format, int k,
+                                   int max_freq, int also_revcomp, const uint8_t *d_lut, int64_t *consumed, int64_t *n_records)
+{
+    const size_t n_words = (size_t)n_bytes / 32 + 2;
+    KMMCHK(ensure(s.start_bits, n_words * 4));
+    KMMCHK(ensure(s.kmers, (size_t)n_bytes + 64));
+    HIPCHK(hipMemsetAsync(s.start_bits.p, 0, n_words * 4, ix->copy_stream));
+    int64_t flat_end = 0, L = 0;
+    KMMCHK(rec_compact_piece(ix, s, d_raw, n_bytes, format, d_lut, 0, (uint8_t *)s.kmers.p, (uint32_t *)s.start_bits.p, consumed,
+                             n_records, &flat_end, &L));
+    if (*consumed <= 0 || flat_end <= 0)
+        return KMM_OK;
+    return rec_launch_flat(ix, (const uint8_t *)s.kmers.p, flat_end, *n_records, (const uint32_t *)s.start_bits.p, (int64_t)n_words,
+                           L, k, max_freq, also_revcomp);
+}
+
+// A whole kmm_map_records call on the radix path: the pieces (at most 2^30 raw bytes each, every one starting where the
+// previous one's last complete record ended) are compacted one after the other into ONE array of flat reads, which then
+// takes the radix path as one batch — the passes' fixed costs per batch (0.85 ms at the 100 M index) are paid once per
+// call, not once per GiB of FASTQ.
+static int map_records_radix_call(kmm_index_t *ix, const uint8_t *raw, int64_t n_bytes, int format, int k, int max_freq,
+                                  int also_revcomp, const uint8_t *lut, int64_t *consumed, int64_t *n_records)
+{
+    Stage &s = next_stage(ix);
+    KMMCHK(stage_acquire(ix, s));
+    ix->map_calls++;
+    bool staged = false;
+    const uint8_t *d_lut = nullptr;
+    KMMCHK(resolve_lut(ix, s, lut, &d_lut, &staged));
+    const bool on_device = is_device_ptr(raw);
+    const size_t n_words = (size_t)n_bytes / 32 + 2;
+    KMMCHK(ensure(s.start_bits, n_words * 4));
+    KMMCHK(ensure(s.kmers, (size_t)n_bytes + 64));
+    HIPCHK(hipMemsetAsync(s.start_bits.p, 0, n_words * 4, ix->copy_stream));
+    const int64_t piece_max = (int64_t)1 << 30;
+    int64_t off = 0, recs = 0, flat = 0, L = -1;
+    while (off < n_bytes) {
+        const int64_t len = n_bytes - off < piece_max ? n_bytes - off : piece_max;
+        const uint8_t *d_raw = raw + off;
+        if (!on_device) {
+            KMMCHK(ensure(s.bases, (size_t)len));
+            HIPCHK(hipMemcpyAsync(s.bases.p, raw + off, (size_t)len, hipMemcpyHostToDevice, ix->copy_stream));
+            d_raw = (const uint8_t *)s.bases.p;
+        }
+        int64_t used = 0, nr = 0, flat_end = flat, Lp = 0;
+        KMMCHK(rec_compact_piece(ix, s, d_raw, len, format, d_lut, flat, (uint8_t *)s.kmers.p, (uint32_t *)s.start_bits.p, &used, &nr,
+                                 &flat_end, &Lp));
+        if (used > 0) {
+            L = (L == -1 || L == Lp) ? Lp : 0; // one length over all pieces, or none
+            flat = flat_end;
+        }
+        off += used;
+        recs += nr;
+        if (used == 0 || len < piece_max)
+            break; // no complete record left in reach / the last piece
+    }
+    if (consumed)
+        *consumed = off;
+    if (n_records)
+        *n_records = recs;
+    if (flat > 0)
+        KMMCHK(rec_launch_flat(ix, (const uint8_t *)s.kmers.p, flat, recs, (const uint32_t *)s.start_bits.p, (int64_t)n_words,
+                               L > 0 ? L : 0, k, max_freq, also_revcomp));
+    return stage_release(ix, s, false);
 }
 
 // One piece of at most 2^30 bytes (the newline census is a two-level scan over 1024 x 1024 tiles of 1024 bytes).
@@ -1978,6 +2111,8 @@ int kmm_map_records(kmm_index_t *ix, const uint8_t *raw, int64_t n_bytes, int fo
     HIPCHK(hipSetDevice(ix->device));
     // chunks beyond 2^30 bytes are mapped piece by piece: every piece starts where the previous one's last complete
     // record ended, so the pieces cut the chunk exactly as one census over all of it would
+    if (format != KMM_FORMAT_FASTA && records_take_radix(ix, n_bytes, format))
+        return map_records_radix_call(ix, raw, n_bytes, format, k, max_freq, also_revcomp, lut, consumed, n_records);
     const int64_t piece_max = (int64_t)1 << 30;
     int64_t off = 0, recs = 0;
     while (off < n_bytes) {
@@ -2415,6 +2550,12 @@ int kmm_set_param(kmm_index_t *ix, const char *name, int64_t value)
         if (value < 4 * RX_B || value > ((int64_t)1 << 32) - 2 * RX_B)
             return fail(KMM_ERR_INVALID_ARG, "radix_sub_batch_kmers outside [%d, 2^32 - %d]", 4 * RX_B, 2 * RX_B);
         ix->rx_sub_cap = value;
+    } else if (!strcmp(name, "comm_overlap_slices")) {
+        // kmm_comm_reduce_counts: node ranges whose flush runs under the previous range's reduce (1: flush, then one reduce)
+        if (value < 1 || value > 64)
+            return fail(KMM_ERR_INVALID_ARG, "comm_overlap_slices outside [1, 64]");
+        ix->comm_slices = (int)value;
+        ix->flush_cuts.clear();
     } else if (!strcmp(name, "radix_sorted_flush")) {
         ix->rx_flush_sorted = value != 0;
     } else if (!strcmp(name, "radix_grid_per_cu")) {
@@ -2477,6 +2618,8 @@ int kmm_get_param(kmm_index_t *ix, const char *name, int64_t *value)
         *value = ix->rx_grid_per_cu;
     else if (!strcmp(name, "radix_sub_batch_kmers"))
         *value = ix->rx_sub_cap;
+    else if (!strcmp(name, "comm_overlap_slices"))
+        *value = ix->comm_slices;
     else if (!strcmp(name, "radix_sorted_flush"))
         *value = (ix->rx_flush_sorted && ix->rx_norder) ? 1 : 0;
     else if (!strcmp(name, "radix_available"))

@@ -21,16 +21,20 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
 #include <deque>
 #include <functional>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
+
+#include "kmm_inflate.hpp"
 
 namespace {
 
@@ -138,12 +142,26 @@ size_t bgzf_member_size(const uint8_t *p, size_t n)
     const unsigned xlen = rd16(p + 10);
     if (xlen < 6 || p[12] != 'B' || p[13] != 'C' || rd16(p + 14) != 2)
         return 0;
-    return (size_t)rd16(p + 16) + 1;
+    const size_t ms = (size_t)rd16(p + 16) + 1;
+    if (ms < 12 + (size_t)xlen + 8) // header + extra field + CRC32 + ISIZE: the planner reads the trailer at p + ms - 4
+        return 0;
+    return ms;
 }
 
 struct Member {
     size_t src_off, src_len; // whole member in the file
     size_t dst_off, dst_len; // where its inflated bytes go
+};
+
+// inflated bytes on their way from the read-ahead thread to the reader (uninitialised storage: no zero-fill)
+struct Piece {
+    std::unique_ptr<uint8_t[]> p;
+    size_t n = 0;
+    Piece() = default;
+    explicit Piece(size_t size) : p(new uint8_t[size ? size : 1]), n(size) {}
+    uint8_t *data() { return p.get(); }
+    size_t size() const { return n; }
+    bool empty() const { return n == 0; }
 };
 
 } // namespace
@@ -163,7 +181,7 @@ struct kmm_io {
     std::thread ahead;
     std::mutex m;
     std::condition_variable cv;
-    std::deque<std::vector<uint8_t>> ready;
+    std::deque<Piece> ready;
     size_t ready_bytes = 0, front_pos = 0;
     bool ahead_done = false, ahead_stop = false;
     std::string ahead_err;
@@ -196,9 +214,19 @@ bool inflate_member(const uint8_t *src, size_t src_len, uint8_t *dst, size_t dst
     }
     Deflate &dl = deflate_lib();
     if (dl.ok) {
-        static thread_local void *dec = nullptr;
-        if (!dec)
-            dec = dl.alloc();
+        // one decompressor per worker thread, freed when the thread ends (every kmm_io_open has its own pool)
+        struct Dec {
+            void *p = nullptr;
+            ~Dec()
+            {
+                if (p)
+                    deflate_lib().free_(p);
+            }
+        };
+        static thread_local Dec dec_holder;
+        if (!dec_holder.p)
+            dec_holder.p = dl.alloc();
+        void *dec = dec_holder.p;
         size_t got = 0;
         if (!dec || dl.decompress(dec, payload, payload_len, dst, dst_len, &got) != 0 || got != dst_len) {
             *why = "corrupt BGZF member (inflate failed or size differs from the trailer)";
@@ -262,8 +290,10 @@ int64_t read_bgzf(kmm_io *h, uint8_t *dst, int64_t n)
         out += isize;
         p += ms;
     }
-    if (plan.empty() && p < h->size && done == 0) {
-        // not even one member fits: inflate it aside and hand out what fits
+    if (out == 0 && p < h->size) {
+        // nothing planned holds a byte (no member before p, or only empty ones — a BGZF end-of-file marker in the middle
+        // of a concatenated file) and the member at p does not fit: inflate it aside and hand out what fits.  (0 is
+        // returned at the end of the file only.)
         const size_t ms = bgzf_member_size(h->map + p, h->size - p);
         const size_t isize = rd32(h->map + p + ms - 4);
         h->carry.resize(isize);
@@ -313,8 +343,7 @@ void ahead_main(kmm_io *h)
     bool open = false, fed = false;
     size_t p = 0;
     std::string err;
-    std::vector<uint8_t> out;
-    auto push = [&](std::vector<uint8_t> &&v) {
+    auto push = [&](Piece &&v) {
         std::unique_lock<std::mutex> g(h->m);
         h->cv.wait(g, [&] { return h->ahead_stop || h->ready_bytes < max_ahead; });
         if (h->ahead_stop)
@@ -324,8 +353,22 @@ void ahead_main(kmm_io *h)
         h->cv.notify_all();
         return true;
     };
+    bool any_member = false;
     while (p < h->size || open) {
         if (!open) {
+            if (any_member) {
+                // bytes behind a member's end marker: zero padding is skipped (gzip.open — the reference's reader through
+                // bnp.open — does the same), another member must start with the gzip magic, anything else is an error
+                while (p < h->size && h->map[p] == 0)
+                    ++p;
+                if (p >= h->size)
+                    break;
+                if (p + 2 > h->size || h->map[p] != 0x1f || h->map[p + 1] != 0x8b) {
+                    err = "trailing bytes after the gzip stream are neither zero padding nor another gzip member (at byte " +
+                          std::to_string(p) + ")";
+                    break;
+                }
+            }
             memset(&z, 0, sizeof z);
             if (inflateInit2(&z, 31) != Z_OK) {
                 err = "inflateInit2 failed";
@@ -346,7 +389,7 @@ void ahead_main(kmm_io *h)
         z.avail_in = (uInt)chunk;
         int rc = Z_OK;
         while (z.avail_in && rc != Z_STREAM_END) {
-            out.resize(piece);
+            Piece out(piece);
             z.next_out = out.data();
             z.avail_out = (uInt)piece;
             rc = inflate(&z, Z_NO_FLUSH);
@@ -355,12 +398,11 @@ void ahead_main(kmm_io *h)
                 err = std::string("corrupt gzip stream: ") + (z.msg ? z.msg : "inflate error");
                 break;
             }
-            out.resize(piece - z.avail_out);
+            out.n = piece - z.avail_out;
             if (!out.empty() && !push(std::move(out))) {
                 err = "stopped";
                 break;
             }
-            out = std::vector<uint8_t>();
             if (rc == Z_BUF_ERROR && z.avail_in == 0)
                 break;
         }
@@ -370,12 +412,257 @@ void ahead_main(kmm_io *h)
         if (rc == Z_STREAM_END) { // next member of a concatenated file (zlib has checked CRC32 and ISIZE)
             inflateEnd(&z);
             open = false;
+            any_member = true;
         }
     }
     if (open)
         inflateEnd(&z);
     std::lock_guard<std::mutex> g(h->m);
     if (err != "stopped")
+        h->ahead_err = err;
+    h->ahead_done = true;
+    h->cv.notify_all();
+}
+
+// ---- one gzip member on many cores (kmm_inflate.hpp) ---------------------------------------------------------------
+// end of the gzip member header at p (RFC 1952), or 0 if it is not one / truncated
+size_t gzip_header_end(const uint8_t *d, size_t n, size_t p)
+{
+    if (p + 10 > n || d[p] != 0x1f || d[p + 1] != 0x8b || d[p + 2] != 8)
+        return 0;
+    const unsigned flg = d[p + 3];
+    size_t q = p + 10;
+    if (flg & 4) { // FEXTRA
+        if (q + 2 > n)
+            return 0;
+        q += 2 + (size_t)rd16(d + q);
+    }
+    for (unsigned bit : {8u, 16u}) // FNAME, FCOMMENT: zero-terminated
+        if (flg & bit) {
+            while (q < n && d[q])
+                ++q;
+            ++q;
+        }
+    if (flg & 2) // FHCRC
+        q += 2;
+    return q <= n ? q : 0;
+}
+
+// The stream is cut into chunks of `csize` compressed bytes; a wave = as many chunks as there are workers.  Every
+// chunk but the wave's first starts at the first dynamic-block header found in its byte range and is decoded with
+// markers for the unknown history; the wave's first chunk starts where the previous wave ended.  A chunk is accepted if
+// the chunk before it stopped exactly at its start (a block boundary); else it was a false start and the chunk
+// before it decodes on through its range.  Then the 32 KiB windows are resolved in order, the chunks in parallel.
+void ahead_main_parallel(kmm_io *h)
+{
+    using namespace kmm_inflate;
+    const size_t max_ahead = (size_t)512 << 20;
+    const uint8_t *d = h->map;
+    const size_t n = h->size;
+    const int T = h->pool->size();
+    std::string err;
+    auto push = [&](Piece &&v) {
+        if (v.empty())
+            return true;
+        std::unique_lock<std::mutex> g(h->m);
+        h->cv.wait(g, [&] { return h->ahead_stop || h->ready_bytes < max_ahead; });
+        if (h->ahead_stop)
+            return false;
+        h->ready_bytes += v.size();
+        h->ready.push_back(std::move(v));
+        h->cv.notify_all();
+        return true;
+    };
+    std::vector<Chunk> chunks((size_t)T);
+    std::vector<uint64_t> starts((size_t)T);
+    std::vector<Piece> bytes((size_t)T);
+    std::vector<std::vector<uint8_t>> windows((size_t)T + 1, std::vector<uint8_t>(WINDOW, 0));
+    std::vector<uint32_t> crcs((size_t)T), lowest((size_t)T);
+    size_t p = 0;
+    bool any_member = false, stopped = false;
+    while (p < n && err.empty() && !stopped) {
+        if (any_member) { // behind a member: zero padding is skipped, another member must start with the magic
+            while (p < n && d[p] == 0)
+                ++p;
+            if (p >= n)
+                break;
+            if (p + 2 > n || d[p] != 0x1f || d[p + 1] != 0x8b) {
+                err = "trailing bytes after the gzip stream are neither zero padding nor another gzip member (at byte " +
+                      std::to_string(p) + ")";
+                break;
+            }
+        }
+        const size_t body = gzip_header_end(d, n, p);
+        if (!body) {
+            err = p + 18 > n ? "compressed file ended before the end-of-stream marker was reached"
+                             : "corrupt gzip stream: incorrect header check";
+            break;
+        }
+        uint64_t cur_bit = (uint64_t)body * 8;
+        uint32_t crc = 0;
+        uint64_t total_out = 0;
+        size_t hist = 0; // real bytes at the end of windows[0]
+        bool final = false;
+        int barren = 0;  // waves in a row whose byte ranges held no dynamic block start (stored blocks: incompressible data)
+        while (!final && err.empty() && !stopped) {
+            const size_t cur_byte = (size_t)(cur_bit >> 3), left = n - cur_byte;
+            size_t csize = left / (size_t)(2 * T);
+            csize = std::min<size_t>(std::max<size_t>(csize, (size_t)256 << 10), (size_t)2 << 20);
+            if (const char *env = getenv("KMM_IO_GZIP_CHUNK")) // (tests: many chunks in a small file)
+                csize = std::max<size_t>((size_t)strtoull(env, nullptr, 10), 1024);
+            int n_ch = (int)std::min<size_t>((size_t)T, (left + csize - 1) / csize);
+            if (barren >= 2) { // no starting points to be found: one chunk per wave, decoded in order, no search
+                csize *= (size_t)n_ch;
+                n_ch = 1;
+            }
+            const uint64_t wave_end_bit = (uint64_t)std::min(n, cur_byte + (size_t)n_ch * csize) * 8;
+            // phase A: where the chunks start
+            const bool dbg = getenv("KMM_IO_DEBUG") != nullptr;
+            auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+            const double t_a = now();
+            starts[0] = cur_bit;
+            std::function<void(int64_t)> find = [&](int64_t j) {
+                if (j == 0)
+                    return;
+                const uint64_t a = (uint64_t)(cur_byte + (size_t)j * csize) * 8;
+                const uint64_t b = std::min<uint64_t>((uint64_t)(cur_byte + (size_t)(j + 1) * csize) * 8, (uint64_t)n * 8);
+                starts[(size_t)j] = find_block(d, n, a, b);
+            };
+            h->pool->parallel_for(n_ch, find);
+            // phase B: decode; a chunk stops at the first block boundary at or behind the next chunk's start
+            std::function<void(int64_t)> dec = [&](int64_t j) {
+                Chunk &c = chunks[(size_t)j];
+                if (starts[(size_t)j] == NPOS) {
+                    c.failed = true;
+                    c.n_out = 0;
+                    return;
+                }
+                uint64_t stop = wave_end_bit;
+                for (int x = (int)j + 1; x < n_ch; ++x)
+                    if (starts[(size_t)x] != NPOS) {
+                        stop = starts[(size_t)x];
+                        break;
+                    }
+                c.init(starts[(size_t)j], csize * 5);
+                decode_chunk(d, n, c, stop, j == 0 ? ~(size_t)0 : csize * 40);
+            };
+            h->pool->parallel_for(n_ch, dec);
+            const double t_b = now();
+            // accept the chunks that continue each other
+            std::vector<int> ok;
+            ok.push_back(0);
+            Chunk *cur = &chunks[0];
+            auto stream_error = [](const std::string &why) {
+                return why.rfind("compressed data ended", 0) == 0 ? std::string("compressed file ended before the end-of-stream marker was reached")
+                                                                  : "corrupt gzip stream: " + why;
+            };
+            if (cur->failed && !cur->final_seen) {
+                err = stream_error(cur->err);
+                break;
+            }
+            for (int j = 1; j < n_ch && !cur->final_seen; ++j) {
+                if (starts[(size_t)j] == NPOS)
+                    continue;
+                Chunk &c = chunks[(size_t)j];
+                if (cur->end_bit == starts[(size_t)j] && !c.failed) {
+                    ok.push_back(j);
+                    cur = &c;
+                    continue;
+                }
+                // a false start (or one that decoded into an error): the chunk before it goes on through its range
+                uint64_t stop = wave_end_bit;
+                for (int x = j + 1; x < n_ch; ++x)
+                    if (starts[(size_t)x] != NPOS) {
+                        stop = starts[(size_t)x];
+                        break;
+                    }
+                if (cur->end_bit < stop) {
+                    decode_chunk(d, n, *cur, stop, ~(size_t)0);
+                    if (cur->failed) {
+                        err = stream_error(cur->err);
+                        break;
+                    }
+                }
+            }
+            if (!err.empty())
+                break;
+            barren = (n_ch > 1 && ok.size() == 1) ? barren + 1 : (n_ch > 1 ? 0 : barren);
+            // the windows in order (32 KiB each), then every accepted chunk in parallel
+            const double t_c = now();
+            for (size_t q = 0; q < ok.size(); ++q) {
+                const Chunk &c = chunks[(size_t)ok[q]];
+                const std::vector<uint8_t> &w = windows[q];
+                std::vector<uint8_t> &wn = windows[q + 1];
+                const size_t tail = std::min<size_t>(c.n_out, WINDOW);
+                if (tail < WINDOW)
+                    memmove(wn.data(), w.data() + tail, WINDOW - tail);
+                (void)resolve(c.sym.data() + WINDOW + c.n_out - tail, tail, w.data(), wn.data() + WINDOW - tail);
+            }
+            std::function<void(int64_t)> res = [&](int64_t q) {
+                const Chunk &c = chunks[(size_t)ok[(size_t)q]];
+                Piece &out = bytes[(size_t)q];
+                out = Piece(c.n_out);
+                lowest[(size_t)q] = resolve(c.sym.data() + WINDOW, c.n_out, windows[(size_t)q].data(), out.data());
+                Deflate &dl = deflate_lib();
+                uint32_t cr = 0;
+                if (dl.ok) {
+                    cr = dl.crc32(0, out.data(), out.size());
+                } else {
+                    size_t done = 0;
+                    while (done < out.size()) { // (zlib's length argument is 32 bits)
+                        const size_t step = std::min<size_t>(out.size() - done, (size_t)1 << 30);
+                        cr = (uint32_t)::crc32(cr, out.data() + done, (uInt)step);
+                        done += step;
+                    }
+                }
+                crcs[(size_t)q] = cr;
+            };
+            h->pool->parallel_for((int64_t)ok.size(), res);
+            const double t_d = now();
+            if (dbg)
+                fprintf(stderr, "[kmm_io] wave at byte %zu: %d chunks of %zu bytes, %zu accepted; find+decode %.1f ms, continue %.1f ms, "
+                        "resolve %.1f ms\n", cur_byte, n_ch, csize, ok.size(), (t_b - t_a) * 1e3, (t_c - t_b) * 1e3, (t_d - t_c) * 1e3);
+            for (size_t q = 0; q < ok.size() && err.empty(); ++q) {
+                // a marker may only point at history that exists: the last `hist` bytes of the window
+                if (lowest[q] < WINDOW && (size_t)(WINDOW - lowest[q]) > hist)
+                    err = "corrupt gzip stream: invalid distance too far back";
+                hist = std::min<size_t>(WINDOW, hist + bytes[q].size());
+                crc = (uint32_t)crc32_combine(crc, crcs[q], (z_off_t)bytes[q].size());
+                total_out += bytes[q].size();
+            }
+            if (!err.empty())
+                break;
+            for (size_t q = 0; q < ok.size(); ++q)
+                if (!push(std::move(bytes[q]))) {
+                    stopped = true;
+                    break;
+                }
+            windows[0].swap(windows[ok.size()]);
+            cur_bit = cur->end_bit;
+            final = cur->final_seen;
+            if (!final && cur_bit >= (uint64_t)n * 8)
+                err = "compressed file ended before the end-of-stream marker was reached";
+        }
+        if (!err.empty() || stopped)
+            break;
+        const size_t t = (size_t)((cur_bit + 7) >> 3);
+        if (t + 8 > n) {
+            err = "compressed file ended before the end-of-stream marker was reached";
+            break;
+        }
+        if (rd32(d + t) != crc) {
+            err = "corrupt gzip stream: incorrect data check";
+            break;
+        }
+        if (rd32(d + t + 4) != (uint32_t)total_out) {
+            err = "corrupt gzip stream: incorrect length check";
+            break;
+        }
+        p = t + 8;
+        any_member = true;
+    }
+    std::lock_guard<std::mutex> g(h->m);
+    if (!stopped)
         h->ahead_err = err;
     h->ahead_done = true;
     h->cv.notify_all();
@@ -392,7 +679,7 @@ int64_t read_gzip(kmm_io *h, uint8_t *dst, int64_t n)
                 return fail(h, h->ahead_err);
             break; // end of stream
         }
-        std::vector<uint8_t> &v = h->ready.front();
+        Piece &v = h->ready.front();
         const size_t take = std::min<size_t>(v.size() - h->front_pos, (size_t)(n - done));
         g.unlock();
         memcpy(dst + done, v.data() + h->front_pos, take);
@@ -482,10 +769,16 @@ kmm_io *kmm_io_open(const char *path, int n_threads)
             madvise(m, h->size, MADV_SEQUENTIAL);
         }
     }
-    if (h->kind != 2)
+    if (h->kind != 2) {
         h->pool = new Pool(n_threads);
-    else
+    } else if (n_threads >= 2 && !getenv("KMM_IO_GZIP_SERIAL") &&
+               h->size >= (getenv("KMM_IO_GZIP_CHUNK") ? (size_t)1 : (size_t)1 << 20)) {
+        // one gzip member on many cores: speculative chunks with markers for the unknown history (kmm_inflate.hpp)
+        h->pool = new Pool(n_threads);
+        h->ahead = std::thread(ahead_main_parallel, h);
+    } else {
         h->ahead = std::thread(ahead_main, h);
+    }
     return h;
 }
 

@@ -1986,6 +1986,24 @@ __global__ void __launch_bounds__(256) k_rx_flush_sorted(IndexView iv, const uin
     }
 }
 
+// cuts[t] = first position j of the node-ordered entry list with nnode[j] >= bounds[t] (lane t; binary search)
+__global__ void k_rx_node_cuts(const uint32_t *__restrict__ nnode, uint64_t n, const uint32_t *__restrict__ bounds, int n_bounds,
+                               unsigned long long *__restrict__ cuts)
+{
+    for (int t = threadIdx.x; t < n_bounds; t += blockDim.x) {
+        const uint32_t b = bounds[t];
+        uint64_t lo = 0, hi = n;
+        while (lo < hi) {
+            const uint64_t mid = lo + (hi - lo) / 2;
+            if (nnode[mid] < b)
+                lo = mid + 1;
+            else
+                hi = mid;
+        }
+        cuts[t] = lo;
+    }
+}
+
 // most entries in one slice of 2^w buckets
 __global__ void __launch_bounds__(256) k_rx_max_slice(const uint32_t *__restrict__ pstart, uint64_t modulo, int w,
                                                       uint32_t PF, unsigned long long *out)

@@ -430,7 +430,8 @@ __global__ void __launch_bounds__(256) k_rec_scatter(const uint8_t *__restrict__
                                                      const uint32_t *__restrict__ tile_pre, const uint32_t *__restrict__ super_pre,
                                                      const int64_t *__restrict__ info, const uint8_t *__restrict__ lut,
                                                      uint32_t period_mask, uint32_t header_char, uint8_t *__restrict__ flat,
-                                                     uint32_t *__restrict__ start_bits, unsigned long long *__restrict__ first_bad,
+                                                     uint64_t flat_base, uint32_t *__restrict__ start_bits,
+                                                     unsigned long long *__restrict__ first_bad,
                                                      unsigned long long *__restrict__ out_info)
 {
     __shared__ uint32_t s_lut[256];
@@ -487,7 +488,7 @@ __global__ void __launch_bounds__(256) k_rec_scatter(const uint8_t *__restrict__
     const uint32_t cnt = (uint32_t)__popc(seq);
     const uint32_t pre = wave_scan_incl(cnt) - cnt;
     const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)(pre + cnt), 63);
-    const uint64_t dst0 = (uint64_t)super_pre[tile >> 10] + tile_pre[tile]; // flat position of the tile's first sequence byte
+    const uint64_t dst0 = flat_base + super_pre[tile >> 10] + tile_pre[tile]; // flat position of the tile's first sequence byte
     // read starts: the first byte of every sequence line; and whatever follows a '\r' inside a sequence line (no window
     // may span it: the records front end treats every '\r' as a break)
     {
@@ -545,25 +546,28 @@ __global__ void __launch_bounds__(256) k_rec_scatter(const uint8_t *__restrict__
         out_info[0] = dst0 + pre + cnt;
 }
 
-// Do all reads of the compacted chunk have one length?  info[1] = records, out_info[0] = flat bases; counts the read
-// starts below the flat length into out_info[1] and those that are no multiple of L = bases / records into out_info[2]:
-// with as many distinct starts as records, all of them multiples of L, every multiple of L is a start.
-__global__ void __launch_bounds__(256) k_rec_uniform(const uint32_t *__restrict__ start_bits, const int64_t *__restrict__ info,
-                                                     unsigned long long *__restrict__ out_info)
+// Do all reads of the compacted piece have one length?  The piece's flat bases are [flat_base, out_info[0]), info[1] =
+// its records; counts the read starts inside that range into out_info[1] and those whose distance from flat_base is no
+// multiple of L = bases / records into out_info[2]: with as many distinct starts as records, all of them multiples of L,
+// every multiple of L is a start.
+__global__ void __launch_bounds__(256) k_rec_uniform(const uint32_t *__restrict__ start_bits, uint64_t flat_base,
+                                                     const int64_t *__restrict__ info, unsigned long long *__restrict__ out_info)
 {
-    const uint64_t total = out_info[0], recs = (uint64_t)info[1];
-    if (!recs || !total || total % recs)
+    const uint64_t end = out_info[0], recs = (uint64_t)info[1];
+    if (info[0] <= 0 || !recs || end <= flat_base || (end - flat_base) % recs)
         return; // (out_info[1] stays 0: not uniform)
-    const uint32_t L = (uint32_t)(total / recs);
-    const uint64_t n_words = (total + 31) / 32;
+    const uint32_t L = (uint32_t)((end - flat_base) / recs);
+    const uint64_t w0 = flat_base >> 5, w1 = (end + 31) >> 5;
     uint32_t n_set = 0, n_off = 0;
-    for (uint64_t wd = (uint64_t)blockIdx.x * 256 + threadIdx.x; wd < n_words; wd += (uint64_t)gridDim.x * 256) {
+    for (uint64_t wd = w0 + (uint64_t)blockIdx.x * 256 + threadIdx.x; wd < w1; wd += (uint64_t)gridDim.x * 256) {
         uint32_t m = start_bits[wd];
-        if (wd * 32 + 32 > total)
-            m &= (1u << (total - wd * 32)) - 1u;
+        if (wd * 32 < flat_base)
+            m &= ~((1u << (flat_base - wd * 32)) - 1u);
+        if (wd * 32 + 32 > end)
+            m &= (1u << (end - wd * 32)) - 1u;
         n_set += (uint32_t)__popc(m);
         while (m) {
-            const uint64_t pos = wd * 32 + (uint32_t)__builtin_ctz(m);
+            const uint64_t pos = wd * 32 + (uint32_t)__builtin_ctz(m) - flat_base;
             m &= m - 1u;
             n_off += pos % L ? 1u : 0u;
         }

@@ -131,20 +131,39 @@ def _bgzf_pieces(path, n_threads, group_bytes=1 << 22):
 
 
 def _gzip_pieces(path, piece=1 << 24):
-    """One (or several concatenated) plain gzip member(s): a single thread, large reads."""
+    """One (or several concatenated) plain gzip member(s): a single thread, large reads.  Behind a member's end marker
+    zero padding is skipped (as gzip.open does, the reference's reader through bnp.open); anything else must be another
+    member."""
     with open(path, "rb", buffering=0) as f:
         d = zlib.decompressobj(wbits=31)
         fed = False                            # has the current member received any input?
+        between = False                        # behind a member's end marker, before the next member's first byte
+        carry = b""
         while True:
             raw = f.read(piece)
             if not raw:
+                if carry:                      # a lone 0x1f at the very end
+                    raise ValueError("%s: trailing bytes after the gzip stream are neither zero padding nor another "
+                                     "gzip member" % path)
                 tail = d.flush()
                 if tail:
                     yield tail
                 if fed and not d.eof:          # gzip.open raises EOFError here; partial counts must never pass silently
                     raise EOFError("%s: compressed file ended before the end-of-stream marker was reached" % path)
                 return
+            raw, carry = carry + raw, b""
             while raw:
+                if between:
+                    raw = raw.lstrip(b"\0")
+                    if not raw:
+                        break
+                    if len(raw) == 1 and raw == b"\x1f":
+                        carry = raw            # the magic's second byte comes with the next read
+                        break
+                    if raw[:2] != b"\x1f\x8b":
+                        raise ValueError("%s: trailing bytes after the gzip stream are neither zero padding nor another "
+                                         "gzip member" % path)
+                    between = False
                 try:
                     out = d.decompress(raw)
                 except zlib.error as exc:
@@ -156,6 +175,7 @@ def _gzip_pieces(path, piece=1 << 24):
                     raw = d.unused_data
                     d = zlib.decompressobj(wbits=31)
                     fed = False
+                    between = True
                 else:
                     raw = b""
 

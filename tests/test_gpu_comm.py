@@ -38,6 +38,34 @@ def test_single_rank_communicator_reduce_in_place(oracle):
             _lib.check(_lib.lib().kmm_reduce_counts(arr, 1, 3))
 
 
+def test_flush_of_node_ranges_under_the_reduce_of_the_previous_range(oracle):
+    """kmm_comm_reduce_counts on the radix path: the per-entry hits are flushed node range by node range (the entries
+    are listed in node order) and every range's RCCL reduce is issued on a second stream behind its flush
+    (`comm_overlap_slices`, default 8) — same counts as the plain flush + one reduce, for uniform nodes, for a skewed
+    node distribution (many entries per node: the ranges are cut at node boundaries) and for slice counts that do not
+    divide the vector; accumulated over two jobs on one handle (additivity of command_line_interface.py:124-130)."""
+    from kmer_mapper_amd import synthetic as syn
+    from kmer_mapper_amd.engine import DeviceIndex
+    for skewed, n_index in ((False, 60_000), (True, 60_000)):
+        index, genome = syn.make_index(n_index, seed=411, skewed=skewed)
+        mx = index.max_node_id()
+        bases, offs = syn.make_reads(genome, 30000, 150, seed=412)
+        expect, _ = oracle.map_reads(index, mx, bases, offs, 31, n_threads=4)
+        with DeviceIndex.from_index(index, mx) as dev:
+            dev.comm_init(DeviceIndex.comm_unique_id(), 1, 0)
+            dev.set_param("path", 2)
+            for slices in (8, 1, 7, 64):
+                dev.set_param("comm_overlap_slices", slices)
+                assert dev.get_param("comm_overlap_slices") == slices
+                dev.reset()
+                dev.map_reads_uniform(bases, 30000, 150, 31)
+                dev.comm_reduce_counts(root=0)
+                assert np.array_equal(dev.get_node_counts(), expect), (skewed, slices)
+                dev.map_reads_uniform(bases, 30000, 150, 31)        # a second job on top: counts accumulate
+                dev.comm_reduce_counts(root=-1)
+                assert np.array_equal(dev.get_node_counts(), 2 * expect), (skewed, slices)
+
+
 @pytest.mark.parametrize("n_ranks", [2, 3])
 def test_multi_rank_cli_flow_with_the_hip_engine(n_ranks, tmp_path):
     """The N > 1 flow end to end with the HIP engine on every rank (they share the box's one GPU, the sum of the count

@@ -178,3 +178,20 @@ def test_kmer_index_npz_fixture_loads_like_the_reference_reads_it(oracle, golden
     rebuilt = oracle.build_index(ix._kmers, ix._nodes.astype(np.int64), ix._modulo)
     for name in ("_hashes_to_index", "_n_kmers", "_kmers", "_nodes", "_frequencies"):
         assert np.array_equal(getattr(rebuilt, name), getattr(ix, name)), name
+
+
+def test_console_script_is_declared_like_the_reference():
+    """reference setup.py:31-33 installs `kmer_mapper = kmer_mapper.command_line_interface:main`; pyproject.toml declares
+    the same command on this package's CLI module, and that function exists and prints the reference's usage."""
+    import importlib
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "pyproject.toml")).read()
+    m = re.search(r'^\s*kmer_mapper\s*=\s*"([\w.]+):(\w+)"', text, re.M)
+    assert m, "console script missing"
+    fn = getattr(importlib.import_module(m.group(1)), m.group(2))
+    assert callable(fn)
+    from kmer_mapper_amd.command_line_interface import run_argument_parser
+    with pytest.raises(SystemExit):
+        run_argument_parser([])            # prints help and exits, like the reference (command_line_interface.py:186-188)

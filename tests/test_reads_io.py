@@ -493,3 +493,129 @@ def test_prefetching_chunker_reports_a_truncated_gz_in_the_consumers_thread(tmp_
                 ch.consumed(used)
         finally:
             ch.close()
+
+
+def test_native_reader_corner_cases_from_the_round_3_review(tmp_path):
+    """ADVICE r3 on csrc/kmm_io.cpp: (1) a BGZF file that starts with an EMPTY member followed by members larger than the
+    caller's buffer must not read as end-of-stream; (2) a BGZF header whose BSIZE is smaller than the member's own
+    fixed parts is 'not a BGZF member', not an out-of-bounds trailer read; (3) zero padding behind a gzip stream is
+    skipped as gzip.open does, other trailing bytes are an error — native reader and pure-Python fallback alike."""
+    import gzip
+    import struct
+    from kmer_mapper_amd import _io, gz_io
+    _io.build()
+    rng = np.random.default_rng(77)
+    data = bytes(rng.integers(65, 91, size=300_000, dtype=np.uint8))
+    # (1) empty member first, then 60 kB members, read through a 1000-byte buffer
+    p1 = str(tmp_path / "lead_empty.gz")
+    gz_io.write_bgzf(p1, data, block=60_000)
+    body = open(p1, "rb").read()
+    open(p1, "wb").write(gz_io._BGZF_EOF + body)
+    with _io.NativeStream(p1, 2) as s:
+        buf = bytearray(1000)
+        assert s.readinto(buf) == 1000 and bytes(buf) == data[:1000]
+        rest = s.read()
+    assert bytes(buf) + rest == data
+    with gz_io.open_gz(p1, 2, native=False) as s:
+        assert s.read() == data
+    # (2) BSIZE 0 in an otherwise well-formed BGZF header
+    p2 = str(tmp_path / "bad_bsize.gz")
+    open(p2, "wb").write(b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", 0) + b"\0" * 64)
+    with pytest.raises((ValueError, EOFError, OSError)):
+        with _io.NativeStream(p2, 1) as s:      # (a gzip-magic file that is no BGZF member: read as a gzip stream, which fails too)
+            s.read()
+    # a later member with a broken BSIZE: reported by the planner
+    p2b = str(tmp_path / "bad_bsize_later.gz")
+    good = body[:gz_io._bgzf_block_size(body[:18])]
+    open(p2b, "wb").write(good + b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", 3) + b"\0" * 64)
+    with pytest.raises(ValueError, match="not a BGZF member"):
+        with _io.NativeStream(p2b, 1) as s:
+            s.read()
+    # (3) trailing zero padding / garbage behind a plain gzip stream
+    small = data[:50_000]
+    p3, p4, p5 = str(tmp_path / "pad.gz"), str(tmp_path / "junk.gz"), str(tmp_path / "pad_then_member.gz")
+    open(p3, "wb").write(gzip.compress(small) + b"\0" * 512)
+    open(p4, "wb").write(gzip.compress(small) + b"\0" * 7 + b"junk")
+    open(p5, "wb").write(gzip.compress(small) + b"\0" * 100 + gzip.compress(small[::-1]))
+    assert gzip.open(p3, "rb").read() == small                       # what the reference's reader does
+    for native in (True, False):
+        with gz_io.open_gz(p3, 1, native=native) as s:
+            assert s.read() == small, native
+        with gz_io.open_gz(p5, 1, native=native) as s:
+            assert s.read() == small + small[::-1], native
+        with pytest.raises(ValueError, match="trailing bytes"):
+            with gz_io.open_gz(p4, 1, native=native) as s:
+                s.read()
+
+
+@pytest.mark.parametrize("chunk", [None, 40_000])
+def test_one_gzip_member_is_inflated_on_many_threads(tmp_path, monkeypatch, chunk):
+    """A plain .gz (ONE deflate stream, what `gzip reads.fq` writes) through the native reader with several threads:
+    chunks of the compressed stream are decoded from block boundaries found by search, with markers for the unknown
+    32 KiB history, and resolved once the previous chunk's end is known (csrc/kmm_inflate.hpp).  Same bytes as
+    gzip.open — the reference's reader through bnp.open (command_line_interface.py:102) — for every compression level,
+    stored and fixed-Huffman blocks, several members with padding; truncation, a flipped bit and a wrong CRC raise."""
+    import gzip
+    import zlib
+    from kmer_mapper_amd import _io, gz_io
+    _io.build()
+    if chunk:                 # many small chunks per wave: starts found by search in every one of them
+        monkeypatch.setenv("KMM_IO_GZIP_CHUNK", str(chunk))
+    rng = np.random.default_rng(31)
+    n_rec, L = 12_000, 150                                     # FASTQ-shaped text, generated without a Python loop
+    rec = np.empty((n_rec, 10 + L + 3 + L + 1), dtype=np.uint8)
+    rec[:, 0:10] = np.frombuffer(b"@SRR77.000", dtype=np.uint8)
+    rec[:, 7:10] = rng.integers(48, 58, size=(n_rec, 3))
+    rec[:, 9] = 10
+    rec[:, 10:10 + L] = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=(n_rec, L))
+    rec[:, 10 + L:13 + L] = np.frombuffer(b"\n+\n", dtype=np.uint8)
+    rec[:, 13 + L:13 + 2 * L] = rng.choice(np.frombuffer(b"FFFFFF:,#@+", dtype=np.uint8), size=(n_rec, L))
+    rec[:, -1] = 10
+    data = rec.tobytes()
+    assert len(data) > 3_000_000
+    files = {}
+    for lvl in (1, 6):
+        files["l%d" % lvl] = (gzip.compress(data, compresslevel=lvl), data)
+    files["l9"] = (gzip.compress(data[:1_500_000], compresslevel=9), data[:1_500_000])
+    noise = rng.integers(0, 256, size=400_000, dtype=np.uint8).tobytes()
+    files["noise_and_text"] = (gzip.compress(noise + data[:1_000_000] + noise, compresslevel=6), noise + data[:1_000_000] + noise)
+    co = zlib.compressobj(6, zlib.DEFLATED, 31, 9, zlib.Z_FIXED)
+    files["fixed"] = (co.compress(data[:1_000_000]) + co.flush(), data[:1_000_000])
+    co = zlib.compressobj(0, zlib.DEFLATED, 31)
+    files["stored"] = (co.compress(data[:1_000_000]) + co.flush(), data[:1_000_000])
+    half = len(data) // 2
+    files["members"] = (gzip.compress(data[:half], 6) + b"\0" * 37 + gzip.compress(data[half:], 2) + b"\0" * 5, data)
+    named = bytearray(gzip.compress(data[:2_000_000], 6))
+    named[3] |= 8                                                   # FNAME: a zero-terminated name behind the fixed header
+    files["with_name"] = (bytes(named[:10]) + b"reads.fq\0" + bytes(named[10:]), data[:2_000_000])
+    for name, (blob, expect) in files.items():
+        path = str(tmp_path / (name + ".gz"))
+        open(path, "wb").write(blob)
+        for n_threads in (4, 1):
+            with _io.NativeStream(path, n_threads) as s:
+                assert s.kind == 2
+                got = bytearray()
+                while True:
+                    piece = s.read(1_234_567)
+                    if not piece:
+                        break
+                    got += piece
+            assert bytes(got) == expect, (name, n_threads)
+    # errors: truncated (EOFError like gzip.open), corrupted payload, wrong CRC / length in the trailer
+    blob = files["l6"][0]
+    cases = {"trunc_mid": (blob[: len(blob) // 2], EOFError), "trunc_trailer": (blob[:-5], EOFError)}
+    flipped = bytearray(blob)
+    flipped[len(blob) // 3] ^= 0x10
+    cases["bitflip"] = (bytes(flipped), ValueError)
+    badcrc = bytearray(blob)
+    badcrc[-6] ^= 0xFF
+    cases["crc"] = (bytes(badcrc), ValueError)
+    badlen = bytearray(blob)
+    badlen[-1] ^= 0x01
+    cases["isize"] = (bytes(badlen), ValueError)
+    for name, (b2, exc) in cases.items():
+        path = str(tmp_path / (name + ".gz"))
+        open(path, "wb").write(b2)
+        with pytest.raises((exc, ValueError) if name == "bitflip" else exc):
+            with _io.NativeStream(path, 4) as s:
+                s.read()
