@@ -7,11 +7,12 @@
 One "step" = one pass of the hot path (kmm_map_reads_uniform: encode -> rolling 31-mer pack ->
 modulo -> bucket gather -> compare/filter -> atomic node counts) over one batch of synthetic reads
 that is already resident in HBM.  Workload at N=1 (default, --config 2): BASELINE configs[2] — synthetic
-150 bp reads in batches of 10 M (--steps batches: 10 by default = 100 M reads), k=31, 100 M-k-mer index (the
-headline config; --config 1 = configs[1], the 10 M-k-mer index; --index-kmers 1000000000 = configs[4]'s index).
-With N ranks every rank maps its own 10 M-read batch per step (reads shard by chunk: weak scaling) against a
+150 bp reads in batches of 20 M (--steps batches: 5 by default = 100 M reads), k=31, 100 M-k-mer index (the
+headline config; --config 1 = configs[1], the 10 M-k-mer index in 10 M-read batches; --index-kmers 1000000000 =
+configs[4]'s index).
+With N ranks every rank maps its own batch per step (reads shard by chunk: weak scaling) against a
 replicated index and the per-rank uint32 count vectors are summed once with RCCL at the end of the job, inside the
-timed region; the same invocation then also times BASELINE configs[3] — the SAME --steps x 10 M reads split over
+timed region; the same invocation then also times BASELINE configs[3] — the SAME --steps x --reads reads split over
 the ranks (`strong`) — and the PCIe-inclusive leg on every rank at once (`value_incl_h2d`).
 
 Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for every field).
@@ -52,12 +53,13 @@ def log(*a):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", type=int, default=2, choices=(1, 2),
-                    help="BASELINE.json configs[]: 2 = 100 M-k-mer index (headline, default), 1 = 10 M-k-mer index; "
-                         "both map 10 M-read batches (--steps of them; the default 10 steps = 100 M reads)")
-    ap.add_argument("--reads", type=int, default=10_000_000, help="reads per batch per GPU")
+                    help="BASELINE.json configs[]: 2 = 100 M-k-mer index (headline, default), 1 = 10 M-k-mer index")
+    ap.add_argument("--reads", type=int, default=None,
+                    help="reads per batch per GPU (default: 20 M at --config 2 — 5 steps = BASELINE configs[2]'s 100 M reads; "
+                         "10 M at --config 1 = configs[1]'s chunk size; 10 M-read batches of configs[2]: --reads 10000000)")
     ap.add_argument("--index-kmers", type=int, default=None, help="overrides --config's index size")
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--numpy-builder", action="store_true", help="build the synthetic index with numpy instead of kmm_build_index")
@@ -101,6 +103,11 @@ def main():
     args = ap.parse_args()
     if args.index_kmers is None:
         args.index_kmers = {1: 10_000_000, 2: 100_000_000}[args.config]
+    if args.reads is None:
+        # configs[1] names its chunk size (10 M reads); configs[2] is "100 M reads" on one GPU: batches sized for 288 GB of
+        # HBM — every batch pays the radix passes' fixed costs once (152 / 165 / 164 G k-mers/s at
+        # 10 / 20 / 30 M reads per batch)
+        args.reads = 10_000_000 if args.config == 1 else 20_000_000
 
     import torch
     import torch.distributed as dist
@@ -387,8 +394,8 @@ def main():
                 traffic = None
         if args.index_kmers == 1_000_000_000:
             cfg_label = "configs[4]'s index on one GPU (1 B-k-mer index resident in HBM)"
-        elif args.index_kmers == 100_000_000 and R == 10_000_000:
-            cfg_label = "configs[2] (100 M reads as batches of 10 M, 100 M-k-mer index)"
+        elif args.index_kmers == 100_000_000:
+            cfg_label = "configs[2] (100 M-k-mer index; %d reads = %d batches of %d)" % (R * args.steps, args.steps, R)
         elif args.index_kmers == 10_000_000 and R == 10_000_000:
             cfg_label = "configs[1] (10 M reads per batch, 10 M-k-mer index)"
         else:
@@ -497,7 +504,8 @@ def main():
     if world > 1 and plain_fused and not args.strong:
         from kmer_mapper_amd.distributed import shard_range
         lo_r, hi_r = shard_range(R * args.steps, rank, world)
-        s_sizes = [R] * ((hi_r - lo_r) // R) + ([(hi_r - lo_r) % R] if (hi_r - lo_r) % R else [])
+        n_b = max(1, -(-(hi_r - lo_r) // R))                      # equal batches of at most R reads (no small last one)
+        s_sizes = [(hi_r - lo_r) // n_b + (1 if j < (hi_r - lo_r) % n_b else 0) for j in range(n_b)]
         st = timed_job(s_sizes, lambda j: batches[j & 1])
         if rank == 0:
             t_strong = max(st["elapsed_ms"])

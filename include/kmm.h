@@ -163,9 +163,10 @@ int kmm_map_reads_uniform(kmm_index_t *idx, const uint8_t *bases, int64_t n_read
  * with a newline) and in *n_records the number of reads mapped.  '\r' before '\n' is tolerated.
  * The call returns once the chunk is staged and scanned (so *consumed is valid and the host buffer is
  * free); the mapping kernels run asynchronously like every other map call.  Chunks of any size: beyond 2^30
- * bytes the library maps the chunk piece by piece (each piece starts at the end of the previous one's last
- * complete record).  Large chunks let the batch reach the radix path: kmer_mapper map accumulates file chunks up
- * to kmm_get_param("radix_min_units") positions per call.
+ * bytes the library scans the chunk piece by piece (each piece starts at the end of the previous one's last
+ * complete record).  A chunk large enough for the radix path (FASTQ: 2 x kmm_get_param("radix_min_units") bytes) is
+ * first compacted on the device — only the bytes of its sequence lines survive, as 2-bit codes — and mapped as ONE
+ * batch of flat reads; kmer_mapper map accumulates file chunks to such sizes.
  * A line that should start a record ('@' / '>') or the FASTQ '+' line but does not (e.g. multi-line
  * FASTA) makes the next synchronising call fail with KMM_ERR_MALFORMED.
  */
@@ -272,6 +273,12 @@ int kmm_get_kmer_counts(kmm_index_t *idx, uint32_t *out);
  *   "radix_packed_tiles" 1 (default) = pass 1 on reads of one length works on tiles of whole reads (no windows across
  *                      read boundaries are computed)
  *   "fine_bits"        experiments: log2 fine partitions per coarse partition of the radix path
+ *   "radix_sub_batch_kmers" k-mer slots per sub-batch of the radix path: a larger map call is cut into equal sub-batches,
+ *                      each a full run of the passes (the index slices are streamed once per sub-batch); default and
+ *                      maximum 2^32 - 2 * 8192 (a coarse partition's k-mers are numbered with 32 bits); halved by the
+ *                      library when the batch buffers of that size do not fit the free HBM
+ *   "comm_overlap_slices" kmm_comm_reduce_counts: node ranges whose flush (per-entry hits -> node counts) runs under the
+ *                      previous range's RCCL reduce on a second stream (default 8; 1 = flush, then one reduce)
  * Read-only (kmm_get_param): "radix_available", "radix_unavailable_reason" (0 available, 1 modulo >= 2^31, 2 slices too
  *   dense for LDS, 3 out of memory, 4 the index's buckets overlap), "n_partitions", "n_coarse_partitions",
  *   "n_fine_per_coarse", "radix_p2_kmers" / "radix_p3_kmers" / "radix_p2_dropped" (the conservation counters every

@@ -131,7 +131,10 @@ def map_gpu_raw(index, path, chunk_size, fmt, k, map_reverse_complements=False,
         n_file = 0
     if dev.get_param("radix_available") and not os.environ.get("KMM_CLI_NO_BATCHING"):
         # (radix_min_units is where the radix path BREAKS EVEN with the direct kernel, in base positions ~ half the
-        # FASTQ bytes; a batch twelve times that runs within 20 % of the path's large-batch rate)
+        # FASTQ bytes; a batch twelve times that runs within 20 % of the path's large-batch rate.  Larger batches would
+        # run the GPU closer to its large-batch rate, but end to end the host is the bound — reading the file into pinned
+        # memory at 8-11 GB/s — and several batches per file let that overlap the copies and kernels: a 3 GB FASTQ took
+        # 0.27 s in five batches of 615 MB and 0.62 s as ONE batch, profiles/r04/cli_e2e_large_fastq.txt.)
         want = min(max(int(12 * dev.get_param("radix_min_units")), 256 << 20), 2 << 30)
         share = n_file / max(world_size, 1)
         if share >= want > batch_bytes:

@@ -44,6 +44,8 @@ struct ReadsView {
     // packed uniform tiles (radix pass 1, kmm_tile.hpp tile_packed_*): a tile = pk_rpt whole reads, pk_lpr lanes per read
     // with pk_S consecutive windows each — every window a lane computes is a real k-mer (0 = packed tiles not used)
     uint32_t pk_rpt, pk_lpr, pk_S, pk_W, pk_inv;
+    uint32_t codes2;           // != 0: `bases` is a stream of 2-bit codes, 16 per 32-bit word (position p = bits [2 (p & 15), +2)
+                               // of word p >> 4): what k_rec_scatter compacts raw records into; no lookup table, no invalid bytes
     const uint8_t *lut;        // 256 bytes in HBM
     unsigned long long *first_bad; // [0] min position of a non-nucleotide byte, [1] of a malformed
                                    //     record line (both init ~0)

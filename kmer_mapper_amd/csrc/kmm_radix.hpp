@@ -561,7 +561,7 @@ __device__ __forceinline__ uint32_t rx_pop(unsigned long long *counters, uint32_
 // ------------------------------------------------------------------------------------------------
 // pass 1
 // ------------------------------------------------------------------------------------------------
-template <int MODE, bool RC>
+template <int MODE, bool RC, bool C2 = false>
 __global__ void __launch_bounds__(RX_NT, 4) k_rx_p1(ReadsView rv, const uint64_t *__restrict__ kmers_in, int64_t n_in,
                                                  IndexView iv, RxView rx, int k, int64_t tile_begin, uint32_t n_src)
 {
@@ -629,9 +629,9 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p1(ReadsView rv, const uint64_t
     __syncthreads(); // also: the code table is in LDS
     auto load_tile = [&](int64_t tile, Raw &raw) {
         if constexpr (PACKED)
-            tile_packed_load(rv, tile, ltid, raw);
+            tile_packed_load<C2>(rv, tile, ltid, raw);
         else
-            tile_load_vec<S, TM>(rv, tc, tile, ltid, raw);
+            tile_load_vec<S, TM, C2>(rv, tc, tile, ltid, raw);
     };
     for (uint32_t sb = blockIdx.x; sb < n_src; sb += gridDim.x) {
         uint64_t q[RX_KPT];
@@ -655,7 +655,7 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p1(ReadsView rv, const uint64_t
                 const int64_t tile = tile_begin + ((int64_t)sb * 2 + half);
                 if (sb == blockIdx.x) {
                     load_tile(tile, pw[0]);
-                    tile_packed_stage(rv, tile, sm[half], ltid, pw[0]);
+                    tile_packed_stage<C2>(rv, tile, sm[half], ltid, pw[0]);
                     __syncthreads();
                 }
                 valid = tile_packed_fetch(rv, tc, tile, sm[half], q, ltid, &win);
@@ -676,10 +676,10 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p1(ReadsView rv, const uint64_t
                 uint32_t v;
                 // (the first tile of a block needs no opening barrier: the previous block's sort lies in between)
                 if constexpr (PACKED)
-                    v = tile_packed_kmers<false>(rv, tc, tile, k, sm[half], qq, ltid, pw[r], &win);
+                    v = tile_packed_kmers<false, C2>(rv, tc, tile, k, sm[half], qq, ltid, pw[r], &win);
                 else
-                    v = r == 0 ? tile_kmers<S, TM, false>(rv, tc, tile, k, sm[half], qq, ltid, pw[r], &win)
-                               : tile_kmers<S, TM, true>(rv, tc, tile, k, sm[half], qq, ltid, pw[r]);
+                    v = r == 0 ? tile_kmers<S, TM, false, C2>(rv, tc, tile, k, sm[half], qq, ltid, pw[r], &win)
+                               : tile_kmers<S, TM, true, C2>(rv, tc, tile, k, sm[half], qq, ltid, pw[r]);
 #pragma unroll
                 for (int j = 0; j < S; ++j)
                     q[r * S + j] = qq[j];
@@ -766,7 +766,7 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p1(ReadsView rv, const uint64_t
             auto post = [&]() { // behind the placement: the next block's codes into LDS (the sort's barrier publishes them)
                 if constexpr (STAGE_EARLY) {
                     if (sb + gridDim.x < n_src)
-                        tile_packed_stage(rv, tile_begin + ((int64_t)(sb + gridDim.x) * 2 + half), sm[half], ltid, pw[0]);
+                        tile_packed_stage<C2>(rv, tile_begin + ((int64_t)(sb + gridDim.x) * 2 + half), sm[half], ltid, pw[0]);
                 }
             };
             rx_sort_emit<RX_RB1, MODE == MODE_KMERS, true, RX_NT, true, decltype(fwd), RxNoHook, 0, true, decltype(post)>(

@@ -62,9 +62,10 @@ __global__ void __launch_bounds__(1024) k_rec_scan1(uint32_t *tile_cnt, uint32_t
 
 // One workgroup: exclusive prefix over the super-tiles, then the byte position just after the last
 // newline that completes a record (records have `period` lines).  out = {consumed, n_records, n_lines}.
+// tile_bytes: 1024 (direct path's census) or 4096 (the radix path's compaction).
 __global__ void __launch_bounds__(1024) k_rec_scan2(const uint8_t *__restrict__ raw, int64_t n,
                                                     int n_super, const uint32_t *__restrict__ tile_pre,
-                                                    uint32_t *super_tot, uint32_t period, int64_t *out)
+                                                    uint32_t *super_tot, uint32_t period, int64_t *out, int tile_bytes)
 {
     __shared__ uint32_t s_a[1024];
     __shared__ uint32_t s_super, s_rem, s_super_cnt;
@@ -101,14 +102,21 @@ __global__ void __launch_bounds__(1024) k_rec_scan2(const uint8_t *__restrict__ 
         s_tile = (int64_t)sup * 1024 + t;
     __syncthreads();
     const int64_t tile = s_tile;
-    const uint32_t r = rem - tile_pre[tile];
-    const int64_t pos = tile * 1024 + t;
-    const uint32_t is_nl = (pos < n && raw[pos] == 10u) ? 1u : 0u;
-    s_a[t] = is_nl;
-    __syncthreads();
-    block_scan_1024(s_a);
-    if (is_nl && s_a[t] == r)
-        out[0] = pos + 1;
+    uint32_t r = rem - tile_pre[tile]; // the r-th newline of the tile ends the last complete record
+    for (int part = 0; part < tile_bytes / 1024; ++part) {
+        const int64_t pos = tile * tile_bytes + part * 1024 + t;
+        const uint32_t is_nl = (pos < n && raw[pos] == 10u) ? 1u : 0u;
+        __syncthreads();
+        s_a[t] = is_nl;
+        __syncthreads();
+        block_scan_1024(s_a);
+        if (is_nl && s_a[t] == r)
+            out[0] = pos + 1;
+        const uint32_t in_part = s_a[1023];
+        if (r <= in_part)
+            break; // (uniform)
+        r -= in_part;
+    }
     if (t == 0) {
         out[1] = target / period;
         out[2] = total;
@@ -315,26 +323,39 @@ __global__ void __launch_bounds__(256) k_ml_scatter(const uint8_t *__restrict__ 
 // front end (line numbering per byte, four <4>-window tiles per block) at 0.57 TB/s — ten times slower than on flat
 // reads (profiles/r03/final_entry_points.txt), and that is the path `kmer_mapper map` runs
 // (command_line_interface.py:102-111).  Now the raw chunk is COMPACTED on the device first, at line granularity: only
-// the bytes of sequence lines survive, as 2-bit codes one per byte (the lookup table — and with it the reference
-// encoder's error for a non-nucleotide, util.py:72 — is applied here, where raw byte offsets are still known), every
-// read start is marked in the bitset the ragged-read front end takes, and pass 1 then runs on flat reads (on packed
-// tiles when all reads of the chunk have one length, which k_rec_uniform checks).
-//   k_rec_count2   per 1024-byte tile: newlines + non-terminator bytes per (line inside the tile) mod 4
+// the bytes of sequence lines survive, as a stream of 2-BIT CODES (16 per 32-bit word, first base in the lowest bits:
+// the very words pass 1's tiles keep in LDS, so its byte -> code stage disappears; the lookup table — and with it the
+// reference encoder's error for a non-nucleotide, util.py:72 — is applied here, where raw byte offsets are still
+// known), every read start is marked in the bitset the ragged-read front end takes, and pass 1 then runs on flat reads
+// (on packed tiles when all reads of the chunk have one length, which k_rec_uniform checks).
+//   k_rec_count2   per 4 KiB tile: newlines + non-terminator bytes per (line inside the tile) mod 4
 //   (k_rec_scan1, k_rec_scan2: newline prefix + where the last complete record ends, as before)
 //   k_rec_seq_scan per tile: its sequence bytes (the count that belongs to the phase of its first line) -> prefix
 //   (k_super_scan)
-//   k_rec_scatter  sequence bytes before `limit` -> codes, compacted; read starts -> bitset; record structure checked
+//   k_rec_scatter  sequence bytes before `limit` -> 2-bit codes, compacted; read starts -> bitset; record structure checked
 //   k_rec_uniform  do all reads have one length?
+// Both per-byte kernels are persistent: one wavefront per 4 KiB tile, 64 contiguous bytes per lane (four 16-byte loads),
+// the next tile's bytes requested before the current tile is processed.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void rec_load16(const uint8_t *__restrict__ raw, int64_t n, int64_t p, uint32_t (&w)[4])
+__device__ __forceinline__ void rec_load16(const uint8_t *__restrict__ raw, uint32_t n, uint32_t p, uint32_t (&w)[4])
 {
-    if ((((uintptr_t)raw) & 15u) == 0 && p + 16 <= n) {
-        const u32x4 x = *reinterpret_cast<const u32x4 *>(raw + p);
+    // (positions inside a piece of at most 2^30 bytes: 32-bit)
+    if ((((uintptr_t)raw) & 15u) == 0 && p + 16u <= n) {
+        const u32x4 x = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(raw + p));
         w[0] = x[0]; w[1] = x[1]; w[2] = x[2]; w[3] = x[3];
-    } else {
+    } else if (p + 16u <= n) {
+        // a piece that starts where the previous one's last record ended: any byte offset.  One 16-byte load at an
+        // unaligned address (gfx950 runs with unaligned access enabled; the compiler emits global_load_dwordx4 for it) —
+        // with byte-wise loads the middle piece of a 3 GiB call took 2.6 ms instead of 1.3
+        u32x4 x;
+        __builtin_memcpy(&x, raw + p, 16);
+        w[0] = x[0]; w[1] = x[1]; w[2] = x[2]; w[3] = x[3];
+    } else if (p < n) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            w[i] = tile_load_bytes4(raw, n, p + 4 * i);
+            w[i] = tile_load_bytes4(raw, (int64_t)n, (int64_t)p + 4 * i);
+    } else {
+        w[0] = w[1] = w[2] = w[3] = 0u;
     }
 }
 
@@ -350,46 +371,100 @@ __device__ __forceinline__ void rec_masks(const uint32_t (&w)[4], uint32_t &nl, 
     }
 }
 
+// sum over the wavefront's lanes, in every lane (DPP additions: no LDS crossbar)
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_incl(v), 63);
+}
+
+// bit i of the result = XOR of the bits 0 .. i of x
+__device__ __forceinline__ uint64_t prefix_xor64(uint64_t x)
+{
+    x ^= x << 1;
+    x ^= x << 2;
+    x ^= x << 4;
+    x ^= x << 8;
+    x ^= x << 16;
+    x ^= x << 32;
+    return x;
+}
+
+// For the lane's 64 bytes with newline mask nl: (number of newlines before byte i + base) mod 4, as two 64-bit masks
+// (s0 = bit 0, s1 = bit 1 of that sum for every byte) — loop-free: a byte's count is odd iff the prefix XOR of the
+// newline bits before it is 1, and bit 1 of the count flips at every SECOND newline (the newlines that have an odd
+// number of newlines before them).  A newline itself still belongs to the line it ends.
+__device__ __forceinline__ void rec_line_phase(uint64_t nl, uint32_t base, uint64_t &s0, uint64_t &s1)
+{
+    const uint64_t r0 = prefix_xor64(nl << 1);            // parity of the newlines before byte i
+    const uint64_t r1 = prefix_xor64((nl & r0) << 1);     // ... of the 2nd, 4th, ... newlines before byte i
+    const uint64_t b0 = (base & 1u) ? ~0ull : 0ull, b1 = (base & 2u) ? ~0ull : 0ull;
+    s0 = r0 ^ b0;
+    s1 = r1 ^ b1 ^ (r0 & b0);
+}
+
+constexpr uint32_t REC_TB = 4096; // bytes per tile of the compaction kernels: one wavefront, 64 contiguous bytes per lane
+
+// the lane's 64 bytes (four 16-byte loads in flight) and their '\n' / '\r' masks
+struct RecLane {
+    uint32_t w[4][4];
+};
+__device__ __forceinline__ void rec_load64(const uint8_t *__restrict__ raw, uint32_t n, uint32_t p, RecLane &r)
+{
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        rec_load16(raw, n, p + 16u * (uint32_t)j, r.w[j]);
+}
+__device__ __forceinline__ void rec_masks64(const RecLane &r, uint64_t &nl, uint64_t &cr)
+{
+    nl = 0;
+    cr = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        uint32_t a, b;
+        rec_masks(r.w[j], a, b);
+        nl |= (uint64_t)a << (16 * j);
+        cr |= (uint64_t)b << (16 * j);
+    }
+}
+__device__ __forceinline__ uint64_t rec_inside64(int32_t left) // the first `left` of 64 bytes
+{
+    return left >= 64 ? ~0ull : (left > 0 ? (1ull << left) - 1ull : 0ull);
+}
+
 // tile_cnt[t] = newlines of tile t; tile_seq[t] = four 16-bit counts: bytes that are no line terminator, by the number
 // of newlines before them inside the tile, mod 4 (bytes past the end of the chunk count nowhere).
 __global__ void __launch_bounds__(256) k_rec_count2(const uint8_t *__restrict__ raw, int64_t n, int64_t n_tiles,
                                                     uint32_t *__restrict__ tile_cnt, unsigned long long *__restrict__ tile_seq)
 {
-    const int lane = threadIdx.x & 63;
-    const int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); // one wavefront per tile
-    if (tile >= n_tiles)
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t stride = gridDim.x * 4u, nt = (uint32_t)n_tiles, n32 = (uint32_t)n; // (a piece holds at most 2^30 bytes)
+    uint32_t tile = blockIdx.x * 4u + (threadIdx.x >> 6); // one wavefront per tile
+    if (tile >= nt)
         return;
-    const int64_t p = tile * 1024 + lane * 16;
-    uint32_t w[4], nl, cr;
-    rec_load16(raw, n, p, w);
-    rec_masks(w, nl, cr);
-    const int64_t left = n - p;
-    const uint32_t inside = left >= 16 ? 0xFFFFu : (left > 0 ? (1u << left) - 1u : 0u);
-    nl &= inside;
-    const uint32_t c = (uint32_t)__popc(nl);
-    const uint32_t before = wave_scan_incl(c) - c; // newlines of the tile before this lane's bytes
-    // the lane's bytes fall into popc(nl) + 1 segments of one line each
-    unsigned long long acc = 0;
-    uint32_t body = inside & ~(nl | cr), rest = nl, from = 0, rel = before;
-    for (;;) {
-        const uint32_t to = rest ? (uint32_t)__builtin_ctz(rest) : 16u; // the segment's bytes: [from, to)
-        const uint32_t seg = (to >= 16u ? 0xFFFFu : (1u << to) - 1u) & ~((1u << from) - 1u);
-        acc += (unsigned long long)__popc(body & seg) << (16u * (rel & 3u));
-        if (!rest)
-            break;
-        rest &= rest - 1u;
-        from = to + 1u;
-        ++rel;
-    }
-    uint32_t cs = c;
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) {
-        cs += __shfl_xor(cs, d);
-        acc += __shfl_xor(acc, d); // (no field exceeds 1024)
-    }
-    if (lane == 0) {
-        tile_cnt[tile] = cs;
-        tile_seq[tile] = acc;
+    RecLane cur, nxt;
+    rec_load64(raw, n32, tile * REC_TB + lane * 64u, cur);
+    for (; tile < nt; tile += stride) {
+        const uint32_t p = tile * REC_TB + lane * 64u;
+        if (tile + stride < nt)
+            rec_load64(raw, n32, (tile + stride) * REC_TB + lane * 64u, nxt); // the next tile is in flight while this one is counted
+        uint64_t nl, cr;
+        rec_masks64(cur, nl, cr);
+        const uint64_t inside = rec_inside64((int32_t)n32 - (int32_t)p);
+        nl &= inside;
+        const uint32_t c = (uint32_t)__popcll(nl);
+        const uint32_t inc = wave_scan_incl(c);
+        // the lane's bytes by (newlines before them inside the tile) mod 4; two 16-bit counters per 32-bit word
+        uint64_t s0, s1;
+        rec_line_phase(nl, inc - c, s0, s1);
+        const uint64_t body = inside & ~(nl | cr);
+        const uint32_t a01 = (uint32_t)__popcll(body & ~s1 & ~s0) | ((uint32_t)__popcll(body & ~s1 & s0) << 16);
+        const uint32_t a23 = (uint32_t)__popcll(body & s1 & ~s0) | ((uint32_t)__popcll(body & s1 & s0) << 16);
+        const uint32_t s01 = wave_sum(a01), s23 = wave_sum(a23); // (no field exceeds 4096)
+        if (lane == 63) {
+            tile_cnt[tile] = inc;
+            tile_seq[tile] = ((unsigned long long)s23 << 32) | s01;
+        }
+        cur = nxt;
     }
 }
 
@@ -421,129 +496,176 @@ __global__ void __launch_bounds__(1024) k_rec_seq_scan(const unsigned long long 
         super_tot[blockIdx.x] = s_a[t];
 }
 
-// One wavefront per tile.  info = {consumed, n_records, n_lines} of k_rec_scan2 (read on the device: no host round trip
-// between the census and the scatter); out_info[0] = number of flat bases (the sequence bytes before `consumed`).
-// first_bad as in the tile front end: [0] a sequence byte without a code, [1] a record line that does not start with
-// the header character / '+' (raw byte offsets).
+// One wavefront per 4 KiB tile (64 contiguous bytes per lane), over a contiguous range of tiles.  info = {consumed,
+// n_records, n_lines} of k_rec_scan2 (read on the device: no host round trip between the census and the scatter);
+// out_info[0] = flat bases behind the piece (flat_base + the sequence bytes before `consumed`).  codes: the 2-bit stream
+// (zeroed by the caller: the words two tiles share are OR-ed in).  first_bad as in the tile front end: [0] a sequence byte
+// without a code, [1] a record line that does not start with the header character / '+' (raw byte offsets).
+// (r04 history: 16 bytes per lane and 1 KiB tiles cost ~700 instructions per tile, most of them per-tile overhead —
+// scans, table lookups, loop control — and ran at 1.35 ms per GiB; 64 bytes per lane share that overhead four ways.)
 __global__ void __launch_bounds__(256) k_rec_scatter(const uint8_t *__restrict__ raw, int64_t n, int64_t n_tiles,
                                                      const uint32_t *__restrict__ tile_nl, const uint32_t *__restrict__ super_nl,
                                                      const uint32_t *__restrict__ tile_pre, const uint32_t *__restrict__ super_pre,
                                                      const int64_t *__restrict__ info, const uint8_t *__restrict__ lut,
-                                                     uint32_t period_mask, uint32_t header_char, uint8_t *__restrict__ flat,
+                                                     uint32_t period_mask, uint32_t header_char, uint32_t *__restrict__ codes,
                                                      uint64_t flat_base, uint32_t *__restrict__ start_bits,
                                                      unsigned long long *__restrict__ first_bad,
                                                      unsigned long long *__restrict__ out_info)
 {
     __shared__ uint32_t s_lut[256];
-    __shared__ uint32_t s_out[4][1024 / 4 + 2];
+    __shared__ uint32_t s_row[4][264]; // a tile's codes: at most 4096 + 15 -> 257 words
     s_lut[threadIdx.x] = lut[threadIdx.x];
     __syncthreads();
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int64_t tile = (int64_t)blockIdx.x * 4 + wv;
-    const int64_t limit = info[0];
-    if (tile >= n_tiles || tile * 1024 >= limit) // (limit > 0: the caller does not launch for a chunk without a record)
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    // (positions inside a piece fit 32 bits — at most 2^30 bytes: no 64-bit arithmetic per tile or lane)
+    const uint32_t limit = (uint32_t)info[0], n32 = (uint32_t)n;
+    const uint32_t n_live = (limit + REC_TB - 1u) / REC_TB < (uint32_t)n_tiles ? (limit + REC_TB - 1u) / REC_TB : (uint32_t)n_tiles;
+    // A wavefront takes a CONTIGUOUS range of tiles: what a tile needs besides its bytes — the line number and the
+    // flat position of its first byte, and whether the byte before it ends a line — comes from one coalesced load
+    // per 64 tiles (lane i holds tile t0 + i's) and from the previous tile.
+    const uint32_t n_waves = gridDim.x * 4u;
+    const uint32_t per_wave = (n_live + n_waves - 1u) / n_waves;
+    const uint32_t t_begin = (blockIdx.x * 4u + (uint32_t)wv) * per_wave;
+    const uint32_t t_end = t_begin + per_wave < n_live ? t_begin + per_wave : n_live;
+    if (t_begin >= t_end)
         return;
-    const int64_t p = tile * 1024 + lane * 16;
-    uint32_t w[4], nl, cr;
-    rec_load16(raw, n, p, w);
-    rec_masks(w, nl, cr);
-    const uint64_t w01 = ((uint64_t)w[1] << 32) | w[0], w23 = ((uint64_t)w[3] << 32) | w[2];
-    auto byte_at = [&](uint32_t i) { return (uint32_t)((i < 8u ? w01 >> (8u * i) : w23 >> (8u * (i - 8u))) & 0xFFu); };
-    const int64_t left = limit - p; // bytes of this lane before the limit
-    const uint32_t inside = left >= 16 ? 0xFFFFu : (left > 0 ? (1u << left) - 1u : 0u);
-    nl &= inside;
-    const uint32_t c_nl = (uint32_t)__popc(nl);
-    const uint32_t line_lane = super_nl[tile >> 10] + tile_nl[tile] + (wave_scan_incl(c_nl) - c_nl); // line of the lane's first byte
-    // first byte of a line: preceded by '\n' (or the first byte of the chunk)
-    uint32_t prev_nl = (uint32_t)__shfl_up((int)(nl >> 15), 1) & 1u;
-    if (lane == 0)
-        prev_nl = p == 0 ? 1u : (raw[p - 1] == 10u ? 1u : 0u);
-    const uint32_t first = ((nl << 1) | prev_nl) & inside;
-    // sequence bytes, line by line (segments as in k_rec_count2)
-    uint32_t seq = 0, seq_line = 0, bad_struct = 0xFFFFFFFFu;
-    {
-        uint32_t rest = nl, from = 0, line = line_lane;
-        for (;;) {
-            const uint32_t to = rest ? (uint32_t)__builtin_ctz(rest) : 16u;
-            const uint32_t seg = (to >= 16u ? 0xFFFFu : (1u << to) - 1u) & ~((1u << from) - 1u);
-            const uint32_t phase = line & period_mask;
-            if (phase == 1u)
-                seq_line |= seg | (to < 16u ? 1u << to : 0u); // (the line's terminator included)
-            if ((first >> from) & 1u) { // the segment starts its line: the record structure is checked on that byte
-                const uint32_t ch = byte_at(from);
-                if ((phase == 0u && ch != header_char) || (phase == 2u && ch != (uint32_t)'+'))
-                    bad_struct = bad_struct < from ? bad_struct : from;
+    uint32_t *row = s_row[wv];
+    RecLane cur, nxt;
+    rec_load64(raw, n32, t_begin * REC_TB + (uint32_t)lane * 64u, cur);
+    uint32_t carry_nl = t_begin == 0 ? 1u : (raw[t_begin * REC_TB - 1u] == 10u ? 1u : 0u); // does the byte before the tile end a line?
+    uint32_t m_line = 0, m_dst = 0;
+    for (uint32_t tile = t_begin; tile < t_end; ++tile) {
+        const uint32_t p = tile * REC_TB + (uint32_t)lane * 64u;
+        const int slot = (int)((tile - t_begin) & 63u);
+        if (slot == 0) { // the next 64 tiles' table entries
+            const uint32_t t = tile + (uint32_t)lane;
+            if (t < t_end) {
+                m_line = super_nl[t >> 10] + tile_nl[t];
+                m_dst = super_pre[t >> 10] + tile_pre[t];
             }
-            if (!rest)
-                break;
-            rest &= rest - 1u;
-            from = to + 1u;
-            ++line;
         }
-        seq_line &= inside;
-        seq = seq_line & ~(nl | cr);
-    }
-    if (bad_struct != 0xFFFFFFFFu)
-        atomicMin(&first_bad[1], (unsigned long long)(p + bad_struct));
-    const uint32_t cnt = (uint32_t)__popc(seq);
-    const uint32_t pre = wave_scan_incl(cnt) - cnt;
-    const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)(pre + cnt), 63);
-    const uint64_t dst0 = flat_base + super_pre[tile >> 10] + tile_pre[tile]; // flat position of the tile's first sequence byte
-    // read starts: the first byte of every sequence line; and whatever follows a '\r' inside a sequence line (no window
-    // may span it: the records front end treats every '\r' as a break)
-    {
-        uint32_t marks = (first | ((cr & seq_line) << 1)) & seq_line & 0xFFFFu;
-        while (marks) {
-            const uint32_t i = (uint32_t)__builtin_ctz(marks);
-            marks &= marks - 1u;
-            const uint64_t f = dst0 + pre + (uint32_t)__popc(seq & ((1u << i) - 1u));
-            atomicOr(&start_bits[f >> 5], 1u << (f & 31u));
+        if (tile + 1u < t_end)
+            rec_load64(raw, n32, (tile + 1u) * REC_TB + (uint32_t)lane * 64u, nxt);
+        const uint32_t line0 = (uint32_t)__builtin_amdgcn_readlane((int)m_line, slot);
+        const uint64_t dst0 = flat_base + (uint32_t)__builtin_amdgcn_readlane((int)m_dst, slot); // flat position of the tile's first sequence byte
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            row[lane + 64 * j] = 0u;
+        if (lane < 8)
+            row[256 + lane] = 0u;
+        uint64_t nl, cr;
+        rec_masks64(cur, nl, cr);
+        const uint64_t inside = rec_inside64((int32_t)limit - (int32_t)p); // the lane's bytes before the limit
+        const uint32_t last_nl = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(nl >> 63), 63) & 1u; // (before the limit is applied)
+        nl &= inside;
+        const uint32_t c_nl = (uint32_t)__popcll(nl);
+        const uint32_t line_lane = line0 + (wave_scan_incl(c_nl) - c_nl); // line of the lane's first byte
+        // first byte of a line: preceded by '\n' (or the first byte of the chunk)
+        uint32_t prev_nl = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(nl >> 63), 0x138, 0xF, 0xF, false) & 1u; // wave_shr:1
+        if (lane == 0)
+            prev_nl = carry_nl;
+        carry_nl = last_nl;
+        const uint64_t first = ((nl << 1) | prev_nl) & inside;
+        // the line phase of every byte (line number mod period), loop-free; sequence lines have phase 1
+        uint64_t s0, s1;
+        rec_line_phase(nl, line_lane, s0, s1);
+        const uint64_t hi_ok = period_mask == 3u ? ~s1 : ~0ull; // (two-line FASTA: only bit 0 of the line number counts)
+        const uint64_t seq_line = s0 & hi_ok & inside;           // (the line's terminator included)
+        {
+            // record structure: a header line starts with the header character, the third line of a FASTQ record with '+'
+            uint64_t chk = first & ~s0;                           // line starts with phase 0 or 2
+            uint32_t bad_struct = 0xFFFFFFFFu;
+            while (chk) {
+                const uint32_t i = (uint32_t)__builtin_ctzll(chk);
+                chk &= chk - 1ull;
+                const uint32_t ch = raw[p + i];                   // (rare: a cache hit on the lane's own bytes)
+                const bool third = period_mask == 3u && ((s1 >> i) & 1ull);
+                if (third ? ch != (uint32_t)'+' : ch != header_char)
+                    bad_struct = bad_struct < i ? bad_struct : i;
+            }
+            if (bad_struct != 0xFFFFFFFFu)
+                atomicMin(&first_bad[1], (unsigned long long)(p + bad_struct));
         }
-        // (a '\r' in the lane's last byte: the next lane's first byte — if it is a sequence byte it gets the mark there)
-        const uint32_t cr_before = (uint32_t)__shfl_up((int)((cr & seq_line) >> 15), 1) & 1u;
-        if (lane != 0 && cr_before && (seq_line & 1u)) {
-            const uint64_t f = dst0 + pre;
-            atomicOr(&start_bits[f >> 5], 1u << (f & 31u));
+        const uint64_t seq = seq_line & ~(nl | cr);
+        const uint32_t cnt = (uint32_t)__popcll(seq);
+        const uint32_t incl = wave_scan_incl(cnt);
+        const uint32_t pre = incl - cnt;
+        const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        // read starts: the first byte of every sequence line; and whatever follows a '\r' inside a sequence line (no
+        // window may span it: the records front end treats every '\r' as a break)
+        {
+            uint64_t marks = (first | ((cr & seq_line) << 1)) & seq_line;
+            while (marks) {
+                const uint32_t i = (uint32_t)__builtin_ctzll(marks);
+                marks &= marks - 1ull;
+                const uint64_t f = dst0 + pre + (uint32_t)__popcll(seq & ((1ull << i) - 1ull));
+                atomicOr(&start_bits[f >> 5], 1u << (f & 31u));
+            }
+            // (a '\r' in the previous lane's last byte: this lane's first byte — if it is on the sequence line — gets the mark)
+            const uint32_t cr_before = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)((cr & seq_line) >> 63), 0x138, 0xF, 0xF, false) & 1u;
+            if (lane != 0 && cr_before && (seq_line & 1ull)) {
+                const uint64_t f = dst0 + pre;
+                atomicOr(&start_bits[f >> 5], 1u << (f & 31u));
+            }
         }
-    }
-    // codes of the sequence bytes -> the wavefront's LDS row, at byte offset (dst0 & 3) + rank: LDS word j then is word
-    // (dst0 >> 2) + j of the output
-    uint8_t *row = reinterpret_cast<uint8_t *>(s_out[wv]);
-    const uint32_t mis = (uint32_t)dst0 & 3u;
-    uint32_t bad = 0xFFFFFFFFu;
-    {
-        uint32_t m = seq, o = mis + pre;
-        while (m) {
-            const uint32_t i = (uint32_t)__builtin_ctz(m);
-            m &= m - 1u;
-            const uint32_t l = s_lut[byte_at(i)];
-            if (l == 0xFFu)
-                bad = bad < i ? bad : i;
-            row[o++] = (uint8_t)(l & 3u);
+        // 16 bytes at a time: all of them through the table (the codes of bytes that are no sequence bytes are dropped),
+        // the runs of sequence bytes moved down to bit 0, the word OR-ed into the wavefront's row at code position
+        // (dst0 & 15) + rank: word j of the row is word (dst0 >> 4) + j of the output
+        const uint32_t mis = (uint32_t)dst0 & 15u;
+        uint32_t q = mis + pre, bad = 0xFFFFFFFFu;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t seq16 = (uint32_t)(seq >> (16 * j)) & 0xFFFFu;
+            if (!seq16)
+                continue;
+            uint32_t call = 0, bad_m = 0;
+#pragma unroll
+            for (uint32_t i = 0; i < 16u; ++i) {
+                const uint32_t l = s_lut[(cur.w[j][i >> 2] >> (8u * (i & 3u))) & 0xFFu];
+                bad_m |= (l == 0xFFu ? 1u : 0u) << i;
+                call |= (l & 3u) << (2u * i);
+            }
+            bad_m &= seq16;
+            if (bad_m && bad == 0xFFFFFFFFu)
+                bad = 16u * (uint32_t)j + (uint32_t)__builtin_ctz(bad_m);
+            uint32_t cw = 0, k2 = 0, m = seq16;
+            while (m) {
+                const uint32_t a = (uint32_t)__builtin_ctz(m);               // the run [a, a + len)
+                const uint32_t inv = ~(m >> a);
+                const uint32_t len = (uint32_t)__builtin_ctz(inv);            // (m has 16 bits: inv is never 0)
+                const uint32_t run = len >= 16u ? 0xFFFFFFFFu : (1u << (2u * len)) - 1u;
+                cw |= ((call >> (2u * a)) & run) << k2;
+                k2 += 2u * len;
+                m &= ~(((1u << len) - 1u) << a);
+            }
+            const uint32_t sh = (q & 15u) * 2u;
+            atomicOr(&row[q >> 4], cw << sh);
+            if (sh && (k2 + sh > 32u))
+                atomicOr(&row[(q >> 4) + 1u], cw >> (32u - sh));
+            q += k2 >> 1;
         }
+        if (bad != 0xFFFFFFFFu)
+            atomicMin(&first_bad[0], (unsigned long long)(p + bad));
+        __builtin_amdgcn_wave_barrier();
+        // words only this tile writes by plain stores; the first and last word may be shared with the neighbouring tiles
+        const uint32_t n_w = (mis + tot + 15u) >> 4;       // words of the row that hold codes
+        uint32_t *out = codes + (dst0 >> 4);
+        for (uint32_t j = (uint32_t)lane; j < n_w; j += 64u) {
+            const uint32_t v = row[j];
+            if (j == 0u || j + 1u == n_w) {
+                if (v)
+                    atomicOr(&out[j], v);
+            } else {
+                out[j] = v;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // the flat length = the flat position behind the lane that holds the last byte before the limit
+        const int32_t left = (int32_t)limit - (int32_t)p;
+        if (left >= 1 && left <= 64)
+            out_info[0] = dst0 + pre + cnt;
+        cur = nxt;
     }
-    if (bad != 0xFFFFFFFFu)
-        atomicMin(&first_bad[0], (unsigned long long)(p + bad));
-    __builtin_amdgcn_wave_barrier();
-    __threadfence_block(); // the row is written and read by this wavefront only
-    // whole words by 4-byte stores; the bytes of the first and last word that belong to this tile by byte stores (the
-    // neighbouring tiles write the rest of those words)
-    const uint32_t end = mis + tot;               // bytes [mis, end) of the row are this tile's
-    const uint32_t w_lo = mis ? 1u : 0u;          // whole words: [w_lo, w_hi)
-    const uint32_t w_hi = (end >> 2) > w_lo ? end >> 2 : w_lo;
-    uint32_t *out32 = reinterpret_cast<uint32_t *>(flat) + (dst0 >> 2);
-    for (uint32_t j = w_lo + (uint32_t)lane; j < w_hi; j += 64u)
-        out32[j] = s_out[wv][j];
-    if ((uint32_t)lane < 8u) {
-        // head bytes [mis, min(end, 4 w_lo)) by lanes 0..3, tail bytes [4 w_hi, end) by lanes 4..7
-        const uint32_t b = (uint32_t)lane < 4u ? (uint32_t)lane : (w_hi << 2) + ((uint32_t)lane - 4u);
-        const bool mine = (uint32_t)lane < 4u ? (b >= mis && b < end && b < (w_lo << 2)) : (b < end);
-        if (mine)
-            flat[(dst0 - mis) + b] = row[b];
-    }
-    // the flat length = the flat position behind the lane that holds the last byte before the limit
-    if (left >= 1 && left <= 16)
-        out_info[0] = dst0 + pre + cnt;
 }
 
 // Do all reads of the compacted piece have one length?  The piece's flat bases are [flat_base, out_info[0]), info[1] =

@@ -88,7 +88,9 @@ __device__ __forceinline__ uint32_t tile_load_bytes4(const ReadsView &rv, int64_
     return tile_load_bytes4(rv.bases, rv.total, p);
 }
 
-template <int S, int MODE>
+// C2: `bases` is a stream of 2-bit codes (ReadsView::codes2; a template parameter so that the byte path's kernels do
+// not carry the second loader: with a run-time branch pass 1's packed-tile kernel spilled three registers)
+template <int S, int MODE, bool C2 = false>
 __device__ __forceinline__ void tile_load_vec(const ReadsView &rv, const TileConst &tc, int64_t tile, const int tid,
                                               TileRaw &raw)
 {
@@ -104,6 +106,19 @@ __device__ __forceinline__ void tile_load_vec(const ReadsView &rv, const TileCon
         const int64_t wi = tile * (T / 32) + tid;
         if (wi < rv.n_start_words)
             raw.sbits = rv.start_bits[wi];
+    }
+    if constexpr (C2) { // 2-bit codes: one staged word (16 positions) per thread, three halo words
+        const uint32_t *cw = reinterpret_cast<const uint32_t *>(rv.bases);
+        const int64_t n_words = (total + 15) >> 4;
+        if (tid < T / 16) {
+            const int64_t wi = tile * (T / 16) + tid;
+            raw.w[0] = wi < n_words ? __builtin_nontemporal_load(cw + wi) : 0u;
+        }
+        if (tid < 3) {
+            const int64_t wi = tile * (T / 16) + T / 16 + tid;
+            raw.halo = wi < n_words ? __builtin_nontemporal_load(cw + wi) : 0u;
+        }
+        return;
     }
     if (tid < NMAIN) {
         const int64_t p = tile * T + (int64_t)tid * 16;
@@ -131,7 +146,7 @@ __device__ __forceinline__ void tile_load_vec(const ReadsView &rv, const TileCon
 // own TileSmem, and all of them pass through the same barriers.
 // TOPBAR = false: the caller guarantees that a workgroup barrier already lies between the previous tile's last LDS
 // read (and the code table's staging) and this call.
-template <int S, int MODE, bool TOPBAR = true>
+template <int S, int MODE, bool TOPBAR = true, bool C2 = false>
 __device__ __forceinline__ uint32_t tile_kmers(const ReadsView &rv, const TileConst &tc, int64_t tile,
                                                int k, TileSmem<S> &sm, uint64_t (&q)[S], const int tid,
                                                const TileRaw &raw, TileWin *win = nullptr)
@@ -208,6 +223,12 @@ __device__ __forceinline__ uint32_t tile_kmers(const ReadsView &rv, const TileCo
     } else {
 
     // ---- stage 1: bytes -> 2-bit codes in LDS ----------------------------------------------
+    if constexpr (C2) { // (the input already is what this stage produces)
+        if (tid < T / 16)
+            sm.codes[tid] = w[0];
+        if (tid < 3)
+            sm.codes[T / 16 + tid] = raw.halo;
+    } else {
     if (tid < T / 16) {
         const int v = tid;
         const int64_t p = t0 + (int64_t)v * 16;
@@ -245,6 +266,7 @@ __device__ __forceinline__ uint32_t tile_kmers(const ReadsView &rv, const TileCo
         reinterpret_cast<uint8_t *>(&sm.codes[T / 16])[tid] = (uint8_t)code;
         if (bad >= 0)
             atomicMin(rv.first_bad, (unsigned long long)(p + bad));
+    }
     }
     __syncthreads();
     } // !RECORDS
@@ -411,12 +433,24 @@ struct TilePackedRaw {
     uint32_t w[2][4];
 };
 
+template <bool C2 = false>
 __device__ __forceinline__ void tile_packed_load(const ReadsView &rv, int64_t tile, const int tid, TilePackedRaw &raw)
 {
     const int64_t first = tile * (int64_t)rv.pk_rpt * (int64_t)rv.read_len; // byte of the tile's first read
     const int64_t base = first & ~(int64_t)15;
     const uint32_t nbytes = (uint32_t)(first - base) + rv.pk_rpt * (uint32_t)rv.read_len;
     const bool aligned = (((uintptr_t)rv.bases) & 15u) == 0;
+    if constexpr (C2) { // 2-bit codes: the tile's words (16 positions each) from the aligned position below its first read
+        const uint32_t *cw = reinterpret_cast<const uint32_t *>(rv.bases);
+        const int64_t n_words = (rv.total + 15) >> 4;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const uint32_t wo = (uint32_t)(tid + h * 256);
+            const int64_t wi = (base >> 4) + wo;
+            raw.w[h][0] = (wo * 16u < nbytes && wi < n_words) ? __builtin_nontemporal_load(cw + wi) : 0u;
+        }
+        return;
+    }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const uint32_t off = (uint32_t)(tid + h * 256) * 16u;
@@ -438,6 +472,7 @@ __device__ __forceinline__ void tile_packed_load(const ReadsView &rv, int64_t ti
 // Stage the tile's bytes as 2-bit codes in LDS (bytes before the first read / past the chunk are staged as code 0,
 // unflagged).  A workgroup barrier must follow before tile_packed_fetch; one must lie between the previous tile's
 // fetch and this call.
+template <bool C2 = false>
 __device__ __forceinline__ void tile_packed_stage(const ReadsView &rv, int64_t tile, TilePackedSmem &sm, const int tid,
                                                   const TilePackedRaw &raw)
 {
@@ -446,6 +481,17 @@ __device__ __forceinline__ void tile_packed_stage(const ReadsView &rv, int64_t t
     const int64_t base = first & ~(int64_t)15;
     const uint32_t delta = (uint32_t)(first - base);
     const uint32_t nbytes = delta + rv.pk_rpt * L;
+    if constexpr (C2) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const uint32_t wo = (uint32_t)(tid + h * 256);
+            if (wo * 16u < nbytes)
+                sm.codes[wo] = raw.w[h][0];
+        }
+        if (tid < 4)
+            sm.codes[((nbytes + 15u) >> 4) + (uint32_t)tid] = 0u;
+        return;
+    }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const uint32_t off = (uint32_t)(tid + h * 256) * 16u;
@@ -512,7 +558,7 @@ __device__ __forceinline__ uint32_t tile_packed_fetch(const ReadsView &rv, const
 }
 
 // Returns the lane's windows (q[0 .. pk_S)) and the mask of the real ones.  TOPBAR as in tile_kmers.
-template <bool TOPBAR>
+template <bool TOPBAR, bool C2 = false>
 __device__ __forceinline__ uint32_t tile_packed_kmers(const ReadsView &rv, const TileConst &tc, int64_t tile, int k,
                                                       TilePackedSmem &sm, uint64_t (&q)[16], const int tid,
                                                       const TilePackedRaw &raw, TileWin *win = nullptr)
@@ -520,7 +566,7 @@ __device__ __forceinline__ uint32_t tile_packed_kmers(const ReadsView &rv, const
     (void)k;
     if (TOPBAR)
         __syncthreads(); // every wave has finished reading the previous tile's LDS words
-    tile_packed_stage(rv, tile, sm, tid, raw);
+    tile_packed_stage<C2>(rv, tile, sm, tid, raw);
     __syncthreads();
     return tile_packed_fetch(rv, tc, tile, sm, q, tid, win);
 }

@@ -219,6 +219,65 @@ def test_configs4_index_on_one_gpu(kmm, oracle):
         assert np.array_equal(dev.in_index(km), oracle.in_index(host, km))
 
 
+def test_back_to_back_record_calls_at_configs2_size_keep_every_kmer(kmm, oracle):
+    """Round-4 fault, kept as a test: with the compaction kernels of call i + 1 on the copy stream, BESIDE the radix
+    passes of call i, pass 2 gathered 100-600 k-mers fewer than pass 1 had emitted in 18 of 25 rounds of two
+    back-to-back 10 M-read FASTQ calls (the conservation self-check caught every one).  The kernels now run on the
+    handle's own stream.  Six rounds of two 3 GB raw FASTQ calls against the 100 M index: every synchronising call
+    passes the self-check, all rounds give one count vector, and a 100 k-read sample of it equals the oracle's."""
+    import torch
+    from kmer_mapper_amd import _lib, synthetic as syn
+    R, L, k = 10_000_000, 150, 31
+    index, genome = syn.make_index(100_000_000, k=k, seed=1, gpu_builder=True)
+    mx = index.max_node_id()
+    g = torch.from_numpy(syn.ACGT[genome]).cuda()
+    fq, reads0 = [], None
+    for b in range(2):
+        reads = syn.make_reads_torch(g, R, L, seed=1000 + b)
+        rec = torch.empty((R, 4 + L + 3 + L + 1), dtype=torch.uint8, device="cuda")
+        rec[:, 0:4] = torch.tensor(list(b"@rd\n"), dtype=torch.uint8, device="cuda")
+        rec[:, 4:4 + L] = reads.view(R, L)
+        rec[:, 4 + L:7 + L] = torch.tensor(list(b"\n+\n"), dtype=torch.uint8, device="cuda")
+        rec[:, 7 + L:7 + 2 * L] = ord("F")
+        rec[:, -1] = 10
+        fq.append(rec.reshape(-1))
+        if b == 0:
+            reads0 = reads
+        del rec
+    del g
+    torch.cuda.synchronize()
+    with kmm.DeviceIndex.from_index(index, mx) as dev:
+        first = None
+        for r in range(6):
+            dev.reset()
+            for b in range(2):
+                used, n_rec = dev.map_records(fq[b], fmt=_lib.FORMAT_FASTQ, k=k)
+                assert (used, n_rec) == (fq[b].numel(), R)
+            got = dev.get_node_counts()                 # (runs the conservation self-check: KMM_ERR_INTERNAL if it fails)
+            assert dev.get_param("radix_p2_kmers") == 2 * R * (L - k + 1)
+            assert dev.get_stats(reset=True)[0] == 2 * R * (L - k + 1)     # (also clears the passes' counters for the next round)
+            if first is None:
+                first = got
+            assert np.array_equal(got, first), r
+        assert dev.get_param("direct_batches") == 0
+        # the same reads as flat uniform batches give the same vector; a sample of batch 0 equals the oracle
+        dev.reset()
+        views = [fq[b].view(R, 4 + L + 3 + L + 1)[:, 4:4 + L].contiguous().view(-1) for b in range(2)]
+        torch.cuda.synchronize()          # (torch's copy kernels run on torch's stream, the map calls on the handle's)
+        for b in range(2):
+            dev.map_reads_uniform(views[b], R, L, k)          # (asynchronous: the buffers stay alive until the sync below)
+        assert np.array_equal(dev.get_node_counts(), first)
+        del views
+        n_s = 100_000
+        sample = reads0[:n_s * L].cpu().numpy()
+        expect, _ = oracle.map_reads(index, mx, sample, np.arange(n_s + 1, dtype=np.int64) * L, k, n_threads=8)
+        dev.reset()
+        raw = fq[0][: n_s * (4 + L + 3 + L + 1)].contiguous()
+        torch.cuda.synchronize()
+        assert dev.map_records(raw, fmt=_lib.FORMAT_FASTQ, k=k) == (raw.numel(), n_s)
+        assert np.array_equal(dev.get_node_counts(), expect)
+
+
 def test_direct_view_is_packed_on_first_use_when_deferred(kmm, oracle, monkeypatch):
     """HBM budget of large indexes: with the direct view deferred (forced here on a small index) the radix path
     works without it, the first direct-path batch / kmm_in_index packs it from the radix view's bucket-ordered

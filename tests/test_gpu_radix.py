@@ -255,6 +255,30 @@ def test_radix_records_of_one_length_take_packed_tiles(kmm, syn, oracle, eol, re
         assert dev.get_param("radix_batches") >= 2 and dev.get_param("direct_batches") == 0
 
 
+def test_radix_records_from_a_device_buffer_at_any_byte_offset(kmm, syn, oracle):
+    """A raw chunk that already lies in HBM and starts at an address that is no multiple of 16 (the second piece of a
+    call beyond 2^30 bytes starts where the first one's last record ended): the compaction kernels load 16 bytes per
+    lane from unaligned addresses.  Same counts as the oracle for every offset 0..17."""
+    import torch
+    from kmer_mapper_amd import _lib
+    index, genome = syn.make_index(5000, seed=391)
+    mx = index.max_node_id()
+    bases, offs = syn.make_ragged_reads(genome, 4000, 20, 200, seed=392)
+    expect, _ = oracle.map_reads(index, mx, bases, offs, 31)
+    raw = _fastq([bases[offs[i]:offs[i + 1]].tobytes() for i in range(4000)])
+    with kmm.DeviceIndex.from_index(index, mx) as dev:
+        dev.set_param("path", 2)
+        for shift in (0, 1, 3, 4, 7, 8, 15, 16, 17):
+            buf = torch.zeros(raw.shape[0] + 64, dtype=torch.uint8, device="cuda")
+            buf[shift:shift + raw.shape[0]] = torch.from_numpy(raw.copy()).cuda()
+            view = buf[shift:shift + raw.shape[0]]
+            torch.cuda.synchronize()      # (torch's copy runs on torch's stream, the map call on the handle's)
+            dev.reset()
+            used, n_rec = dev.map_records(view, fmt=_lib.FORMAT_FASTQ)
+            assert (used, n_rec) == (raw.shape[0], 4000), shift
+            assert np.array_equal(dev.get_node_counts(), expect), shift
+
+
 def test_radix_records_edge_cases(kmm, syn, oracle):
     """Compaction corner cases: empty sequence lines, reads shorter than k, a read that ends exactly at a 16-byte lane /
     1024-byte tile boundary, headers and quality lines full of newline-free junk, FASTA2, and the error reports (raw

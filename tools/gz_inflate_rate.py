@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Inflate rate of .gz read files on the host cores (VERDICT r1 item 8): BGZF members on 1 / 4 / 16 threads
-against a plain gzip stream on one thread, then `kmer_mapper map` end to end on the BGZF file.
+"""Inflate rate of .gz read files on the host cores (VERDICT r1 item 8, r3 item 6): BGZF members on 1 / 4 / 16 threads
+and ONE plain gzip member on 1 thread (zlib) and on 4 .. 32 threads (speculative chunks with markers,
+csrc/kmm_inflate.hpp), then `kmer_mapper map` end to end on both files.
     python tools/gz_inflate_rate.py [n_reads] [out_dir]"""
 import gzip
 import os
@@ -37,7 +38,9 @@ def main():
     print("FASTQ %.1f MB -> bgzf %.1f MB, gzip %.1f MB (written in %.1f s)"
           % (len(data) / 1e6, os.path.getsize(pb) / 1e6, os.path.getsize(pg) / 1e6, time.perf_counter() - t), flush=True)
     buf = bytearray(len(data))
-    for label, path, nt in (("plain gzip, 1 thread", pg, 1), ("bgzf, 1 thread", pb, 1), ("bgzf, 4 threads", pb, 4),
+    for label, path, nt in (("plain gzip, 1 thread", pg, 1), ("plain gzip, 4 threads", pg, 4), ("plain gzip, 8 threads", pg, 8),
+                            ("plain gzip, 16 threads", pg, 16), ("plain gzip, 32 threads", pg, 32),
+                            ("bgzf, 1 thread", pb, 1), ("bgzf, 4 threads", pb, 4),
                             ("bgzf, 8 threads", pb, 8), ("bgzf, 16 threads", pb, 16)):
         t = time.perf_counter()
         with gz_io.open_gz(path, nt) as s:
