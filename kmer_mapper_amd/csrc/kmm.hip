@@ -187,6 +187,9 @@ struct kmm_index {
     int rx_grid_per_cu = 2;   // persistent workgroups of passes 2 and 3 per CU (1: leave room for another stream's kernels)
     int64_t rx_min_units = 0; // auto: batches of at least this many positions / k-mers take the radix path
     int64_t rx_sub_cap = ((int64_t)1 << 32) - 2 * RX_B; // k-mer slots per sub-batch of the radix path ("radix_sub_batch_kmers")
+    const uint32_t *dbg_T1 = nullptr, *dbg_item_base = nullptr; // the latest sub-batch's tables (debug_rx_* parameters)
+    const uint16_t *dbg_start1 = nullptr;
+    uint32_t dbg_F1 = 0, dbg_NB = 0;
     int dbg_rec_copy_stream = 0; // experiments (tools/records_overlap_bisect.py): compaction kernels on the copy stream again,
     int dbg_rec_skip = 0;        // and which of them to leave out (1 count2, 2 scans, 4 scatter, 8 uniform, 16 the large memsets)
     uint64_t rx_S = 0;        // entries in bucket order
@@ -599,6 +602,7 @@ int launch_rx(kmm_index *ix, const ReadsView &rv, const uint64_t *kmers_in, int6
         rx.queue = (unsigned long long *)(m + o_queue);
         rx.buf1 = (uint64_t *)ix->rx_buf1.p;
         rx.buf2 = (uint64_t *)ix->rx_buf2.p;
+        ix->dbg_T1 = rx.T1; ix->dbg_item_base = rx.item_base; ix->dbg_start1 = rx.start1; ix->dbg_F1 = F1; ix->dbg_NB = NB;
         HIPCHK(hipMemsetAsync(m + o_ctrl, 0, align256(64) + 2048, ix->stream));
         ScopedTimer tm;
         KMMCHK(tm.begin(ix, KMM_KERNEL_RX_P1));
@@ -1859,11 +1863,11 @@ static int rec_compact_piece(kmm_index_t *ix, Stage &s, const uint8_t *d_raw, in
     unsigned long long *tile_seq = (unsigned long long *)(a + o_seq), *d_out = (unsigned long long *)(a + o_out);
     int64_t *d_info = (int64_t *)(a + o_info);
     // The compaction kernels run on the handle's OWN stream, behind the previous call's passes — not on the copy stream
-    // beside them.  Beside them they gained nothing (both fill the CUs: 64.7 against 65.2 ms per two 10 M-read calls) and
-    // the passes lost k-mers: in 18 of 25 rounds of tools/records_stress.py pass 2 gathered 100-600 k-mers fewer than
-    // pass 1 had emitted (caught by the conservation self-check, never with the kernels serialised, never with other
-    // kernels — torch element-wise — on a second stream: tools/concurrency_stress.py); the cause is not understood
-    // (profiles/r04/records_overlap_fault.txt), so the overlap is gone.  Host -> HBM copies stay on the copy stream.
+    // beside them: beside them they gain nothing (both fill the CUs: 64.7 against 65.2 ms per two 10 M-read calls).
+    // (Running them there is how round 4 found a race in pass 1 that round 3 had left behind — foreign wavefronts on
+    // pass 1's SIMDs delayed a counter clear past another wavefront's next ranking atomic, rx_sort_emit; fixed there,
+    // profiles/r04/records_overlap_fault.txt — and tools/records_overlap_bisect.py still can: debug_records_copy_stream.)
+    // Host -> HBM copies stay on the copy stream; every kernel of a handle runs on the handle's stream.
     hipStream_t cs = ix->dbg_rec_copy_stream ? ix->copy_stream : ix->stream;
     const int skip = ix->dbg_rec_skip;
     const uint32_t pm = (uint32_t)format - 1u, hc = format == KMM_FORMAT_FASTQ ? (uint32_t)'@' : (uint32_t)'>';
@@ -2667,6 +2671,33 @@ int kmm_get_param(kmm_index_t *ix, const char *name, int64_t *value)
         *value = ix->rx_sub_cap;
     else if (!strcmp(name, "comm_overlap_slices"))
         *value = ix->comm_slices;
+    else if (!strcmp(name, "debug_rx_t1_sum") || !strcmp(name, "debug_rx_start1_sum") || !strcmp(name, "debug_rx_items")) {
+        // diagnostics of the latest radix sub-batch (both streams drained first): the k-mers its directory accounts for —
+        // by coarse partition (T1), by pass-1 block (last entry of every start1 row) — and its items
+        HIPCHK(hipSetDevice(ix->device));
+        HIPCHK(hipStreamSynchronize(ix->copy_stream));
+        HIPCHK(hipStreamSynchronize(ix->stream));
+        if (!ix->dbg_T1)
+            return fail(KMM_ERR_INVALID_ARG, "no radix batch has run on this handle");
+        uint64_t sum = 0;
+        if (name[9] == 't') {
+            std::vector<uint32_t> t(ix->dbg_F1);
+            HIPCHK(hipMemcpy(t.data(), ix->dbg_T1, t.size() * 4, hipMemcpyDeviceToHost));
+            for (uint32_t v : t)
+                sum += v;
+        } else if (name[9] == 'i') {
+            uint32_t v = 0;
+            HIPCHK(hipMemcpy(&v, ix->dbg_item_base + ix->dbg_F1, 4, hipMemcpyDeviceToHost));
+            sum = v;
+        } else {
+            const size_t ld = (size_t)ix->dbg_F1 + 1;
+            std::vector<uint16_t> r((size_t)ix->dbg_NB * ld);
+            HIPCHK(hipMemcpy(r.data(), ix->dbg_start1, r.size() * 2, hipMemcpyDeviceToHost));
+            for (size_t b = 0; b < ix->dbg_NB; ++b)
+                sum += r[b * ld + ld - 1];
+        }
+        *value = (int64_t)sum;
+    }
     else if (!strcmp(name, "radix_sorted_flush"))
         *value = (ix->rx_flush_sorted && ix->rx_norder) ? 1 : 0;
     else if (!strcmp(name, "radix_available"))

@@ -415,6 +415,17 @@ __device__ __forceinline__ void rx_sort_emit(uint64_t (&q)[RX_B / NT], PrepFn pr
     tid = tid_now();
     total = F <= 256 ? rx_scan256<ONEBAR>(s_cnt, s_base, F, s_wave, tid) : rx_scan512<ONEBAR>(s_cnt, s_base, F, s_wave, tid);
     tid = tid_now();
+    // The counters are cleared for the next call HERE — every read of them lies before the scan's (last) barrier, and the
+    // barrier behind the placement then orders the clear before the next call's ranking.  (Until round 4 they were
+    // cleared behind that barrier, during the copy-out; with ENDBAR = false nothing separated the clear from the next
+    // block's first ranking atomic in pass 1's packed-tile loop, whose own tile barrier had gone in round 3: a wavefront
+    // without clearing duty could rank into a counter a slower wavefront zeroed afterwards.  It took foreign wavefronts
+    // on the same SIMDs — the records compaction on a second stream — to make the slow wavefront slow enough: 100-600
+    // of 1.2e9 k-mers lost per batch, caught by the conservation self-check; profiles/r04/records_overlap_fault.txt.)
+    if (tid <= F)
+        s_cnt[tid] = 0;
+    if (NT == RX_MAXF && F == NT && tid == 0)
+        s_cnt[NT] = 0;
     if (tid <= F)
         dir_row[tid] = (uint16_t)s_base[tid];
     if (NT == RX_MAXF && F == NT && tid == 0) // (fan-out 512 on 512 threads: one more entry than threads)
@@ -435,10 +446,14 @@ __device__ __forceinline__ void rx_sort_emit(uint64_t (&q)[RX_B / NT], PrepFn pr
     __syncthreads();
     RX_PT(3); // scan + placement
     tid = tid_now();
-    if (tid <= F)
-        s_cnt[tid] = 0; // for the next call (every wavefront's scan has read the counts: they lie before the barrier)
-    if (NT == RX_MAXF && F == NT && tid == 0)
-        s_cnt[NT] = 0;
+    if (WAVESCAN == 2 || (WAVESCAN == 1 && F <= 128)) {
+        // (per-wavefront scans read the counters up to here; the callers of this form alternate between two counter
+        // arrays, so the next ranking never touches the array cleared now)
+        if (tid <= F)
+            s_cnt[tid] = 0;
+        if (NT == RX_MAXF && F == NT && tid == 0)
+            s_cnt[NT] = 0;
+    }
     const uint4 *s4 = reinterpret_cast<const uint4 *>(sbuf);
     uint4 *o4 = reinterpret_cast<uint4 *>(out);
     for (uint32_t i = tid; i < (total + 1) / 2; i += NT) {

@@ -220,11 +220,13 @@ def test_configs4_index_on_one_gpu(kmm, oracle):
 
 
 def test_back_to_back_record_calls_at_configs2_size_keep_every_kmer(kmm, oracle):
-    """Round-4 fault, kept as a test: with the compaction kernels of call i + 1 on the copy stream, BESIDE the radix
-    passes of call i, pass 2 gathered 100-600 k-mers fewer than pass 1 had emitted in 18 of 25 rounds of two
-    back-to-back 10 M-read FASTQ calls (the conservation self-check caught every one).  The kernels now run on the
-    handle's own stream.  Six rounds of two 3 GB raw FASTQ calls against the 100 M index: every synchronising call
-    passes the self-check, all rounds give one count vector, and a 100 k-read sample of it equals the oracle's."""
+    """Round-4 fault, kept as a test: with the compaction kernels of call i + 1 running BESIDE the radix passes of call i,
+    pass 1's counting sort lost 100-600 of 1.2e9 k-mers per call in most rounds (a counter cleared by a slow wavefront
+    after a faster one had already ranked into it for the next block: rx_sort_emit, fixed; the conservation self-check
+    caught every occurrence; profiles/r04/records_overlap_fault.txt).  Six rounds of two 3 GB raw FASTQ calls against the
+    100 M index, then the same with the second call's compaction forced onto the copy stream (the constellation that
+    exposed the race): every synchronising call passes the self-check, all rounds give one count vector, the flat
+    reads give the same vector, and a 100 k-read sample equals the oracle's."""
     import torch
     from kmer_mapper_amd import _lib, synthetic as syn
     R, L, k = 10_000_000, 150, 31
@@ -260,6 +262,21 @@ def test_back_to_back_record_calls_at_configs2_size_keep_every_kmer(kmm, oracle)
                 first = got
             assert np.array_equal(got, first), r
         assert dev.get_param("direct_batches") == 0
+        # foreign wavefronts beside pass 1: the second call only runs its compaction, on the copy stream, while the first
+        # call's passes are under way (tools/records_overlap_bisect.py); the first call's counts must be those of one call
+        dev.reset()
+        dev.map_records(fq[0], fmt=_lib.FORMAT_FASTQ, k=k)
+        single = dev.get_node_counts()
+        dev.get_stats(reset=True)
+        for r in range(6):
+            dev.reset()
+            dev.set_param("debug_records_copy_stream", 0)
+            dev.map_records(fq[0], fmt=_lib.FORMAT_FASTQ, k=k)
+            dev.set_param("debug_records_copy_stream", 1)          # (maps nothing: its kernels only keep the CUs company)
+            dev.map_records(fq[1], fmt=_lib.FORMAT_FASTQ, k=k)
+            dev.set_param("debug_records_copy_stream", 0)
+            assert np.array_equal(dev.get_node_counts(), single), r
+            assert dev.get_stats(reset=True)[0] == R * (L - k + 1)
         # the same reads as flat uniform batches give the same vector; a sample of batch 0 equals the oracle
         dev.reset()
         views = [fq[b].view(R, 4 + L + 3 + L + 1)[:, 4:4 + L].contiguous().view(-1) for b in range(2)]

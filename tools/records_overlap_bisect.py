@@ -17,6 +17,8 @@ def main():
     from kmer_mapper_amd import _lib, synthetic as syn
     from kmer_mapper_amd.engine import DeviceIndex
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+    no_filter = len(sys.argv) > 2 and sys.argv[2] == "nofilter"     # pass 2 without its filter: the variant without scratch
+    only = len(sys.argv) > 2 and sys.argv[2] == "count2"            # just the variant that fails, with the directory sums
     R, L, k = 10_000_000, 150, 31
     index, genome = syn.make_index(100_000_000, k=k, seed=1, gpu_builder=True)
     mx = index.max_node_id()
@@ -39,6 +41,12 @@ def main():
                 ("only count2", 30), ("only count2 + scans", 28), ("all but scatter", 4), ("all but count2", 1),
                 ("only scatter (stale tables)", 27), ("all but the large memsets", 16)]
     with DeviceIndex.from_index(index, mx) as dev:
+        if no_filter:
+            dev.set_param("radix_filter", 0)
+            variants = [v for v in variants if v[1] in (30, 1)]
+            print("radix_filter = 0: k_rx_p2f<false, ...> (no scratch)", flush=True)
+        if only:
+            variants = [v for v in variants if v[1] == 30]
         for label, skip in variants:
             fails = 0
             for r in range(rounds):
@@ -53,8 +61,11 @@ def main():
                     dev.get_node_counts()
                 except Exception as e:      # noqa: BLE001
                     fails += 1
-                    if fails == 1:
-                        print("   first failure:", str(e)[40:170], flush=True)
+                    if fails <= 2:
+                        print("   failure:", str(e)[40:170], flush=True)
+                        print("   the failing call's directory: blocks account for %d k-mers, coarse partitions for %d, %d items"
+                              % (dev.get_param("debug_rx_start1_sum"), dev.get_param("debug_rx_t1_sum"),
+                                 dev.get_param("debug_rx_items")), flush=True)
                 dev.reset()                 # (clears the sticky error)
                 dev.get_stats(reset=True)   # (and the passes' counters)
             left = [n for b, n in names.items() if not skip & b]
