@@ -281,8 +281,8 @@ def main():
 
     for i in range(args.warmup):
         step(i)
-    if world > 1:                                   # warm the RCCL communicator too
-        reduce_counts(torch.zeros_like(counts))
+    if world > 1:                                   # warm the communicator the timed reduce will use (the first collective
+        reduce_counts(counts)                       # of an RCCL communicator sets up its channels); counts are zeroed below
     fence()
     counts.zero_()
     fence()

@@ -1492,7 +1492,10 @@ int kmm_comm_reduce_counts(kmm_index_t *ix, int root)
     // writes that range of the count vector, so range s is flushed while range s - 1 travels: the ranges' reduces go to
     // a second stream, each behind the event of its flush.  Every rank issues the same sequence of reduces.
     const int S = ix->comm_slices;
-    if (S > 1 && ix->ecnt_dirty && ix->rx_norder && !ix->rx_ecnt_acc && ix->rx_flush_sorted && n >= (size_t)S * 1024) {
+    // (Whether the reduce is sliced must not depend on what THIS rank has mapped — a rank without a radix batch since its
+    // last flush would issue one reduce against the others' S and the job would hang: only properties of the index and
+    // of the parameters, the same on every rank, decide; a rank with nothing to flush skips the flush kernels only.)
+    if (S > 1 && ix->rx_norder && !ix->rx_ecnt_acc && ix->rx_flush_sorted && n >= (size_t)S * 1024) {
         if (!ix->comm_stream)
             HIPCHK(hipStreamCreateWithFlags(&ix->comm_stream, hipStreamNonBlocking));
         while ((int)ix->comm_events.size() < S + 1) {
@@ -1523,7 +1526,7 @@ int kmm_comm_reduce_counts(kmm_index_t *ix, int root)
         KMMCHK(tm.begin(ix, KMM_KERNEL_RX_FLUSH));
         for (int t = 0; t < S; ++t) {
             const uint64_t j0 = ix->flush_cuts[t], j1 = ix->flush_cuts[t + 1];
-            if (j1 > j0)
+            if (j1 > j0 && ix->ecnt_dirty)
                 hipLaunchKernelGGL(k_rx_flush_sorted, dim3(grid_for(ix, (int64_t)((j1 - j0 + 1023) / 1024), 8)), dim3(256), 0, ix->stream,
                                    view_of(ix), ix->rx_ecnt, ix->rx_norder + j0, ix->rx_nnode + j0, j1 - j0);
             HIPCHK(hipGetLastError());
@@ -1532,7 +1535,8 @@ int kmm_comm_reduce_counts(kmm_index_t *ix, int root)
             const size_t first = n * (size_t)t / (size_t)S, end = n * (size_t)(t + 1) / (size_t)S;
             RCCLCHK(reduce(first, end - first, ix->comm_stream));
         }
-        HIPCHK(hipMemsetAsync(ix->rx_ecnt, 0, (size_t)ix->rx_S * 4, ix->stream));
+        if (ix->ecnt_dirty)
+            HIPCHK(hipMemsetAsync(ix->rx_ecnt, 0, (size_t)ix->rx_S * 4, ix->stream));
         KMMCHK(tm.end());
         ix->ecnt_dirty = false;
         HIPCHK(hipEventRecord(ix->comm_events[S], ix->comm_stream));

@@ -64,6 +64,16 @@ def test_flush_of_node_ranges_under_the_reduce_of_the_previous_range(oracle):
                 dev.map_reads_uniform(bases, 30000, 150, 31)        # a second job on top: counts accumulate
                 dev.comm_reduce_counts(root=-1)
                 assert np.array_equal(dev.get_node_counts(), 2 * expect), (skewed, slices)
+            # A rank with no radix batch behind it (nothing mapped at all; only direct-kernel batches) must issue the SAME
+            # sequence of reduces as the others: whether the reduce is sliced may not depend on what the rank has mapped.
+            dev.set_param("comm_overlap_slices", 8)
+            dev.reset()
+            dev.comm_reduce_counts(root=0)
+            assert not dev.get_node_counts().any()
+            dev.set_param("path", 1)
+            dev.map_reads_uniform(bases, 30000, 150, 31)
+            dev.comm_reduce_counts(root=0)
+            assert np.array_equal(dev.get_node_counts(), expect), skewed
 
 
 @pytest.mark.parametrize("n_ranks", [2, 3])
