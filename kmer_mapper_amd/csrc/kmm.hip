@@ -606,7 +606,8 @@ int launch_rx(kmm_index *ix, const ReadsView &rv, const uint64_t *kmers_in, int6
         HIPCHK(hipMemsetAsync(m + o_ctrl, 0, align256(64) + 2048, ix->stream));
         ScopedTimer tm;
         KMMCHK(tm.begin(ix, KMM_KERNEL_RX_P1));
-        const int64_t g1cap = (int64_t)ix->n_cu * 8;
+        static const int p1_per_cu = getenv("KMM_RX_P1_GRID_PER_CU") ? atoi(getenv("KMM_RX_P1_GRID_PER_CU")) : 8; // (experiments)
+        const int64_t g1cap = (int64_t)ix->n_cu * (p1_per_cu > 0 ? p1_per_cu : 8);
         const dim3 g1((unsigned)(n_src < g1cap ? n_src : g1cap));
         const int64_t tile0 = s0 * (RX_B / (MODE == MODE_RECORDS ? 1024 : 4096));
         const uint64_t *src_kmers = kmers_in ? kmers_in + s0 * RX_B : nullptr;

@@ -648,7 +648,19 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p1(ReadsView rv, const uint64_t
         else
             tile_load_vec<S, TM, C2>(rv, tc, tile, ltid, raw);
     };
-    for (uint32_t sb = blockIdx.x; sb < n_src; sb += gridDim.x) {
+    // Blocks of a workgroup: every gridDim.x-th block of the source, or (RX_P1_CHUNKED) a contiguous range of it.  A plain
+    // write stream sustains ~5.8 TB/s with one sequential region per workgroup against 4.6-5.6 for 64 KB tiles handed
+    // out round-robin (tools/stream_bench.hip, profiles/r04/stream_bench.txt), but pass 1 does not notice: 2.251 vs
+    // 2.269 ms at configs[2], whatever the grid (profiles/r04/ab_pass1_chunked_blocks.txt) — its stores are not what it
+    // waits for.  Round-robin stays.
+#ifndef RX_P1_CHUNKED
+#define RX_P1_CHUNKED 0
+#endif
+    const uint32_t sb_per = (n_src + gridDim.x - 1) / gridDim.x;
+    const uint32_t sb_first = RX_P1_CHUNKED ? blockIdx.x * sb_per : blockIdx.x;
+    const uint32_t sb_end = RX_P1_CHUNKED ? (sb_first + sb_per < n_src ? sb_first + sb_per : n_src) : n_src;
+    const uint32_t sb_step = RX_P1_CHUNKED ? 1u : gridDim.x;
+    for (uint32_t sb = sb_first; sb < sb_end; sb += sb_step) {
         uint64_t q[RX_KPT];
         uint32_t valid = 0;
         TileWin win;
@@ -668,18 +680,18 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p1(ReadsView rv, const uint64_t
                 // packed tiles: this block's codes were staged in LDS behind the previous block's placement (its barrier
                 // published them); the next block's bytes are requested now and staged behind this block's placement
                 const int64_t tile = tile_begin + ((int64_t)sb * 2 + half);
-                if (sb == blockIdx.x) {
+                if (sb == sb_first) {
                     load_tile(tile, pw[0]);
                     tile_packed_stage<C2>(rv, tile, sm[half], ltid, pw[0]);
                     __syncthreads();
                 }
                 valid = tile_packed_fetch(rv, tc, tile, sm[half], q, ltid, &win);
-                if (sb + gridDim.x < n_src)
-                    load_tile(tile_begin + ((int64_t)(sb + gridDim.x) * 2 + half), pw[0]);
+                if (sb + sb_step < sb_end)
+                    load_tile(tile_begin + ((int64_t)(sb + sb_step) * 2 + half), pw[0]);
             } else {
             // the block's staged bytes: all tiles' loads are in flight together; flat reads (one tile per half):
             // the NEXT block's bytes are requested before this block is sorted, so their latency hides behind it
-            if (!PREFETCH || sb == blockIdx.x) {
+            if (!PREFETCH || sb == sb_first) {
 #pragma unroll
                 for (int r = 0; r < R; ++r)
                     load_tile(tile_begin + ((int64_t)sb * 2 + half) * R + r, pw[r]);
@@ -700,10 +712,10 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p1(ReadsView rv, const uint64_t
                     q[r * S + j] = qq[j];
                 valid |= v << (r * S);
             }
-            if (PREFETCH && sb + gridDim.x < n_src) {
+            if (PREFETCH && sb + sb_step < sb_end) {
 #pragma unroll
                 for (int r = 0; r < R; ++r)
-                    load_tile(tile_begin + ((int64_t)(sb + gridDim.x) * 2 + half) * R + r, pw[r]);
+                    load_tile(tile_begin + ((int64_t)(sb + sb_step) * 2 + half) * R + r, pw[r]);
             }
             }
         }
@@ -780,8 +792,8 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p1(ReadsView rv, const uint64_t
             };
             auto post = [&]() { // behind the placement: the next block's codes into LDS (the sort's barrier publishes them)
                 if constexpr (STAGE_EARLY) {
-                    if (sb + gridDim.x < n_src)
-                        tile_packed_stage<C2>(rv, tile_begin + ((int64_t)(sb + gridDim.x) * 2 + half), sm[half], ltid, pw[0]);
+                    if (sb + sb_step < sb_end)
+                        tile_packed_stage<C2>(rv, tile_begin + ((int64_t)(sb + sb_step) * 2 + half), sm[half], ltid, pw[0]);
                 }
             };
             rx_sort_emit<RX_RB1, MODE == MODE_KMERS, true, RX_NT, true, decltype(fwd), RxNoHook, 0, true, decltype(post)>(
