@@ -284,6 +284,11 @@ int64_t read_bgzf(kmm_io *h, uint8_t *dst, int64_t n)
             return fail(h, p + 18 > h->size || (ms && p + ms > h->size) ? "BGZF file is truncated (member reaches beyond the end of the file)"
                                                                         : "not a BGZF member at byte " + std::to_string(p));
         const size_t isize = rd32(h->map + p + ms - 4);
+        // (deflate expands at most ~1032 : 1: an ISIZE beyond that is damage, and must not size a buffer — a fuzzed
+        // file made the carry buffer below 4 GB)
+        if (isize > ms * 1032 + 64)
+            return fail(h, "corrupt BGZF member: ISIZE " + std::to_string(isize) + " is impossible for " + std::to_string(ms) +
+                               " compressed bytes, at byte " + std::to_string(p));
         if (out + isize > (size_t)n)
             break;
         plan.push_back({p, ms, out, isize});
