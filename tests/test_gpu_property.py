@@ -76,3 +76,113 @@ def test_random_cases_bit_exact(oracle, c):
         assert np.array_equal(dev.get_node_counts(), expect)
         assert np.array_equal(dev.in_index(km), oracle.in_index(index, km))
     assert np.array_equal(extract_kmers(c["bases"], c["offs"], c["k"]), km)
+
+
+VALID = set(b"ACGTacgtNn")
+
+
+def _records_model(raw, lpr=4):
+    """What kmm_map_records must make of a FASTQ (lpr = 4 lines per record) or two-line FASTA (lpr = 2) chunk
+    (include/kmm.h): complete lines in groups of lpr, '@' and '+' ('>') where they belong, every byte of a sequence line
+    a nucleotide ('\\r' before the newline dropped).  Returns (consumed, reads) or (consumed, None) when the chunk must be
+    refused."""
+    lines, start = [], 0
+    while True:
+        e = raw.find(b"\n", start)
+        if e < 0:
+            break
+        lines.append((start, e))
+        start = e + 1
+    n_rec = len(lines) // lpr
+    consumed = lines[lpr * n_rec - 1][1] + 1 if n_rec else 0
+    reads, ok = [], True
+    for r in range(n_rec):
+        (h0, _), (s0, s1) = lines[lpr * r], lines[lpr * r + 1]
+        if raw[h0:h0 + 1] != (b"@" if lpr == 4 else b">"):
+            ok = False
+        if lpr == 4 and raw[lines[lpr * r + 2][0]:lines[lpr * r + 2][0] + 1] != b"+":
+            ok = False
+        seq = raw[s0:s1]
+        if seq.endswith(b"\r"):
+            seq = seq[:-1]
+        if not set(seq) <= VALID:
+            ok = False
+        reads.append(seq)
+    return consumed, (reads if ok else None)
+
+
+@pytest.mark.parametrize("seed,lpr", [(11, 4), (12, 4), (13, 4), (14, 2), (15, 2)])
+def test_damaged_fastq_is_refused_or_mapped_like_the_model(oracle, seed, lpr):
+    """Fuzz of the GPU record parser (kmm_map_records, both paths): FASTQ and two-line FASTA chunks with bytes overwritten, newlines
+    removed and inserted, lines dropped, the end cut anywhere.  Either the next synchronising call raises (the
+    reference's reader raises on a malformed file: bnp.open(...).read_chunks, command_line_interface.py:102-111) or
+    `consumed`, the record count and the node counts are exactly what the line model above gives — on the direct path
+    (census + windows over raw bytes) and on the radix path (compaction into 2-bit flat reads): never other counts."""
+    from kmer_mapper_amd import _lib, synthetic as syn
+    from kmer_mapper_amd.engine import DeviceIndex
+    rng = np.random.default_rng(seed)
+    k = int(rng.choice([5, 11, 31]))
+    index, genome = syn.make_index(4000, k=k, seed=500 + seed, plant=False)
+    mx = index.max_node_id()
+    g = syn.ACGT[genome]
+    reads, pos = [], 0
+    for i in range(1500):
+        n = int(rng.choice([0, 3, k - 1, k, k + 1, 36, 100, 150, 151, 700]))
+        reads.append(g[pos:pos + n].tobytes())
+        pos = (pos + n + 3) % (len(g) - 1000)
+    if lpr == 4:
+        clean = b"".join(b"@r%d/1 len=%d\n" % (i, len(r)) + r + b"\n+\n" + bytes(rng.choice(np.frombuffer(b"FI:@+#,5", dtype=np.uint8), size=len(r))) + b"\n"
+                         for i, r in enumerate(reads))
+    else:
+        clean = b"".join(b">r%d len=%d\n" % (i, len(r)) + r + b"\n" for i, r in enumerate(reads))
+    fmt = _lib.FORMAT_FASTQ if lpr == 4 else _lib.FORMAT_FASTA2
+    pool = np.frombuffer(b"ACGTNacgtn@+>XZ-.*0 \t\n\n\n", dtype=np.uint8)
+    n_refused = n_mapped = 0
+    with DeviceIndex.from_index(index, mx) as dev:
+        for trial in range(24):
+            b = bytearray(clean)
+            for _ in range(int(rng.integers(0, 4))):
+                kind = int(rng.integers(0, 6))
+                p = int(rng.integers(0, len(b) - 1))
+                if kind == 0:                                   # one byte overwritten
+                    b[p] = int(rng.choice(pool))
+                elif kind == 1:                                 # a run overwritten
+                    n = int(rng.integers(1, 300))
+                    b[p:p + n] = bytes(rng.choice(pool, size=len(b[p:p + n])))
+                elif kind == 2:                                 # the next newline removed
+                    e = b.find(b"\n", p)
+                    if e >= 0:
+                        del b[e]
+                elif kind == 3:                                 # a newline inserted
+                    b[p:p] = b"\n"
+                elif kind == 4:                                 # a whole line dropped
+                    e0 = b.find(b"\n", p)
+                    e1 = b.find(b"\n", e0 + 1) if e0 >= 0 else -1
+                    if e1 >= 0:
+                        del b[e0 + 1:e1 + 1]
+                else:                                           # cut anywhere
+                    del b[p:]
+            raw_b = bytes(b)
+            consumed, model = _records_model(raw_b, lpr)
+            raw = np.frombuffer(raw_b, dtype=np.uint8) if raw_b else np.zeros(0, dtype=np.uint8)
+            expect = None
+            if model is not None:
+                bases = np.frombuffer(b"".join(model), dtype=np.uint8)
+                offs = np.concatenate([[0], np.cumsum([len(r) for r in model])]).astype(np.int64)
+                expect, _ = oracle.map_reads(index, mx, bases, offs, k)
+            for path in (1, 2):
+                dev.reset()
+                dev.set_param("path", path)
+                try:
+                    used, n_rec = dev.map_records(raw, fmt=fmt, k=k) if raw.shape[0] else (0, 0)
+                    got = dev.get_node_counts()
+                except ValueError:
+                    assert model is None, ("refused a chunk the line model accepts", trial, path)
+                    n_refused += 1
+                    dev.reset()
+                    continue
+                assert model is not None, ("mapped a chunk the line model refuses", trial, path)
+                assert (used, n_rec) == (consumed, len(model)), (trial, path)
+                assert np.array_equal(got, expect), (trial, path)
+                n_mapped += 1
+    assert n_refused and n_mapped
