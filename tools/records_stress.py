@@ -38,13 +38,23 @@ def main():
     torch.cuda.synchronize()
     first, fails = None, 0
     with DeviceIndex.from_index(index, mx) as dev:
+        # KMM_RECORDS_COPY_STREAM=1: the variant that exposed the counter-clear race of round 3's sort — the second call
+        # only runs its compaction kernels, on the copy stream, beside the first call's radix passes (it maps nothing:
+        # "debug_records_copy_stream"); the counts must be those of the first call alone
+        beside = bool(os.environ.get("KMM_RECORDS_COPY_STREAM"))
+        if beside:
+            print("second call = compaction kernels only, on the copy stream, beside the first call's radix passes")
         for r in range(rounds):
             dev.reset()
             t = time.perf_counter()
             try:
                 for b in range(2):
+                    if beside:
+                        dev.set_param("debug_records_copy_stream", b)
                     used, n_rec = dev.map_records(fq[b], fmt=_lib.FORMAT_FASTQ, k=k)
                     assert n_rec == R and used == fq[b].numel()
+                if beside:
+                    dev.set_param("debug_records_copy_stream", 0)
                 got = dev.get_node_counts()
             except Exception as e:      # noqa: BLE001
                 fails += 1
