@@ -466,3 +466,56 @@ def test_filter_with_several_buckets_per_bit(kmm, syn, oracle, fine_bits, per_bi
         dropped = dev.get_param("radix_p2_dropped")
         assert 0 < dropped < 2 * n
         assert dev.get_param("radix_p3_kmers") + dropped == 2 * n
+
+
+def test_calls_larger_than_a_sub_batch(kmm, syn, oracle):
+    """A map call with more k-mer slots than `radix_sub_batch_kmers` (default 2^32 - 2 blocks: configs[4]'s batches beyond
+    ~35 M reads; halved by the library when HBM is short) is cut into equal sub-batches, each a full run of the three
+    passes.  Forced here with the smallest cap (4 blocks of 8192 slots = some eighty sub-batches per call) on every
+    entry point of the radix path: whole-read tiles, position tiles, ragged reads, the k-mer operator, reverse
+    complements, raw records — the counts are those of the oracle (mapper.pyx:53-69) and of one uncut call."""
+    from kmer_mapper_amd import _lib
+    index, genome = syn.make_index(40_000, seed=901)
+    mx = index.max_node_id()
+    R, L, k = 20_000, 150, 31
+    bases, offs = syn.make_reads(genome, R, L, seed=902)
+    expect, _ = oracle.map_reads(index, mx, bases, offs, k, n_threads=4)
+    expect_rc, _ = oracle.map_reads(index, mx, bases, offs, k, also_revcomp=True, n_threads=4)
+    rng = np.random.default_rng(903)
+    lens = rng.integers(0, 400, size=6000)
+    roffs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    rbases = np.ascontiguousarray(np.tile(syn.ACGT[genome], 8)[: int(roffs[-1])])
+    expect_ragged, _ = oracle.map_reads(index, mx, rbases, roffs, k, n_threads=4)
+    kmers = oracle.extract(bases, offs, k)
+    with kmm.DeviceIndex.from_index(index, mx) as dev:
+        dev.set_param("path", 2)
+        default_cap = dev.get_param("radix_sub_batch_kmers")
+        assert default_cap == 2 ** 32 - 2 * 8192
+        for bad in (0, 8192, 2 ** 32):
+            with pytest.raises(ValueError):
+                dev.set_param("radix_sub_batch_kmers", bad)
+        for cap in (4 * 8192, 5 * 8192 + 17, default_cap):
+            dev.set_param("radix_sub_batch_kmers", cap)
+            assert dev.get_param("radix_sub_batch_kmers") == cap
+            for packed in (1, 0):
+                dev.set_param("radix_packed_tiles", packed)
+                dev.reset()
+                dev.map_reads_uniform(bases, R, L, k)
+                assert np.array_equal(dev.get_node_counts(), expect), (cap, packed)
+            dev.set_param("radix_packed_tiles", 1)
+            dev.reset()
+            dev.map_reads_uniform(bases, R, L, k, also_revcomp=True)
+            assert np.array_equal(dev.get_node_counts(), expect_rc), cap
+            dev.reset()
+            dev.map_reads(rbases, roffs, k)
+            assert np.array_equal(dev.get_node_counts(), expect_ragged), cap
+            dev.reset()
+            dev.map_kmers(kmers)
+            assert np.array_equal(dev.get_node_counts(), expect), cap
+            dev.reset()
+            dev.get_stats(reset=True)
+            raw = _fastq([bases[offs[i]:offs[i + 1]].tobytes() for i in range(R)])
+            assert dev.map_records(raw, fmt=_lib.FORMAT_FASTQ, k=k) == (raw.shape[0], R)
+            assert np.array_equal(dev.get_node_counts(), expect), cap
+            lookups, hits = dev.get_stats(reset=True)
+            assert hits == int(expect.astype(np.uint64).sum())
