@@ -190,6 +190,7 @@ struct kmm_index {
     const uint32_t *dbg_T1 = nullptr, *dbg_item_base = nullptr; // the latest sub-batch's tables (debug_rx_* parameters)
     const uint16_t *dbg_start1 = nullptr;
     uint32_t dbg_F1 = 0, dbg_NB = 0;
+    int64_t dbg_rx_buf_limit = 0; // test hook ("debug_rx_buffer_limit"): a pass-1 buffer beyond this many bytes counts as out of memory
     int dbg_rec_copy_stream = 0; // experiments (tools/records_overlap_bisect.py): compaction kernels on the copy stream again,
     int dbg_rec_skip = 0;        // and which of them to leave out (1 count2, 2 scans, 4 scatter, 8 uniform, 16 the large memsets)
     uint64_t rx_S = 0;        // entries in bucket order
@@ -554,7 +555,8 @@ int launch_rx(kmm_index *ix, const ReadsView &rv, const uint64_t *kmers_in, int6
         const size_t meta = align256(NBm * (F1 + 1) * 2) + align256((size_t)F1 * (NBm + 1) * 4) + align256((size_t)F1 * NBm * 2) +
                             align256(chunks_m * F1 * 4) + 3 * align256((size_t)(F1 + 1) * 4) + align256(items_m * 8) +
                             align256(items_m * (F2 + 1) * 2) + align256(items_m * (F2 + 1) * 2 + 256) + align256(64) + align256(2048);
-        int rc = ensure(ix->rx_meta, meta);
+        int rc = ix->dbg_rx_buf_limit && NBm * RX_B * 8 > (size_t)ix->dbg_rx_buf_limit ? (int)KMM_ERR_NOMEM // (test hook)
+                                                                                         : ensure(ix->rx_meta, meta);
         if (rc == KMM_OK)
             rc = ensure(ix->rx_buf1, NBm * RX_B * 8);
         if (rc == KMM_OK)
@@ -2643,6 +2645,9 @@ int kmm_set_param(kmm_index_t *ix, const char *name, int64_t value)
         // experiments only (tools/records_overlap_bisect.py): the compaction kernels of kmm_map_records on the copy stream,
         // beside the previous call's passes, WITHOUT mapping the call's reads
         ix->dbg_rec_copy_stream = value != 0;
+    } else if (!strcmp(name, "debug_rx_buffer_limit")) {
+        // test hook of the out-of-memory route of launch_rx (the sub-batch cap is halved until the buffers fit)
+        ix->dbg_rx_buf_limit = value;
     } else if (!strcmp(name, "debug_records_skip")) {
         ix->dbg_rec_skip = (int)value;
     } else if (!strcmp(name, "debug_skew_p2_counter")) {

@@ -219,6 +219,58 @@ def test_configs4_index_on_one_gpu(kmm, oracle):
         assert np.array_equal(dev.in_index(km), oracle.in_index(host, km))
 
 
+def test_sub_batch_cap_is_halved_when_the_buffers_do_not_fit(kmm, oracle):
+    """The out-of-memory route of the radix path's buffer sizing: when the buffers of a sub-batch at the current cap
+    cannot be allocated the cap is halved (and stays halved for the handle) until the call is cut finely enough — here
+    forced with a test hook that treats a pass-1 buffer beyond 1.6 GB as out of memory: a 2.5 M-read call (3.0e8 k-mer
+    slots, 2.4 GB at one sub-batch) ends up as two sub-batches at a cap of 2^28.  Same counts as the direct path and,
+    on a sample, as the oracle (mapper.pyx:53-69); below the floor of 2^28 slots the call fails with MemoryError."""
+    import torch
+    from kmer_mapper_amd import synthetic as syn
+    R, L, k = 2_500_000, 150, 31
+    index, genome = syn.make_index(1_000_000, k=k, seed=5, gpu_builder=True)
+    mx = index.max_node_id()
+    g_ascii = torch.from_numpy(syn.ACGT[genome]).cuda()
+    reads = syn.make_reads_torch(g_ascii, R, L, seed=77)
+    del g_ascii
+    torch.cuda.synchronize()
+    with kmm.DeviceIndex.from_index(index, mx) as dev:
+        dev.set_param("path", 1)
+        dev.map_reads_uniform(reads, R, L, k)
+        direct = dev.get_node_counts()
+        dev.reset()
+        dev.set_param("path", 2)
+        dev.set_param("debug_rx_buffer_limit", 1_600_000_000)
+        for packed in (1, 0):
+            dev.set_param("radix_packed_tiles", packed)
+            dev.set_param("radix_sub_batch_kmers", 2 ** 32 - 2 * 8192)
+            dev.reset()
+            dev.set_timing(True)
+            dev.map_reads_uniform(reads, R, L, k)
+            assert np.array_equal(dev.get_node_counts(), direct), packed
+            assert dev.get_param("radix_sub_batch_kmers") == (2 ** 32 - 2 * 8192) // 16      # four halvings: just under 2^28
+            assert dev.get_timing()["k_rx_p1"][1] == 2, "two sub-batches"
+            dev.set_timing(False)
+            assert dev.get_param("radix_p2_kmers") == R * (L - k + 1)
+            dev.get_stats(reset=True)
+        dev.set_param("debug_rx_buffer_limit", 100_000_000)         # nothing at or above the floor fits
+        dev.reset()
+        with pytest.raises(MemoryError):
+            dev.map_reads_uniform(reads, R, L, k)
+        dev.set_param("debug_rx_buffer_limit", 0)
+        dev.reset()
+        dev.map_reads_uniform(reads, R, L, k)
+        assert np.array_equal(dev.get_node_counts(), direct)
+    n_s = 50_000
+    sample = reads[: n_s * L].cpu().numpy()
+    expect, _ = oracle.map_reads(index, mx, sample, np.arange(n_s + 1, dtype=np.int64) * L, k, n_threads=8)
+    with kmm.DeviceIndex.from_index(index, mx) as dev:
+        dev.set_param("path", 2)
+        dev.set_param("radix_sub_batch_kmers", 4 * 8192)
+        dev.map_reads_uniform(sample, n_s, L, k)
+        assert np.array_equal(dev.get_node_counts(), expect)
+
+
 def test_back_to_back_record_calls_at_configs2_size_keep_every_kmer(kmm, oracle):
     """Round-4 fault, kept as a test: with the compaction kernels of call i + 1 running BESIDE the radix passes of call i,
     pass 1's counting sort lost 100-600 of 1.2e9 k-mers per call in most rounds (a counter cleared by a slow wavefront
