@@ -519,3 +519,38 @@ def test_calls_larger_than_a_sub_batch(kmm, syn, oracle):
             assert np.array_equal(dev.get_node_counts(), expect), cap
             lookups, hits = dev.get_stats(reset=True)
             assert hits == int(expect.astype(np.uint64).sum())
+
+
+def test_tuning_knobs_change_no_result(kmm, syn, oracle):
+    """Every tuning knob of include/kmm.h that only moves work around — grids, schedules, the pre-filters of both paths,
+    the flush order — leaves the counts exactly the oracle's (mapper.pyx:53-69); out-of-range values are refused and
+    unknown names too."""
+    index, genome = syn.make_index(30_000, seed=951)
+    mx = index.max_node_id()
+    R, L, k = 30_000, 150, 31
+    bases, offs = syn.make_reads(genome, R, L, seed=952)
+    expect, _ = oracle.map_reads(index, mx, bases, offs, k, n_threads=4)
+    knobs = [("path", 1, "grid_per_cu", (1, 3, 64)), ("path", 1, "dynamic_schedule", (0, 1)), ("path", 1, "dyn_chunk", (1, 7, 4096)),
+             ("path", 1, "occupancy_filter", (0, 1)),
+             ("path", 2, "radix_grid_per_cu", (1, 2)), ("path", 2, "radix_filter", (0, 1)), ("path", 2, "radix_sorted_flush", (0, 1)),
+             ("path", 2, "radix_packed_tiles", (0, 1)), ("path", 2, "comm_overlap_slices", (1, 64))]
+    with kmm.DeviceIndex.from_index(index, mx) as dev:
+        for _, path, name, values in knobs:
+            dev.set_param("path", path)
+            before = dev.get_param(name) if name not in ("dyn_chunk",) else None
+            for v in values:
+                dev.set_param(name, v)
+                dev.reset()
+                dev.map_reads_uniform(bases, R, L, k)
+                dev.map_reads(bases, offs, k)
+                assert np.array_equal(dev.get_node_counts(), 2 * expect), (name, v)
+            if before is not None:
+                dev.set_param(name, before)
+        for name, bad in (("grid_per_cu", 0), ("grid_per_cu", 5000), ("dyn_chunk", 0), ("radix_grid_per_cu", 3),
+                          ("comm_overlap_slices", 0), ("part_shift", 14), ("no_such_knob", 1)):
+            with pytest.raises(ValueError):
+                dev.set_param(name, bad)
+        with pytest.raises(ValueError):
+            dev.get_param("no_such_knob")
+        for name in ("radix_view_bytes", "direct_view_bytes"):
+            assert dev.get_param(name) > 0
