@@ -932,7 +932,10 @@ __global__ void __launch_bounds__(512) k_rx_tables(RxView rx)
 
 // Prefix of every coarse partition's runs over the blocks of one chunk.  Thread c walks column c of the directory
 // rows (coalesced across c); the results leave through an LDS tile of 32 blocks so that each partition's 32
-// consecutive values are written as one 128-byte (P1T) / 64-byte (S1T) piece.
+// consecutive values are written as one 128-byte (P1T) / 64-byte (S1T) piece.  (Round 4 tried the stores straight from
+// registers instead — a thread holds 32 consecutive entries of its row: 16-byte stores, no LDS, no barrier — and it was
+// slower, the more so the shorter the pieces: directory scans 0.624 -> 0.675 ms at 32 blocks per step, 0.825 at 16,
+// 0.976 at 8 (profiles/r04/ab_colscan_direct_stores.txt): the kernel is bound by the granularity of its writes.)
 __global__ void __launch_bounds__(256) k_rx_colscan(RxView rx)
 {
     constexpr int TB = 32, CW = 256; // blocks per tile; coarse partitions per sweep (F1 > 256: two sweeps = grid.y)
