@@ -33,8 +33,13 @@ int rccl_load()
         return KMM_OK;
     const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     void *h = nullptr;
+    // first a copy the process has already mapped (PyTorch's wheel carries its own librccl.so, SONAME librccl.so.1: two
+    // RCCL instances in one process would each own a set of channels and proxy threads), then the system's
     for (const char *n : names)
-        if ((h = dlopen(n, RTLD_NOW | RTLD_GLOBAL)))
+        if ((h = dlopen(n, RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD)))
+            break;
+    for (const char *n : names)
+        if (h || (h = dlopen(n, RTLD_NOW | RTLD_GLOBAL)))
             break;
     if (!h)
         return fail(KMM_ERR_HIP, "RCCL is not available (dlopen librccl.so.1: %s)", dlerror());

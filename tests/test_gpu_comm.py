@@ -3,6 +3,7 @@ of reference kmer_mapper/command_line_interface.py:124-130.  A 1-GPU box can onl
 rank: that still loads RCCL, creates the communicator, runs ncclReduce / ncclAllReduce on the count vector in
 place and synchronises; the N > 1 arithmetic (uint32 wrap-around sums) is covered by tests/test_distributed.py."""
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -30,6 +31,10 @@ def test_single_rank_communicator_reduce_in_place(oracle):
             assert np.array_equal(dev.get_node_counts(), expect)
             dev.comm_reduce_counts(root=-1)       # all-reduce form
             assert np.array_equal(dev.get_node_counts(), expect)
+        # ONE copy of RCCL in the process: the library takes the one torch has mapped (csrc/kmm_comm.hpp: rccl_load)
+        import torch  # noqa: F401  (libtorch_hip needs librccl)
+        mapped = {line.split()[-1] for line in open("/proc/self/maps") if "librccl" in line}
+        assert len({os.path.realpath(m) for m in mapped}) == 1, mapped
         # single-process form: an array of handles (here of one)
         arr = (ctypes.c_void_p * 1)(dev._h)
         _lib.check(_lib.lib().kmm_reduce_counts(arr, 1, 0))
