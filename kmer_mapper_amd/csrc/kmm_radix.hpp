@@ -1866,6 +1866,16 @@ __global__ void __launch_bounds__(RX_NT, WPS) k_rx_p3(IndexView iv, RxView rx, i
                             }
                             mx = cn[i] > mx ? cn[i] : mx;
                         }
+                        // One loop over j < the longest of the group's buckets: ~4.2 trips per wavefront (the longest of its
+                        // 64 x RX_G3 buckets) for 1.3 entries per bucket.  Round 4 measured what the trips behind the second
+                        // cost — capping the loop (wrong counts) takes pass 3 from 3.00 ms to 2.37 / 2.43 / 2.73 / 2.91 at 1 /
+                        // 2 / 3 / 4 trips (configs[2], 20 M reads) — and then every way of doing that work differently, all
+                        // bit-exact, none faster: entries 0-1 (0-2, 0-3) unrolled and the rest walked by the owning lane per
+                        // group 2.95 (2.93, 2.97); the same with the walk once per batch of RX_U k-mers 3.29; the long
+                        // buckets' entries queued per wavefront in LDS and probed 64 at a time 3.01; idle lanes issuing
+                        // no read from the second trip on 3.01.  The 5 % of probes that meet a bucket of three or more entries
+                        // cost ~15 % of the pass whichever lanes do them: it is their SIMD slots, not the loop's form
+                        // (profiles/r04/ab_pass3_entry_loop.txt).
                         for (uint32_t j = 0; j < mx; ++j) {
                             uint64_t key[RX_G3];
 #pragma unroll
