@@ -99,3 +99,57 @@ def test_multi_rank_cli_flow_with_the_hip_engine(n_ranks, tmp_path):
     out = r.stdout + r.stderr
     assert r.returncode == 0, out[-2000:]
     assert out.count("BIT-EXACT") == 3 and "MISMATCH" not in out, out[-2000:]   # .fq, .fq.gz, .fa.gz
+
+
+def _bench_line(args, n_ranks=1, port=29655):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    bench = os.path.join(root, "bench.py")
+    if n_ranks == 1:
+        cmd = [sys.executable, bench] + args
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), bench] + args
+    r = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=500,
+                       env=dict(os.environ, MASTER_ADDR="127.0.0.1"))
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, "rank 0 prints ONE JSON line: %r" % r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_line_has_what_the_contract_names():
+    """`python bench.py` at a reduced size: one JSON line with the metric, the roofline object (bound, achieved, peak,
+    frac, per-kernel times from HIP events), the CPU baseline leg of the oracle on the same reads (parity checked in the
+    same run), and the staged figure."""
+    j = _bench_line(["--steps", "3", "--warmup", "1", "--index-kmers", "2000000", "--reads", "600000",
+                     "--cpu-sample-reads", "100000"])
+    assert j["unit"] == "M k-mers/s" and j["n_gpus"] == 1 and j["steps"] == 3 and j["higher_is_better"] is True
+    assert j["value"] > 0 and j["dtype"] == "u64" and j["data"] == "synthetic" and j["vs_baseline"] is None
+    assert abs(j["value"] - 3 * 600000 * 120 / (j["ms_per_step"] * 3 / 1e3) / 1e6) / j["value"] < 0.02
+    roof = j["roofline"]
+    assert roof["bound"] == "hbm" and roof["peak"] == 8000.0 and 0 < roof["frac"] < 1
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
+    cpu = j["cpu_baseline"]
+    assert cpu["kind"] == "port" and cpu["cores"] >= 1 and cpu["value"] > 0
+    assert j["parity_vs_oracle_on_sample"] is True
+    assert j["config"]["reads_in_hbm_when_timed"] is True and j["value_incl_h2d"] > 0
+
+
+def test_bench_line_of_two_ranks_carries_the_strong_and_the_staged_leg():
+    """The driver's N > 1 invocation (`torch.distributed.run ... bench.py --gpus N --steps K --warmup W`) rehearsed with
+    two ranks on this box's one GPU, the reduce over gloo: weak `value` over both ranks, the configs[3] `strong` leg
+    (the same reads as ONE job split over the ranks: map, flush, reduce) and the staged leg on every rank."""
+    j = _bench_line(["--gpus", "2", "--steps", "3", "--warmup", "1", "--index-kmers", "2000000", "--reads", "600000",
+                     "--dist-backend", "gloo"], n_ranks=2)
+    assert j["n_gpus"] == 2 and j["scaling"] == "weak"
+    assert abs(j["value"] - 2 * 3 * 600000 * 120 / (j["ms_per_step"] * 3 / 1e3) / 1e6) / j["value"] < 0.02
+    assert len(j["config"]["per_rank_map_ms"]) == 2
+    s = j["strong"]
+    assert s["value"] > 0 and len(s["per_rank_map_ms"]) == 2 and len(s["flush_ms"]) == 2 and s["final_reduce_ms"] >= 0
+    assert 0 < s["efficiency_vs_n1"] <= 1.5
+    h = j["config"]["h2d_leg"]
+    assert len(h["per_rank_read_GB_per_s"]) == 2 and j["value_incl_h2d"] > 0
+    assert j["cpu_baseline"] is None          # rank 0 at N = 1 only
