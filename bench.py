@@ -561,6 +561,29 @@ def main():
         result["roofline"]["frac_incl_h2d"] = round(v_h2d * 1e6 * B_ALG_PER_KMER / 1e9 / HBM_PEAK_GBPS, 4)
         result["roofline"]["note"] = ("frac prices the HBM-resident pipeline (sum of the kernels' average durations); "
                                       "frac_incl_h2d the whole map phase with read staging over PCIe included (wall clock)")
+        # the same leg with the reads packed to 2 bits per base on the host before they cross the link
+        # (kmm_set_param "host_pack_threads", csrc/kmm_hostpack.hpp): host cores for PCIe bytes
+        try:
+            n_pack = min(16, len(os.sched_getaffinity(0)))
+        except AttributeError:
+            n_pack = min(16, os.cpu_count() or 1)
+        dev.set_param("host_pack_threads", n_pack)
+        dev.reset()
+        dev.map_reads_uniform(host_batches[0], R, L, k, args.max_freq)      # (allocates the page-locked packed buffer)
+        dev.synchronize()
+        packed_before = dev.get_param("host_packed_calls")
+        tp0 = time.perf_counter()
+        for i in range(len(sizes)):
+            dev.map_reads_uniform(host_batches[i & 1][:sizes[i] * L], sizes[i], L, k, args.max_freq)
+        dev.synchronize()
+        tp = time.perf_counter() - tp0
+        if dev.get_param("host_packed_calls") - packed_before == len(sizes):
+            result["config"]["value_incl_h2d_host_packed"] = round(my_kmers / tp / 1e6, 1)
+            result["config"]["h2d_leg_host_packed"] = (
+                "the same steps with the reads packed to 2 bits per base by %d host threads inside the call, then copied: "
+                "%.1f GB/s of read bytes taken from host memory, %.1f GB/s over PCIe" %
+                (n_pack, sum(sizes) * L / tp / 1e9, sum(sizes) * L / 4 / tp / 1e9))
+        dev.set_param("host_pack_threads", 0)
         del host_batches
 
     # ---- CPU baseline + parity on a bounded sample (rank 0, N=1 only) ---------------------------

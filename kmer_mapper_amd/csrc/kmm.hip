@@ -137,6 +137,7 @@ constexpr unsigned long long NO_BAD = ~0ull;
 } // namespace
 
 #include "kmm_comm.hpp"
+#include "kmm_hostpack.hpp"
 
 struct TimedEvent {
     hipEvent_t start, stop;
@@ -190,6 +191,10 @@ struct kmm_index {
     const uint32_t *dbg_T1 = nullptr, *dbg_item_base = nullptr; // the latest sub-batch's tables (debug_rx_* parameters)
     const uint16_t *dbg_start1 = nullptr;
     uint32_t dbg_F1 = 0, dbg_NB = 0;
+    int host_pack_threads = 0;     // "host_pack_threads": flat reads in host memory are packed to 2 bits per base before they cross PCIe
+    uint8_t *pack_pinned = nullptr; // page-locked home of the packed batch (kmm_hostpack.hpp)
+    size_t pack_pinned_bytes = 0;
+    int64_t host_packed_calls = 0;
     int64_t dbg_rx_buf_limit = 0; // test hook ("debug_rx_buffer_limit"): a pass-1 buffer beyond this many bytes counts as out of memory
     int dbg_rec_copy_stream = 0; // experiments (tools/records_overlap_bisect.py): compaction kernels on the copy stream again,
     int dbg_rec_skip = 0;        // and which of them to leave out (1 count2, 2 scans, 4 scatter, 8 uniform, 16 the large memsets)
@@ -922,6 +927,8 @@ void kmm_index_destroy(kmm_index_t *ix)
     release(ix->rx_meta);
     release(ix->rx_buf1);
     release(ix->rx_buf2);
+    if (ix->pack_pinned)
+        (void)hipHostFree(ix->pack_pinned);
     for (hipEvent_t e : ix->comm_events)
         (void)hipEventDestroy(e);
     if (ix->comm_stream)
@@ -1732,6 +1739,68 @@ static void set_uniform_geometry(const kmm_index_t *ix, ReadsView &rv, int64_t r
     }
 }
 
+static int rec_launch_flat(kmm_index_t *ix, const uint32_t *flat, int64_t total, int64_t n_reads, const uint32_t *start_bits,
+                           int64_t n_words, int64_t uniform_len, int k, int max_freq, int also_revcomp);
+
+// Reads of one length in HOST memory, default lookup table, a batch of radix size, "host_pack_threads" > 0: packed to 2 bits
+// per base by that many host threads into a page-locked buffer, chunk by chunk, each chunk copied to HBM as soon as it is
+// packed (copy stream: under the previous call's kernels and under the packing of the next chunks), then mapped like the
+// flat reads the records compaction makes (pass 1 on 2-bit codes).  *done = false: a byte outside the table — the caller
+// takes the ordinary route, whose kernels report the byte's offset (mapper semantics unchanged: nothing was mapped here).
+static int map_reads_host_packed(kmm_index_t *ix, const uint8_t *bases, int64_t n_reads, int64_t read_len, int k, int max_freq,
+                                 int also_revcomp, bool *done)
+{
+    *done = false;
+    const size_t total = (size_t)(n_reads * read_len);
+    const size_t code_bytes = ((total + 3) / 4 + 256 + 63) & ~(size_t)63;
+    if (ix->pack_pinned_bytes < code_bytes) {
+        if (ix->pack_pinned)
+            (void)hipHostFree(ix->pack_pinned);
+        ix->pack_pinned = nullptr;
+        ix->pack_pinned_bytes = 0;
+        const size_t want = code_bytes + code_bytes / 8;
+        if (hipHostMalloc(reinterpret_cast<void **>(&ix->pack_pinned), want, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            ix->pack_pinned = nullptr;
+            return KMM_OK; // (no page-locked memory to be had: the ordinary route)
+        }
+        ix->pack_pinned_bytes = want;
+    }
+    Stage &s = next_stage(ix);
+    KMMCHK(stage_acquire(ix, s));
+    KMMCHK(ensure(s.kmers, code_bytes));
+    constexpr size_t CHUNK = (size_t)4 << 20;      // bases per packing task (1 MiB packed)
+    constexpr size_t GROUP = 8;                    // tasks per copy (8 MiB packed)
+    kmm_hostpack::Job job;
+    job.start(bases, total, ix->pack_pinned, CHUNK, ix->host_pack_threads);
+    const size_t packed_total = (total + 3) / 4;
+    memset(ix->pack_pinned + packed_total, 0, code_bytes - packed_total); // (the halo words pass 1 loads behind the last read)
+    int rc = KMM_OK;
+    for (size_t c0 = 0; c0 < job.n_chunks && rc == KMM_OK; c0 += GROUP) {
+        const size_t c1 = c0 + GROUP < job.n_chunks ? c0 + GROUP : job.n_chunks;
+        for (size_t c = c0; c < c1; ++c)
+            job.wait_chunk(c);
+        if (job.bad.load())
+            break;
+        const size_t b0 = c0 * CHUNK / 4, b1 = c1 == job.n_chunks ? code_bytes : c1 * CHUNK / 4;
+        if (hipMemcpyAsync((uint8_t *)s.kmers.p + b0, ix->pack_pinned + b0, b1 - b0, hipMemcpyHostToDevice, ix->copy_stream) != hipSuccess)
+            rc = fail(KMM_ERR_HIP, "hipMemcpyAsync of packed reads: %s", hipGetErrorString(hipGetLastError()));
+    }
+    job.join();
+    if (rc != KMM_OK || job.bad.load()) {
+        // nothing was launched on the handle's stream; the copies issued so far only touched this stage's own buffer
+        HIPCHK(hipEventRecord(ix->copied, ix->copy_stream));
+        HIPCHK(hipEventSynchronize(ix->copied));
+        ix->cur ^= 1; // (hand the stage back: the ordinary route takes it again)
+        return rc;
+    }
+    ix->map_calls++;
+    ix->host_packed_calls++;
+    KMMCHK(rec_launch_flat(ix, (const uint32_t *)s.kmers.p, (int64_t)total, n_reads, nullptr, 0, read_len, k, max_freq, also_revcomp));
+    *done = true;
+    return stage_release(ix, s, true);
+}
+
 static int map_reads_common(kmm_index_t *ix, const uint8_t *bases, const int64_t *read_offsets,
                             int64_t n_reads, int64_t read_len, int k, int max_freq,
                             int also_revcomp, const uint8_t *lut)
@@ -1761,6 +1830,12 @@ static int map_reads_common(kmm_index_t *ix, const uint8_t *bases, const int64_t
         return KMM_OK;
     if (!bases)
         return fail(KMM_ERR_INVALID_ARG, "bases is NULL");
+    if (ix->host_pack_threads > 0 && uniform && read_len >= 16 && !lut && use_radix(ix, total) && !is_device_ptr(bases)) {
+        bool done = false;
+        KMMCHK(map_reads_host_packed(ix, bases, n_reads, read_len, k, max_freq, also_revcomp, &done));
+        if (done)
+            return KMM_OK;
+    }
 
     Stage &s = next_stage(ix);
     KMMCHK(stage_acquire(ix, s));
@@ -2645,6 +2720,12 @@ int kmm_set_param(kmm_index_t *ix, const char *name, int64_t value)
         // experiments only (tools/records_overlap_bisect.py): the compaction kernels of kmm_map_records on the copy stream,
         // beside the previous call's passes, WITHOUT mapping the call's reads
         ix->dbg_rec_copy_stream = value != 0;
+    } else if (!strcmp(name, "host_pack_threads")) {
+        // > 0: reads of one length that arrive in host memory (default lookup table, radix-sized batch) are packed to 2 bits per
+        // base by that many host threads before they cross PCIe (kmm_hostpack.hpp); 0 (default): they cross as they are
+        if (value < 0 || value > 256)
+            return fail(KMM_ERR_INVALID_ARG, "host_pack_threads outside [0, 256]");
+        ix->host_pack_threads = (int)value;
     } else if (!strcmp(name, "debug_rx_buffer_limit")) {
         // test hook of the out-of-memory route of launch_rx (the sub-batch cap is halved until the buffers fit)
         ix->dbg_rx_buf_limit = value;
@@ -2677,6 +2758,10 @@ int kmm_get_param(kmm_index_t *ix, const char *name, int64_t *value)
         *value = ix->rx_min_units;
     else if (!strcmp(name, "radix_grid_per_cu"))
         *value = ix->rx_grid_per_cu;
+    else if (!strcmp(name, "host_pack_threads"))
+        *value = ix->host_pack_threads;
+    else if (!strcmp(name, "host_packed_calls")) // map calls whose reads crossed PCIe as 2-bit codes
+        *value = ix->host_packed_calls;
     else if (!strcmp(name, "radix_sub_batch_kmers"))
         *value = ix->rx_sub_cap;
     else if (!strcmp(name, "comm_overlap_slices"))

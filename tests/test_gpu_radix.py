@@ -554,3 +554,55 @@ def test_tuning_knobs_change_no_result(kmm, syn, oracle):
             dev.get_param("no_such_knob")
         for name in ("radix_view_bytes", "direct_view_bytes"):
             assert dev.get_param(name) > 0
+
+
+def test_reads_packed_on_the_host_before_they_cross_pcie(kmm, syn, oracle):
+    """`host_pack_threads` > 0: reads of one length in host memory (default table, a batch that takes the radix path) are
+    packed to 2 bits per base by host threads (csrc/kmm_hostpack.hpp) and mapped by pass 1's 2-bit front end — the
+    counts are the oracle's (extraction as util.py:71-75 with N -> A, command_line_interface.py:41; lookup
+    mapper.pyx:53-69), for read lengths that are no multiple of 4, lower case and N, reverse complements, and across
+    calls; a byte outside the table sends the call down the ordinary route, which reports it; device buffers, custom
+    tables and small batches never take the packed route."""
+    index, genome = syn.make_index(50_000, seed=971)
+    mx = index.max_node_id()
+    with kmm.DeviceIndex.from_index(index, mx) as dev:
+        dev.set_param("path", 2)
+        dev.set_param("host_pack_threads", 3)
+        assert dev.get_param("host_pack_threads") == 3
+        n_packed = 0
+        for R, L, k in ((40_000, 150, 31), (30_001, 151, 31), (70_000, 37, 21), (9_999, 1003, 31)):
+            bases, offs = syn.make_reads(genome, R, L, seed=972 + L)          # (lower case, N, substitutions)
+            for rc in (False, True):
+                expect, _ = oracle.map_reads(index, mx, bases, offs, k, also_revcomp=rc, n_threads=4)
+                dev.reset()
+                dev.map_reads_uniform(bases, R, L, k, also_revcomp=rc)
+                dev.map_reads_uniform(bases, R, L, k, also_revcomp=rc)         # (the page-locked buffer is reused)
+                assert np.array_equal(dev.get_node_counts(), 2 * expect), (R, L, k, rc)
+                n_packed += 2
+                assert dev.get_param("host_packed_calls") == n_packed
+        # a byte that is no nucleotide: the ordinary route maps the call and reports the byte's offset
+        R, L, k = 40_000, 150, 31
+        bases, offs = syn.make_reads(genome, R, L, seed=980)
+        broken = bases.copy()
+        broken[123_457] = ord("X")
+        dev.reset()
+        dev.map_reads_uniform(broken, R, L, k)
+        with pytest.raises(ValueError, match="offset 123457"):
+            dev.get_node_counts()
+        assert dev.get_param("host_packed_calls") == n_packed
+        dev.reset()
+        expect, _ = oracle.map_reads(index, mx, bases, offs, k, n_threads=4)
+        # not taken: a caller's table, a batch on the direct path
+        lut = np.full(256, 0xFF, dtype=np.uint8)
+        for i, c in enumerate(b"ACGT"):
+            lut[c] = lut[c + 32] = i
+        lut[ord("N")] = lut[ord("n")] = 0
+        dev.map_reads_uniform(bases, R, L, k, lut=lut)
+        assert np.array_equal(dev.get_node_counts(), expect)
+        dev.reset()
+        dev.set_param("path", 1)
+        dev.map_reads_uniform(bases, R, L, k)
+        assert np.array_equal(dev.get_node_counts(), expect)
+        assert dev.get_param("host_packed_calls") == n_packed
+        with pytest.raises(ValueError):
+            dev.set_param("host_pack_threads", -1)
