@@ -277,7 +277,7 @@ int kmm_get_kmer_counts(kmm_index_t *idx, uint32_t *out);
  *                      each a full run of the passes (the index slices are streamed once per sub-batch); default and
  *                      maximum 2^32 - 2 * 8192 (a coarse partition's k-mers are numbered with 32 bits); halved by the
  *                      library when the batch buffers of that size do not fit the free HBM
- *   "host_pack_threads" > 0: reads of one length that arrive in HOST memory (kmm_map_reads_uniform, default lookup table, a
+ *   "host_pack_threads" > 0: flat reads that arrive in HOST memory (kmm_map_reads_uniform; kmm_map_reads with host offsets; default lookup table, a
  *                      batch large enough for the radix path) are packed to 2 bits per base by that many host threads inside
  *                      the call and cross PCIe at a quarter of their size (csrc/kmm_hostpack.hpp; the staged map phase
  *                      goes from 44 to 124 G k-mers/s at configs[2] with 16 threads); a byte outside the table sends the

@@ -1747,11 +1747,11 @@ static int rec_launch_flat(kmm_index_t *ix, const uint32_t *flat, int64_t total,
 // packed (copy stream: under the previous call's kernels and under the packing of the next chunks), then mapped like the
 // flat reads the records compaction makes (pass 1 on 2-bit codes).  *done = false: a byte outside the table — the caller
 // takes the ordinary route, whose kernels report the byte's offset (mapper semantics unchanged: nothing was mapped here).
-static int map_reads_host_packed(kmm_index_t *ix, const uint8_t *bases, int64_t n_reads, int64_t read_len, int k, int max_freq,
-                                 int also_revcomp, bool *done)
+static int map_reads_host_packed(kmm_index_t *ix, const uint8_t *bases, const int64_t *read_offsets, int64_t total_bases,
+                                 int64_t n_reads, int64_t read_len, int k, int max_freq, int also_revcomp, bool *done)
 {
     *done = false;
-    const size_t total = (size_t)(n_reads * read_len);
+    const size_t total = (size_t)total_bases;
     const size_t code_bytes = ((total + 3) / 4 + 256 + 63) & ~(size_t)63;
     if (ix->pack_pinned_bytes < code_bytes) {
         if (ix->pack_pinned)
@@ -1796,7 +1796,25 @@ static int map_reads_host_packed(kmm_index_t *ix, const uint8_t *bases, int64_t 
     }
     ix->map_calls++;
     ix->host_packed_calls++;
-    KMMCHK(rec_launch_flat(ix, (const uint32_t *)s.kmers.p, (int64_t)total, n_reads, nullptr, 0, read_len, k, max_freq, also_revcomp));
+    const uint32_t *start_bits = nullptr;
+    int64_t n_words = 0;
+    if (read_offsets) { // ragged reads: where they start, as a bitset over the flat bases (what pass 1's flat front end reads)
+        bool staged = false;
+        const int64_t *d_offs = nullptr;
+        KMMCHK(stage_in<int64_t>(ix, s.offsets, read_offsets, (size_t)(n_reads + 1), &d_offs, &staged));
+        n_words = (int64_t)total / 32 + 2;
+        KMMCHK(ensure(s.start_bits, (size_t)n_words * 4));
+        KMMCHK(stage_copies_done(ix));
+        HIPCHK(hipMemsetAsync(s.start_bits.p, 0, (size_t)n_words * 4, ix->stream));
+        hipLaunchKernelGGL(k_mark_starts, dim3(grid_for(ix, (n_reads + 256) / 256, 8)), dim3(256), 0, ix->stream, d_offs, n_reads,
+                           (int64_t)total, (uint32_t *)s.start_bits.p);
+        hipLaunchKernelGGL(k_check_offsets, dim3(grid_for(ix, (n_reads + 255) / 256, 8)), dim3(256), 0, ix->stream, d_offs, n_reads,
+                           ix->first_bad);
+        HIPCHK(hipGetLastError());
+        start_bits = (const uint32_t *)s.start_bits.p;
+    }
+    KMMCHK(rec_launch_flat(ix, (const uint32_t *)s.kmers.p, (int64_t)total, n_reads, start_bits, n_words, read_offsets ? 0 : read_len, k,
+                           max_freq, also_revcomp));
     *done = true;
     return stage_release(ix, s, true);
 }
@@ -1830,9 +1848,11 @@ static int map_reads_common(kmm_index_t *ix, const uint8_t *bases, const int64_t
         return KMM_OK;
     if (!bases)
         return fail(KMM_ERR_INVALID_ARG, "bases is NULL");
-    if (ix->host_pack_threads > 0 && uniform && read_len >= 16 && !lut && use_radix(ix, total) && !is_device_ptr(bases)) {
+    if (ix->host_pack_threads > 0 && (uniform ? read_len >= 16 : !offs_on_device) && !lut && use_radix(ix, total) &&
+        !is_device_ptr(bases)) {
         bool done = false;
-        KMMCHK(map_reads_host_packed(ix, bases, n_reads, read_len, k, max_freq, also_revcomp, &done));
+        KMMCHK(map_reads_host_packed(ix, bases, uniform ? nullptr : read_offsets, total, n_reads, read_len, k, max_freq, also_revcomp,
+                                     &done));
         if (done)
             return KMM_OK;
     }

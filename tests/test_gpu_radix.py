@@ -560,8 +560,8 @@ def test_reads_packed_on_the_host_before_they_cross_pcie(kmm, syn, oracle):
     """`host_pack_threads` > 0: reads of one length in host memory (default table, a batch that takes the radix path) are
     packed to 2 bits per base by host threads (csrc/kmm_hostpack.hpp) and mapped by pass 1's 2-bit front end — the
     counts are the oracle's (extraction as util.py:71-75 with N -> A, command_line_interface.py:41; lookup
-    mapper.pyx:53-69), for read lengths that are no multiple of 4, lower case and N, reverse complements, and across
-    calls; a byte outside the table sends the call down the ordinary route, which reports it; device buffers, custom
+    mapper.pyx:53-69), for read lengths that are no multiple of 4, lower case and N, reverse complements, ragged reads
+    with their offsets, and across calls; a byte outside the table sends the call down the ordinary route, which reports it; device buffers, custom
     tables and small batches never take the packed route."""
     index, genome = syn.make_index(50_000, seed=971)
     mx = index.max_node_id()
@@ -580,6 +580,23 @@ def test_reads_packed_on_the_host_before_they_cross_pcie(kmm, syn, oracle):
                 assert np.array_equal(dev.get_node_counts(), 2 * expect), (R, L, k, rc)
                 n_packed += 2
                 assert dev.get_param("host_packed_calls") == n_packed
+        # ragged reads (kmm_map_reads with host offsets): the same packed bases + the read-start bitset
+        rbases, roffs = syn.make_ragged_reads(genome, 60_000, 0, 260, seed=975)
+        for k in (31, 9):
+            expect, _ = oracle.map_reads(index, mx, rbases, roffs, k, n_threads=4)
+            dev.reset()
+            dev.map_reads(rbases, roffs, k)
+            assert np.array_equal(dev.get_node_counts(), expect), k
+            n_packed += 1
+            assert dev.get_param("host_packed_calls") == n_packed
+        bad_offs = roffs.copy()
+        bad_offs[1000] = bad_offs[999] - 1 if bad_offs[999] > 0 else bad_offs[1001] + 5
+        dev.reset()
+        dev.map_reads(rbases, bad_offs, 31)
+        with pytest.raises(ValueError, match="non-decreasing"):
+            dev.get_node_counts()
+        n_packed += 1
+        dev.reset()
         # a byte that is no nucleotide: the ordinary route maps the call and reports the byte's offset
         R, L, k = 40_000, 150, 31
         bases, offs = syn.make_reads(genome, R, L, seed=980)
