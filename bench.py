@@ -578,7 +578,9 @@ def main():
         dev.synchronize()
         tp = time.perf_counter() - tp0
         if dev.get_param("host_packed_calls") - packed_before == len(sizes):
+            result["value_incl_h2d_host_packed"] = round(my_kmers / tp / 1e6, 1)
             result["config"]["value_incl_h2d_host_packed"] = round(my_kmers / tp / 1e6, 1)
+            result["roofline"]["frac_incl_h2d_host_packed"] = round(my_kmers / tp * B_ALG_PER_KMER / 1e9 / HBM_PEAK_GBPS, 4)
             result["config"]["h2d_leg_host_packed"] = (
                 "the same steps with the reads packed to 2 bits per base by %d host threads inside the call, then copied: "
                 "%.1f GB/s of read bytes taken from host memory, %.1f GB/s over PCIe" %

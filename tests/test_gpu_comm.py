@@ -136,6 +136,7 @@ def test_bench_line_has_what_the_contract_names():
     assert cpu["kind"] == "port" and cpu["cores"] >= 1 and cpu["value"] > 0
     assert j["parity_vs_oracle_on_sample"] is True
     assert j["config"]["reads_in_hbm_when_timed"] is True and j["value_incl_h2d"] > 0
+    assert j["value_incl_h2d_host_packed"] > 0 and "host threads" in j["config"]["h2d_leg_host_packed"]
 
 
 def test_bench_line_of_two_ranks_carries_the_strong_and_the_staged_leg():
