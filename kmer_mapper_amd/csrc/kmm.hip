@@ -204,6 +204,7 @@ struct kmm_index {
     uint64_t *rx_pkeys_raw = nullptr; // the k-mers themselves (re-packed when part_shift changes)
     uint16_t *rx_pstart16 = nullptr;  // slice-relative 16-bit directory + first entry of every slice (for the current
     uint32_t *rx_slice_e0 = nullptr;  // part_shift; null when a slice holds more than 65535 entries or HBM is short)
+    uint16_t *rx_slice_fmax = nullptr; // largest frequency of every slice (with the two above)
     uint16_t *rx_pfreq = nullptr;
     uint32_t *rx_pnodes = nullptr, *rx_porig = nullptr, *rx_ecnt = nullptr, *rx_ecnt_acc = nullptr;
     uint32_t *rx_norder = nullptr, *rx_nnode = nullptr; // entries in node order (k_rx_flush_sorted); absent if memory is short
@@ -583,7 +584,7 @@ int launch_rx(kmm_index *ix, const ReadsView &rv, const uint64_t *kmers_in, int6
         RxView rx;
         memset(&rx, 0, sizeof rx);
         rx.pstart = ix->rx_pstart; rx.pkeys = ix->rx_pkeys; rx.pfreq = ix->rx_pfreq; rx.ecnt = ix->rx_ecnt;
-        rx.pstart16 = ix->rx_pstart16; rx.slice_e0 = ix->rx_slice_e0;
+        rx.pstart16 = ix->rx_pstart16; rx.slice_e0 = ix->rx_slice_e0; rx.slice_fmax = ix->rx_slice_fmax;
         rx.occ = ix->rx_occ;
         rx.occ_shift = rx_filter_active(ix) ? ix->rx_occ_shift : 3; // (3: k_rx_p2f without its filter)
         rx.p2f_k = NB / 2048u < 4u ? 4u : (NB / 2048u > (uint32_t)P2F_KMAX ? (uint32_t)P2F_KMAX : NB / 2048u);
@@ -933,7 +934,7 @@ void kmm_index_destroy(kmm_index_t *ix)
         (void)hipEventDestroy(e);
     if (ix->comm_stream)
         (void)hipStreamDestroy(ix->comm_stream);
-    for (void *q : {(void *)ix->rx_pstart16, (void *)ix->rx_slice_e0, (void *)ix->rx_pstart, (void *)ix->rx_pkeys, (void *)ix->rx_pkeys_raw, (void *)ix->rx_pfreq, (void *)ix->rx_pnodes,
+    for (void *q : {(void *)ix->rx_pstart16, (void *)ix->rx_slice_e0, (void *)ix->rx_slice_fmax, (void *)ix->rx_pstart, (void *)ix->rx_pkeys, (void *)ix->rx_pkeys_raw, (void *)ix->rx_pfreq, (void *)ix->rx_pnodes,
                     (void *)ix->rx_porig, (void *)ix->rx_ecnt, (void *)ix->rx_ecnt_acc, (void *)ix->rx_norder, (void *)ix->rx_nnode,
                     (void *)ix->rx_occ})
         if (q)
@@ -997,7 +998,7 @@ static int rx_repack_keys(kmm_index *ix)
     ix->rx_fits_small = mx[1] <= odd;
     ix->rx_fits_mid = mx[2] <= odd;
     // 16-bit slice-relative directory: pass 3 loads 2 B per bucket instead of 4 (optional: 2 B x modulo of HBM)
-    for (void **q : {(void **)&ix->rx_pstart16, (void **)&ix->rx_slice_e0}) {
+    for (void **q : {(void **)&ix->rx_pstart16, (void **)&ix->rx_slice_e0, (void **)&ix->rx_slice_fmax}) {
         if (*q)
             (void)hipFree(*q);
         *q = nullptr;
@@ -1005,14 +1006,18 @@ static int rx_repack_keys(kmm_index *ix)
     if (ix->rx_max_slice <= 65535u && !getenv("KMM_RX_NO_P16")) {
         const size_t n16 = ((size_t)ix->rx_PF << ix->rx_w) + 8;
         if (hipMalloc(&ix->rx_pstart16, n16 * 2) == hipSuccess &&
-            hipMalloc(&ix->rx_slice_e0, ((size_t)ix->rx_PF + 2) * 4) == hipSuccess) {
+            hipMalloc(&ix->rx_slice_e0, ((size_t)ix->rx_PF + 2) * 4) == hipSuccess &&
+            hipMalloc(&ix->rx_slice_fmax, ((size_t)ix->rx_PF + 2) * 2) == hipSuccess) {
             hipLaunchKernelGGL(k_rx_pstart16, dim3(grid_for(ix, (int64_t)((n16 + 255) / 256), 16)), dim3(256), 0, ix->stream,
                                ix->rx_pstart, ix->modulo, ix->rx_w, ix->rx_PF, ix->rx_pstart16, ix->rx_slice_e0);
+            HIPCHK(hipGetLastError());
+            hipLaunchKernelGGL(k_rx_slice_fmax, dim3(grid_for(ix, (int64_t)((ix->rx_PF + 3) / 4), 16)), dim3(256), 0, ix->stream,
+                               ix->rx_slice_e0, ix->rx_pfreq, ix->rx_PF, ix->rx_slice_fmax);
             HIPCHK(hipGetLastError());
             HIPCHK(hipStreamSynchronize(ix->stream));
         } else {
             (void)hipGetLastError();
-            for (void **q : {(void **)&ix->rx_pstart16, (void **)&ix->rx_slice_e0}) {
+            for (void **q : {(void **)&ix->rx_pstart16, (void **)&ix->rx_slice_e0, (void **)&ix->rx_slice_fmax}) {
                 if (*q)
                     (void)hipFree(*q);
                 *q = nullptr;
@@ -1132,7 +1137,7 @@ static int rx_build(kmm_index *ix, const int32_t *h2i, const int32_t *nk, const 
         // direct path serves every batch; any other failure is an error
         const bool nomem = rc == KMM_ERR_NOMEM || e == hipErrorOutOfMemory;
         (void)hipGetLastError();
-        for (void **q : {(void **)&ix->rx_pstart16, (void **)&ix->rx_slice_e0, (void **)&ix->rx_pstart, (void **)&ix->rx_pkeys, (void **)&ix->rx_pkeys_raw, (void **)&ix->rx_pfreq,
+        for (void **q : {(void **)&ix->rx_pstart16, (void **)&ix->rx_slice_e0, (void **)&ix->rx_slice_fmax, (void **)&ix->rx_pstart, (void **)&ix->rx_pkeys, (void **)&ix->rx_pkeys_raw, (void **)&ix->rx_pfreq,
                          (void **)&ix->rx_pnodes, (void **)&ix->rx_porig, (void **)&ix->rx_ecnt, (void **)&ix->rx_norder,
                          (void **)&ix->rx_nnode, (void **)&ix->rx_occ}) {
             if (*q)

@@ -123,6 +123,8 @@ struct RxView {
     // index side (built once at kmm_index_create)
     const uint16_t *pstart16; // [PF << w] the same relative to the first entry of the bucket's slice (pass 3 loads half
     const uint32_t *slice_e0; // the bytes); [PF + 1] first entry of every slice.  Null: slices beyond 65535 entries
+    const uint16_t *slice_fmax; // [PF] largest frequency among a slice's entries: pass 3 loads a slice's frequencies only when
+                                // the call's max_index_lookup_frequency lies below it (mapper.pyx:64-66 filters nothing else)
     const uint32_t *pstart; // [modulo + 1] first entry of every bucket in bucket order (exclusive prefix of the
                             //              bucket sizes; pstart[modulo] = S): any 2^w-bucket slice is a directory
     const uint64_t *pkeys;  // [S] entry k-mers in bucket order, in the packed form the passes carry (rx_pack)
@@ -1634,12 +1636,12 @@ __global__ void __launch_bounds__(RX_NT, WPS) k_rx_p3(IndexView iv, RxView rx, i
     // A work item's description (uniform): its fine partition's place in the index and its items.  It is worked
     // out — two dependent loads — while the PREVIOUS work item streams its k-mers.
     struct Slice {
-        uint32_t valid, g, e0, ne, it0, n_it, over, tot;
+        uint32_t valid, g, e0, ne, it0, n_it, over, tot, fmax;
         uint64_t h0;
     };
     auto describe = [&](uint32_t sub, uint32_t idx) {
         Slice d;
-        d.valid = 0; d.g = 0; d.e0 = 0; d.ne = 0; d.it0 = 0; d.n_it = 0; d.h0 = 0; d.over = 0; d.tot = 0;
+        d.valid = 0; d.g = 0; d.e0 = 0; d.ne = 0; d.it0 = 0; d.n_it = 0; d.h0 = 0; d.over = 0; d.tot = 0; d.fmax = 0xFFFFu;
         if (idx >= limit)
             return d;
         const uint32_t row = idx / gs, g = sub * gs + idx % gs;
@@ -1663,6 +1665,7 @@ __global__ void __launch_bounds__(RX_NT, WPS) k_rx_p3(IndexView iv, RxView rx, i
         if (P16) {
             d.e0 = rx.slice_e0[c * F2 + g];
             e1 = rx.slice_e0[c * F2 + g + 1u];
+            d.fmax = rx.slice_fmax ? (uint32_t)rx.slice_fmax[c * F2 + g] : 0xFFFFu;
         } else {
             d.e0 = rx.pstart[d.h0];
             e1 = rx.pstart[d.h0 + W < M ? d.h0 + W : M];
@@ -1705,6 +1708,12 @@ __global__ void __launch_bounds__(RX_NT, WPS) k_rx_p3(IndexView iv, RxView rx, i
         uint32_t dv[WMAX / RX_NT + 1];
         uint64_t kv[ECAP / RX_NT];
         uint32_t fv[ECAP / RX_NT];
+        // (the frequency filter of mapper.pyx:64-66 can only exclude an entry of a slice whose largest frequency lies above
+        // the call's threshold: every other slice's frequencies — 2 of its 12 bytes per entry — stay in HBM)
+#ifndef RX_P3_FMAX
+#define RX_P3_FMAX 1
+#endif
+        const bool need_f = RX_P3_FMAX == 0 || (int)sl.fmax > max_freq;
         if (P16) { // two buckets per word (W is even from w = 1 on; w = 0: one 16-bit load by thread 0)
             const uint32_t *p32 = reinterpret_cast<const uint32_t *>(rx.pstart16 + h0);
 #pragma unroll
@@ -1725,7 +1734,7 @@ __global__ void __launch_bounds__(RX_NT, WPS) k_rx_p3(IndexView iv, RxView rx, i
         for (int j = 0; j < ECAP / RX_NT; ++j) {
             const uint32_t i = tid + j * RX_NT;
             kv[j] = i < ne ? rx.pkeys[(size_t)e0 + i] : 0ull;
-            fv[j] = i < ne ? rx.pfreq[(size_t)e0 + i] : 0u;
+            fv[j] = i < ne && need_f ? rx.pfreq[(size_t)e0 + i] : 0u;
         }
         const uint16_t *rfp = rx.start2T + (size_t)g * rx.max_items + it0;
         const uint16_t *rtp = rfp + rx.max_items;
@@ -2106,6 +2115,27 @@ __global__ void k_rx_bucket_sizes(const int32_t *__restrict__ h2i, const int32_t
                 c = (uint32_t)n;
         }
         out[h] = c;
+    }
+}
+
+// largest frequency among the entries of every slice: one wavefront per slice
+__global__ void __launch_bounds__(256) k_rx_slice_fmax(const uint32_t *__restrict__ slice_e0, const uint16_t *__restrict__ pfreq,
+                                                       uint32_t PF, uint16_t *__restrict__ out)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    for (uint64_t f = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); f < PF; f += (uint64_t)gridDim.x * 4) {
+        uint32_t m = 0;
+        for (uint64_t e = (uint64_t)slice_e0[f] + lane; e < slice_e0[f + 1]; e += 64) {
+            const uint32_t v = pfreq[e];
+            m = v > m ? v : m;
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+            const uint32_t o = __shfl_xor(m, d);
+            m = o > m ? o : m;
+        }
+        if (lane == 0)
+            out[f] = (uint16_t)m;
     }
 }
 
