@@ -153,4 +153,5 @@ def test_bench_line_of_two_ranks_carries_the_strong_and_the_staged_leg():
     assert 0 < s["efficiency_vs_n1"] <= 1.5
     h = j["config"]["h2d_leg"]
     assert len(h["per_rank_read_GB_per_s"]) == 2 and j["value_incl_h2d"] > 0
+    assert j["value_incl_h2d_host_packed"] > 0 and len(j["config"]["h2d_leg_host_packed"]["per_rank_read_GB_per_s"]) == 2
     assert j["cpu_baseline"] is None          # rank 0 at N = 1 only
