@@ -195,3 +195,68 @@ def test_console_script_is_declared_like_the_reference():
     from kmer_mapper_amd.command_line_interface import run_argument_parser
     with pytest.raises(SystemExit):
         run_argument_parser([])            # prints help and exits, like the reference (command_line_interface.py:186-188)
+
+
+def test_host_packer_equals_numpy_packing(tmp_path):
+    """csrc/kmm_hostpack.hpp (the host-side 2-bit packing behind kmm_set_param "host_pack_threads"), compiled by itself
+    with g++: 16 codes per 32-bit word, first base lowest, A C G T a c g t -> 0..3 and N n -> 0
+    (command_line_interface.py:41) — the form pass 1's 2-bit front end reads; the AVX2 body, the scalar tail and the
+    threaded job give the bytes numpy gives, the byte behind the last packed one stays untouched, and any byte outside
+    the table is reported (the call then takes the ordinary route)."""
+    import ctypes
+    import subprocess
+    src = tmp_path / "shim.cpp"
+    src.write_text('#include "kmm_hostpack.hpp"\n'
+                   'extern "C" int shim_pack(const uint8_t *s, size_t n, uint8_t *d) { return kmm_hostpack::pack2(s, n, d) ? 1 : 0; }\n'
+                   'extern "C" int shim_pack_scalar(const uint8_t *s, size_t n, uint8_t *d) { return kmm_hostpack::pack2_scalar(s, n, d) ? 1 : 0; }\n'
+                   'extern "C" int shim_job(const uint8_t *s, size_t n, uint8_t *d, size_t chunk, int threads) {\n'
+                   '    kmm_hostpack::Job j; j.start(s, n, d, chunk, threads);\n'
+                   '    for (size_t c = 0; c < j.n_chunks; ++c) j.wait_chunk(c);\n'
+                   '    j.join(); return j.bad.load() ? 0 : 1; }\n')
+    so = str(tmp_path / "shim.so")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-pthread",
+                           "-I" + os.path.join(ROOT, "kmer_mapper_amd", "csrc"), str(src), "-o", so])
+    lib = ctypes.CDLL(so)
+    for f in (lib.shim_pack, lib.shim_pack_scalar):
+        f.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+    lib.shim_job.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    rng = np.random.default_rng(5)
+    alphabet = np.frombuffer(b"ACGTacgtNn", dtype=np.uint8)
+    code_of = np.full(256, 0xFF, dtype=np.uint8)
+    for i, c in enumerate(b"ACGT"):
+        code_of[c] = code_of[c + 32] = i
+    code_of[ord("N")] = code_of[ord("n")] = 0
+
+    def numpy_pack(a):
+        c = code_of[a].astype(np.uint8)
+        c = np.concatenate([c, np.zeros((-len(c)) % 4, dtype=np.uint8)]).reshape(-1, 4)
+        return (c[:, 0] | (c[:, 1] << 2) | (c[:, 2] << 4) | (c[:, 3] << 6)).astype(np.uint8)
+
+    for n in (1, 3, 4, 31, 32, 33, 63, 64, 65, 1000, 4099, 100_003):
+        a = np.ascontiguousarray(alphabet[rng.integers(0, len(alphabet), size=n)])
+        want = numpy_pack(a)
+        for f in (lib.shim_pack, lib.shim_pack_scalar):
+            out = np.full(len(want) + 8, 0xAA, dtype=np.uint8)
+            assert f(a.ctypes.data, n, out.ctypes.data) == 1
+            assert np.array_equal(out[:len(want)], want) and (out[len(want):] == 0xAA).all(), n
+        for bad in (b"X", b"@", b"\n", b"-", b"\x00", b"\xc1", b"1"):
+            b = a.copy()
+            b[rng.integers(0, n)] = bad[0]
+            out = np.zeros(len(want) + 8, dtype=np.uint8)
+            assert lib.shim_pack(b.ctypes.data, n, out.ctypes.data) == 0, (n, bad)
+            assert lib.shim_pack_scalar(b.ctypes.data, n, out.ctypes.data) == 0, (n, bad)
+    n = 3_000_017
+    a = np.ascontiguousarray(alphabet[rng.integers(0, len(alphabet), size=n)])
+    want = numpy_pack(a)
+    for threads, chunk in ((1, 1 << 20), (4, 1 << 18), (7, 64)):
+        if chunk == 64:
+            a2, want2 = a[:20_000], numpy_pack(a[:20_000])
+        else:
+            a2, want2 = a, want
+        out = np.full(len(want2) + 8, 0xAA, dtype=np.uint8)
+        assert lib.shim_job(a2.ctypes.data, len(a2), out.ctypes.data, chunk, threads) == 1
+        assert np.array_equal(out[:len(want2)], want2) and (out[len(want2):] == 0xAA).all(), (threads, chunk)
+    b = a.copy()
+    b[2_000_000] = ord("?")
+    out = np.zeros(len(want) + 8, dtype=np.uint8)
+    assert lib.shim_job(b.ctypes.data, n, out.ctypes.data, 1 << 18, 4) == 0
