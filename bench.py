@@ -90,12 +90,18 @@ def main():
     ap.add_argument("--cpu-sample-reads", type=int, default=10_000_000,
                     help="CPU baseline sample: a prefix of batch 0 (BASELINE.md section 3: 10 M-read prefix)")
     ap.add_argument("--no-h2d-leg", action="store_true", help="skip the PCIe-inclusive measurement (value_incl_h2d)")
+    ap.add_argument("--host-pack-threads", type=int, default=None,
+                    help="host threads that pack host-resident reads to 2 bits per base inside the map call (default: the library's "
+                         "own default, min(16, CPU budget of the rank); 0 = the bytes cross PCIe as they are)")
+    ap.add_argument("--no-records-host-leg", action="store_true",
+                    help="skip the raw-FASTQ-in-host-memory measurement (config.records_from_host_memory)")
+    ap.add_argument("--no-numa-bind", action="store_true", help="leave the process's CPU affinity alone")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl",
                     help="nccl (= RCCL, the real multi-GPU path) or gloo (rehearsal on a 1-GPU box: all "
                          "ranks share device LOCAL_RANK %% device_count, the reduce runs on host copies)")
     ap.add_argument("--strong", action="store_true",
-                    help="strong scaling (BASELINE configs[3]): the job is --steps x --reads reads IN TOTAL (default 10 x 10 M "
+                    help="strong scaling (BASELINE configs[3]): the job is --steps x --reads reads IN TOTAL (default 5 x 20 M "
                          "= 100 M), split evenly over the ranks; timed region = map + flush + RCCL reduce as always. "
                          "Default (weak): every rank maps --steps batches of --reads reads.")
     ap.add_argument("--max-freq", type=int, default=1000,
@@ -132,8 +138,26 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
     from kmer_mapper_amd import synthetic as syn
-    from kmer_mapper_amd.distributed import init_rccl_comm, reduce_node_counts
+    from kmer_mapper_amd.distributed import bind_to_gpu_numa_node, init_rccl_comm, reduce_node_counts
     from kmer_mapper_amd.engine import DeviceIndex
+
+    # every rank next to its own GPU: the threads that pack its reads and the page-locked buffers they fill live on the
+    # NUMA node the GPU hangs off (eight ranks pulling from host DRAM at once)
+    if args.no_numa_bind:
+        os.environ["KMM_NO_NUMA_BIND"] = "1"
+    numa = bind_to_gpu_numa_node(local_rank)
+    from kmer_mapper_amd import _io as kmm_io
+    # this rank's share of the host's cores: the CPUs of its affinity mask split among the ranks bound to the same mask,
+    # and its share of the cgroup's CPU quota where there is one
+    ranks_here = 1
+    if world > 1:
+        masks = [None] * world
+        dist.all_gather_object(masks, (numa["numa_node"] if numa["bound"] else -1))
+        ranks_here = sum(1 for m in masks if m == masks[rank])
+    quota = kmm_io.cpu_quota()
+    cpu_budget = max(1, kmm_io.affinity_count() // ranks_here)
+    if quota is not None:
+        cpu_budget = max(1, min(cpu_budget, quota // world))
 
     k, L, R = args.kmer_size, args.read_len, args.reads
     t_setup = time.time()
@@ -149,9 +173,16 @@ def main():
     log("index: %d entries, modulo %d, max_node_id %d (%.1fs)" % (n_entries, modulo_used, mx, time.time() - t_setup))
     dev = DeviceIndex.from_index(index, mx, device=local_rank)
     if torch_index:          # the handle owns its own copy: keep only what the CPU leg needs (host arrays, on demand)
-        index = index.to_host() if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
+        index = index.to_host() if (rank == 0 and not args.no_cpu_baseline) else None
         torch.cuda.empty_cache()
     dev.set_param("path", args.path)
+    # the host cores' share (kmm_set_param "host_pack_threads"): the library's default is min(16, budget of the process);
+    # with several ranks on one host every rank takes its share of the cores
+    if args.host_pack_threads is not None:
+        dev.set_param("host_pack_threads", args.host_pack_threads)
+    elif world > 1:
+        dev.set_param("host_pack_threads", min(16, cpu_budget) if cpu_budget >= 4 else 0)
+    n_pack_default = dev.get_param("host_pack_threads")
     if args.no_filter:
         dev.set_param("occupancy_filter", 0)
     if args.dyn_chunk is not None:
@@ -253,6 +284,7 @@ def main():
             torch.cuda.synchronize()
 
     own_comm = False
+    comm_note = ""
     if world > 1 and args.dist_backend == "nccl":
         # the library's own communicator (kmm_comm_init_rank); every rank must have it, else all of them reduce
         # through torch.distributed (same RCCL sum of the same vector)
@@ -260,11 +292,18 @@ def main():
             init_rccl_comm(dev)
             ok = 1
         except Exception as e:                       # noqa: BLE001 - any failure means "fall back", on every rank
-            log("kmm_comm_init_rank failed (%s): reducing through torch.distributed" % e)
+            print("rank %d: kmm_comm_init_rank failed (%s): reducing through torch.distributed" % (rank, e), file=sys.stderr, flush=True)
+            comm_note = "rank %d: %s" % (rank, str(e)[:200])
             ok = 0
         flag = torch.tensor([ok], dtype=torch.int32, device=dev_t)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         own_comm = bool(flag.item())
+        if not own_comm:                             # which rank(s) could not join, and why: the record says which reduce ran
+            notes = [None] * world
+            dist.all_gather_object(notes, comm_note)
+            comm_note = "; ".join(n for n in notes if n) or "a rank failed to join"
+    elif world > 1:
+        comm_note = "--dist-backend %s (rehearsal: the sum runs on host copies)" % args.dist_backend
 
     def reduce_counts(t):
         if args.dist_backend == "nccl":
@@ -315,6 +354,20 @@ def main():
         total_kmers = int(sum(t[1].item() for t in every))
     else:
         total_kmers = my_kmers
+    # SURVEY 8(d) counts "final D2H/reduce" into the map phase; the reference's own GPU timer stops before it
+    # (command_line_interface.py:78-79), the bench contract's `value` likewise: reported beside it
+    td0 = time.perf_counter()
+    counts_host = torch.empty(mx + 1, dtype=torch.int32).pin_memory() if rank == 0 else None
+    if rank == 0:
+        counts_host.copy_(counts)
+        torch.cuda.synchronize()
+    final_d2h_ms = (time.perf_counter() - td0) * 1e3
+    td1 = time.perf_counter()
+    if rank == 0:
+        counts_host.copy_(counts)
+        torch.cuda.synchronize()
+    final_d2h_ms = min(final_d2h_ms, (time.perf_counter() - td1) * 1e3)      # (the first copy also page-locks the buffer)
+    del counts_host
     hits = int(counts.to(torch.int64).bitwise_and(0xFFFFFFFF).sum().item()) if rank == 0 else 0
     hbm_free, hbm_total = torch.cuda.mem_get_info(dev_t)
     survivors = None
@@ -445,8 +498,14 @@ def main():
                 "occupancy_bits_per_bucket": dev.get_param("occupancy_bits_per_bucket"),
                 "bloom_filter_bytes": dev.get_param("bloom_filter_bytes"),
                 "final_reduce_ms": round(reduce_s * 1e3, 3) if world > 1 else 0.0,
+                "final_d2h_ms": round(final_d2h_ms, 3),
+                "final_d2h_note": "%d-byte count vector -> page-locked host memory, outside the timed region (the reference's own "
+                                  "timer stops before the fetch, command_line_interface.py:78-79)" % (4 * (mx + 1)),
                 "parallelism": "reads sharded by batch over %d GPU(s), index replicated, one RCCL sum (%s)"
-                               % (world, "kmm_comm_reduce_counts" if own_comm or world == 1 else "torch.distributed"),
+                               % (world, "kmm_comm_reduce_counts" if own_comm or world == 1 else
+                                  "torch.distributed reduce, because kmm_comm_init_rank did not come up on every rank: " + comm_note),
+                "numa_binding": numa,
+                "host_cores_of_this_rank": cpu_budget,
                 "kernel_ms_per_step": {n: round(t[0] / max(len(sizes), 1), 3) for n, t in timing.items() if t[1]},
             },
             "roofline": {
@@ -521,94 +580,100 @@ def main():
                 "efficiency_vs_n1": round(t_n1 / (world * t_strong), 4),
                 "timed_region": "map + flush + RCCL reduce, barrier / synchronize on both sides, max over ranks",
             }
-    if world > 1 and plain_fused and not args.no_h2d_leg:
+    # ---- SURVEY 8(d)'s map-phase figure: the SAME steps with the reads in (page-locked) HOST memory, handed to the map call
+    # as the reference hands a chunk to a worker (command_line_interface.py:109-111).  `value` above times reads that are
+    # already resident in HBM (the bench contract).  By default the call packs the reads to 2 bits per base on the rank's
+    # host threads first ("host_pack_threads": the reference's -t, its default 16 where the rank has the cores) and a quarter
+    # of the bytes crosses PCIe: `value_incl_h2d`; with 0 threads the ASCII bytes cross as they are (~55 GB/s per link):
+    # `value_incl_h2d_plain_copy`.  At N > 1 every rank runs the leg at once, each over its own link, reduce included.
+    if plain_fused and not args.no_h2d_leg:
         host_batches = [b.cpu().pin_memory() for b in batches]
-        dev.map_reads_uniform(host_batches[0], R, L, k, args.max_freq)      # warm the staging buffers
-        dev.synchronize()
-        sg = timed_job(sizes, lambda j: host_batches[j & 1])
-        # ... and once more with the reads packed to 2 bits per base on the host before they cross the link: every rank
-        # takes its share of the host's cores (at most 16, the reference's -t default)
-        try:
-            n_cores = len(os.sched_getaffinity(0))
-        except AttributeError:
-            n_cores = os.cpu_count() or 1
-        n_pack = max(1, min(16, n_cores // world))
-        dev.set_param("host_pack_threads", n_pack)
-        dev.map_reads_uniform(host_batches[0], R, L, k, args.max_freq)      # (allocates the page-locked packed buffer)
-        dev.synchronize()
-        sp = timed_job(sizes, lambda j: host_batches[j & 1])
-        dev.set_param("host_pack_threads", 0)
+
+        def staged_leg(threads):
+            dev.set_param("host_pack_threads", threads)
+            dev.reset()
+            dev.map_reads_uniform(host_batches[0], R, L, k, args.max_freq)      # warm the staging / page-locked buffers
+            dev.synchronize()
+            packed_before = dev.get_param("host_packed_calls")
+            job = timed_job(sizes, lambda j: host_batches[j & 1])
+            job["packed_calls"] = dev.get_param("host_packed_calls") - packed_before
+            return job
+
+        legs = {"plain": staged_leg(0)}
+        if n_pack_default > 0:
+            legs["packed"] = staged_leg(n_pack_default)
+        dev.set_param("host_pack_threads", n_pack_default)
         del host_batches
         if rank == 0:
-            t_sp = max(sp["elapsed_ms"])
-            result["value_incl_h2d_host_packed"] = round(sp["kmers"] / (t_sp * 1e-3) / 1e6, 1)
-            result["config"]["h2d_leg_host_packed"] = {
-                "what": "the staged leg with the reads packed to 2 bits per base by %d host threads per rank inside the call "
-                        "(kmm_set_param host_pack_threads), on all %d ranks at once; reduce included" % (n_pack, world),
-                "per_rank_read_GB_per_s": [round(r_ * L / (m_ * 1e-3) / 1e9, 1) for r_, m_ in zip(sp["reads"], sp["map_ms"])],
-                "elapsed_ms": round(t_sp, 3)}
-            t_st = max(sg["elapsed_ms"])
-            v_h2d = sg["kmers"] / (t_st * 1e-3) / 1e6
-            result["value_incl_h2d"] = round(v_h2d, 1)
-            result["config"]["value_incl_h2d"] = round(v_h2d, 1)
-            result["config"]["h2d_leg"] = {
-                "what": "the weak job again with every batch in pinned host memory, copied to HBM by the call that maps it "
-                        "(double-buffered staging on a copy stream), on all %d ranks at once; reduce included" % world,
-                "per_rank_read_GB_per_s": [round(r_ * L / (m_ * 1e-3) / 1e9, 1) for r_, m_ in zip(sg["reads"], sg["map_ms"])],
-                "host_read_GB_per_s_total": round(sum(sg["reads"]) * L / (t_st * 1e-3) / 1e9, 1),
-                "elapsed_ms": round(t_st, 3)}
-            result["roofline"]["frac_incl_h2d"] = round(v_h2d * 1e6 * B_ALG_PER_KMER / 1e9 / (HBM_PEAK_GBPS * world), 4)
+            def describe(job, what):
+                t = max(job["elapsed_ms"])
+                return round(job["kmers"] / (t * 1e-3) / 1e6, 1), {
+                    "what": what,
+                    "per_rank_read_GB_per_s": [round(r_ * L / (m_ * 1e-3) / 1e9, 1) for r_, m_ in zip(job["reads"], job["map_ms"])],
+                    "host_read_GB_per_s_total": round(sum(job["reads"]) * L / (t * 1e-3) / 1e9, 1),
+                    "elapsed_ms": round(t, 3)}
+            v_plain, d_plain = describe(legs["plain"], "every batch in page-locked host memory, copied to HBM as ASCII bytes by the call "
+                                        "that maps it (double-buffered staging on a copy stream)%s"
+                                        % (", on all %d ranks at once; reduce included" % world if world > 1 else ""))
+            result["value_incl_h2d_plain_copy"] = v_plain
+            result["config"]["h2d_leg_plain_copy"] = d_plain
+            v_def, d_def, frac_key = v_plain, d_plain, "plain copy (no host threads to pack with)"
+            if "packed" in legs and legs["packed"]["packed_calls"] == len(sizes):
+                v_def, d_def = describe(legs["packed"], "every batch in host memory, packed to 2 bits per base by %d host threads per rank "
+                                        "inside the call (kmm_set_param host_pack_threads; library default = min(16, the rank's cores): "
+                                        "this rank has %d), a quarter of the bytes over PCIe%s"
+                                        % (n_pack_default, cpu_budget, ", on all %d ranks at once; reduce included" % world if world > 1 else ""))
+                d_def["host_pack_threads"] = n_pack_default
+                d_def["pcie_GB_per_s_total"] = round(d_def["host_read_GB_per_s_total"] / 4, 1)
+                frac_key = "reads packed to 2 bits per base by %d host threads per rank" % n_pack_default
+                result["value_incl_h2d_host_packed"] = v_def
+            result["value_incl_h2d"] = v_def
+            result["config"]["value_incl_h2d"] = v_def
+            result["config"]["h2d_leg"] = d_def
+            result["config"]["h2d_in_value_incl_h2d"] = frac_key
+            result["roofline"]["frac_incl_h2d"] = round(v_def * 1e6 * B_ALG_PER_KMER / 1e9 / (HBM_PEAK_GBPS * world), 4)
+            result["roofline"]["frac_incl_h2d_plain_copy"] = round(v_plain * 1e6 * B_ALG_PER_KMER / 1e9 / (HBM_PEAK_GBPS * world), 4)
+            result["roofline"]["note"] = ("frac prices the HBM-resident pipeline (sum of the kernels' average durations); "
+                                          "frac_incl_h2d the whole map phase with the reads starting in host memory (wall clock)")
 
-    # ---- SURVEY 8(d)'s map-phase figure: the SAME steps with the reads in pinned host memory, staged by every call
-    # (double-buffered on a copy stream).  `value` above times reads that are already resident in HBM (the bench
-    # contract); this one includes the read H2D and is bound by the PCIe link (~50 GB/s of read bytes per GPU).
-    if rank == 0 and world == 1 and not args.no_h2d_leg and not (args.records or args.operator or args.general_path):
-        host_batches = [b.cpu().pin_memory() for b in batches]
-        dev.map_reads_uniform(host_batches[0], R, L, k, args.max_freq)      # warm the staging buffers
-        dev.synchronize()
-        th0 = time.perf_counter()
-        for i in range(len(sizes)):
-            dev.map_reads_uniform(host_batches[i & 1][:sizes[i] * L], sizes[i], L, k, args.max_freq)
-        dev.synchronize()
-        th = time.perf_counter() - th0
-        v_h2d = my_kmers / th / 1e6
-        result["value_incl_h2d"] = round(v_h2d, 1)
-        result["config"]["value_incl_h2d"] = round(v_h2d, 1)
-        result["config"]["h2d_leg"] = ("%d steps with the batch in pinned host memory, copied to HBM by every call "
-                                       "(double-buffered staging on a copy stream): %.1f GB/s of read bytes over PCIe"
-                                       % (len(sizes), sum(sizes) * L / th / 1e9))
-        result["roofline"]["frac_incl_h2d"] = round(v_h2d * 1e6 * B_ALG_PER_KMER / 1e9 / HBM_PEAK_GBPS, 4)
-        result["roofline"]["note"] = ("frac prices the HBM-resident pipeline (sum of the kernels' average durations); "
-                                      "frac_incl_h2d the whole map phase with read staging over PCIe included (wall clock)")
-        # the same leg with the reads packed to 2 bits per base on the host before they cross the link
-        # (kmm_set_param "host_pack_threads", csrc/kmm_hostpack.hpp): host cores for PCIe bytes
-        try:
-            n_pack = min(16, len(os.sched_getaffinity(0)))
-        except AttributeError:
-            n_pack = min(16, os.cpu_count() or 1)
-        dev.set_param("host_pack_threads", n_pack)
+    # ---- raw FASTQ in host memory -> kmm_map_records (what `kmer_mapper map` does with a file mapping): the host threads pack
+    # the sequence lines, the GPU maps; N = 1 only, 10 M-record chunks (3.08 GB each)
+    if rank == 0 and world == 1 and plain_fused and not args.no_records_host_leg and n_pack_default > 0:
+        from kmer_mapper_amd import _lib as kmm_lib
+        R_rec = min(R, 10_000_000)
+        rec_len = 4 + L + 3 + L + 1
+        host_fq = []
+        for b in batches:
+            rec = torch.empty((R_rec, rec_len), dtype=torch.uint8, device=dev_t)
+            rec[:, 0:4] = torch.tensor(list(b"@rd\n"), dtype=torch.uint8, device=dev_t)
+            rec[:, 4:4 + L] = b[:R_rec * L].view(R_rec, L)
+            rec[:, 4 + L:4 + L + 3] = torch.tensor(list(b"\n+\n"), dtype=torch.uint8, device=dev_t)
+            rec[:, 4 + L + 3:4 + L + 3 + L] = ord("F")
+            rec[:, -1] = 10
+            host_fq.append(rec.reshape(-1).cpu().numpy())         # pageable host memory, like a file mapping
+            del rec
+        n_steps_rec = max(2, min(len(sizes) * R // R_rec, 8))
         dev.reset()
-        dev.map_reads_uniform(host_batches[0], R, L, k, args.max_freq)      # (allocates the page-locked packed buffer)
+        dev.map_records(host_fq[0], fmt=kmm_lib.FORMAT_FASTQ, k=k, max_index_lookup_frequency=args.max_freq)
         dev.synchronize()
-        packed_before = dev.get_param("host_packed_calls")
-        tp0 = time.perf_counter()
-        for i in range(len(sizes)):
-            dev.map_reads_uniform(host_batches[i & 1][:sizes[i] * L], sizes[i], L, k, args.max_freq)
+        before = dev.get_param("host_packed_record_calls")
+        tr0 = time.perf_counter()
+        for i in range(n_steps_rec):
+            used, n_rec = dev.map_records(host_fq[i & 1], fmt=kmm_lib.FORMAT_FASTQ, k=k, max_index_lookup_frequency=args.max_freq)
+            assert n_rec == R_rec
         dev.synchronize()
-        tp = time.perf_counter() - tp0
-        if dev.get_param("host_packed_calls") - packed_before == len(sizes):
-            result["value_incl_h2d_host_packed"] = round(my_kmers / tp / 1e6, 1)
-            result["config"]["value_incl_h2d_host_packed"] = round(my_kmers / tp / 1e6, 1)
-            result["roofline"]["frac_incl_h2d_host_packed"] = round(my_kmers / tp * B_ALG_PER_KMER / 1e9 / HBM_PEAK_GBPS, 4)
-            result["config"]["h2d_leg_host_packed"] = (
-                "the same steps with the reads packed to 2 bits per base by %d host threads inside the call, then copied: "
-                "%.1f GB/s of read bytes taken from host memory, %.1f GB/s over PCIe" %
-                (n_pack, sum(sizes) * L / tp / 1e9, sum(sizes) * L / 4 / tp / 1e9))
-        dev.set_param("host_pack_threads", 0)
-        del host_batches
+        tr = time.perf_counter() - tr0
+        result["config"]["records_from_host_memory"] = {
+            "what": "%d calls of kmm_map_records on %d-record raw FASTQ chunks (%.2f GB each) in pageable host memory: the sequence "
+                    "lines are packed to 2 bits per base by %d host threads inside the call (kmm_hostpack.hpp RecordsJob), the "
+                    "stream crosses PCIe, the radix path maps it" % (n_steps_rec, R_rec, host_fq[0].nbytes / 1e9, n_pack_default),
+            "M_kmers_per_s": round(n_steps_rec * R_rec * max(L - k + 1, 0) / tr / 1e6, 1),
+            "fastq_GB_per_s": round(n_steps_rec * host_fq[0].nbytes / tr / 1e9, 1),
+            "host_packed_calls": dev.get_param("host_packed_record_calls") - before}
+        del host_fq
 
     # ---- CPU baseline + parity on a bounded sample (rank 0, N=1 only) ---------------------------
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and not args.no_cpu_baseline and index is not None:
         from oracle import oracle        # checker / reported baseline only
         oracle_flags = oracle.use_native_build()      # -O3 -march=native, built on the box that runs it (setup.py:10-15)
         n_s = min(args.cpu_sample_reads, R)
@@ -636,13 +701,14 @@ def main():
             "cores": n_threads,
             "kind": "port",
             "sample": "first %d reads of batch 0 (%d k-mers, %.1f s wall); oracle/kmm_oracle.c "
-                      "oracle_map_reads, gcc %s, %d pthreads, private count vectors summed"
-                      % (n_s, n_k, tc, oracle_flags, n_threads),
+                      "oracle_map_reads, gcc %s, %d pthreads (the reference CLI's -t default; more threads are SLOWER with "
+                      "one private %d-byte count vector each, see all_cores), private count vectors summed"
+                      % (n_s, n_k, tc, oracle_flags, n_threads, 4 * (mx + 1)),
         }
         # BASELINE.md section 3 also promises "all physical cores": every core this process may run on,
         # capped so that the private count vectors (4 B x nodes per thread) stay within 32 GB
         n_all = min(avail, max(1, int(32e9 // (4 * (mx + 1)))))
-        if n_all > n_threads:
+        if n_all > n_threads and world == 1:          # (N > 1: the other ranks wait at the barrier; the 16-thread leg is the baseline)
             ta0 = time.perf_counter()
             expect_all, _ = oracle.map_reads(index, mx, sample, s_offs, k, n_threads=n_all)
             ta = time.perf_counter() - ta0
@@ -655,6 +721,8 @@ def main():
             parity = parity and bool(np.array_equal(expect_all, expect))
         result["cpu_baseline"]["available_cores"] = avail
         result["speedup_vs_cpu_16_threads"] = round(result["value"] / max(result["cpu_baseline"]["value"], 1e-9), 1)
+        if "value_incl_h2d" in result:
+            result["speedup_vs_cpu_16_threads_incl_h2d"] = round(result["value_incl_h2d"] / max(result["cpu_baseline"]["value"], 1e-9), 1)
         result["parity_vs_oracle_on_sample"] = parity
         if not parity:
             log("PARITY FAILURE: GPU counts differ from the oracle on the CPU sample")

@@ -59,6 +59,10 @@ typedef struct kmm_index kmm_index_t;
 const char *kmm_version(void);
 const char *kmm_last_error(void);
 int kmm_device_count(int *n_devices);
+/* "0000:5a:00.0" of HIP device `device` (hipDeviceGetPCIBusId): /sys/bus/pci/devices/<id>/numa_node and local_cpulist
+ * name the host cores and memory next to that GPU — where a rank's packing threads and page-locked buffers belong
+ * (kmer_mapper_amd/distributed.py bind_to_gpu_numa_node; the reference leaves its workers unbound). */
+int kmm_device_pci_bus_id(int device, char *out, int out_bytes);
 
 /*
  * kmm_index_create — replaces the typed-memoryview binding of the five index arrays at
@@ -183,6 +187,22 @@ int kmm_map_records(kmm_index_t *idx, const uint8_t *raw, int64_t n_bytes, int f
                     int64_t *consumed, int64_t *n_records);
 
 /*
+ * kmm_map_packed — reads the caller already holds as 2-BIT CODES (its own encoder, a .2bit-style store, the output of a
+ * host-side packer): the same mapping as kmm_map_reads without the byte -> code step, and a quarter of the bytes over
+ * PCIe.  This is the form the library's own host packer produces when kmm_map_reads* / kmm_map_records are handed host
+ * memory ("host_pack_threads" below) — the work the reference spends its `-t` worker processes on
+ * (bnp.as_encoded_array in util.py:71-72, command_line_interface.py:124-130,168).
+ * codes: uint32 words, 16 codes per word, base p of the flat read stream in bits [2 (p & 15), 2 (p & 15) + 2) of word
+ * p >> 4 (first base lowest; A,C,G,T = 0,1,2,3 — the packing of util.py:72-73), (n_bases + 15) / 16 words, host or device.
+ * read_len > 0: n_reads reads of that length back to back (n_reads * read_len == n_bases), read_starts ignored.
+ * read_len == 0: ragged reads; read_starts = bitset over the base positions, bit p & 31 of word p >> 5 set iff a read
+ * starts at base p (n_bases / 32 + 1 words, host or device): no k-mer spans a set bit (util.py:72).
+ * Served by the radix path at every batch size (KMM_ERR_INVALID_ARG when the index has none: "radix_available").
+ */
+int kmm_map_packed(kmm_index_t *idx, const uint32_t *codes, int64_t n_bases, int64_t n_reads, int64_t read_len,
+                   const uint32_t *read_starts, int k, int max_index_lookup_frequency, int also_revcomp);
+
+/*
  * kmm_host_alloc / kmm_host_free — page-locked host memory (hipHostMalloc) for the caller's read buffers: the
  * staging copy of a map call then runs at the PCIe link's rate (~50 GB/s) instead of the pageable path's.  The
  * reference keeps its chunks in POSIX shared memory (command_line_interface.py:110); this is the GPU counterpart.
@@ -277,14 +297,24 @@ int kmm_get_kmer_counts(kmm_index_t *idx, uint32_t *out);
  *                      each a full run of the passes (the index slices are streamed once per sub-batch); default and
  *                      maximum 2^32 - 2 * 8192 (a coarse partition's k-mers are numbered with 32 bits); halved by the
  *                      library when the batch buffers of that size do not fit the free HBM
- *   "host_pack_threads" > 0: flat reads that arrive in HOST memory (kmm_map_reads_uniform; kmm_map_reads with host offsets; default lookup table, a
- *                      batch large enough for the radix path) are packed to 2 bits per base by that many host threads inside
- *                      the call and cross PCIe at a quarter of their size (csrc/kmm_hostpack.hpp; the staged map phase
- *                      goes from 44 to 124 G k-mers/s at configs[2] with 16 threads); a byte outside the table sends the
- *                      call down the ordinary route, which reports it.  0 (default): the bytes cross as they are.
- *                      "host_packed_calls" (read-only) counts the calls that took the packed route
+ *   "host_pack_threads" the host cores' share of the read bytes — the reference's `-t` (command_line_interface.py:168).  > 0: reads
+ *                      that arrive in HOST memory (kmm_map_reads_uniform; kmm_map_reads with host offsets; kmm_map_records
+ *                      with FASTQ / two-line FASTA bytes — a file mapping or an inflater's output, pinned or not; default
+ *                      lookup table, a batch large enough for the radix path) are packed to 2 bits per base by that many
+ *                      threads of a per-handle pool inside the call and cross PCIe at a quarter of their size
+ *                      (csrc/kmm_hostpack.hpp: AVX-512 VBMI / AVX2 / scalar; for records the sequence lines go straight
+ *                      from the raw bytes to the 2-bit stream + read-start bitset, by the rules of the device parser); a
+ *                      byte outside the table or a malformed record sends the call down the ordinary route, which reports
+ *                      it with its offset.  0: the bytes cross as they are.  Default: min(16, "host_cpu_budget") when that
+ *                      budget — the CPUs of the affinity mask but one, cut by the cgroup's CPU quota — is at least 8, else
+ *                      0; environment KMM_HOST_PACK_THREADS overrides it at index creation.
+ *                      "host_packed_calls" / "host_packed_record_calls" (read-only) count the calls that took the route
  *   "comm_overlap_slices" kmm_comm_reduce_counts: node ranges whose flush (per-entry hits -> node counts) runs under the
- *                      previous range's RCCL reduce on a second stream (default 8; 1 = flush, then one reduce)
+ *                      previous range's RCCL reduce on a second stream (default 8; 1 = flush, then one reduce).  A
+ *                      parameter of the JOB: every rank must use the same value — it alone (with the vector's length)
+ *                      decides how many collectives a rank issues; a rank that cannot flush by node range (no node-ordered
+ *                      entry list for lack of HBM, "count_kmers" mode, "radix_sorted_flush" 0) flushes everything first and
+ *                      issues the same reduces.  "comm_sliced_reduces" (read-only) counts the calls that issued them
  *   "debug_records_copy_stream" / "debug_records_skip" / "debug_rx_*"  test hooks of tools/records_overlap_bisect.py (run
  *                      the compaction kernels of kmm_map_records on the copy stream, next to the radix passes; skip one
  *                      of them; directory sums of pass 1) and of the tests ("debug_rx_buffer_limit": a pass-1 buffer

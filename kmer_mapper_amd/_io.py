@@ -10,6 +10,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_HERE)
 SO_PATH = os.path.join(_HERE, "libkmm_io.so")
 SRC = os.path.join(_HERE, "csrc", "kmm_io.cpp")
+DEPS = [SRC, os.path.join(_HERE, "csrc", "kmm_inflate.hpp"), os.path.join(ROOT, "include", "kmm_io.h")]
+
+
+def _src_mtime():
+    return max(os.path.getmtime(d) for d in DEPS if os.path.exists(d))
 
 _c = ctypes
 _P = ctypes.c_void_p
@@ -26,7 +31,7 @@ SIGNATURES = {
 
 def build(force=False):
     """g++ -O3 -shared (zlib linked; libdeflate, when installed, is found at run time through dlopen)."""
-    if not force and os.path.exists(SO_PATH) and os.path.getmtime(SO_PATH) >= os.path.getmtime(SRC):
+    if not force and os.path.exists(SO_PATH) and os.path.getmtime(SO_PATH) >= _src_mtime():
         return SO_PATH
     subprocess.check_call([os.environ.get("CXX", "g++"), "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread",
                            "-I" + os.path.join(ROOT, "include"), "-o", SO_PATH, SRC, "-lz", "-ldl"])
@@ -37,15 +42,18 @@ _lib = None
 
 
 def _fresh():
-    """libkmm_io.so exists and is not older than its source (rebuilt here when it is and a compiler is at hand: an edit
-    of kmm_io.cpp alone must not leave a stale reader in use)."""
+    """libkmm_io.so exists and is not older than its sources — kmm_io.cpp, the inflater's header, the C header —
+    (rebuilt here when it is and a compiler is at hand: an edit of any of them must not leave a stale reader in use)."""
     if not os.path.exists(SO_PATH):
         return False
-    try:
-        if _lib is None and os.path.exists(SRC) and os.path.getmtime(SO_PATH) < os.path.getmtime(SRC):
+    if _lib is None and os.path.exists(SRC) and os.path.getmtime(SO_PATH) < _src_mtime():
+        try:
             build()
-    except Exception:           # no compiler on this box: the existing library is what there is
-        pass
+        except FileNotFoundError:       # no compiler on this box: the existing library is what there is
+            pass
+        except subprocess.CalledProcessError as exc:     # a compile error must not hide behind the old library
+            import logging
+            logging.getLogger(__name__).error("rebuilding %s failed (%s): the existing, OLDER library stays in use", SO_PATH, exc)
     return True
 
 
@@ -66,12 +74,45 @@ def lib():
     return _lib
 
 
-def default_threads():
+_threads = None
+
+
+def affinity_count():
     try:
-        n = len(os.sched_getaffinity(0))
+        return len(os.sched_getaffinity(0))
     except AttributeError:
-        n = os.cpu_count() or 1
-    return max(1, min(16, n))          # the reference CLI's -t default
+        return os.cpu_count() or 1
+
+
+def cpu_quota():
+    """CPUs' worth of time the cgroup grants (cpu.max: quota / period, rounded up), or None when it sets no limit."""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max" and int(period) > 0:
+            return max(1, -(-int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return None
+
+
+def cpu_budget():
+    """Cores this process may keep busy: its affinity mask, cut by the cgroup's CPU quota (cpu.max) where there is one —
+    a container that sees 256 CPUs with a quota of 16 gets 16 cores' worth of time, and more busy threads are throttled."""
+    n, q = affinity_count(), cpu_quota()
+    return max(1, n if q is None else min(n, q))
+
+
+def set_default_threads(n):
+    """`kmer_mapper map -t N` (command_line_interface.py:168): worker threads of the readers opened from here on."""
+    global _threads
+    _threads = max(1, int(n)) if n else None
+
+
+def default_threads():
+    if _threads is not None:
+        return _threads
+    return max(1, min(16, cpu_budget()))          # the reference CLI's -t default
 
 
 class NativeStream:

@@ -37,6 +37,7 @@ SIGNATURES = {
     "kmm_version": (_c.c_char_p, []),
     "kmm_last_error": (_c.c_char_p, []),
     "kmm_device_count": (_c.c_int, [_P]),
+    "kmm_device_pci_bus_id": (_c.c_int, [_c.c_int, _c.c_char_p, _c.c_int]),
     "kmm_host_alloc": (_c.c_int, [_c.c_size_t, _P]),
     "kmm_host_free": (_c.c_int, [_P]),
     "kmm_index_create": (_c.c_int, [_P, _P, _c.c_uint64, _P, _P, _P, _c.c_int64, _c.c_int64,
@@ -58,6 +59,7 @@ SIGNATURES = {
     "kmm_map_reads_uniform": (_c.c_int, [_P, _P, _c.c_int64, _c.c_int64, _c.c_int, _c.c_int,
                                          _c.c_int, _P]),
     "kmm_map_records": (_c.c_int, [_P, _P, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _P, _P, _P]),
+    "kmm_map_packed": (_c.c_int, [_P, _P, _c.c_int64, _c.c_int64, _c.c_int64, _P, _c.c_int, _c.c_int, _c.c_int]),
     "kmm_extract_kmers": (_c.c_int, [_c.c_int, _P, _P, _c.c_int64, _c.c_int, _P, _P, _c.c_int64]),
     "kmm_build_index": (_c.c_int, [_c.c_int, _P, _P, _c.c_int64, _c.c_uint64, _P, _P, _P, _P, _P]),
     "kmm_in_index": (_c.c_int, [_P, _P, _c.c_int64, _P]),

@@ -2,9 +2,13 @@
 on the MI355X engine.  Same flags, defaults and output file; the work runs in libkmm.so.
 
 Differences that follow from replacing the engine (all documented in DESIGN.md):
-  * there is one engine, the GPU: `-g/--gpu` and `-t/--n-threads` are accepted and ignored
-    (`-t` is still echoed in the final log line); `-s/--gpu-hash-map-size` is ignored (the index's own
-    modulo is the hash table);
+  * there is one engine, the GPU: `-g/--gpu` is accepted and ignored; `-s/--gpu-hash-map-size` is ignored (the
+    index's own modulo is the hash table);
+  * `-t/--n-threads` keeps its meaning — how many host cores work on the read bytes (the reference: a pool of `-t`
+    processes that encode and hash every chunk, :124-130,168) — but the cores do less: they read / inflate the file
+    and pack the sequence lines to 2 bits per base (libkmm's host packer, kmm_set_param "host_pack_threads"), so that
+    a quarter of the bases' bytes cross PCIe; everything after that happens on the GPU.  Capped by the CPUs the
+    process may actually use (affinity mask, cgroup quota);
   * results follow the reference's CPU path (uint32 node counts with the frequency filter of
     mapper.pyx:64-66).  The reference parses `-I/--max-hits-per-kmer` but never forwards it
     (command_line_interface.py:51 passes 3 arguments), so its effective filter is always 1000; the same
@@ -28,7 +32,8 @@ from .distributed import chunk_owner
 from .engine import DeviceIndex
 from .kmer_index import KmerIndex
 from . import _lib
-from .reads_io import RawChunker, PrefetchingRawChunker, prefetch, rank_byte_range, read_chunks, records_cut, sniff_format
+from .reads_io import (MmapChunker, RawChunker, PrefetchingRawChunker, prefetch, rank_byte_range, read_chunks, records_cut,
+                       sniff_format)
 
 
 def main():
@@ -73,13 +78,21 @@ def map_cpu(args, kmer_index, chunk_sequence):
     return dev.get_node_counts()
 
 
+def host_threads(n_threads, world_size=1):
+    """`-t` as the number of host threads that work on the read bytes of THIS rank: at most the cores the process may keep
+    busy (affinity mask, cgroup quota), shared between the ranks of a node."""
+    from . import _io
+    return max(1, min(int(n_threads), _io.cpu_budget() // max(int(world_size), 1)))
+
+
 def map_gpu(index, chunks, k, hash_map_size=0, map_reverse_complements=False,
-            max_index_lookup_frequency=1000, device=0, rank=0, world_size=1, before_fetch=None):
+            max_index_lookup_frequency=1000, device=0, rank=0, world_size=1, before_fetch=None, n_threads=16):
     """command_line_interface.py:59-79 on the HIP engine: chunks -> fused kmm_map_reads calls.
     before_fetch(dev): called with the open handle after the last chunk and before the counts are copied to the
     host (the multi-rank reduce runs there, on the device)."""
     max_node_id = index.max_node_id() if hasattr(index, "max_node_id") else int(np.max(index._nodes))
     dev = DeviceIndex.from_index(index, max_node_id, device=device)
+    dev.set_param("host_pack_threads", host_threads(n_threads, world_size) if n_threads > 1 else 0)
     t_start = time.perf_counter()
     n_kmers = 0
     try:
@@ -109,13 +122,21 @@ def map_gpu(index, chunks, k, hash_map_size=0, map_reverse_complements=False,
 
 
 def map_gpu_raw(index, path, chunk_size, fmt, k, map_reverse_complements=False,
-                max_index_lookup_frequency=1000, device=0, rank=0, world_size=1, before_fetch=None):
+                max_index_lookup_frequency=1000, device=0, rank=0, world_size=1, before_fetch=None, n_threads=16):
     """Same job as map_gpu, but the FASTQ / two-line FASTA records are parsed ON THE GPU
     (kmm_map_records): the host only reads (and for .gz inflates) raw bytes."""
     t_index = time.perf_counter()
     max_node_id = index.max_node_id() if hasattr(index, "max_node_id") else int(np.max(index._nodes))
     dev = DeviceIndex.from_index(index, max_node_id, device=device)
     logging.info("Index resident in HBM after %.3f sec (max_node_id scan + upload + repack)", time.perf_counter() - t_index)
+    # -t: the host cores' share of the work (reference: command_line_interface.py:124-130,168) — reader / inflate threads
+    # and the threads that pack the sequence lines to 2 bits per base inside kmm_map_records; -t 1 = no host packing,
+    # the raw bytes cross PCIe and the GPU parses them
+    n_host = host_threads(n_threads, world_size)
+    dev.set_param("host_pack_threads", n_host if n_threads > 1 else 0)
+    from . import _io
+    _io.set_default_threads(n_host)
+    logging.info("%d host thread(s) read and pack the read bytes (-t %d, CPU budget %d)", n_host, n_threads, _io.cpu_budget())
     seekable = not str(path).endswith(".gz")
     byte_range = rank_byte_range(path, fmt, rank, world_size) if (world_size > 1 and seekable) else None
     if byte_range is not None:
@@ -145,7 +166,11 @@ def map_gpu_raw(index, path, chunk_size, fmt, k, map_reverse_complements=False,
     # (BGZF 5.7 -> 6.5 GB/s end to end); plain files are read at memory speed and the second pinned buffer costs more
     # than the overlap returns (3 GB FASTQ: 0.30 s with one buffer, 0.37 s with two)
     use_prefetch = not seekable and not os.environ.get("KMM_CLI_NO_PREFETCH")
-    chunker = (PrefetchingRawChunker if use_prefetch else RawChunker)(path, batch_bytes, byte_range, pinned=True)
+    # plain FASTQ / two-line FASTA with host packing: the chunks are views of the file mapping (no copy, nothing pinned)
+    use_mmap = (seekable and fmt in ("fastq", "fasta") and dev.get_param("host_pack_threads") > 0
+                and not os.environ.get("KMM_CLI_NO_MMAP"))
+    chunker = (MmapChunker if use_mmap else PrefetchingRawChunker if use_prefetch else RawChunker)(path, batch_bytes, byte_range,
+                                                                                                   pinned=True)
     owns = (lambda i: True) if (world_size == 1 or seekable) else (lambda i: chunk_owner(i, world_size) == rank)
     # FASTQ and two-line FASTA are parsed as they are; FASTA with wrapped sequence lines is unwrapped on the GPU first
     kfmt = {"fastq": _lib.FORMAT_FASTQ, "fasta": _lib.FORMAT_FASTA2, "fasta_ml": _lib.FORMAT_FASTA}[fmt]
@@ -175,6 +200,7 @@ def map_gpu_raw(index, path, chunk_size, fmt, k, map_reverse_complements=False,
             i += 1
         n_lookups, n_hits = dev.get_stats()
         n_radix, n_direct = dev.get_param("radix_batches"), dev.get_param("direct_batches")
+        n_host_packed = dev.get_param("host_packed_record_calls")
         if before_fetch is not None:
             before_fetch(dev)
         node_counts = dev.get_node_counts()
@@ -186,8 +212,10 @@ def map_gpu_raw(index, path, chunk_size, fmt, k, map_reverse_complements=False,
     logging.info("Mapped %d reads from %d bytes (%.1f MB/s, GPU record parser): %d k-mer lookups "
                  "(%.1f M/s), %d index hits" % (n_reads, n_bytes, n_bytes / max(dt, 1e-9) / 1e6, n_lookups,
                                                   n_lookups / max(dt, 1e-9) / 1e6, n_hits))
-    logging.info("path_taken: %s (%d batches on the radix path, %d on the direct path)"
-                 % ("radix" if n_radix and not n_direct else "direct" if n_direct and not n_radix else "mixed", n_radix, n_direct))
+    logging.info("path_taken: %s (%d batches on the radix path, %d on the direct path; %d batches packed to 2 bits per base "
+                 "by the host threads)"
+                 % ("radix" if n_radix and not n_direct else "direct" if n_direct and not n_radix else "mixed", n_radix, n_direct,
+                    n_host_packed))
     return node_counts
 
 
@@ -235,13 +263,18 @@ def map_bnp(args):
                 init_rccl_comm(dev)
                 dev.comm_reduce_counts(root=0)
                 logging.info("Rank %d: RCCL reduce of the node counts on the device: %.5f sec", rank, time.perf_counter() - t0)
+    if world > 1:
+        # every rank next to its own GPU: reader / packing threads and their page-locked buffers on that NUMA node
+        from .distributed import bind_to_gpu_numa_node
+        logging.info("Rank %d: host side bound to its GPU's NUMA node: %s", rank, bind_to_gpu_numa_node(device))
     revcomp = bool(getattr(args, "map_reverse_complements", False))
     fmt, two_line = sniff_format(args.reads)
     if not getattr(args, "host_parser", False):
         if fmt == "fasta" and not two_line:
             fmt = "fasta_ml"           # wrapped sequence lines: unwrapped on the GPU (KMM_FORMAT_FASTA)
         node_counts = map_gpu_raw(kmer_index, args.reads, args.chunk_size, fmt, k, revcomp, max_freq,
-                                  device=device, rank=rank, world_size=world, before_fetch=before_fetch)
+                                  device=device, rank=rank, world_size=world, before_fetch=before_fetch,
+                                  n_threads=args.n_threads)
     else:
         logging.info("Using the host FASTA/FASTQ parser")
         seekable = not str(args.reads).endswith(".gz")
@@ -255,7 +288,8 @@ def map_bnp(args):
             chunks = read_chunks(args.reads, min_chunk_size=args.chunk_size)
         chunks = prefetch(chunks)
         node_counts = map_gpu(kmer_index, chunks, k, getattr(args, "gpu_hash_map_size", 0), revcomp,
-                              max_freq, device=device, rank=rank, world_size=world, before_fetch=before_fetch)
+                              max_freq, device=device, rank=rank, world_size=world, before_fetch=before_fetch,
+                              n_threads=args.n_threads)
 
     if world > 1:
         if before_fetch is None:        # gloo rehearsal on a 1-GPU box: the sum runs on the host copies
@@ -289,7 +323,9 @@ def run_argument_parser(args):
     subparser.add_argument("-b", "--index-bundle", required=False)
     subparser.add_argument("-f", "--reads", required=True, help="Reads in .fa, .fq, .fa.gz, or fq.gz format")
     subparser.add_argument("-k", "--kmer-size", required=False, default=31, type=int)
-    subparser.add_argument("-t", "--n-threads", required=False, default=16, type=int)
+    subparser.add_argument("-t", "--n-threads", required=False, default=16, type=int,
+                           help="Host threads that read / inflate the reads and pack them to 2 bits per base before they "
+                                "cross PCIe (1: none, the raw bytes cross). Default 16.")
     subparser.add_argument("-c", "--chunk-size", required=False, type=int, default=2500000,
                            help="N bytes to process in each chunk")
     subparser.add_argument("-o", "--output-file", required=True)

@@ -15,8 +15,11 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
+#include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "kmm.h"
@@ -191,10 +194,14 @@ struct kmm_index {
     const uint32_t *dbg_T1 = nullptr, *dbg_item_base = nullptr; // the latest sub-batch's tables (debug_rx_* parameters)
     const uint16_t *dbg_start1 = nullptr;
     uint32_t dbg_F1 = 0, dbg_NB = 0;
-    int host_pack_threads = 0;     // "host_pack_threads": flat reads in host memory are packed to 2 bits per base before they cross PCIe
+    int host_pack_threads = 0;     // "host_pack_threads": reads / raw records in host memory are packed to 2 bits per base by that
+                                   // many host threads before they cross PCIe (default: min(16, the process's CPU budget))
+    std::unique_ptr<kmm_hostpack::Workers> pack_pool; // the packing threads, asleep between calls
     uint8_t *pack_pinned = nullptr; // page-locked home of the packed batch (kmm_hostpack.hpp)
     size_t pack_pinned_bytes = 0;
-    int64_t host_packed_calls = 0;
+    uint8_t *pack_bits_pinned = nullptr; // ... and of the read-start bitset of packed raw records
+    size_t pack_bits_pinned_bytes = 0;
+    int64_t host_packed_calls = 0, host_packed_record_calls = 0;
     int64_t dbg_rx_buf_limit = 0; // test hook ("debug_rx_buffer_limit"): a pass-1 buffer beyond this many bytes counts as out of memory
     int dbg_rec_copy_stream = 0; // experiments (tools/records_overlap_bisect.py): compaction kernels on the copy stream again,
     int dbg_rec_skip = 0;        // and which of them to leave out (1 count2, 2 scans, 4 scatter, 8 uniform, 16 the large memsets)
@@ -224,6 +231,7 @@ struct kmm_index {
     int comm_rank = -1, comm_size = 0;
     // flush of node range s under the reduce of node range s - 1 (kmm_comm_reduce_counts): "comm_overlap_slices"
     int comm_slices = 8;
+    int64_t comm_sliced_reduces = 0; // kmm_comm_reduce_counts calls that issued one reduce per node range ("comm_sliced_reduces")
     hipStream_t comm_stream = nullptr;
     std::vector<hipEvent_t> comm_events;
     std::vector<uint64_t> flush_cuts; // entry (node order) where node range s begins, for comm_slices ranges; [slices + 1]
@@ -905,6 +913,15 @@ int kmm_device_count(int *n_devices)
     return KMM_OK;
 }
 
+int kmm_device_pci_bus_id(int device, char *out, int out_bytes)
+{
+    if (!out || out_bytes < 16)
+        return fail(KMM_ERR_INVALID_ARG, "out is NULL or shorter than 16 bytes");
+    out[0] = 0;
+    HIPCHK(hipDeviceGetPCIBusId(out, out_bytes, device));
+    return KMM_OK;
+}
+
 void kmm_index_destroy(kmm_index_t *ix)
 {
     if (!ix)
@@ -928,8 +945,11 @@ void kmm_index_destroy(kmm_index_t *ix)
     release(ix->rx_meta);
     release(ix->rx_buf1);
     release(ix->rx_buf2);
+    ix->pack_pool.reset();
     if (ix->pack_pinned)
         (void)hipHostFree(ix->pack_pinned);
+    if (ix->pack_bits_pinned)
+        (void)hipHostFree(ix->pack_bits_pinned);
     for (hipEvent_t e : ix->comm_events)
         (void)hipEventDestroy(e);
     if (ix->comm_stream)
@@ -1280,6 +1300,16 @@ static int index_create_impl(kmm_index *ix, const int32_t *h2i, const int32_t *n
     HIPCHK(hipMemcpy(ix->lut_codes, lut, 256, hipMemcpyHostToDevice));
     unsigned long long nb[3] = {NO_BAD, NO_BAD, NO_BAD};
     HIPCHK(hipMemcpy(ix->first_bad, nb, sizeof nb, hipMemcpyHostToDevice));
+    {   // host packing of reads that arrive in host memory: on by default with the reference CLI's worker count
+        // (-t 16, command_line_interface.py:168) where the process has the cores for it — with fewer than 8 the plain
+        // copy over PCIe is the faster way
+        const int budget = kmm_hostpack::cpu_budget();
+        ix->host_pack_threads = budget >= 8 ? (budget < 16 ? budget : 16) : 0;
+        if (const char *env = getenv("KMM_HOST_PACK_THREADS")) {
+            const int v = atoi(env);
+            ix->host_pack_threads = v < 0 ? 0 : (v > 256 ? 256 : v);
+        }
+    }
 
     // raw arrays -> HBM (temporary); validate, build the radix view, and the direct view now or on first use
     DevBuf d_h2i, d_nk, d_km, d_nd, d_fr, d_err;
@@ -1507,10 +1537,14 @@ int kmm_comm_reduce_counts(kmm_index_t *ix, int root)
     // writes that range of the count vector, so range s is flushed while range s - 1 travels: the ranges' reduces go to
     // a second stream, each behind the event of its flush.  Every rank issues the same sequence of reduces.
     const int S = ix->comm_slices;
-    // (Whether the reduce is sliced must not depend on what THIS rank has mapped — a rank without a radix batch since its
-    // last flush would issue one reduce against the others' S and the job would hang: only properties of the index and
-    // of the parameters, the same on every rank, decide; a rank with nothing to flush skips the flush kernels only.)
-    if (S > 1 && ix->rx_norder && !ix->rx_ecnt_acc && ix->rx_flush_sorted && n >= (size_t)S * 1024) {
+    // How many collectives a rank issues must not depend on anything rank-local — what THIS rank has mapped, whether ITS
+    // node-ordered entry list could be allocated ("absent if memory is short", rx_build), per-handle modes: a rank that
+    // issued one reduce of n elements against its peers' S reduces of n / S would hang the job or corrupt the counts.
+    // Only the vector's length and "comm_overlap_slices" (the same on every rank: a parameter of the job) decide; a rank
+    // that cannot flush by node range flushes everything first and then issues the same S range reduces.
+    if (S > 1 && n >= (size_t)S * 1024) {
+        const bool by_range = ix->rx_norder && !ix->rx_ecnt_acc && ix->rx_flush_sorted;
+        ix->comm_sliced_reduces++;
         if (!ix->comm_stream)
             HIPCHK(hipStreamCreateWithFlags(&ix->comm_stream, hipStreamNonBlocking));
         while ((int)ix->comm_events.size() < S + 1) {
@@ -1518,7 +1552,9 @@ int kmm_comm_reduce_counts(kmm_index_t *ix, int root)
             HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
             ix->comm_events.push_back(e);
         }
-        if ((int)ix->flush_cuts.size() != S + 1) { // once per handle: where the node ranges begin in the node-ordered list
+        if (!by_range)
+            KMMCHK(rx_flush(ix)); // (every hit is in `counts`; the ranges below then only travel)
+        if (by_range && (int)ix->flush_cuts.size() != S + 1) { // once per handle: where the node ranges begin in the node-ordered list
             std::vector<uint32_t> bounds(S + 1);
             for (int t = 0; t <= S; ++t)
                 bounds[t] = (uint32_t)(n * (size_t)t / (size_t)S);
@@ -1540,17 +1576,19 @@ int kmm_comm_reduce_counts(kmm_index_t *ix, int root)
         ScopedTimer tm;
         KMMCHK(tm.begin(ix, KMM_KERNEL_RX_FLUSH));
         for (int t = 0; t < S; ++t) {
-            const uint64_t j0 = ix->flush_cuts[t], j1 = ix->flush_cuts[t + 1];
-            if (j1 > j0 && ix->ecnt_dirty)
-                hipLaunchKernelGGL(k_rx_flush_sorted, dim3(grid_for(ix, (int64_t)((j1 - j0 + 1023) / 1024), 8)), dim3(256), 0, ix->stream,
-                                   view_of(ix), ix->rx_ecnt, ix->rx_norder + j0, ix->rx_nnode + j0, j1 - j0);
-            HIPCHK(hipGetLastError());
+            if (by_range && ix->ecnt_dirty) {
+                const uint64_t j0 = ix->flush_cuts[t], j1 = ix->flush_cuts[t + 1];
+                if (j1 > j0)
+                    hipLaunchKernelGGL(k_rx_flush_sorted, dim3(grid_for(ix, (int64_t)((j1 - j0 + 1023) / 1024), 8)), dim3(256), 0, ix->stream,
+                                       view_of(ix), ix->rx_ecnt, ix->rx_norder + j0, ix->rx_nnode + j0, j1 - j0);
+                HIPCHK(hipGetLastError());
+            }
             HIPCHK(hipEventRecord(ix->comm_events[t], ix->stream));
             HIPCHK(hipStreamWaitEvent(ix->comm_stream, ix->comm_events[t], 0));
             const size_t first = n * (size_t)t / (size_t)S, end = n * (size_t)(t + 1) / (size_t)S;
             RCCLCHK(reduce(first, end - first, ix->comm_stream));
         }
-        if (ix->ecnt_dirty)
+        if (by_range && ix->ecnt_dirty)
             HIPCHK(hipMemsetAsync(ix->rx_ecnt, 0, (size_t)ix->rx_S * 4, ix->stream));
         KMMCHK(tm.end());
         ix->ecnt_dirty = false;
@@ -1747,7 +1785,44 @@ static void set_uniform_geometry(const kmm_index_t *ix, ReadsView &rv, int64_t r
 static int rec_launch_flat(kmm_index_t *ix, const uint32_t *flat, int64_t total, int64_t n_reads, const uint32_t *start_bits,
                            int64_t n_words, int64_t uniform_len, int k, int max_freq, int also_revcomp);
 
-// Reads of one length in HOST memory, default lookup table, a batch of radix size, "host_pack_threads" > 0: packed to 2 bits
+// The handle's packing threads ("host_pack_threads"), created at first use and kept asleep between calls.  false: no
+// threads to be had (the caller takes the ordinary route) — nothing thrown by the thread library crosses the C ABI.
+static bool ensure_pack_pool(kmm_index_t *ix)
+{
+    if (ix->host_pack_threads < 1)
+        return false;
+    if (ix->pack_pool && ix->pack_pool->size() == ix->host_pack_threads)
+        return true;
+    try {
+        ix->pack_pool.reset();
+        ix->pack_pool.reset(new kmm_hostpack::Workers(ix->host_pack_threads));
+    } catch (...) {
+        ix->pack_pool.reset();
+        return false;
+    }
+    return true;
+}
+
+// page-locked home of a packed batch: grown, never shrunk; false = none to be had
+static bool ensure_pinned(uint8_t *&p, size_t &have, size_t want)
+{
+    if (have >= want)
+        return true;
+    if (p)
+        (void)hipHostFree(p);
+    p = nullptr;
+    have = 0;
+    const size_t take = want + want / 8;
+    if (hipHostMalloc(reinterpret_cast<void **>(&p), take, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        p = nullptr;
+        return false;
+    }
+    have = take;
+    return true;
+}
+
+// Flat reads in HOST memory, default lookup table, a batch of radix size, "host_pack_threads" > 0: packed to 2 bits
 // per base by that many host threads into a page-locked buffer, chunk by chunk, each chunk copied to HBM as soon as it is
 // packed (copy stream: under the previous call's kernels and under the packing of the next chunks), then mapped like the
 // flat reads the records compaction makes (pass 1 on 2-bit codes).  *done = false: a byte outside the table — the caller
@@ -1758,26 +1833,16 @@ static int map_reads_host_packed(kmm_index_t *ix, const uint8_t *bases, const in
     *done = false;
     const size_t total = (size_t)total_bases;
     const size_t code_bytes = ((total + 3) / 4 + 256 + 63) & ~(size_t)63;
-    if (ix->pack_pinned_bytes < code_bytes) {
-        if (ix->pack_pinned)
-            (void)hipHostFree(ix->pack_pinned);
-        ix->pack_pinned = nullptr;
-        ix->pack_pinned_bytes = 0;
-        const size_t want = code_bytes + code_bytes / 8;
-        if (hipHostMalloc(reinterpret_cast<void **>(&ix->pack_pinned), want, hipHostMallocDefault) != hipSuccess) {
-            (void)hipGetLastError();
-            ix->pack_pinned = nullptr;
-            return KMM_OK; // (no page-locked memory to be had: the ordinary route)
-        }
-        ix->pack_pinned_bytes = want;
-    }
+    if (!ensure_pack_pool(ix) || !ensure_pinned(ix->pack_pinned, ix->pack_pinned_bytes, code_bytes))
+        return KMM_OK; // (no threads / no page-locked memory to be had: the ordinary route)
     Stage &s = next_stage(ix);
     KMMCHK(stage_acquire(ix, s));
     KMMCHK(ensure(s.kmers, code_bytes));
     constexpr size_t CHUNK = (size_t)4 << 20;      // bases per packing task (1 MiB packed)
     constexpr size_t GROUP = 8;                    // tasks per copy (8 MiB packed)
-    kmm_hostpack::Job job;
-    job.start(bases, total, ix->pack_pinned, CHUNK, ix->host_pack_threads);
+    kmm_hostpack::FlatJob job;
+    job.prepare(bases, total, ix->pack_pinned, CHUNK);
+    ix->pack_pool->start([&job](int) { job.run(); });
     const size_t packed_total = (total + 3) / 4;
     memset(ix->pack_pinned + packed_total, 0, code_bytes - packed_total); // (the halo words pass 1 loads behind the last read)
     int rc = KMM_OK;
@@ -1791,7 +1856,7 @@ static int map_reads_host_packed(kmm_index_t *ix, const uint8_t *bases, const in
         if (hipMemcpyAsync((uint8_t *)s.kmers.p + b0, ix->pack_pinned + b0, b1 - b0, hipMemcpyHostToDevice, ix->copy_stream) != hipSuccess)
             rc = fail(KMM_ERR_HIP, "hipMemcpyAsync of packed reads: %s", hipGetErrorString(hipGetLastError()));
     }
-    job.join();
+    ix->pack_pool->wait();
     if (rc != KMM_OK || job.bad.load()) {
         // nothing was launched on the handle's stream; the copies issued so far only touched this stage's own buffer
         HIPCHK(hipEventRecord(ix->copied, ix->copy_stream));
@@ -1821,6 +1886,79 @@ static int map_reads_host_packed(kmm_index_t *ix, const uint8_t *bases, const in
     KMMCHK(rec_launch_flat(ix, (const uint32_t *)s.kmers.p, (int64_t)total, n_reads, start_bits, n_words, read_offsets ? 0 : read_len, k,
                            max_freq, also_revcomp));
     *done = true;
+    return stage_release(ix, s, true);
+}
+
+// Raw FASTQ / two-line FASTA records in HOST memory (the file mapping, the inflater's output: no page-locked copy of the raw
+// bytes is made), default lookup table, a chunk of radix size, "host_pack_threads" > 0: the host threads put the bases
+// of the sequence lines straight into the 2-bit stream and the read starts into the bitset (kmm_hostpack::RecordsJob: the
+// rules of the device-side compaction, kmm_records.hpp), the stream crosses PCIe while the rest is still being packed,
+// and pass 1 runs on it as on the compaction's output.  This is what the reference's `-t` workers do with a chunk
+// (bnp parser + encoder, command_line_interface.py:102-111,124-130), minus the k-mer hashing.  *done = false: a byte without
+// a code or a malformed record line — the ordinary route maps the chunk and reports the byte's offset.
+static int map_records_host_packed(kmm_index_t *ix, const uint8_t *raw, int64_t n_bytes, int format, int k, int max_freq,
+                                   int also_revcomp, int64_t *consumed, int64_t *n_records, bool *done)
+{
+    *done = false;
+    const size_t n = (size_t)n_bytes;
+    const size_t code_bytes = (n / 4 + 1024 + 63) & ~(size_t)63, bits_bytes = (n / 8 + 256 + 63) & ~(size_t)63;
+    if (!ensure_pack_pool(ix) || !ensure_pinned(ix->pack_pinned, ix->pack_pinned_bytes, code_bytes) ||
+        !ensure_pinned(ix->pack_bits_pinned, ix->pack_bits_pinned_bytes, bits_bytes))
+        return KMM_OK;
+    Stage &s = next_stage(ix);
+    KMMCHK(stage_acquire(ix, s));
+    KMMCHK(ensure(s.kmers, code_bytes));
+    kmm_hostpack::RecordsJob job;
+    job.prepare(raw, n, format == KMM_FORMAT_FASTQ ? 4 : 2, reinterpret_cast<uint64_t *>(ix->pack_pinned),
+                reinterpret_cast<uint32_t *>(ix->pack_bits_pinned));
+    ix->pack_pool->start([&job](int) { job.run(); });
+    // groups of slices (16 MiB of raw bytes): the words of the stream that lie wholly below the group's end are final
+    constexpr size_t GROUP = 64;
+    int rc = KMM_OK;
+    uint64_t copied_w = 0;
+    for (size_t g1 = GROUP; g1 < job.n_slices() && rc == KMM_OK; g1 += GROUP) {
+        const uint64_t upto_w = job.wait_packed_prefix(g1) >> 5;
+        if (upto_w > copied_w) {
+            if (hipMemcpyAsync((uint8_t *)s.kmers.p + copied_w * 8, ix->pack_pinned + copied_w * 8, (size_t)(upto_w - copied_w) * 8,
+                               hipMemcpyHostToDevice, ix->copy_stream) != hipSuccess)
+                rc = fail(KMM_ERR_HIP, "hipMemcpyAsync of packed records: %s", hipGetErrorString(hipGetLastError()));
+            copied_w = upto_w;
+        }
+    }
+    ix->pack_pool->wait();
+    const kmm_hostpack::RecordsResult r = job.finish();
+    if (rc != KMM_OK || !r.ok) {
+        HIPCHK(hipEventRecord(ix->copied, ix->copy_stream));
+        HIPCHK(hipEventSynchronize(ix->copied));
+        ix->cur ^= 1; // (hand the stage back: the ordinary route takes it again)
+        return rc;
+    }
+    ix->map_calls++;
+    ix->host_packed_record_calls++;
+    if (consumed)
+        *consumed = r.consumed;
+    if (n_records)
+        *n_records = r.n_records;
+    *done = true;
+    if (r.n_bases <= 0)
+        return stage_release(ix, s, copied_w != 0);
+    {   // the rest of the stream: from the word that holds the last base's neighbourhood (finish() cleaned it) to the zero
+        // words behind it
+        const uint64_t end_w = ((uint64_t)r.n_bases >> 5) + 40, from_w = copied_w < ((uint64_t)r.n_bases >> 5) ? copied_w : ((uint64_t)r.n_bases >> 5);
+        HIPCHK(hipMemcpyAsync((uint8_t *)s.kmers.p + from_w * 8, ix->pack_pinned + from_w * 8, (size_t)(end_w - from_w) * 8,
+                              hipMemcpyHostToDevice, ix->copy_stream));
+    }
+    const bool uniform = r.uniform_len >= 16;
+    const uint32_t *start_bits = nullptr;
+    int64_t n_words = 0;
+    if (!uniform) { // ragged reads: the read-start bitset crosses too (1 bit per base)
+        n_words = r.n_bases / 32 + 2;
+        KMMCHK(ensure(s.start_bits, (size_t)n_words * 4));
+        HIPCHK(hipMemcpyAsync(s.start_bits.p, ix->pack_bits_pinned, (size_t)n_words * 4, hipMemcpyHostToDevice, ix->copy_stream));
+        start_bits = (const uint32_t *)s.start_bits.p;
+    }
+    KMMCHK(rec_launch_flat(ix, (const uint32_t *)s.kmers.p, r.n_bases, r.n_records, start_bits, n_words, uniform ? r.uniform_len : 0, k,
+                           max_freq, also_revcomp));
     return stage_release(ix, s, true);
 }
 
@@ -2262,8 +2400,16 @@ int kmm_map_records(kmm_index_t *ix, const uint8_t *raw, int64_t n_bytes, int fo
     HIPCHK(hipSetDevice(ix->device));
     // chunks beyond 2^30 bytes are mapped piece by piece: every piece starts where the previous one's last complete
     // record ended, so the pieces cut the chunk exactly as one census over all of it would
-    if (format != KMM_FORMAT_FASTA && records_take_radix(ix, n_bytes, format))
+    if (format != KMM_FORMAT_FASTA && records_take_radix(ix, n_bytes, format)) {
+        // raw bytes in host memory: the host threads pack the sequence lines to 2 bits per base before they cross PCIe
+        if (ix->host_pack_threads > 0 && !lut && !ix->dbg_rec_skip && !ix->dbg_rec_copy_stream && !is_device_ptr(raw)) {
+            bool done = false;
+            KMMCHK(map_records_host_packed(ix, raw, n_bytes, format, k, max_freq, also_revcomp, consumed, n_records, &done));
+            if (done)
+                return KMM_OK;
+        }
         return map_records_radix_call(ix, raw, n_bytes, format, k, max_freq, also_revcomp, lut, consumed, n_records);
+    }
     const int64_t piece_max = (int64_t)1 << 30;
     int64_t off = 0, recs = 0;
     while (off < n_bytes) {
@@ -2284,6 +2430,50 @@ int kmm_map_records(kmm_index_t *ix, const uint8_t *raw, int64_t n_bytes, int fo
     if (n_records)
         *n_records = recs;
     return KMM_OK;
+}
+
+int kmm_map_packed(kmm_index_t *ix, const uint32_t *codes, int64_t n_bases, int64_t n_reads, int64_t read_len,
+                   const uint32_t *read_starts, int k, int max_freq, int also_revcomp)
+{
+    if (!ix)
+        return fail(KMM_ERR_INVALID_ARG, "idx is NULL");
+    KMMCHK(check_k(k));
+    if (n_bases < 0 || n_reads < 0 || read_len < 0)
+        return fail(KMM_ERR_INVALID_ARG, "n_bases / n_reads / read_len negative");
+    if (n_bases == 0)
+        return KMM_OK;
+    if (!codes)
+        return fail(KMM_ERR_INVALID_ARG, "codes is NULL");
+    if (read_len > 0 ? n_reads * read_len != n_bases : !read_starts)
+        return fail(KMM_ERR_INVALID_ARG, read_len > 0 ? "n_reads * read_len != n_bases" : "read_starts is NULL and read_len is 0");
+    if (!ix->rx_ok)
+        return fail(KMM_ERR_INVALID_ARG, "packed reads are mapped by the radix path, which is not available for this index "
+                    "(kmm_get_param \"radix_unavailable_reason\")");
+    HIPCHK(hipSetDevice(ix->device));
+    Stage &s = next_stage(ix);
+    KMMCHK(stage_acquire(ix, s));
+    ix->map_calls++;
+    bool staged = false;
+    const uint32_t *d_codes = nullptr, *d_starts = nullptr;
+    KMMCHK(stage_in<uint32_t>(ix, s.kmers, codes, (size_t)((n_bases + 15) / 16), &d_codes, &staged));
+    int64_t n_words = 0;
+    if (read_len == 0) {
+        n_words = n_bases / 32 + 1;
+        KMMCHK(stage_in<uint32_t>(ix, s.start_bits, read_starts, (size_t)n_words, &d_starts, &staged));
+    } else if (read_len < 16) { // (the uniform front ends need reads of at least 16 bases: shorter ones go as ragged reads)
+        n_words = n_bases / 32 + 2;
+        KMMCHK(ensure(s.offsets, (size_t)(n_reads + 1) * 8));
+        KMMCHK(ensure(s.start_bits, (size_t)n_words * 4));
+        HIPCHK(hipMemsetAsync(s.start_bits.p, 0, (size_t)n_words * 4, ix->stream));
+        hipLaunchKernelGGL(k_iota_offsets, dim3((unsigned)((n_reads + 1 + 255) / 256)), dim3(256), 0, ix->stream, (int64_t *)s.offsets.p,
+                           n_reads, read_len);
+        hipLaunchKernelGGL(k_mark_starts, dim3(grid_for(ix, (n_reads + 256) / 256, 8)), dim3(256), 0, ix->stream,
+                           (const int64_t *)s.offsets.p, n_reads, n_bases, (uint32_t *)s.start_bits.p);
+        HIPCHK(hipGetLastError());
+        d_starts = (const uint32_t *)s.start_bits.p;
+    }
+    KMMCHK(rec_launch_flat(ix, d_codes, n_bases, n_reads, d_starts, n_words, read_len >= 16 ? read_len : 0, k, max_freq, also_revcomp));
+    return stage_release(ix, s, staged);
 }
 
 int kmm_in_index(kmm_index_t *ix, const uint64_t *kmers, int64_t n, uint8_t *out)
@@ -2746,8 +2936,8 @@ int kmm_set_param(kmm_index_t *ix, const char *name, int64_t value)
         // beside the previous call's passes, WITHOUT mapping the call's reads
         ix->dbg_rec_copy_stream = value != 0;
     } else if (!strcmp(name, "host_pack_threads")) {
-        // > 0: reads of one length that arrive in host memory (default lookup table, radix-sized batch) are packed to 2 bits per
-        // base by that many host threads before they cross PCIe (kmm_hostpack.hpp); 0 (default): they cross as they are
+        // > 0: reads / raw records that arrive in host memory (default lookup table, radix-sized batch) are packed to 2 bits per
+        // base by that many host threads before they cross PCIe (kmm_hostpack.hpp); 0: they cross as they are
         if (value < 0 || value > 256)
             return fail(KMM_ERR_INVALID_ARG, "host_pack_threads outside [0, 256]");
         ix->host_pack_threads = (int)value;
@@ -2785,12 +2975,18 @@ int kmm_get_param(kmm_index_t *ix, const char *name, int64_t *value)
         *value = ix->rx_grid_per_cu;
     else if (!strcmp(name, "host_pack_threads"))
         *value = ix->host_pack_threads;
-    else if (!strcmp(name, "host_packed_calls")) // map calls whose reads crossed PCIe as 2-bit codes
+    else if (!strcmp(name, "host_packed_calls")) // map calls whose flat reads crossed PCIe as 2-bit codes
         *value = ix->host_packed_calls;
+    else if (!strcmp(name, "host_packed_record_calls")) // kmm_map_records calls whose sequence lines were packed on the host
+        *value = ix->host_packed_record_calls;
+    else if (!strcmp(name, "host_cpu_budget")) // cores the process may keep busy (affinity mask, cgroup quota)
+        *value = kmm_hostpack::cpu_budget();
     else if (!strcmp(name, "radix_sub_batch_kmers"))
         *value = ix->rx_sub_cap;
     else if (!strcmp(name, "comm_overlap_slices"))
         *value = ix->comm_slices;
+    else if (!strcmp(name, "comm_sliced_reduces")) // kmm_comm_reduce_counts calls that issued one reduce per node range
+        *value = ix->comm_sliced_reduces;
     else if (!strcmp(name, "debug_rx_t1_sum") || !strcmp(name, "debug_rx_start1_sum") || !strcmp(name, "debug_rx_items")) {
         // diagnostics of the latest radix sub-batch (both streams drained first): the k-mers its directory accounts for —
         // by coarse partition (T1), by pass-1 block (last entry of every start1 row) — and its items

@@ -70,3 +70,59 @@ def init_rccl_comm(dev, group=None):
         t = t.cuda(dev.device)
     dist.broadcast(t, src=0, group=group)
     dev.comm_init(bytes(t.cpu().numpy().tobytes()), world, rank)
+
+
+def _parse_cpulist(text):
+    cpus = set()
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        a, _, b = part.partition("-")
+        cpus.update(range(int(a), int(b or a) + 1))
+    return cpus
+
+
+def bind_to_gpu_numa_node(device, sysfs="/sys/bus/pci/devices"):
+    """One process per GPU: keep this rank's host side — the threads that read, inflate and pack its reads and the page-locked
+    buffers they fill — on the NUMA node its GPU hangs off.  The GPU's PCI bus id (kmm_device_pci_bus_id) names
+    <sysfs>/<id>/numa_node and local_cpulist; the process's CPU affinity is cut to those CPUs (memory then comes from the
+    same node by first touch).  The reference leaves its worker processes unbound (command_line_interface.py:124-130); with
+    eight ranks pulling ~55-200 GB/s each from host DRAM the placement decides whether a socket's memory channels or the
+    inter-socket links carry it.  Returns {"pci": ..., "numa_node": ..., "cpus": n, "bound": bool, "why": ...};
+    KMM_NO_NUMA_BIND=1 leaves the affinity alone."""
+    import ctypes
+    import os
+    from . import _lib
+    info = {"pci": None, "numa_node": None, "cpus": None, "bound": False, "why": ""}
+    buf = ctypes.create_string_buffer(64)
+    try:
+        _lib.check(_lib.lib().kmm_device_pci_bus_id(int(device), buf, 64))
+    except Exception as exc:                                            # noqa: BLE001 - binding is an optimisation
+        info["why"] = "no PCI bus id: %s" % exc
+        return info
+    info["pci"] = buf.value.decode().lower()
+    base = os.path.join(sysfs, info["pci"])
+    try:
+        node = int(open(os.path.join(base, "numa_node")).read())
+        cpus = _parse_cpulist(open(os.path.join(base, "local_cpulist")).read())
+    except (OSError, ValueError) as exc:
+        info["why"] = "sysfs: %s" % exc
+        return info
+    info["numa_node"] = node
+    if os.environ.get("KMM_NO_NUMA_BIND") == "1":
+        info["why"] = "KMM_NO_NUMA_BIND=1"
+        return info
+    if node < 0 or not cpus:
+        info["why"] = "the platform reports no NUMA node for the device"
+        return info
+    try:
+        allowed = os.sched_getaffinity(0) & cpus
+        if not allowed:
+            info["why"] = "none of the node's CPUs is in this process's affinity mask"
+            return info
+        os.sched_setaffinity(0, allowed)
+        info["cpus"] = len(allowed)
+        info["bound"] = True
+    except (AttributeError, OSError) as exc:
+        info["why"] = "sched_setaffinity: %s" % exc
+    return info

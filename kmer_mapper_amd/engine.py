@@ -28,8 +28,10 @@ class _Arg:
         if _is_torch_tensor(x):
             import torch
             want = {np.uint8: torch.uint8, np.int64: torch.int64, np.int32: torch.int32,
-                    np.uint64: getattr(torch, "uint64", None), np.uint16: getattr(torch, "uint16", None)}[dtype]
-            if x.dtype != want and not (dtype is np.uint64 and x.dtype == torch.int64):
+                    np.uint64: getattr(torch, "uint64", None), np.uint16: getattr(torch, "uint16", None),
+                    np.uint32: getattr(torch, "uint32", None)}[dtype]
+            if x.dtype != want and not (dtype is np.uint64 and x.dtype == torch.int64) \
+                    and not (dtype is np.uint32 and x.dtype == torch.int32):
                 raise ValueError("Buffer dtype mismatch for %s: expected %s got %s"
                                  % (name, np.dtype(dtype), x.dtype))
             if not x.is_contiguous():
@@ -200,6 +202,19 @@ class DeviceIndex:
                                               int(max_index_lookup_frequency), int(bool(also_revcomp)),
                                               t.ptr, ctypes.byref(consumed), ctypes.byref(n_rec)))
         return consumed.value, n_rec.value
+
+    def map_packed(self, codes, n_bases, n_reads, read_len=0, read_starts=None, k=31, max_index_lookup_frequency=1000,
+                   also_revcomp=False):
+        """Reads held as 2-bit codes (uint32 words, 16 codes per word, first base lowest): kmm_map_packed.  read_len > 0:
+        n_reads reads of one length; else `read_starts` = uint32 bitset over the base positions."""
+        c = _Arg(codes, np.uint32, "codes")
+        st = _Arg(read_starts, np.uint32, "read_starts")
+        if c.n < (int(n_bases) + 15) // 16:
+            raise ValueError("codes holds %d words, need %d" % (c.n, (int(n_bases) + 15) // 16))
+        if not read_len and st.n < int(n_bases) // 32 + 1:
+            raise ValueError("read_starts needs n_bases / 32 + 1 words")
+        _lib.check(_lib.lib().kmm_map_packed(self._h, c.ptr, int(n_bases), int(n_reads), int(read_len), st.ptr, int(k),
+                                             int(max_index_lookup_frequency), int(bool(also_revcomp))))
 
     def in_index(self, kmers):
         a = _Arg(kmers, np.uint64, "kmers")

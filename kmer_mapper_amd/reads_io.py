@@ -432,6 +432,58 @@ class RawChunker:
             self._pinned = None
 
 
+class MmapChunker:
+    """RawChunker's interface over a FILE MAPPING of an uncompressed read file: next_chunk() hands out views of the page
+    cache itself, nothing is copied on the way to kmm_map_records — whose host threads read the sequence lines straight
+    from the mapping and pack them to 2 bits per base ("host_pack_threads") — and nothing needs to be page-locked.
+    The unused tail of a chunk simply stays where it is: the next chunk starts there."""
+
+    def __init__(self, path, chunk_size, byte_range=None, pinned=False):
+        import mmap
+        import os
+        self.chunk_size = int(chunk_size)
+        self._f = open(path, "rb")
+        size = os.fstat(self._f.fileno()).st_size
+        self._mm = mmap.mmap(self._f.fileno(), 0, access=mmap.ACCESS_READ) if size else None
+        if self._mm is not None and hasattr(self._mm, "madvise") and hasattr(mmap, "MADV_SEQUENTIAL"):
+            self._mm.madvise(mmap.MADV_SEQUENTIAL)
+        self._all = np.frombuffer(self._mm, dtype=np.uint8) if self._mm is not None else np.zeros(0, np.uint8)
+        self.pos, self.hi = (0, size) if byte_range is None else (int(byte_range[0]), int(byte_range[1]))
+        self.eof = False
+        self._tail = None            # the file's last bytes + the newline its last line lacks
+
+    def next_chunk(self):
+        if self._tail is not None:
+            return self._tail if self._tail.shape[0] else None
+        if self.pos >= self.hi:
+            self.eof = True
+            return None
+        end = min(self.pos + self.chunk_size, self.hi)
+        self.eof = end == self.hi
+        view = self._all[self.pos:end]
+        if self.eof and view[-1] != _NL:          # a last line without its newline gets one (a copy of this last chunk)
+            self._tail = np.concatenate([view, np.array([_NL], dtype=np.uint8)])
+            return self._tail
+        return view
+
+    def consumed(self, n):
+        if self._tail is not None:
+            self._tail = self._tail[n:]
+            self.pos = self.hi if not self._tail.shape[0] else self.pos
+            return
+        self.pos += int(n)
+
+    def close(self):
+        self._all = np.zeros(0, np.uint8)
+        self._tail = None
+        try:
+            if self._mm is not None:
+                self._mm.close()
+        except BufferError:          # a view handed out earlier is still alive somewhere: the mapping goes with it
+            pass
+        self._f.close()
+
+
 class PrefetchingRawChunker:
     """RawChunker's interface with TWO buffers and a reader thread: while the consumer (kmm_map_records: staging copy over
     PCIe, record parser, map kernels) works on one chunk, the next one is read — and, for .gz input, inflated by the

@@ -79,6 +79,20 @@ def test_flush_of_node_ranges_under_the_reduce_of_the_previous_range(oracle):
             dev.map_reads_uniform(bases, 30000, 150, 31)
             dev.comm_reduce_counts(root=0)
             assert np.array_equal(dev.get_node_counts(), expect), skewed
+            # ... nor on rank-local state: a handle that cannot flush by node range (here: the sorted flush switched off —
+            # the same branch a rank takes whose node-ordered entry list did not fit its HBM; per-k-mer counting mode) issues
+            # the SAME S range reduces as its peers, behind one full flush (one reduce of n against S of n / S
+            # hangs the job)
+            dev.set_param("path", 2)
+            before = dev.get_param("comm_sliced_reduces")
+            for knob in ("radix_sorted_flush", "count_kmers"):
+                dev.set_param(knob, 0 if knob == "radix_sorted_flush" else 1)
+                dev.reset()
+                dev.map_reads_uniform(bases, 30000, 150, 31)
+                dev.comm_reduce_counts(root=0)
+                assert np.array_equal(dev.get_node_counts(), expect), (skewed, knob)
+                dev.set_param(knob, 1 if knob == "radix_sorted_flush" else 0)
+            assert dev.get_param("comm_sliced_reduces") == before + 2
 
 
 @pytest.mark.parametrize("n_ranks", [2, 3])

@@ -117,7 +117,8 @@ def test_damaged_fastq_is_refused_or_mapped_like_the_model(oracle, seed, lpr):
     removed and inserted, lines dropped, the end cut anywhere.  Either the next synchronising call raises (the
     reference's reader raises on a malformed file: bnp.open(...).read_chunks, command_line_interface.py:102-111) or
     `consumed`, the record count and the node counts are exactly what the line model above gives — on the direct path
-    (census + windows over raw bytes) and on the radix path (compaction into 2-bit flat reads): never other counts."""
+    (census + windows over raw bytes), on the radix path with the compaction into 2-bit flat reads done on the device, and
+    with it done by the host threads (kmm_hostpack.hpp; a chunk they refuse goes to the device parser): never other counts."""
     from kmer_mapper_amd import _lib, synthetic as syn
     from kmer_mapper_amd.engine import DeviceIndex
     rng = np.random.default_rng(seed)
@@ -170,9 +171,10 @@ def test_damaged_fastq_is_refused_or_mapped_like_the_model(oracle, seed, lpr):
                 bases = np.frombuffer(b"".join(model), dtype=np.uint8)
                 offs = np.concatenate([[0], np.cumsum([len(r) for r in model])]).astype(np.int64)
                 expect, _ = oracle.map_reads(index, mx, bases, offs, k)
-            for path in (1, 2):
+            for path, threads in ((1, 0), (2, 0), (2, 3)):      # direct kernel; device-side compaction; the host threads' packing
                 dev.reset()
                 dev.set_param("path", path)
+                dev.set_param("host_pack_threads", threads)
                 try:
                     used, n_rec = dev.map_records(raw, fmt=fmt, k=k) if raw.shape[0] else (0, 0)
                     got = dev.get_node_counts()

@@ -213,9 +213,13 @@ def test_radix_records_mode_and_long_reads(kmm, syn, oracle):
         raw = np.frombuffer(b"".join(lines), dtype=np.uint8)
         with kmm.DeviceIndex.from_index(index, mx) as dev:
             dev.set_param("path", 2)
-            used, n_rec = dev.map_records(raw, fmt=_lib.FORMAT_FASTQ)
-            assert used == raw.shape[0] and n_rec == n_reads
-            assert np.array_equal(dev.get_node_counts(), expect)
+            for threads in (0, 3):          # the device-side compaction; the host threads' packing (kmm_hostpack.hpp)
+                dev.set_param("host_pack_threads", threads)
+                dev.reset()
+                used, n_rec = dev.map_records(raw, fmt=_lib.FORMAT_FASTQ)
+                assert used == raw.shape[0] and n_rec == n_reads
+                assert np.array_equal(dev.get_node_counts(), expect), threads
+            assert dev.get_param("host_packed_record_calls") == 1
 
 
 def _fastq(reads, eol=b"\n", qual=b"I"):
@@ -240,6 +244,7 @@ def test_radix_records_of_one_length_take_packed_tiles(kmm, syn, oracle, eol, re
     with kmm.DeviceIndex.from_index(index, mx) as dev:
         dev.set_param("path", 2)
         dev.set_param("part_shift", 6)
+        dev.set_param("host_pack_threads", 0)          # (this test is about the DEVICE-side compaction; test_gpu_hostpack.py has the host's)
         used, n_rec = dev.map_records(raw, fmt=_lib.FORMAT_FASTQ)
         assert (used, n_rec) == (raw.shape[0], n_reads)
         assert np.array_equal(dev.get_node_counts(), expect)
@@ -298,6 +303,7 @@ def test_radix_records_edge_cases(kmm, syn, oracle):
     expect, _ = oracle.map_reads(index, mx, bases, offs, 5)
     with kmm.DeviceIndex.from_index(index, mx) as dev:
         dev.set_param("path", 2)
+        dev.set_param("host_pack_threads", 0)          # (the device-side compaction's corner cases)
         for fmt, raw in ((_lib.FORMAT_FASTQ, _fastq(reads)),
                          (_lib.FORMAT_FASTA2, np.frombuffer(b"".join(b">h%d\n" % i + r + b"\n" for i, r in enumerate(reads)), dtype=np.uint8))):
             dev.reset()

@@ -209,6 +209,8 @@ def test_host_packer_equals_numpy_packing(tmp_path):
     src.write_text('#include "kmm_hostpack.hpp"\n'
                    'extern "C" int shim_pack(const uint8_t *s, size_t n, uint8_t *d) { return kmm_hostpack::pack2(s, n, d) ? 1 : 0; }\n'
                    'extern "C" int shim_pack_scalar(const uint8_t *s, size_t n, uint8_t *d) { return kmm_hostpack::pack2_scalar(s, n, d) ? 1 : 0; }\n'
+                   'extern "C" int shim_pack_avx2(const uint8_t *s, size_t n, uint8_t *d) { return kmm_hostpack::pack2_avx2(s, n, d) ? 1 : 0; }\n'
+                   'extern "C" int shim_pack_avx512(const uint8_t *s, size_t n, uint8_t *d) { return kmm_hostpack::pack2_avx512(s, n, d) ? 1 : 0; }\n'
                    'extern "C" int shim_job(const uint8_t *s, size_t n, uint8_t *d, size_t chunk, int threads) {\n'
                    '    kmm_hostpack::Job j; j.start(s, n, d, chunk, threads);\n'
                    '    for (size_t c = 0; c < j.n_chunks; ++c) j.wait_chunk(c);\n'
@@ -217,7 +219,11 @@ def test_host_packer_equals_numpy_packing(tmp_path):
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-pthread",
                            "-I" + os.path.join(ROOT, "kmer_mapper_amd", "csrc"), str(src), "-o", so])
     lib = ctypes.CDLL(so)
-    for f in (lib.shim_pack, lib.shim_pack_scalar):
+    flags = open("/proc/cpuinfo").read()
+    packers = [lib.shim_pack, lib.shim_pack_scalar]            # (dispatching entry, scalar, then every vector body the CPU has)
+    packers += [lib.shim_pack_avx2] if " avx2" in flags else []
+    packers += [lib.shim_pack_avx512] if "avx512vbmi" in flags and "avx512bw" in flags else []
+    for f in packers:
         f.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
     lib.shim_job.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
     rng = np.random.default_rng(5)
@@ -232,10 +238,10 @@ def test_host_packer_equals_numpy_packing(tmp_path):
         c = np.concatenate([c, np.zeros((-len(c)) % 4, dtype=np.uint8)]).reshape(-1, 4)
         return (c[:, 0] | (c[:, 1] << 2) | (c[:, 2] << 4) | (c[:, 3] << 6)).astype(np.uint8)
 
-    for n in (1, 3, 4, 31, 32, 33, 63, 64, 65, 1000, 4099, 100_003):
+    for n in (1, 3, 4, 31, 32, 33, 63, 64, 65, 127, 128, 129, 1000, 4099, 100_003):
         a = np.ascontiguousarray(alphabet[rng.integers(0, len(alphabet), size=n)])
         want = numpy_pack(a)
-        for f in (lib.shim_pack, lib.shim_pack_scalar):
+        for f in packers:
             out = np.full(len(want) + 8, 0xAA, dtype=np.uint8)
             assert f(a.ctypes.data, n, out.ctypes.data) == 1
             assert np.array_equal(out[:len(want)], want) and (out[len(want):] == 0xAA).all(), n
@@ -243,8 +249,8 @@ def test_host_packer_equals_numpy_packing(tmp_path):
             b = a.copy()
             b[rng.integers(0, n)] = bad[0]
             out = np.zeros(len(want) + 8, dtype=np.uint8)
-            assert lib.shim_pack(b.ctypes.data, n, out.ctypes.data) == 0, (n, bad)
-            assert lib.shim_pack_scalar(b.ctypes.data, n, out.ctypes.data) == 0, (n, bad)
+            for f in packers:
+                assert f(b.ctypes.data, n, out.ctypes.data) == 0, (n, bad)
     n = 3_000_017
     a = np.ascontiguousarray(alphabet[rng.integers(0, len(alphabet), size=n)])
     want = numpy_pack(a)
@@ -260,3 +266,163 @@ def test_host_packer_equals_numpy_packing(tmp_path):
     b[2_000_000] = ord("?")
     out = np.zeros(len(want) + 8, dtype=np.uint8)
     assert lib.shim_job(b.ctypes.data, n, out.ctypes.data, 1 << 18, 4) == 0
+
+
+# ---------------------------------------------------------------- host records packer (csrc/kmm_hostpack.hpp RecordsJob)
+_CODE = {c: i for i, c in enumerate(b"ACGT")}
+_CODE.update({c: i for i, c in enumerate(b"acgt")})
+_CODE[ord("N")] = _CODE[ord("n")] = 0
+
+
+def _records_rule(raw, period):
+    """Byte-wise restatement of what kmm_map_records makes of a raw chunk (csrc/kmm_records.hpp, include/kmm.h): lines are
+    cut at '\\n'; `consumed` = the byte behind the last newline whose 1-based count is a multiple of the period; line
+    index mod period == 1 is the sequence line; '\\r' is dropped and breaks the read; header lines start with '@' / '>',
+    the third line of a FASTQ record with '+'.  Returns (ok, consumed, records, codes, read starts, uniform length)."""
+    hc = ord("@") if period == 4 else ord(">")
+    nl = [i for i, c in enumerate(raw) if c == 10]
+    target = len(nl) - len(nl) % period
+    cut = nl[target - 1] + 1 if target else 0
+    flat, marks, pending, ok, line, at_start = [], [], False, True, 0, True
+    for i in range(cut):
+        c, phase = raw[i], line % period
+        if at_start:
+            if phase == 0 and c != hc:
+                ok = False
+            if period == 4 and phase == 2 and c != ord("+"):
+                ok = False
+            if phase == 1:
+                pending = True
+        at_start = False
+        if c == 10:
+            line += 1
+            at_start = True
+            continue
+        if phase == 1:
+            if c == 13:
+                pending = True
+                continue
+            if c not in _CODE:
+                ok = False
+                continue
+            if pending:
+                marks.append(len(flat))
+                pending = False
+            flat.append(_CODE[c])
+    recs, n, L = target // period, len(flat), 0
+    if recs and n and n % recs == 0 and marks == list(range(0, n, n // recs)) and len(marks) == recs:
+        L = n // recs
+    return ok, cut, recs, flat, marks, L
+
+
+def test_host_records_packer_equals_the_device_parsers_rules(tmp_path):
+    """kmm_hostpack::RecordsJob — what the host threads make of raw FASTQ / two-line FASTA bytes when kmm_map_records is
+    handed host memory (the reference's `-t` workers parse and encode the chunks, command_line_interface.py:102-111,
+    124-130): the 2-bit stream, the read-start bitset, `consumed`, the record count and the one-length verdict equal the
+    byte-wise rule above for LF and CRLF files, ragged and one-length reads, lower case and N, '@'-leading quality lines,
+    records cut anywhere, '\\r' inside sequence lines and at slice boundaries, on 1, 3 and 8 threads, with every
+    instruction set the packer has; a byte without a code or a malformed record line makes it refuse the chunk; the
+    buffers need not be zeroed, and the words behind the last base come back zero."""
+    import ctypes
+    import subprocess
+    import sys
+    src = tmp_path / "shim.cpp"
+    src.write_text('#include "kmm_hostpack.hpp"\n'
+                   'extern "C" int shim_records(const uint8_t *raw, size_t n, int period, int threads, uint64_t *codes, uint32_t *bits, int64_t *out) {\n'
+                   '    kmm_hostpack::RecordsJob job; job.prepare(raw, n, period, codes, bits);\n'
+                   '    kmm_hostpack::Workers w(threads); w.start([&](int) { job.run(); });\n'
+                   '    job.wait_packed_prefix(job.n_slices()); w.wait();\n'
+                   '    const kmm_hostpack::RecordsResult r = job.finish();\n'
+                   '    out[0] = r.ok; out[1] = r.consumed; out[2] = r.n_records; out[3] = r.n_bases; out[4] = r.uniform_len; return 0; }\n'
+                   'extern "C" int shim_budget() { return kmm_hostpack::cpu_budget(); }\n')
+    so = str(tmp_path / "shim.so")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-pthread",
+                           "-I" + os.path.join(ROOT, "kmer_mapper_amd", "csrc"), str(src), "-o", so])
+    rng = np.random.default_rng(77)
+
+    def fastq(n_rec, lens, eol=b"\n", qual=b"I", alpha=b"ACGT"):
+        parts = []
+        for i in range(n_rec):
+            seq = bytes(rng.choice(np.frombuffer(alpha, dtype=np.uint8), size=lens(i)))
+            q = bytes(rng.choice(np.frombuffer(qual, dtype=np.uint8), size=len(seq)))
+            parts.append(b"@r%d x" % i + eol + seq + eol + b"+" + eol + q + eol)
+        return b"".join(parts)
+
+    big = fastq(6000, lambda i: 150)                        # several 256 KiB slices
+    cases = [("one length", big, 4), ("one length crlf", fastq(1500, lambda i: 150, eol=b"\r\n"), 4),
+             ("ragged", fastq(2500, lambda i: int(rng.integers(0, 300)), qual=b"@+IF#5", alpha=b"ACGTacgtNn"), 4),
+             ("ragged crlf", fastq(1500, lambda i: int(rng.integers(1, 200)), eol=b"\r\n", qual=b"@+I"), 4),
+             ("three records", fastq(3, lambda i: 5), 4), ("one long read", fastq(2, lambda i: 700_000), 4),
+             ("tiny reads", fastq(20_000, lambda i: int(rng.integers(0, 4))), 4),
+             ("cut in the quality line", big[:-100], 4), ("cut in the sequence line", big[:-200], 4),
+             ("cut behind the header", big[:len(big) - 320], 4), ("no final newline", big[:-1], 4),
+             ("empty", b"", 4), ("no line", b"@abc", 4), ("one line", b"@abc\n", 4)]
+    fa = b"".join(b">s%d\n" % i + bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=int(rng.integers(0, 500)))) + b"\n"
+                  for i in range(2500))
+    cases += [("fasta", fa, 2), ("fasta cut", fa[:-3], 2),
+              ("fasta one length", b"".join(b">s%d\n" % i + b"ACGTTGCAAC" * 10 + b"\n" for i in range(4000)), 2)]
+    for pos, ch in ((1000, b"X"), (len(big) // 2, b"\n"), (len(big) - 50, b"?"), (0, b">"), (307, b"\x00"), (5000, b"\xc1")):
+        d = bytearray(big)
+        d[pos:pos + 1] = ch
+        cases.append(("damaged at %d" % pos, bytes(d), 4))
+    d = bytearray(big)
+    for pos in rng.integers(0, len(d), size=40):
+        d[pos] = 13
+    cases.append(("carriage returns anywhere", bytes(d), 4))
+    for pos in (262143, 262144, 262145, 524287, 524288):      # the slice boundaries
+        d = bytearray(big)
+        if d[pos] != 10:
+            d[pos] = 13
+        cases.append(("carriage return at %d" % pos, bytes(d), 4))
+    for it in range(150):                                      # soup with many line ends
+        raw = bytes(rng.choice(np.frombuffer(b"ACGT\n\n\r@+>NnX", dtype=np.uint8), size=int(rng.integers(1, 3000))))
+        cases += [("soup %d" % it, raw, 4), ("soup %d" % it, raw, 2)]
+
+    def run(isa):
+        env = dict(os.environ, KMM_HOSTPACK_ISA=str(isa))
+        code = ("import sys, pickle, ctypes, numpy as np\n"
+                "cases = pickle.load(open(sys.argv[2], 'rb'))\n"
+                "lib = ctypes.CDLL(sys.argv[1])\n"
+                "lib.shim_records.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]\n"
+                "res = []\n"
+                "for name, raw, period in cases:\n"
+                "    a = np.frombuffer(raw, dtype=np.uint8); n = len(a)\n"
+                "    for threads in ((1, 3, 8) if n > 5000 else (2,)):\n"
+                "        codes = np.full(n // 32 + 80, 0xAAAAAAAAAAAAAAAA, dtype=np.uint64); bits = np.full(n // 32 + 20, 0xAAAAAAAA, dtype=np.uint32)\n"
+                "        out = np.zeros(8, dtype=np.int64)\n"
+                "        lib.shim_records(a.ctypes.data, n, period, threads, codes.ctypes.data, bits.ctypes.data, out.ctypes.data)\n"
+                "        res.append((name, period, threads, out.copy(), codes, bits))\n"
+                "pickle.dump(res, open(sys.argv[3], 'wb'))\n")
+        import pickle
+        pickle.dump(cases, open(tmp_path / "cases.pkl", "wb"))
+        subprocess.check_call([sys.executable, "-c", code, so, str(tmp_path / "cases.pkl"), str(tmp_path / "res.pkl")], env=env)
+        return pickle.load(open(tmp_path / "res.pkl", "rb"))
+
+    expect = {(name, period): _records_rule(raw, period) for name, raw, period in cases}
+    n_refused = n_uniform = 0
+    for isa in (0, 1, 2):          # scalar, AVX2 census, AVX-512 VBMI (the packer falls back by itself where the CPU lacks it)
+        if isa == 2 and "avx512vbmi" not in open("/proc/cpuinfo").read():
+            continue
+        for name, period, threads, out, codes, bits in run(isa):
+            ok, cut, recs, flat, marks, L = expect[(name, period)]
+            tag = (isa, name, period, threads)
+            if not ok:
+                assert out[0] == 0, tag
+                n_refused += 1
+                continue
+            assert out[0] == 1, tag
+            assert (out[1], out[2], out[3], out[4]) == (cut, recs, len(flat), L), (tag, out[:5], cut, recs, len(flat), L)
+            n_uniform += 1 if L else 0
+            n = len(flat)
+            idx = np.arange(n)
+            c8 = codes.view(np.uint8)
+            assert np.array_equal((c8[idx >> 2] >> ((idx & 3) * 2).astype(np.uint8)) & 3, np.array(flat, dtype=np.uint8)), (tag, "codes")
+            want = np.zeros(n, dtype=bool)
+            want[marks] = True
+            assert np.array_equal(((bits[idx >> 5] >> (idx & 31).astype(np.uint32)) & 1).astype(bool), want), (tag, "read starts")
+            w = n >> 5
+            assert not codes[w + 1:w + 40].any() and not bits[w + 1:w + 3].any(), (tag, "words behind the last base")
+            assert int(codes[w]) >> (2 * (n & 31)) == 0 and int(bits[w]) >> (n & 31) == 0, (tag, "bits behind the last base")
+    assert n_refused and n_uniform
+    lib = ctypes.CDLL(so)
+    assert 1 <= lib.shim_budget() <= (os.cpu_count() or 1)
