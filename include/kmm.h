@@ -308,7 +308,8 @@ int kmm_get_kmer_counts(kmm_index_t *idx, uint32_t *out);
  *                      it with its offset.  0: the bytes cross as they are.  Default: min(16, "host_cpu_budget") when that
  *                      budget — the CPUs of the affinity mask but one, cut by the cgroup's CPU quota — is at least 8, else
  *                      0; environment KMM_HOST_PACK_THREADS overrides it at index creation.
- *                      "host_packed_calls" / "host_packed_record_calls" (read-only) count the calls that took the route
+ *                      "host_packed_calls" / "host_packed_record_calls" (read-only) count the calls that took the route;
+ *                      "host_pack_slice_kb": raw bytes per slice the records packer hands its threads (0 = default, 1024)
  *   "comm_overlap_slices" kmm_comm_reduce_counts: node ranges whose flush (per-entry hits -> node counts) runs under the
  *                      previous range's RCCL reduce on a second stream (default 8; 1 = flush, then one reduce).  A
  *                      parameter of the JOB: every rank must use the same value — it alone (with the vector's length)

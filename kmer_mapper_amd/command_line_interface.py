@@ -263,10 +263,10 @@ def map_bnp(args):
                 init_rccl_comm(dev)
                 dev.comm_reduce_counts(root=0)
                 logging.info("Rank %d: RCCL reduce of the node counts on the device: %.5f sec", rank, time.perf_counter() - t0)
-    if world > 1:
-        # every rank next to its own GPU: reader / packing threads and their page-locked buffers on that NUMA node
-        from .distributed import bind_to_gpu_numa_node
-        logging.info("Rank %d: host side bound to its GPU's NUMA node: %s", rank, bind_to_gpu_numa_node(device))
+    # the process next to its GPU: reader / packing threads and their page-locked buffers on that NUMA node (16 threads pack
+    # 172 GB/s of FASTQ from the GPU's own node, 132 spread over both sockets: profiles/r05/hostpack_rate.txt)
+    from .distributed import bind_to_gpu_numa_node
+    logging.info("Rank %d: host side bound to its GPU's NUMA node: %s", rank, bind_to_gpu_numa_node(device))
     revcomp = bool(getattr(args, "map_reverse_complements", False))
     fmt, two_line = sniff_format(args.reads)
     if not getattr(args, "host_parser", False):

@@ -202,6 +202,7 @@ struct kmm_index {
     uint8_t *pack_bits_pinned = nullptr; // ... and of the read-start bitset of packed raw records
     size_t pack_bits_pinned_bytes = 0;
     int64_t host_packed_calls = 0, host_packed_record_calls = 0;
+    int64_t host_pack_slice_kb = 0; // "host_pack_slice_kb": raw bytes per slice of the records packer (0: its default)
     int64_t dbg_rx_buf_limit = 0; // test hook ("debug_rx_buffer_limit"): a pass-1 buffer beyond this many bytes counts as out of memory
     int dbg_rec_copy_stream = 0; // experiments (tools/records_overlap_bisect.py): compaction kernels on the copy stream again,
     int dbg_rec_skip = 0;        // and which of them to leave out (1 count2, 2 scans, 4 scatter, 8 uniform, 16 the large memsets)
@@ -221,7 +222,7 @@ struct kmm_index {
     bool rx_packed = true;        // "radix_packed_tiles": pass 1 on reads of one length takes tiles of whole reads
     bool ecnt_dirty = false;  // rx_ecnt holds hits that are not in `counts` yet
     bool rx_unchecked = false; // radix passes have run since the conservation counters were last compared (drain)
-    DevBuf rx_buf1, rx_buf2, rx_meta;
+    DevBuf rx_buf1, rx_buf2, rx_meta, rx_probe; // (rx_probe: scratch of the marginal-byte probe builds, kmm_radix.hpp)
     // deferred device-side error, sticky until kmm_reset_counts
     int sticky_rc = KMM_OK;
     std::string sticky_msg;
@@ -618,6 +619,10 @@ int launch_rx(kmm_index *ix, const ReadsView &rv, const uint64_t *kmers_in, int6
         rx.queue = (unsigned long long *)(m + o_queue);
         rx.buf1 = (uint64_t *)ix->rx_buf1.p;
         rx.buf2 = (uint64_t *)ix->rx_buf2.p;
+#if RX_PROBE_ANY
+        KMMCHK(ensure(ix->rx_probe, max_items * RX_B * 8));
+        rx.probe = (uint64_t *)ix->rx_probe.p;
+#endif
         ix->dbg_T1 = rx.T1; ix->dbg_item_base = rx.item_base; ix->dbg_start1 = rx.start1; ix->dbg_F1 = F1; ix->dbg_NB = NB;
         HIPCHK(hipMemsetAsync(m + o_ctrl, 0, align256(64) + 2048, ix->stream));
         ScopedTimer tm;
@@ -945,6 +950,7 @@ void kmm_index_destroy(kmm_index_t *ix)
     release(ix->rx_meta);
     release(ix->rx_buf1);
     release(ix->rx_buf2);
+    release(ix->rx_probe);
     ix->pack_pool.reset();
     if (ix->pack_pinned)
         (void)hipHostFree(ix->pack_pinned);
@@ -1909,11 +1915,12 @@ static int map_records_host_packed(kmm_index_t *ix, const uint8_t *raw, int64_t 
     KMMCHK(stage_acquire(ix, s));
     KMMCHK(ensure(s.kmers, code_bytes));
     kmm_hostpack::RecordsJob job;
+    const size_t slice = ix->host_pack_slice_kb > 0 ? (size_t)ix->host_pack_slice_kb << 10 : kmm_hostpack::RecordsJob::slice_bytes();
     job.prepare(raw, n, format == KMM_FORMAT_FASTQ ? 4 : 2, reinterpret_cast<uint64_t *>(ix->pack_pinned),
-                reinterpret_cast<uint32_t *>(ix->pack_bits_pinned));
+                reinterpret_cast<uint32_t *>(ix->pack_bits_pinned), slice);
     ix->pack_pool->start([&job](int) { job.run(); });
-    // groups of slices (16 MiB of raw bytes): the words of the stream that lie wholly below the group's end are final
-    constexpr size_t GROUP = 64;
+    // groups of slices (32 MiB of raw bytes): the words of the stream that lie wholly below the group's end are final
+    const size_t GROUP = std::max<size_t>(1, ((size_t)32 << 20) / slice);
     int rc = KMM_OK;
     uint64_t copied_w = 0;
     for (size_t g1 = GROUP; g1 < job.n_slices() && rc == KMM_OK; g1 += GROUP) {
@@ -2941,6 +2948,11 @@ int kmm_set_param(kmm_index_t *ix, const char *name, int64_t value)
         if (value < 0 || value > 256)
             return fail(KMM_ERR_INVALID_ARG, "host_pack_threads outside [0, 256]");
         ix->host_pack_threads = (int)value;
+    } else if (!strcmp(name, "host_pack_slice_kb")) {
+        // raw bytes per slice of the host records packer (kmm_hostpack.hpp RecordsJob), in KiB; 0 = its default (1024)
+        if (value < 0 || value > 65536)
+            return fail(KMM_ERR_INVALID_ARG, "host_pack_slice_kb outside [0, 65536]");
+        ix->host_pack_slice_kb = value;
     } else if (!strcmp(name, "debug_rx_buffer_limit")) {
         // test hook of the out-of-memory route of launch_rx (the sub-batch cap is halved until the buffers fit)
         ix->dbg_rx_buf_limit = value;
@@ -2975,6 +2987,8 @@ int kmm_get_param(kmm_index_t *ix, const char *name, int64_t *value)
         *value = ix->rx_grid_per_cu;
     else if (!strcmp(name, "host_pack_threads"))
         *value = ix->host_pack_threads;
+    else if (!strcmp(name, "host_pack_slice_kb"))
+        *value = ix->host_pack_slice_kb;
     else if (!strcmp(name, "host_packed_calls")) // map calls whose flat reads crossed PCIe as 2-bit codes
         *value = ix->host_packed_calls;
     else if (!strcmp(name, "host_packed_record_calls")) // kmm_map_records calls whose sequence lines were packed on the host

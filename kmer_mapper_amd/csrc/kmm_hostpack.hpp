@@ -464,11 +464,31 @@ struct RecordsResult {
 
 class RecordsJob {
   public:
-    static constexpr size_t SLICE = (size_t)256 << 10; // raw bytes per slice: census and packing meet in the core's L2
+    // raw bytes per slice: census and packing meet in the core's caches; one hand-over of (line, flat position) per slice
+    // (KMM_HOST_PACK_SLICE_KB: 16 threads of the GPU box's host pack 132 GB/s of FASTQ at 256 KB, 163 at 1 MB:
+    // profiles/r05/hostpack_rate.txt)
+    static size_t slice_bytes()
+    {
+        static const size_t v = [] {
+            const char *env = getenv("KMM_HOST_PACK_SLICE_KB");
+            const long kb = env ? atol(env) : 1024;
+            return (size_t)(kb < 4 ? 4 : (kb > 65536 ? 65536 : kb)) << 10;
+        }();
+        return v;
+    }
+    // how long a worker spins for the slice before it, in microseconds, before it starts sleeping (KMM_HOST_PACK_SPIN_US)
+    static long spin_us()
+    {
+        static const long v = [] {
+            const char *env = getenv("KMM_HOST_PACK_SPIN_US");
+            return env ? atol(env) : 300L;
+        }();
+        return v;
+    }
 
     // codes: >= n / 4 + 512 bytes, 8-byte aligned; start_bits: >= n / 8 + 64 bytes, 4-byte aligned.  Neither needs to be
     // zeroed.  period: 4 (FASTQ) or 2 (two-line FASTA).
-    void prepare(const uint8_t *raw, size_t n, int period, uint64_t *codes, uint32_t *start_bits)
+    void prepare(const uint8_t *raw, size_t n, int period, uint64_t *codes, uint32_t *start_bits, size_t slice = 0)
     {
         raw_ = raw;
         n_ = n;
@@ -476,6 +496,7 @@ class RecordsJob {
         hc_ = period == 4 ? (uint8_t)'@' : (uint8_t)'>';
         codes_ = codes;
         bits_ = start_bits;
+        SLICE = slice ? (slice < 4096 ? 4096 : slice) : slice_bytes();
         n_slices_ = (n + SLICE - 1) / SLICE;
         desc_ = std::vector<Desc>(n_slices_ + 1);
         desc_[0].line = 0;
@@ -519,15 +540,21 @@ class RecordsJob {
             c.nlpos = nlbuf.data();
             census(raw_ + b0, b1 - b0, c);
             // the line number and the flat position of the slice's first byte, from the slice before it
-            // (spin briefly — the slice before this one is censused at about the same time — then SLEEP: a thread that spins
-            // or yields on a CPU its predecessor needs stalls the whole chain, and the load balancer never moves threads
-            // that run in short slices)
-            unsigned spins = 0;
-            while (!desc_[i].ready.load(std::memory_order_acquire)) {
-                if (++spins < 400)
+            // (Spin: the slice before this one is censused at about the same time, and its thread publishes as soon as ITS
+            // predecessor has — a ripple of one cache-line hand-over per slice, a microsecond across sockets.  Sleeping early
+            // turns every hand-over into a timer wake-up of ~70 us and the whole job runs at that pace: 7 GB/s on 8 threads
+            // against 39 on 4, measured.  Only a thread that has waited far longer than any healthy ripple — its predecessor
+            // was descheduled, or shares this CPU — gives the CPU away, by sleeping, never by sched_yield: the load balancer
+            // does not move threads that run in short slices.)
+            if (!desc_[i].ready.load(std::memory_order_acquire)) {
+                const auto t_wait = std::chrono::steady_clock::now();
+                unsigned spins = 0;
+                while (!desc_[i].ready.load(std::memory_order_acquire)) {
                     cpu_relax();
-                else
-                    std::this_thread::sleep_for(std::chrono::microseconds(20));
+                    if ((++spins & 255u) == 0 &&
+                        std::chrono::steady_clock::now() - t_wait > std::chrono::microseconds(spin_us()))
+                        std::this_thread::sleep_for(std::chrono::microseconds(50));
+                }
             }
             const uint64_t line0 = desc_[i].line, flat0 = desc_[i].flat;
             uint64_t seq = 0;
@@ -962,6 +989,7 @@ class RecordsJob {
     }
 
     const uint8_t *raw_ = nullptr;
+    size_t SLICE = (size_t)256 << 10;
     size_t n_ = 0, n_slices_ = 0;
     uint32_t pm_ = 3;
     uint8_t hc_ = '@';

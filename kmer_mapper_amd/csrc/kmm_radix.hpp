@@ -152,7 +152,31 @@ struct RxView {
     uint16_t *start2T;     // [F2 + 1][max_items] (transposed for pass 3: one fine partition's run starts are contiguous)
     uint32_t *ctrl;        // [0] items, [1] pass-3 rows, [2] most items of one coarse partition
     unsigned long long *queue; // 2 x 8 work counters, 128 bytes apart: [16 x] pass 2, [128 + 16 x] pass 3, x = XCD
+    uint64_t *probe;       // experiments (RX_PROBE_*: what one more byte costs a pass); null in product builds
 };
+
+// ------------------------------------------------------------------------------------------------
+// Marginal-byte probes (profiles/r05/marginal_bytes.txt).  "Are the passes bound by their bytes?" decides whether narrower
+// records between the passes (7 bytes 1 -> 2, 6 bytes 2 -> 3) can buy time.  Measured directly: a build with
+// -DRX_PROBE_P1W=D makes pass 1 write 8 / D MORE bytes per k-mer (every D-th 16-byte piece of the sorted block a second
+// time, into a scratch buffer of its own), RX_PROBE_P2R / RX_PROBE_P3R make pass 2 / pass 3 read 8 / D more bytes per
+// k-mer (a second, never consumed load per D-th k-mer, half of pass 1's output away: no cache holds it), RX_PROBE_P2W as
+// P1W for pass 2's output.  The time such a build adds per added byte is what a saved byte would return.  Product
+// builds define none of them (the code below compiles to nothing).
+// ------------------------------------------------------------------------------------------------
+#ifndef RX_PROBE_P1W
+#define RX_PROBE_P1W 0
+#endif
+#ifndef RX_PROBE_P2R
+#define RX_PROBE_P2R 0
+#endif
+#ifndef RX_PROBE_P2W
+#define RX_PROBE_P2W 0
+#endif
+#ifndef RX_PROBE_P3R
+#define RX_PROBE_P3R 0
+#endif
+#define RX_PROBE_ANY (RX_PROBE_P1W || RX_PROBE_P2R || RX_PROBE_P2W || RX_PROBE_P3R)
 
 // q -> packed form; *coarse gets the coarse partition (= hash >> (w + f2)).
 __device__ __forceinline__ uint64_t rx_pack(const IndexView &iv, int sh, uint64_t q, uint32_t *coarse)
@@ -341,7 +365,8 @@ __device__ __forceinline__ void rx_sort_emit(uint64_t (&q)[RX_B / NT], PrepFn pr
                                              uint32_t *s_cnt, uint32_t *s_base, uint32_t *s_wave,
                                              uint64_t *__restrict__ out, uint16_t *__restrict__ dir_row,
                                              unsigned long long *pt_acc = nullptr, MidFn mid = MidFn(),
-                                             int n_slots = RX_B / NT, int wave_s = -1, PostFn post = PostFn())
+                                             int n_slots = RX_B / NT, int wave_s = -1, PostFn post = PostFn(),
+                                             uint64_t *probe_out = nullptr, int probe_den = 0)
 {
     // `post` runs after the placement, before its barrier (pass 1 stages the NEXT tile's codes there: that barrier then
     // also publishes them and the tile's own barrier goes)
@@ -466,6 +491,16 @@ __device__ __forceinline__ void rx_sort_emit(uint64_t (&q)[RX_B / NT], PrepFn pr
             __builtin_nontemporal_store(w, reinterpret_cast<u32x4_t *>(o4) + i);
         } else {      // (pass 2: measured slower with non-temporal stores, 4.20 vs 4.15 ms)
             o4[i] = s4[i];
+        }
+        if (RX_PROBE_ANY && probe_den > 0 && i % (uint32_t)probe_den == 0u) { // (marginal-byte probe: the piece once more, elsewhere)
+            if (NTSTORE) {
+                typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+                const uint4 v = s4[i];
+                const u32x4_t w = {v.x, v.y, v.z, v.w};
+                __builtin_nontemporal_store(w, reinterpret_cast<u32x4_t *>(probe_out) + i / (uint32_t)probe_den);
+            } else {
+                reinterpret_cast<uint4 *>(probe_out)[i / (uint32_t)probe_den] = s4[i];
+            }
         }
     }
     if (ENDBAR)
@@ -800,7 +835,8 @@ __global__ void __launch_bounds__(RX_NT, 4) k_rx_p1(ReadsView rv, const uint64_t
             };
             rx_sort_emit<RX_RB1, MODE == MODE_KMERS, true, RX_NT, true, decltype(fwd), RxNoHook, 0, true, decltype(post)>(
                 q, fwd, F1, sbuf, s_cnt, s_base, s_wave, rx.buf1 + (size_t)sb * RX_B,
-                rx.start1 + (size_t)sb * (size_t)(F1 + 1) RX_PT_ARG2, RxNoHook(), RX_KPT, wave_s, post);
+                rx.start1 + (size_t)sb * (size_t)(F1 + 1) RX_PT_ARG2, RxNoHook(), RX_KPT, wave_s, post,
+                RX_PROBE_P1W ? rx.probe + (size_t)sb * RX_B : nullptr, RX_PROBE_P1W);
         }
     }
 #ifdef RX_PT_P1
@@ -1479,6 +1515,13 @@ __global__ void __launch_bounds__(P2F_NT) k_rx_p2f(IndexView iv, RxView rx)
                 el = el < lim ? el : lim; // never leave pass 1's output, whatever the table says
                 const uint64_t y = RX_LOAD2(reinterpret_cast<const uint64_t *>(base + (el << 3)));
                 x[u] = (!MERGE || ((vmask >> u) & 1u)) ? y : x[u];
+#if RX_PROBE_P2R
+                if (u % RX_PROBE_P2R == 0) { // (marginal-byte probe: 8 more bytes, half of pass 1's output away, never consumed)
+                    const size_t all = (size_t)NB * RX_B, far = ((size_t)bbs * RX_B + el + all / 2) % all;
+                    const uint64_t z = RX_LOAD2(rx.buf1 + far);
+                    asm volatile("" ::"v"(z));
+                }
+#endif
             }
             return vmask;
         };
@@ -1557,7 +1600,8 @@ __global__ void __launch_bounds__(P2F_NT) k_rx_p2f(IndexView iv, RxView rx)
             };
             rx_sort_emit<P2F_KPT, false, true, P2F_NT, false, decltype(fine), decltype(mid), (FSMALL ? 2 : 1)>(
                 xa, fine, F2, sbuf, s_cnt2[j & 1u], s_base, s_wave, rx.buf2 + (size_t)item * RX_B,
-                rx.start2 + (size_t)item * (F2 + 1) RX_PT_ARG2, mid);
+                rx.start2 + (size_t)item * (F2 + 1) RX_PT_ARG2, mid, P2F_KPT, -1, RxNoHook(),
+                RX_PROBE_P2W ? rx.probe + (size_t)item * RX_B : nullptr, RX_PROBE_P2W);
             if (tid < RX_B / 32)
                 t_sbits[(j + 1u) & 1u][tid] = 0u; // item j + 1's mask has served (its requests lie before barrier 1); item
             if (tid == 0)                         // j + 3's bits are set behind the next item's barrier 1
@@ -1844,6 +1888,13 @@ __global__ void __launch_bounds__(RX_NT, WPS) k_rx_p3(IndexView iv, RxView rx, i
                         const bool in = (uint32_t)lg < (e[u] & 31u);
                         x[u] = RX_LOAD3(reinterpret_cast<const uint64_t *>(wbase + (((e[u] >> 5) + (in ? (uint32_t)lg : 0u)) << 3)));
                         act |= (in ? 1u : 0u) << u;
+#if RX_PROBE_P3R
+                        if (u % RX_PROBE_P3R == 0) { // (marginal-byte probe: pass 1's output is idle by now — 8 bytes of it per slot)
+                            const size_t far = ((size_t)it0 * RX_B + (e[u] >> 5) + (uint32_t)lg) % ((size_t)rx.NB * RX_B);
+                            const uint64_t z = RX_LOAD3(rx.buf1 + far);
+                            asm volatile("" ::"v"(z));
+                        }
+#endif
                     }
                     return act;
                 };

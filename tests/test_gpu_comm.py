@@ -92,7 +92,8 @@ def test_flush_of_node_ranges_under_the_reduce_of_the_previous_range(oracle):
                 dev.comm_reduce_counts(root=0)
                 assert np.array_equal(dev.get_node_counts(), expect), (skewed, knob)
                 dev.set_param(knob, 1 if knob == "radix_sorted_flush" else 0)
-            assert dev.get_param("comm_sliced_reduces") == before + 2
+            # (the count vector of the skewed index — 1000 nodes — is too short to be cut: one reduce on every rank)
+            assert dev.get_param("comm_sliced_reduces") == before + (2 if mx + 1 >= 8 * 1024 else 0)
 
 
 @pytest.mark.parametrize("n_ranks", [2, 3])
@@ -150,7 +151,15 @@ def test_bench_line_has_what_the_contract_names():
     assert cpu["kind"] == "port" and cpu["cores"] >= 1 and cpu["value"] > 0
     assert j["parity_vs_oracle_on_sample"] is True
     assert j["config"]["reads_in_hbm_when_timed"] is True and j["value_incl_h2d"] > 0
-    assert j["value_incl_h2d_host_packed"] > 0 and "host threads" in j["config"]["h2d_leg_host_packed"]
+    # SURVEY 8(d)'s map-phase figure: by default the reads are packed by the rank's host threads (thread count stated); the
+    # plain copy of the ASCII bytes beside it; the count vector's way back to the host; raw FASTQ from host memory
+    assert j["value_incl_h2d_plain_copy"] > 0 and "ASCII" in j["config"]["h2d_leg_plain_copy"]["what"]
+    if j["config"]["host_cores_of_this_rank"] >= 8:
+        assert j["value_incl_h2d_host_packed"] == j["value_incl_h2d"] and "host threads" in j["config"]["h2d_leg"]["what"]
+        assert j["config"]["h2d_leg"]["host_pack_threads"] == min(16, j["config"]["host_cores_of_this_rank"])
+        rec = j["config"]["records_from_host_memory"]
+        assert rec["M_kmers_per_s"] > 0 and rec["host_packed_calls"] >= 2
+    assert j["config"]["final_d2h_ms"] > 0 and "numa_node" in j["config"]["numa_binding"]
 
 
 def test_bench_line_of_two_ranks_carries_the_strong_and_the_staged_leg():
@@ -167,5 +176,7 @@ def test_bench_line_of_two_ranks_carries_the_strong_and_the_staged_leg():
     assert 0 < s["efficiency_vs_n1"] <= 1.5
     h = j["config"]["h2d_leg"]
     assert len(h["per_rank_read_GB_per_s"]) == 2 and j["value_incl_h2d"] > 0
-    assert j["value_incl_h2d_host_packed"] > 0 and len(j["config"]["h2d_leg_host_packed"]["per_rank_read_GB_per_s"]) == 2
-    assert j["cpu_baseline"] is None          # rank 0 at N = 1 only
+    assert j["value_incl_h2d_plain_copy"] > 0 and len(j["config"]["h2d_leg_plain_copy"]["per_rank_read_GB_per_s"]) == 2
+    # every record of a scaling run stands alone: rank 0 times the CPU baseline and checks parity at N > 1 too
+    assert j["cpu_baseline"]["value"] > 0 and j["cpu_baseline"]["cores"] >= 1 and j["parity_vs_oracle_on_sample"] is True
+    assert "rehearsal" in j["config"]["parallelism"]          # (which reduce ran, and why)

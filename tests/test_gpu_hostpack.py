@@ -72,6 +72,7 @@ def test_records_of_one_length_packed_on_the_host(kmm, syn, oracle, eol, read_le
     with kmm.DeviceIndex.from_index(index, mx) as dev:
         dev.set_param("path", 2)
         dev.set_param("host_pack_threads", 5)
+        dev.set_param("host_pack_slice_kb", 64)          # (many slices in a test-size chunk)
         used, n_rec = dev.map_records(raw, fmt=_lib.FORMAT_FASTQ, k=k)
         assert (used, n_rec) == (raw.shape[0], n_reads)
         assert np.array_equal(dev.get_node_counts(), expect)
@@ -113,6 +114,7 @@ def test_ragged_records_packed_on_the_host(kmm, syn, oracle):
     with kmm.DeviceIndex.from_index(index, mx) as dev:
         dev.set_param("path", 2)
         dev.set_param("host_pack_threads", 7)
+        dev.set_param("host_pack_slice_kb", 128)
         n_calls = 0
         for rc, mf in ((False, 1000), (True, 1000), (False, 1)):
             expect, _ = oracle.map_reads(index, mx, bases, offs, 31, max_index_lookup_frequency=mf, also_revcomp=rc, n_threads=4)
@@ -152,6 +154,7 @@ def test_host_packed_records_edge_cases_and_error_reports(kmm, syn, oracle):
     with kmm.DeviceIndex.from_index(index, mx) as dev:
         dev.set_param("path", 2)
         dev.set_param("host_pack_threads", 4)
+        dev.set_param("host_pack_slice_kb", 32)
         raw = _fastq(reads)
         assert dev.map_records(raw, fmt=_lib.FORMAT_FASTQ, k=5) == (raw.shape[0], len(reads))
         assert np.array_equal(dev.get_node_counts(), expect)

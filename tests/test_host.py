@@ -329,7 +329,7 @@ def test_host_records_packer_equals_the_device_parsers_rules(tmp_path):
     src = tmp_path / "shim.cpp"
     src.write_text('#include "kmm_hostpack.hpp"\n'
                    'extern "C" int shim_records(const uint8_t *raw, size_t n, int period, int threads, uint64_t *codes, uint32_t *bits, int64_t *out) {\n'
-                   '    kmm_hostpack::RecordsJob job; job.prepare(raw, n, period, codes, bits);\n'
+                   '    kmm_hostpack::RecordsJob job; job.prepare(raw, n, period, codes, bits, (size_t)256 << 10);\n'
                    '    kmm_hostpack::Workers w(threads); w.start([&](int) { job.run(); });\n'
                    '    job.wait_packed_prefix(job.n_slices()); w.wait();\n'
                    '    const kmm_hostpack::RecordsResult r = job.finish();\n'

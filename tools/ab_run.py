@@ -18,7 +18,7 @@ names = args or sorted(os.path.basename(p)[7:-3] for p in glob.glob(os.path.join
 for name in names:
     env = dict(os.environ, KMM_LIB_PATH=os.path.join(ROOT, "build_ab", "libkmm_%s.so" % name))
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "2", "--no-cpu-baseline",
-           "--no-h2d-leg"] + extra
+           "--no-h2d-leg", "--no-records-host-leg"] + extra
     if check:
         t = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_radix.py"), "-x", "-q"],
                            env=env, capture_output=True, text=True, cwd=ROOT)
