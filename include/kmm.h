@@ -187,6 +187,29 @@ int kmm_map_records(kmm_index_t *idx, const uint8_t *raw, int64_t n_bytes, int f
                     int64_t *consumed, int64_t *n_records);
 
 /*
+ * kmm_map_bgzf — reads from a BGZF-compressed FASTQ / two-line FASTA file (what bgzip / htslib write: a chain of independent
+ * gzip members of at most 64 KiB of data, each with its size in the header), INFLATED ON THE GPU: replaces
+ * `bnp.open("reads.fq.gz").read_chunks(...)` + the per-chunk map (command_line_interface.py:102-111; ".fa.gz, or fq.gz",
+ * Readme.md:11; the igzip reader of util.py:78-101) without a host-side inflater — the compressed bytes cross PCIe (about a
+ * quarter of the raw ones), one GPU thread inflates one member (thousands per chunk; stored, fixed and dynamic blocks;
+ * every member's ISIZE and CRC32 checked on the device), and the raw records go to the device-side parser as in
+ * kmm_map_records.  comp: n_comp compressed bytes in HOST memory (a file mapping will do) that start at a member boundary;
+ * the call uses the whole members inside (at most 3.5 GiB of inflated bytes) and returns in *consumed_comp how many
+ * compressed bytes that was — the caller continues there.  Records do not end where members end: the handle keeps the
+ * inflated bytes behind the call's last complete record and puts them in front of the next call's (a STREAM per handle:
+ * calls in file order; OR KMM_FORMAT_NEW_STREAM into `format` for the first chunk of a file, KMM_FORMAT_LAST_CHUNK for the
+ * last: a final line without newline gets one, and bytes that then still form no record — or compressed bytes behind the
+ * last whole member — are KMM_ERR_MALFORMED; a call that stops at its own size limit ignores the flag: the caller comes
+ * back with the rest and the same flag).
+ * format: KMM_FORMAT_FASTQ or KMM_FORMAT_FASTA2.  A corrupt member (header, Huffman code, distance, ISIZE, CRC32) makes the
+ * call fail with KMM_ERR_MALFORMED before anything of the chunk is mapped.  A plain gzip file (no member sizes: `gzip`, not
+ * `bgzip`) is refused the same way — inflate it on the host (libkmm_io).  *n_records: reads mapped by this call.
+ */
+#define KMM_FORMAT_NEW_STREAM 0x400
+int kmm_map_bgzf(kmm_index_t *idx, const uint8_t *comp, int64_t n_comp, int format, int k, int max_index_lookup_frequency,
+                 int also_revcomp, const uint8_t *lut, int64_t *consumed_comp, int64_t *n_records);
+
+/*
  * kmm_map_packed — reads the caller already holds as 2-BIT CODES (its own encoder, a .2bit-style store, the output of a
  * host-side packer): the same mapping as kmm_map_reads without the byte -> code step, and a quarter of the bytes over
  * PCIe.  This is the form the library's own host packer produces when kmm_map_reads* / kmm_map_records are handed host
@@ -209,6 +232,11 @@ int kmm_map_packed(kmm_index_t *idx, const uint32_t *codes, int64_t n_bases, int
  */
 int kmm_host_alloc(size_t bytes, void **out);
 int kmm_host_free(void *p);
+/* Prepares the page-locked staging buffers the library needs for host-resident batches of raw_batch_bytes raw bytes
+ * ("host_pack_threads": the packed stream + the read-start bitset) and shelves them for the next handle that asks.  A
+ * page-locked allocation costs ~50 ms per GB: a caller that knows its batch size calls this from another thread while
+ * the index is created (kmer_mapper map does), and the first map call finds the buffers ready.  Optional. */
+int kmm_host_reserve(int64_t raw_batch_bytes);
 
 /*
  * kmm_extract_kmers — replaces get_kmer_hashes_from_chunk_sequence (util.py:71-75) as an

@@ -127,6 +127,23 @@ def map_gpu_raw(index, path, chunk_size, fmt, k, map_reverse_complements=False,
     (kmm_map_records): the host only reads (and for .gz inflates) raw bytes."""
     t_index = time.perf_counter()
     max_node_id = index.max_node_id() if hasattr(index, "max_node_id") else int(np.max(index._nodes))
+    # page-locked memory is slow to make (~50 ms per GB): the staging buffers of the host packer and the count vector's
+    # landing place are made by a helper thread WHILE the index is uploaded and repacked, not inside the map phase
+    import threading
+    prepared = {}
+
+    def prepare_host_memory():
+        try:
+            size = os.stat(path).st_size
+            if n_threads > 1 and not str(path).endswith(".gz"):
+                _lib.check(_lib.lib().kmm_host_reserve(min(size // max(world_size, 1) + (1 << 20), 2 << 30)))
+            prepared["counts"] = _lib.pinned_array(max_node_id + 1, np.uint32)
+        except Exception as exc:                         # noqa: BLE001 - an optimisation: the map calls allocate what is missing
+            logging.debug("host memory was not prepared ahead: %s", exc)
+
+    helper = threading.Thread(target=prepare_host_memory, daemon=True)
+    if _lib.device_count() > 0:
+        helper.start()
     dev = DeviceIndex.from_index(index, max_node_id, device=device)
     logging.info("Index resident in HBM after %.3f sec (max_node_id scan + upload + repack)", time.perf_counter() - t_index)
     # -t: the host cores' share of the work (reference: command_line_interface.py:124-130,168) — reader / inflate threads
@@ -176,6 +193,16 @@ def map_gpu_raw(index, path, chunk_size, fmt, k, map_reverse_complements=False,
     kfmt = {"fastq": _lib.FORMAT_FASTQ, "fasta": _lib.FORMAT_FASTA2, "fasta_ml": _lib.FORMAT_FASTA}[fmt]
     t_start = time.perf_counter()
     n_reads = n_bytes = 0
+    # BGZF (.gz written by bgzip / htslib: independent members of <= 64 KiB): the compressed bytes go to the GPU as they lie
+    # in the file mapping, one GPU thread inflates one member, the records are parsed there too (kmm_map_bgzf) — the host's
+    # inflater (10.8 GB/s of FASTQ on 16 cores) is out of the way.  One process only: ranks that share a .gz keep the host reader.
+    if (not seekable and world_size == 1 and fmt in ("fastq", "fasta") and not os.environ.get("KMM_CLI_NO_GPU_INFLATE")
+            and _is_bgzf(path)):
+        chunker.close()
+        if helper.ident is not None:
+            helper.join()
+        return _map_bgzf_file(dev, path, kfmt, k, max_index_lookup_frequency, map_reverse_complements, before_fetch, t_start,
+                              counts_out=prepared.get("counts"))
     try:
         i = 0
         while True:
@@ -203,7 +230,9 @@ def map_gpu_raw(index, path, chunk_size, fmt, k, map_reverse_complements=False,
         n_host_packed = dev.get_param("host_packed_record_calls")
         if before_fetch is not None:
             before_fetch(dev)
-        node_counts = dev.get_node_counts()
+        if helper.is_alive() or helper.ident is not None:
+            helper.join()
+        node_counts = dev.get_node_counts(out=prepared.get("counts"))
     finally:
         dt = time.perf_counter() - t_start
         chunker.close()
@@ -216,6 +245,68 @@ def map_gpu_raw(index, path, chunk_size, fmt, k, map_reverse_complements=False,
                  "by the host threads)"
                  % ("radix" if n_radix and not n_direct else "direct" if n_direct and not n_radix else "mixed", n_radix, n_direct,
                     n_host_packed))
+    return node_counts
+
+
+def _is_bgzf(path):
+    """Does the file start with a BGZF member (gzip header with the BC extra subfield, SAM specification 4.1)?"""
+    try:
+        with open(path, "rb") as f:
+            h = f.read(18)
+    except OSError:
+        return False
+    return len(h) == 18 and h[:4] == b"\x1f\x8b\x08\x04" and h[12:14] == b"BC" and h[14:16] == b"\x02\x00"
+
+
+def _map_bgzf_file(dev, path, kfmt, k, max_freq, revcomp, before_fetch, t_start, comp_batch=900 << 20, counts_out=None):
+    """`kmer_mapper map -f reads.fq.gz` for BGZF files: compressed chunks of the file mapping -> kmm_map_bgzf (members inflated
+    and records parsed on the GPU; the handle carries the bytes behind a chunk's last complete record to the next chunk)."""
+    import mmap
+    n_reads = 0
+    try:
+        with open(path, "rb") as f:
+            size = os.fstat(f.fileno()).st_size
+            mm = mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ)
+            try:
+                if hasattr(mm, "madvise") and hasattr(mmap, "MADV_SEQUENTIAL"):
+                    mm.madvise(mmap.MADV_SEQUENTIAL)
+                whole = np.frombuffer(mm, dtype=np.uint8)
+                pos, window = 0, int(comp_batch)
+                while pos < size:
+                    end = min(pos + window, size)
+                    used, n_rec = dev.map_bgzf(whole[pos:end], fmt=kfmt, k=k, max_index_lookup_frequency=max_freq,
+                                               also_revcomp=revcomp, first=pos == 0, last=end == size)
+                    if used == 0 and end < size:
+                        window *= 2                      # (a member larger than the window: cannot happen with BGZF's 64 KiB)
+                        continue
+                    if used == 0:
+                        raise ValueError("trailing bytes of %s are no complete BGZF member" % path)
+                    pos += used
+                    n_reads += n_rec
+                    if end == size and pos < size:       # the last window held more than one call takes: go on
+                        continue
+                del whole
+            finally:
+                try:
+                    mm.close()
+                except BufferError:
+                    pass
+        n_lookups, n_hits = dev.get_stats()
+        n_members = dev.get_param("bgzf_members")
+        n_radix, n_direct = dev.get_param("radix_batches"), dev.get_param("direct_batches")
+        if before_fetch is not None:
+            before_fetch(dev)
+        node_counts = dev.get_node_counts(out=counts_out)
+    finally:
+        dt = time.perf_counter() - t_start
+        dev.close()
+    logging.info("Time spent only on hashing and counting hashes: %.5f" % dt)
+    logging.info("Mapped %d reads from %d compressed bytes (%.1f MB/s compressed; %d BGZF members inflated on the GPU): %d k-mer "
+                 "lookups (%.1f M/s), %d index hits" % (n_reads, size, size / max(dt, 1e-9) / 1e6, n_members, n_lookups,
+                                                          n_lookups / max(dt, 1e-9) / 1e6, n_hits))
+    logging.info("path_taken: %s (%d batches on the radix path, %d on the direct path; 0 batches packed to 2 bits per base by "
+                 "the host threads)" % ("radix" if n_radix and not n_direct else "direct" if n_direct and not n_radix else "mixed",
+                                        n_radix, n_direct))
     return node_counts
 
 

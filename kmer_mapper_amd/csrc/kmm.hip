@@ -18,6 +18,7 @@
 #include <chrono>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -141,6 +142,47 @@ constexpr unsigned long long NO_BAD = ~0ull;
 
 #include "kmm_comm.hpp"
 #include "kmm_hostpack.hpp"
+#include "kmm_gpu_inflate.hpp"
+
+// Page-locked buffers are expensive to make (hipHostMalloc: ~50 ms per GB) and cheap to keep: the ones a handle gives up go
+// to a process-wide shelf (at most 8 GiB), and kmm_host_reserve puts buffers there ahead of time — from another thread,
+// while the index is uploaded — so that a one-shot `kmer_mapper map` does not pay for them inside its map phase.
+struct PinnedShelf {
+    std::mutex m;
+    std::vector<std::pair<uint8_t *, size_t>> free_list;
+    size_t bytes = 0;
+    uint8_t *take(size_t want, size_t *got)
+    {
+        std::lock_guard<std::mutex> g(m);
+        size_t best = free_list.size();
+        for (size_t i = 0; i < free_list.size(); ++i)
+            if (free_list[i].second >= want && (best == free_list.size() || free_list[i].second < free_list[best].second))
+                best = i;
+        if (best == free_list.size())
+            return nullptr;
+        uint8_t *p = free_list[best].first;
+        *got = free_list[best].second;
+        bytes -= *got;
+        free_list.erase(free_list.begin() + (long)best);
+        return p;
+    }
+    void give(uint8_t *p, size_t n)
+    {
+        if (!p)
+            return;
+        {
+            std::lock_guard<std::mutex> g(m);
+            if (bytes + n <= ((size_t)8 << 30)) {
+                free_list.emplace_back(p, n);
+                bytes += n;
+                return;
+            }
+        }
+        (void)hipHostFree(p);
+    }
+};
+static PinnedShelf g_shelf;
+
 
 struct TimedEvent {
     hipEvent_t start, stop;
@@ -203,6 +245,15 @@ struct kmm_index {
     size_t pack_bits_pinned_bytes = 0;
     int64_t host_packed_calls = 0, host_packed_record_calls = 0;
     int64_t host_pack_slice_kb = 0; // "host_pack_slice_kb": raw bytes per slice of the records packer (0: its default)
+    // kmm_map_bgzf: BGZF members inflated on the GPU (kmm_gpu_inflate.hpp).  Two sets of buffers in turn (the copy of call
+    // i + 1 runs under the kernels of call i); the uncompressed bytes behind a call's last complete record wait in `carry`
+    // for the next call.
+    DevBuf bgzf_comp[2], bgzf_raw[2], bgzf_meta[2], bgzf_tabs, bgzf_err, bgzf_carry;
+    hipEvent_t bgzf_done[2] = {nullptr, nullptr};
+    bool bgzf_used[2] = {false, false};
+    int bgzf_cur = 0;
+    int64_t bgzf_carry_len = 0;
+    int64_t bgzf_calls = 0, bgzf_members = 0;
     int64_t dbg_rx_buf_limit = 0; // test hook ("debug_rx_buffer_limit"): a pass-1 buffer beyond this many bytes counts as out of memory
     int dbg_rec_copy_stream = 0; // experiments (tools/records_overlap_bisect.py): compaction kernels on the copy stream again,
     int dbg_rec_skip = 0;        // and which of them to leave out (1 count2, 2 scans, 4 scatter, 8 uniform, 16 the large memsets)
@@ -897,6 +948,25 @@ int kmm_host_alloc(size_t bytes, void **out)
     return KMM_OK;
 }
 
+int kmm_host_reserve(int64_t raw_batch_bytes)
+{
+    if (raw_batch_bytes < 0)
+        return fail(KMM_ERR_INVALID_ARG, "raw_batch_bytes negative");
+    // the two page-locked buffers a host-packed batch of that many raw bytes needs (map_records_host_packed / map_reads_host_packed)
+    const size_t n = (size_t)raw_batch_bytes;
+    const size_t want[2] = {(n / 4 + 1024 + 63) & ~(size_t)63, (n / 8 + 256 + 63) & ~(size_t)63};
+    for (size_t w : want) {
+        uint8_t *p = nullptr;
+        const size_t take = w + w / 8;
+        if (hipHostMalloc(reinterpret_cast<void **>(&p), take, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(KMM_ERR_NOMEM, "hipHostMalloc(%zu bytes) failed", take);
+        }
+        g_shelf.give(p, take);
+    }
+    return KMM_OK;
+}
+
 int kmm_host_free(void *p)
 {
     if (p)
@@ -951,11 +1021,19 @@ void kmm_index_destroy(kmm_index_t *ix)
     release(ix->rx_buf1);
     release(ix->rx_buf2);
     release(ix->rx_probe);
+    for (int i = 0; i < 2; ++i) {
+        release(ix->bgzf_comp[i]);
+        release(ix->bgzf_raw[i]);
+        release(ix->bgzf_meta[i]);
+        if (ix->bgzf_done[i])
+            (void)hipEventDestroy(ix->bgzf_done[i]);
+    }
+    release(ix->bgzf_tabs);
+    release(ix->bgzf_err);
+    release(ix->bgzf_carry);
     ix->pack_pool.reset();
-    if (ix->pack_pinned)
-        (void)hipHostFree(ix->pack_pinned);
-    if (ix->pack_bits_pinned)
-        (void)hipHostFree(ix->pack_bits_pinned);
+    g_shelf.give(ix->pack_pinned, ix->pack_pinned_bytes);
+    g_shelf.give(ix->pack_bits_pinned, ix->pack_bits_pinned_bytes);
     for (hipEvent_t e : ix->comm_events)
         (void)hipEventDestroy(e);
     if (ix->comm_stream)
@@ -1814,10 +1892,11 @@ static bool ensure_pinned(uint8_t *&p, size_t &have, size_t want)
 {
     if (have >= want)
         return true;
-    if (p)
-        (void)hipHostFree(p);
+    g_shelf.give(p, have);
     p = nullptr;
     have = 0;
+    if ((p = g_shelf.take(want, &have)))
+        return true;
     const size_t take = want + want / 8;
     if (hipHostMalloc(reinterpret_cast<void **>(&p), take, hipHostMallocDefault) != hipSuccess) {
         (void)hipGetLastError();
@@ -1908,12 +1987,19 @@ static int map_records_host_packed(kmm_index_t *ix, const uint8_t *raw, int64_t 
     *done = false;
     const size_t n = (size_t)n_bytes;
     const size_t code_bytes = (n / 4 + 1024 + 63) & ~(size_t)63, bits_bytes = (n / 8 + 256 + 63) & ~(size_t)63;
+    static const bool verbose = getenv("KMM_VERBOSE") != nullptr;
+    const auto t_0 = std::chrono::steady_clock::now();
+    auto ms_since = [](std::chrono::steady_clock::time_point a) {
+        return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count();
+    };
     if (!ensure_pack_pool(ix) || !ensure_pinned(ix->pack_pinned, ix->pack_pinned_bytes, code_bytes) ||
         !ensure_pinned(ix->pack_bits_pinned, ix->pack_bits_pinned_bytes, bits_bytes))
         return KMM_OK;
     Stage &s = next_stage(ix);
     KMMCHK(stage_acquire(ix, s));
     KMMCHK(ensure(s.kmers, code_bytes));
+    const double ms_alloc = ms_since(t_0);
+    const auto t_1 = std::chrono::steady_clock::now();
     kmm_hostpack::RecordsJob job;
     const size_t slice = ix->host_pack_slice_kb > 0 ? (size_t)ix->host_pack_slice_kb << 10 : kmm_hostpack::RecordsJob::slice_bytes();
     job.prepare(raw, n, format == KMM_FORMAT_FASTQ ? 4 : 2, reinterpret_cast<uint64_t *>(ix->pack_pinned),
@@ -1934,6 +2020,9 @@ static int map_records_host_packed(kmm_index_t *ix, const uint8_t *raw, int64_t 
     }
     ix->pack_pool->wait();
     const kmm_hostpack::RecordsResult r = job.finish();
+    if (verbose)
+        fprintf(stderr, "libkmm: host records packer: %zu bytes, buffers %.2f ms, pack %.2f ms (%.1f GB/s), %d threads, %s\n", n, ms_alloc,
+                ms_since(t_1), (double)n / 1e6 / ms_since(t_1), ix->host_pack_threads, r.ok ? "ok" : "refused");
     if (rc != KMM_OK || !r.ok) {
         HIPCHK(hipEventRecord(ix->copied, ix->copy_stream));
         HIPCHK(hipEventSynchronize(ix->copied));
@@ -2483,6 +2572,173 @@ int kmm_map_packed(kmm_index_t *ix, const uint32_t *codes, int64_t n_bases, int6
     return stage_release(ix, s, staged);
 }
 
+int kmm_map_bgzf(kmm_index_t *ix, const uint8_t *comp, int64_t n_comp, int format, int k, int max_freq, int also_revcomp,
+                 const uint8_t *lut, int64_t *consumed_comp, int64_t *n_records)
+{
+    if (!ix)
+        return fail(KMM_ERR_INVALID_ARG, "idx is NULL");
+    KMMCHK(check_k(k));
+    bool last_chunk = (format & KMM_FORMAT_LAST_CHUNK) != 0;
+    const bool new_stream = (format & KMM_FORMAT_NEW_STREAM) != 0;
+    const int fmt = format & ~(KMM_FORMAT_LAST_CHUNK | KMM_FORMAT_NEW_STREAM);
+    if (fmt != KMM_FORMAT_FASTQ && fmt != KMM_FORMAT_FASTA2)
+        return fail(KMM_ERR_INVALID_ARG, "kmm_map_bgzf: format must be KMM_FORMAT_FASTQ (4) or KMM_FORMAT_FASTA2 (2)");
+    if (n_comp < 0 || (n_comp > 0 && !comp))
+        return fail(KMM_ERR_INVALID_ARG, "comp NULL or n_comp negative");
+    if (consumed_comp)
+        *consumed_comp = 0;
+    if (n_records)
+        *n_records = 0;
+    if (n_comp > 0 && is_device_ptr(comp))
+        return fail(KMM_ERR_INVALID_ARG, "kmm_map_bgzf takes the compressed bytes from host memory (the member chain is read there)");
+    HIPCHK(hipSetDevice(ix->device));
+    if (new_stream)
+        ix->bgzf_carry_len = 0;
+    // the member chain: whole members only, at most 3.5 GiB of inflated bytes per call (the caller comes back with the rest)
+    std::vector<unsigned long long> m_off, o_off;
+    m_off.push_back(0);
+    const int64_t carry = ix->bgzf_carry_len;
+    o_off.push_back((unsigned long long)carry);
+    const unsigned long long out_cap = (7ull << 29) - (unsigned long long)carry; // 3.5 GiB per call
+    uint64_t p = 0;
+    while (p + 18 <= (uint64_t)n_comp) {
+        const uint32_t ms = kmm_gz::bgzf_member_size(comp + p, (uint64_t)n_comp - p);
+        if (!ms) {
+            // (a header that needs more bytes than are left is an incomplete member: the caller brings it again)
+            const uint32_t xlen = (uint32_t)comp[p + 10] | ((uint32_t)comp[p + 11] << 8);
+            if (comp[p] == 0x1f && comp[p + 1] == 0x8b && comp[p + 2] == 8 && (comp[p + 3] & 4) && p + 12 + xlen + 8 > (uint64_t)n_comp)
+                break;
+            return fail(KMM_ERR_MALFORMED, "kmm_map_bgzf: no BGZF member at compressed byte %llu of the chunk (a gzip file that bgzip did "
+                        "not write has no member sizes in its headers: inflate it on the host)", (unsigned long long)p);
+        }
+        if (p + ms > (uint64_t)n_comp)
+            break; // an incomplete member
+        const uint32_t isize = kmm_gz::rd32(comp + p + ms - 4);
+        if ((uint64_t)isize > (uint64_t)ms * 1032ull + 64ull)
+            return fail(KMM_ERR_MALFORMED, "kmm_map_bgzf: member at compressed byte %llu claims %u inflated bytes for %u compressed ones",
+                        (unsigned long long)p, isize, ms);
+        if (o_off.back() - (unsigned long long)carry + isize > out_cap && m_off.size() > 1) {
+            last_chunk = false; // (the call stops at its own size limit: the caller continues with the same flags)
+            break;
+        }
+        p += ms;
+        m_off.push_back(p);
+        o_off.push_back(o_off.back() + isize);
+    }
+    const uint32_t n_members = (uint32_t)(m_off.size() - 1);
+    const int64_t n_used = (int64_t)p, n_total = (int64_t)o_off.back();
+    if (consumed_comp)
+        *consumed_comp = n_used;
+    if (last_chunk && n_used != n_comp)
+        return fail(KMM_ERR_MALFORMED, "kmm_map_bgzf: the file ends inside a BGZF member (%lld bytes behind the last whole member)",
+                    (long long)(n_comp - n_used));
+    if (n_members == 0 && !(last_chunk && carry > 0))
+        return KMM_OK;
+    const int cur = ix->bgzf_cur;
+    ix->bgzf_cur ^= 1;
+    if (!ix->bgzf_done[cur])
+        HIPCHK(hipEventCreateWithFlags(&ix->bgzf_done[cur], hipEventDisableTiming));
+    if (ix->bgzf_used[cur])
+        HIPCHK(hipStreamWaitEvent(ix->copy_stream, ix->bgzf_done[cur], 0)); // the kernels that last read these buffers are done
+    KMMCHK(ensure(ix->bgzf_comp[cur], (size_t)n_used + 64));
+    KMMCHK(ensure(ix->bgzf_raw[cur], (size_t)n_total + 4096));
+    KMMCHK(ensure(ix->bgzf_meta[cur], (size_t)(n_members + 1) * 16 + 64));
+    KMMCHK(ensure(ix->bgzf_err, 64));
+    const uint32_t grid_threads = ((n_members < 65536u ? n_members : 65536u) + 63u) / 64u * 64u;
+    if (n_members)
+        KMMCHK(ensure(ix->bgzf_tabs, (size_t)grid_threads * kmm_gz::TAB_WORDS * 4));
+    uint8_t *d_comp = (uint8_t *)ix->bgzf_comp[cur].p, *d_raw = (uint8_t *)ix->bgzf_raw[cur].p;
+    unsigned long long *d_moff = (unsigned long long *)ix->bgzf_meta[cur].p, *d_ooff = d_moff + (n_members + 1);
+    if (n_members) {
+        // compressed bytes -> HBM.  From a file mapping (pageable memory) the runtime's own staging is slow: the packing threads
+        // copy 8 MiB pieces into the page-locked buffer, each piece leaves as soon as it is there
+        bool staged = false;
+        if (ensure_pack_pool(ix) && ensure_pinned(ix->pack_pinned, ix->pack_pinned_bytes, (size_t)n_used + 64)) {
+            constexpr size_t PIECE = (size_t)8 << 20;
+            const size_t n_pieces = ((size_t)n_used + PIECE - 1) / PIECE;
+            std::vector<std::atomic<uint8_t>> done(n_pieces);
+            for (auto &f : done)
+                f.store(0, std::memory_order_relaxed);
+            std::atomic<size_t> next{0};
+            uint8_t *pin = ix->pack_pinned;
+            ix->pack_pool->start([&](int) {
+                for (;;) {
+                    const size_t c = next.fetch_add(1);
+                    if (c >= n_pieces)
+                        return;
+                    const size_t b0 = c * PIECE, len = (size_t)n_used - b0 < PIECE ? (size_t)n_used - b0 : PIECE;
+                    memcpy(pin + b0, comp + b0, len);
+                    done[c].store(1, std::memory_order_release);
+                }
+            });
+            int rc = KMM_OK;
+            for (size_t c = 0; c < n_pieces && rc == KMM_OK; ++c) {
+                while (!done[c].load(std::memory_order_acquire))
+                    std::this_thread::sleep_for(std::chrono::microseconds(30));
+                const size_t b0 = c * PIECE, len = (size_t)n_used - b0 < PIECE ? (size_t)n_used - b0 : PIECE;
+                if (hipMemcpyAsync(d_comp + b0, pin + b0, len, hipMemcpyHostToDevice, ix->copy_stream) != hipSuccess)
+                    rc = fail(KMM_ERR_HIP, "hipMemcpyAsync of compressed bytes: %s", hipGetErrorString(hipGetLastError()));
+            }
+            ix->pack_pool->wait();
+            KMMCHK(rc);
+            staged = true;
+        }
+        if (!staged)
+            HIPCHK(hipMemcpyAsync(d_comp, comp, (size_t)n_used, hipMemcpyHostToDevice, ix->copy_stream));
+        HIPCHK(hipMemcpyAsync(d_moff, m_off.data(), (size_t)(n_members + 1) * 8, hipMemcpyHostToDevice, ix->copy_stream));
+        HIPCHK(hipMemcpyAsync(d_ooff, o_off.data(), (size_t)(n_members + 1) * 8, hipMemcpyHostToDevice, ix->copy_stream));
+    }
+    const unsigned int err0[4] = {0u, 0xFFFFFFFFu, 0u, 0u};
+    HIPCHK(hipMemcpyAsync(ix->bgzf_err.p, err0, sizeof err0, hipMemcpyHostToDevice, ix->copy_stream));
+    KMMCHK(stage_copies_done(ix)); // (the handle's stream waits for the copies; the page-locked buffer is free after the sync below)
+    if (carry > 0)
+        HIPCHK(hipMemcpyAsync(d_raw, ix->bgzf_carry.p, (size_t)carry, hipMemcpyDeviceToDevice, ix->stream));
+    if (n_members) {
+        hipLaunchKernelGGL(kmm_gz::k_inflate_bgzf, dim3(grid_threads / 64u), dim3(64), 0, ix->stream, d_comp, d_moff, d_ooff, d_raw, n_members,
+                           (uint32_t *)ix->bgzf_tabs.p, (unsigned int *)ix->bgzf_err.p);
+        HIPCHK(hipGetLastError());
+    }
+    unsigned int err[4] = {0, 0, 0, 0};
+    uint8_t last_byte = 10;
+    HIPCHK(hipMemcpyAsync(err, ix->bgzf_err.p, sizeof err, hipMemcpyDeviceToHost, ix->stream));
+    if (last_chunk && n_total > 0)
+        HIPCHK(hipMemcpyAsync(&last_byte, d_raw + n_total - 1, 1, hipMemcpyDeviceToHost, ix->stream));
+    HIPCHK(hipStreamSynchronize(ix->stream)); // (CRC32 / ISIZE of every member are checked before a byte is mapped)
+    ix->bgzf_calls++;
+    ix->bgzf_members += n_members;
+    if (err[0]) {
+        static const char *why[] = {"", "header", "reserved block type", "stored block", "code lengths", "Huffman code", "invalid symbol",
+                                    "distance too far back", "more data than ISIZE", "compressed data ended early", "less data than ISIZE",
+                                    "CRC32 mismatch"};
+        ix->bgzf_carry_len = 0;
+        return fail(KMM_ERR_MALFORMED, "kmm_map_bgzf: %u corrupt BGZF member(s); the first starts at compressed byte %llu of the chunk: %s",
+                    err[0], err[1] < n_members ? m_off[err[1]] : 0ull, err[2] < 12 ? why[err[2]] : "?");
+    }
+    int64_t n_raw = n_total;
+    if (last_chunk && n_raw > 0 && last_byte != 10) { // a last line without its newline gets one (as the file readers do)
+        HIPCHK(hipMemsetAsync(d_raw + n_raw, 10, 1, ix->stream));
+        ++n_raw;
+    }
+    int64_t used = 0, recs = 0;
+    if (n_raw > 0)
+        KMMCHK(kmm_map_records(ix, d_raw, n_raw, fmt, k, max_freq, also_revcomp, lut, &used, &recs));
+    if (n_records)
+        *n_records = recs;
+    const int64_t tail = n_raw - used;
+    if (last_chunk && tail > 0) {
+        ix->bgzf_carry_len = 0;
+        return fail(KMM_ERR_MALFORMED, "kmm_map_bgzf: the stream ends with %lld bytes that form no complete record", (long long)tail);
+    }
+    if (tail > 0) {
+        KMMCHK(ensure(ix->bgzf_carry, (size_t)tail + 64)); // (may free and reallocate: a device-wide sync, rare)
+        HIPCHK(hipMemcpyAsync(ix->bgzf_carry.p, d_raw + used, (size_t)tail, hipMemcpyDeviceToDevice, ix->stream));
+    }
+    ix->bgzf_carry_len = tail;
+    HIPCHK(hipEventRecord(ix->bgzf_done[cur], ix->stream));
+    ix->bgzf_used[cur] = true;
+    return KMM_OK;
+}
+
 int kmm_in_index(kmm_index_t *ix, const uint64_t *kmers, int64_t n, uint8_t *out)
 {
     if (!ix)
@@ -2993,6 +3249,10 @@ int kmm_get_param(kmm_index_t *ix, const char *name, int64_t *value)
         *value = ix->host_packed_calls;
     else if (!strcmp(name, "host_packed_record_calls")) // kmm_map_records calls whose sequence lines were packed on the host
         *value = ix->host_packed_record_calls;
+    else if (!strcmp(name, "bgzf_members")) // BGZF members inflated on the GPU by kmm_map_bgzf
+        *value = ix->bgzf_members;
+    else if (!strcmp(name, "bgzf_carry_bytes")) // inflated bytes behind the last complete record, waiting for the next call
+        *value = ix->bgzf_carry_len;
     else if (!strcmp(name, "host_cpu_budget")) // cores the process may keep busy (affinity mask, cgroup quota)
         *value = kmm_hostpack::cpu_budget();
     else if (!strcmp(name, "radix_sub_batch_kmers"))

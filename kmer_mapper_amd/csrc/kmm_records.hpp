@@ -533,6 +533,7 @@ __global__ void __launch_bounds__(256) k_rec_scatter(const uint8_t *__restrict__
     RecLane cur, nxt;
     rec_load64(raw, n32, t_begin * REC_TB + (uint32_t)lane * 64u, cur);
     uint32_t carry_nl = t_begin == 0 ? 1u : (raw[t_begin * REC_TB - 1u] == 10u ? 1u : 0u); // does the byte before the tile end a line?
+    uint32_t carry_cr = t_begin == 0 ? 0u : (raw[t_begin * REC_TB - 1u] == 13u ? 1u : 0u); // ... is it a '\r'?
     uint32_t m_line = 0, m_dst = 0;
     for (uint32_t tile = t_begin; tile < t_end; ++tile) {
         const uint32_t p = tile * REC_TB + (uint32_t)lane * 64u;
@@ -557,6 +558,7 @@ __global__ void __launch_bounds__(256) k_rec_scatter(const uint8_t *__restrict__
         rec_masks64(cur, nl, cr);
         const uint64_t inside = rec_inside64((int32_t)limit - (int32_t)p); // the lane's bytes before the limit
         const uint32_t last_nl = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(nl >> 63), 63) & 1u; // (before the limit is applied)
+        const uint32_t last_cr = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(cr >> 63), 63) & 1u;
         nl &= inside;
         const uint32_t c_nl = (uint32_t)__popcll(nl);
         const uint32_t line_lane = line0 + (wave_scan_incl(c_nl) - c_nl); // line of the lane's first byte
@@ -565,6 +567,8 @@ __global__ void __launch_bounds__(256) k_rec_scatter(const uint8_t *__restrict__
         if (lane == 0)
             prev_nl = carry_nl;
         carry_nl = last_nl;
+        const uint32_t carry_cr_now = carry_cr;
+        carry_cr = last_cr;
         const uint64_t first = ((nl << 1) | prev_nl) & inside;
         // the line phase of every byte (line number mod period), loop-free; sequence lines have phase 1
         uint64_t s0, s1;
@@ -601,9 +605,13 @@ __global__ void __launch_bounds__(256) k_rec_scatter(const uint8_t *__restrict__
                 const uint64_t f = dst0 + pre + (uint32_t)__popcll(seq & ((1ull << i) - 1ull));
                 atomicOr(&start_bits[f >> 5], 1u << (f & 31u));
             }
-            // (a '\r' in the previous lane's last byte: this lane's first byte — if it is on the sequence line — gets the mark)
-            const uint32_t cr_before = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)((cr & seq_line) >> 63), 0x138, 0xF, 0xF, false) & 1u;
-            if (lane != 0 && cr_before && (seq_line & 1ull)) {
+            // (a '\r' in the previous lane's last byte — for lane 0: in the last byte of the tile before, round 5: until then a
+            // '\r' that fell on the last byte of a 4 KiB tile did not break the read — : this lane's first byte, if it is on
+            // the sequence line (a '\r' ends no line: it lies on the same one), gets the mark)
+            uint32_t cr_before = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(cr >> 63), 0x138, 0xF, 0xF, false) & 1u;
+            if (lane == 0)
+                cr_before = carry_cr_now;
+            if (cr_before && (seq_line & 1ull)) {
                 const uint64_t f = dst0 + pre;
                 atomicOr(&start_bits[f >> 5], 1u << (f & 31u));
             }

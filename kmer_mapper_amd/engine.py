@@ -118,9 +118,12 @@ class DeviceIndex:
     def synchronize(self):
         _lib.check(_lib.lib().kmm_synchronize(self._h))
 
-    def get_node_counts(self, out=None):
+    def get_node_counts(self, out=None, pinned=False):
+        """The count vector on the host.  pinned: into a fresh page-locked array (freed with it) — the copy of a large
+        vector then runs at the link's rate."""
         if out is None:
-            out = np.empty(self.max_node_id + 1, dtype=np.uint32)
+            out = (_lib.pinned_array(self.max_node_id + 1, np.uint32) if pinned
+                   else np.empty(self.max_node_id + 1, dtype=np.uint32))
         _lib.check(_lib.lib().kmm_get_node_counts(self._h, out.ctypes.data_as(_P)))
         return out
 
@@ -202,6 +205,24 @@ class DeviceIndex:
                                               int(max_index_lookup_frequency), int(bool(also_revcomp)),
                                               t.ptr, ctypes.byref(consumed), ctypes.byref(n_rec)))
         return consumed.value, n_rec.value
+
+    def map_bgzf(self, comp, n_bytes=None, fmt=_lib.FORMAT_FASTQ, k=31, max_index_lookup_frequency=1000, also_revcomp=False,
+                 lut=None, first=False, last=False):
+        """Map a chunk of a BGZF-compressed FASTQ (fmt=4) / two-line FASTA (fmt=2) file, inflated on the GPU (kmm_map_bgzf).
+        `comp` starts at a member boundary; returns (compressed bytes used, records mapped): continue at comp[used:].  The
+        handle carries the inflated bytes behind the last complete record to the next call; first / last mark the file's
+        first / last chunk."""
+        b = _Arg(comp, np.uint8, "comp")
+        t = _Arg(lut, np.uint8, "lut")
+        n = b.n if n_bytes is None else int(n_bytes)
+        if n > b.n:
+            raise ValueError("n_bytes exceeds the buffer")
+        used = ctypes.c_int64(0)
+        n_rec = ctypes.c_int64(0)
+        flags = (_lib.FORMAT_NEW_STREAM if first else 0) | (_lib.FORMAT_LAST_CHUNK if last else 0)
+        _lib.check(_lib.lib().kmm_map_bgzf(self._h, b.ptr, n, int(fmt) | flags, int(k), int(max_index_lookup_frequency),
+                                           int(bool(also_revcomp)), t.ptr, ctypes.byref(used), ctypes.byref(n_rec)))
+        return used.value, n_rec.value
 
     def map_packed(self, codes, n_bases, n_reads, read_len=0, read_starts=None, k=31, max_index_lookup_frequency=1000,
                    also_revcomp=False):

@@ -54,9 +54,46 @@ def _check_kmers(kmers):
     return kmers
 
 
-def map_kmers_to_graph_index(index, max_node_id, kmers, max_index_lookup_frequency=1000):
+class NodeCountAccumulator:
+    """The SUM of many map_kmers_to_graph_index calls without the per-call traffic.  The reference's callers add the
+    per-chunk vectors up (command_line_interface.py:51,124-130: one `np.zeros(max_node_id + 1)` per chunk, mapper.pyx:37,
+    summed by the pool); reproduced call for call that is a reset, a map and a copy of 4 (max_node_id + 1) bytes to the host
+    PER CHUNK — 400 MB at the 100 M index for a 2.5 MB chunk.  An accumulator keeps ONE count vector in HBM:
+
+        with NodeCountAccumulator(index, max_node_id) as acc:
+            for kmers in chunks:
+                map_kmers_to_graph_index(index, max_node_id, kmers, accumulate_into=acc)     # returns None: nothing moves
+            counts = acc.node_counts()                                                       # fetched once
+
+    Bit-identical to summing the per-call results (uint32 additions wrap like the reference's, mapper.pyx:37,68)."""
+
+    def __init__(self, index, max_node_id, device=0):
+        self._dev = _device_index(index, max_node_id, device)
+        self._dev.reset()
+
+    def map_kmers(self, kmers, max_index_lookup_frequency=1000):
+        self._dev.map_kmers(_check_kmers(kmers), max_index_lookup_frequency)
+
+    def node_counts(self):
+        return self._dev.get_node_counts()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+def map_kmers_to_graph_index(index, max_node_id, kmers, max_index_lookup_frequency=1000, accumulate_into=None):
+    """mapper.pyx:19-72.  accumulate_into (extension): a NodeCountAccumulator of the same index — the call adds to its
+    vector in HBM and returns None instead of a fresh host array."""
     kmers = _check_kmers(kmers)
     dev = _device_index(index, max_node_id)
+    if accumulate_into is not None:
+        if accumulate_into._dev is not dev:
+            raise ValueError("accumulate_into belongs to another index / max_node_id")
+        dev.map_kmers(kmers, max_index_lookup_frequency)
+        return None
     dev.reset()                      # mapper.pyx:37 — a fresh zeroed vector per call
     dev.map_kmers(kmers, max_index_lookup_frequency)
     return dev.get_node_counts()

@@ -177,6 +177,20 @@ def test_host_packed_records_edge_cases_and_error_reports(kmm, syn, oracle):
             dev.reset()
             assert dev.map_records(raw_s, fmt=_lib.FORMAT_FASTQ, k=5) == (raw_s.shape[0], len(reads))
             assert np.array_equal(dev.get_node_counts(), e_split), threads
+        # ... also when the '\r' is the LAST byte of a 4 KiB tile of the device-side compaction / of a host slice (until round 5
+        # the device compaction let k-mers span such a '\r')
+        long_read = g[100:100 + 9000].tobytes()
+        for at in (4095 - 3, 8191 - 3, 4096 - 3):
+            one = np.frombuffer(b"@r\n" + long_read[:at] + b"\r" + long_read[at:] + b"\n+\n" + b"I" * (len(long_read) + 1) + b"\n", dtype=np.uint8)
+            two = np.frombuffer(long_read, dtype=np.uint8)
+            e_two, _ = oracle.map_reads(index, mx, two, np.array([0, at, len(long_read)], dtype=np.int64), 5)
+            for threads in (4, 0):
+                dev.set_param("host_pack_threads", threads)
+                dev.set_param("host_pack_slice_kb", 4)
+                dev.reset()
+                assert dev.map_records(one, fmt=_lib.FORMAT_FASTQ, k=5) == (one.shape[0], 1)
+                assert np.array_equal(dev.get_node_counts(), e_two), (at, threads)
+        dev.set_param("host_pack_slice_kb", 32)
         dev.set_param("host_pack_threads", 4)
         n_host = dev.get_param("host_packed_record_calls")
         # errors: the host packer steps back, the device parser reports

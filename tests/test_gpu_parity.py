@@ -160,6 +160,17 @@ def test_operator_map_kmers_vs_oracle_and_accumulation(kmm, syn, oracle):
             dev.map_kmers(np.ascontiguousarray(part))
         assert np.array_equal(dev.get_node_counts(), expect)
         assert np.array_equal(dev.in_index(km), oracle.in_index(index, km))
+    # the reference's per-chunk pattern through the façade, summed in HBM instead of on the host: one fetch at the end
+    from kmer_mapper_amd.mapper import NodeCountAccumulator
+    parts = [np.ascontiguousarray(p) for p in np.array_split(km, 5)]
+    summed = sum(map_kmers_to_graph_index(index, mx, p).astype(np.uint64) for p in parts).astype(np.uint32)
+    with NodeCountAccumulator(index, mx) as acc:
+        for p in parts:
+            assert map_kmers_to_graph_index(index, mx, p, accumulate_into=acc) is None
+        assert np.array_equal(acc.node_counts(), summed) and np.array_equal(summed, expect)
+    other, _ = syn.make_index(500, seed=53)
+    with pytest.raises(ValueError):
+        map_kmers_to_graph_index(other, other.max_node_id(), km, accumulate_into=acc)
 
 
 def test_device_resident_inputs_and_bound_counts(kmm, syn, oracle):

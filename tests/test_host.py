@@ -426,3 +426,94 @@ def test_host_records_packer_equals_the_device_parsers_rules(tmp_path):
     assert n_refused and n_uniform
     lib = ctypes.CDLL(so)
     assert 1 <= lib.shim_budget() <= (os.cpu_count() or 1)
+
+
+def test_gpu_inflater_decodes_like_zlib_on_the_cpu(tmp_path):
+    """csrc/kmm_gpu_inflate.hpp — the decoder every GPU thread runs on one BGZF member (kmm_map_bgzf) — compiled by itself with
+    g++ and run on the CPU: deflate streams of every block type and compression setting inflate to zlib's bytes, nothing is
+    written behind the output, CRC32 equals zlib's, BGZF member framing is parsed and checked, and damaged streams end in an
+    error code (or in the bytes zlib gives) without a stray access."""
+    import ctypes
+    import struct
+    import subprocess
+    import zlib
+    src = tmp_path / "shim.cpp"
+    src.write_text('#include "kmm_gpu_inflate.hpp"\n#include <vector>\n'
+                   'static std::vector<uint32_t> g_crc;\n'
+                   'static const uint32_t *crcT() { if (g_crc.empty()) { g_crc.resize(2048); for (int k = 0; k < 8; ++k) for (uint32_t b = 0; b < 256; ++b) '
+                   'g_crc[k * 256 + b] = kmm_gz::crc_table_entry(k, b); } return g_crc.data(); }\n'
+                   'extern "C" int gz_stream(const uint8_t *in, uint32_t n_in, uint8_t *out, uint32_t n_out) {\n'
+                   '    std::vector<uint32_t> tab(kmm_gz::TAB_WORDS); return kmm_gz::inflate_stream(in, n_in, out, n_out, tab.data()); }\n'
+                   'extern "C" int gz_member(const uint8_t *m, uint32_t msize, uint8_t *out, uint32_t n_out) {\n'
+                   '    std::vector<uint32_t> tab(kmm_gz::TAB_WORDS); return kmm_gz::inflate_bgzf_member(m, msize, out, n_out, tab.data(), crcT()); }\n'
+                   'extern "C" uint32_t gz_member_size(const uint8_t *p, uint64_t n) { return kmm_gz::bgzf_member_size(p, n); }\n'
+                   'extern "C" uint32_t gz_crc(const uint8_t *p, uint32_t n) { return kmm_gz::crc32_sliced(crcT(), p, n); }\n')
+    so = str(tmp_path / "shim.so")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-I" + os.path.join(ROOT, "kmer_mapper_amd", "csrc"), str(src), "-o", so])
+    lib = ctypes.CDLL(so)
+    lib.gz_stream.argtypes = [ctypes.c_char_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint32]
+    lib.gz_member.argtypes = [ctypes.c_char_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint32]
+    lib.gz_crc.argtypes = [ctypes.c_char_p, ctypes.c_uint32]
+    lib.gz_crc.restype = ctypes.c_uint32
+    lib.gz_member_size.argtypes = [ctypes.c_char_p, ctypes.c_uint64]
+    lib.gz_member_size.restype = ctypes.c_uint32
+    rng = np.random.default_rng(91)
+
+    def deflate(data, level=6, strategy=zlib.Z_DEFAULT_STRATEGY, mem=8):
+        c = zlib.compressobj(level, zlib.DEFLATED, -15, mem, strategy)
+        return c.compress(data) + c.flush()
+
+    def fastq(n):
+        return b"".join(b"@SRR1.%d %d/1\n" % (i, i) + bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=150)) + b"\n+\n" +
+                        bytes(rng.choice(np.frombuffer(b"FFFFFF:,#", dtype=np.uint8), size=150)) + b"\n" for i in range(n))
+
+    datas = [b"", b"a", b"abc" * 1000, bytes(rng.integers(0, 256, size=65000, dtype=np.uint8)), fastq(200), b"A" * 65000,
+             bytes(rng.integers(0, 4, size=40000, dtype=np.uint8)), b"".join(bytes([i % 251]) * (i % 300) for i in range(500))[:65000]]
+    for di, data in enumerate(datas):
+        for level in (0, 1, 6, 9):
+            for strategy in (zlib.Z_DEFAULT_STRATEGY, zlib.Z_FILTERED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FIXED):
+                for mem in (1, 9):
+                    comp = deflate(data, level, strategy, mem)
+                    out = np.full(len(data) + 16, 0xAA, dtype=np.uint8)
+                    assert lib.gz_stream(comp, len(comp), out.ctypes.data, len(data)) == 0, (di, level, strategy, mem)
+                    assert out[:len(data)].tobytes() == data and (out[len(data):] == 0xAA).all(), (di, level, strategy, mem)
+    data = fastq(150)                                       # several blocks, empty stored blocks in between
+    c = zlib.compressobj(6, zlib.DEFLATED, -15)
+    comp = b"".join(c.compress(data[i:i + 5000]) + c.flush(zlib.Z_SYNC_FLUSH if (i // 5000) % 2 else zlib.Z_FULL_FLUSH)
+                    for i in range(0, len(data), 5000)) + c.flush()
+    out = np.zeros(len(data), dtype=np.uint8)
+    assert lib.gz_stream(comp, len(comp), out.ctypes.data, len(data)) == 0 and out.tobytes() == data
+    for n in (0, 1, 7, 8, 9, 1000, 65280):
+        d = bytes(rng.integers(0, 256, size=n, dtype=np.uint8))
+        assert lib.gz_crc(d, n) == (zlib.crc32(d) & 0xFFFFFFFF)
+    for data in datas:
+        payload = deflate(data)
+        bsize = 18 + len(payload) + 8
+        m = (b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", bsize - 1) + payload +
+             struct.pack("<II", zlib.crc32(data) & 0xFFFFFFFF, len(data)))
+        assert lib.gz_member_size(m, len(m)) == len(m) and lib.gz_member_size(m, 17) == 0 and lib.gz_member_size(b"\x1f\x8b\x08\x00" + m[4:], len(m)) == 0
+        out = np.zeros(len(data) + 16, dtype=np.uint8)          # (the decoder may READ 16 bytes behind the write position)
+        assert lib.gz_member(m, len(m), out.ctypes.data, len(data)) == 0 and out[:len(data)].tobytes() == data
+        bad = bytearray(m)
+        bad[-8] ^= 1
+        assert lib.gz_member(bytes(bad), len(m), out.ctypes.data, len(data)) == 11          # CRC32
+        assert lib.gz_member(m, len(m), out.ctypes.data, len(data) + 1) == 1                # ISIZE of the plan != the trailer's
+    data = fastq(200)
+    comp = deflate(data)
+    outcomes = {}
+    for it in range(1500):
+        b = bytearray(comp)
+        for _ in range(int(rng.integers(1, 4))):
+            b[int(rng.integers(0, len(b)))] = int(rng.integers(0, 256))
+        if rng.integers(0, 4) == 0:
+            b = b[:int(rng.integers(0, len(b)))]
+        out = np.zeros(len(data) + 16, dtype=np.uint8)
+        rc = lib.gz_stream(bytes(b), len(b), out.ctypes.data, len(data))
+        outcomes[rc] = outcomes.get(rc, 0) + 1
+        if rc == 0:
+            try:
+                ref = zlib.decompressobj(-15).decompress(bytes(b))
+            except zlib.error:
+                ref = None
+            assert ref is not None and ref[:len(data)] == out[:len(data)].tobytes(), "accepted a stream zlib refuses"
+    assert sum(v for k2, v in outcomes.items() if k2 != 0) > 1000

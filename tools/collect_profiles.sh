@@ -8,7 +8,7 @@ tag=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/prof_$tag
 rm -rf "$out"; mkdir -p "$out"
-common="--steps 4 --warmup 1 --no-cpu-baseline --no-h2d-leg"
+common="--steps 4 --warmup 1 --no-cpu-baseline --no-h2d-leg --no-records-host-leg"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py $common "$@" > $out/stats.json 2> $out/stats.err || exit 1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/fetch -- python3 bench.py $common "$@" > /dev/null 2> $out/fetch.err || exit 1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/write -- python3 bench.py $common "$@" > /dev/null 2> $out/write.err || exit 1
