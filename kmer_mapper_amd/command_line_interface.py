@@ -137,6 +137,8 @@ def map_gpu_raw(index, path, chunk_size, fmt, k, map_reverse_complements=False,
             size = os.stat(path).st_size
             if n_threads > 1 and not str(path).endswith(".gz"):
                 _lib.check(_lib.lib().kmm_host_reserve(min(size // max(world_size, 1) + (1 << 20), 2 << 30)))
+            elif world_size == 1 and _is_bgzf(path):      # the compressed window's page-locked staging (kmm_map_bgzf)
+                _lib.check(_lib.lib().kmm_host_reserve(4 * (min(size, _BGZF_WINDOW) + (1 << 20))))
             prepared["counts"] = _lib.pinned_array(max_node_id + 1, np.uint32)
         except Exception as exc:                         # noqa: BLE001 - an optimisation: the map calls allocate what is missing
             logging.debug("host memory was not prepared ahead: %s", exc)
@@ -258,7 +260,10 @@ def _is_bgzf(path):
     return len(h) == 18 and h[:4] == b"\x1f\x8b\x08\x04" and h[12:14] == b"BC" and h[14:16] == b"\x02\x00"
 
 
-def _map_bgzf_file(dev, path, kfmt, k, max_freq, revcomp, before_fetch, t_start, comp_batch=900 << 20, counts_out=None):
+_BGZF_WINDOW = 1100 << 20      # compressed bytes per kmm_map_bgzf call (~3.5 GiB inflated at FASTQ's usual 3.3 : 1)
+
+
+def _map_bgzf_file(dev, path, kfmt, k, max_freq, revcomp, before_fetch, t_start, comp_batch=None, counts_out=None):
     """`kmer_mapper map -f reads.fq.gz` for BGZF files: compressed chunks of the file mapping -> kmm_map_bgzf (members inflated
     and records parsed on the GPU; the handle carries the bytes behind a chunk's last complete record to the next chunk)."""
     import mmap
@@ -271,7 +276,10 @@ def _map_bgzf_file(dev, path, kfmt, k, max_freq, revcomp, before_fetch, t_start,
                 if hasattr(mm, "madvise") and hasattr(mmap, "MADV_SEQUENTIAL"):
                     mm.madvise(mmap.MADV_SEQUENTIAL)
                 whole = np.frombuffer(mm, dtype=np.uint8)
-                pos, window = 0, int(comp_batch)
+                # equal windows, none small: one GPU thread inflates one member, a call's time is one member's (~tens of
+                # milliseconds) whatever its size
+                n_calls = max(1, -(-size // _BGZF_WINDOW))
+                pos, window = 0, int(comp_batch) if comp_batch else size // n_calls + (1 << 16)
                 while pos < size:
                     end = min(pos + window, size)
                     used, n_rec = dev.map_bgzf(whole[pos:end], fmt=kfmt, k=k, max_index_lookup_frequency=max_freq,

@@ -248,7 +248,7 @@ struct kmm_index {
     // kmm_map_bgzf: BGZF members inflated on the GPU (kmm_gpu_inflate.hpp).  Two sets of buffers in turn (the copy of call
     // i + 1 runs under the kernels of call i); the uncompressed bytes behind a call's last complete record wait in `carry`
     // for the next call.
-    DevBuf bgzf_comp[2], bgzf_raw[2], bgzf_meta[2], bgzf_tabs, bgzf_err, bgzf_carry;
+    DevBuf bgzf_comp[2], bgzf_raw[2], bgzf_meta[2], bgzf_tabs, bgzf_err, bgzf_carry, bgzf_crc;
     hipEvent_t bgzf_done[2] = {nullptr, nullptr};
     bool bgzf_used[2] = {false, false};
     int bgzf_cur = 0;
@@ -1029,6 +1029,7 @@ void kmm_index_destroy(kmm_index_t *ix)
             (void)hipEventDestroy(ix->bgzf_done[i]);
     }
     release(ix->bgzf_tabs);
+    release(ix->bgzf_crc);
     release(ix->bgzf_err);
     release(ix->bgzf_carry);
     ix->pack_pool.reset();
@@ -2594,6 +2595,56 @@ int kmm_map_bgzf(kmm_index_t *ix, const uint8_t *comp, int64_t n_comp, int forma
     HIPCHK(hipSetDevice(ix->device));
     if (new_stream)
         ix->bgzf_carry_len = 0;
+    static const bool verbose = getenv("KMM_VERBOSE") != nullptr;
+    const auto t_0 = std::chrono::steady_clock::now();
+    auto ms_since = [](std::chrono::steady_clock::time_point a) {
+        return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count();
+    };
+    // The compressed bytes go to a page-locked buffer first (from a file mapping — pageable memory — the runtime's own staging
+    // is slow): the packing threads copy 8 MiB pieces, each piece leaves for HBM as soon as it is there; the member chain is
+    // then read from that copy (the mapping's page faults are spread over the threads instead of all landing on the scan).
+    const int cur = ix->bgzf_cur;
+    ix->bgzf_cur ^= 1;
+    if (!ix->bgzf_done[cur])
+        HIPCHK(hipEventCreateWithFlags(&ix->bgzf_done[cur], hipEventDisableTiming));
+    if (ix->bgzf_used[cur])
+        HIPCHK(hipStreamWaitEvent(ix->copy_stream, ix->bgzf_done[cur], 0)); // the kernels that last read these buffers are done
+    KMMCHK(ensure(ix->bgzf_comp[cur], (size_t)n_comp + 64));
+    uint8_t *d_comp = (uint8_t *)ix->bgzf_comp[cur].p;
+    const uint8_t *scan = comp;
+    bool staged = false;
+    if (n_comp > 0 && ensure_pack_pool(ix) && ensure_pinned(ix->pack_pinned, ix->pack_pinned_bytes, (size_t)n_comp + 64)) {
+        constexpr size_t PIECE = (size_t)8 << 20;
+        const size_t n_pieces = ((size_t)n_comp + PIECE - 1) / PIECE;
+        std::vector<std::atomic<uint8_t>> done(n_pieces);
+        for (auto &f : done)
+            f.store(0, std::memory_order_relaxed);
+        std::atomic<size_t> next{0};
+        uint8_t *pin = ix->pack_pinned;
+        ix->pack_pool->start([&](int) {
+            for (;;) {
+                const size_t c = next.fetch_add(1);
+                if (c >= n_pieces)
+                    return;
+                const size_t b0 = c * PIECE, len = (size_t)n_comp - b0 < PIECE ? (size_t)n_comp - b0 : PIECE;
+                memcpy(pin + b0, comp + b0, len);
+                done[c].store(1, std::memory_order_release);
+            }
+        });
+        int rc = KMM_OK;
+        for (size_t c = 0; c < n_pieces && rc == KMM_OK; ++c) {
+            while (!done[c].load(std::memory_order_acquire))
+                std::this_thread::sleep_for(std::chrono::microseconds(30));
+            const size_t b0 = c * PIECE, len = (size_t)n_comp - b0 < PIECE ? (size_t)n_comp - b0 : PIECE;
+            if (hipMemcpyAsync(d_comp + b0, pin + b0, len, hipMemcpyHostToDevice, ix->copy_stream) != hipSuccess)
+                rc = fail(KMM_ERR_HIP, "hipMemcpyAsync of compressed bytes: %s", hipGetErrorString(hipGetLastError()));
+        }
+        ix->pack_pool->wait();
+        KMMCHK(rc);
+        staged = true;
+        scan = pin;
+    }
+    const double ms_stage = ms_since(t_0);
     // the member chain: whole members only, at most 3.5 GiB of inflated bytes per call (the caller comes back with the rest)
     std::vector<unsigned long long> m_off, o_off;
     m_off.push_back(0);
@@ -2602,21 +2653,24 @@ int kmm_map_bgzf(kmm_index_t *ix, const uint8_t *comp, int64_t n_comp, int forma
     const unsigned long long out_cap = (7ull << 29) - (unsigned long long)carry; // 3.5 GiB per call
     uint64_t p = 0;
     while (p + 18 <= (uint64_t)n_comp) {
-        const uint32_t ms = kmm_gz::bgzf_member_size(comp + p, (uint64_t)n_comp - p);
+        const uint32_t ms = kmm_gz::bgzf_member_size(scan + p, (uint64_t)n_comp - p);
         if (!ms) {
             // (a header that needs more bytes than are left is an incomplete member: the caller brings it again)
-            const uint32_t xlen = (uint32_t)comp[p + 10] | ((uint32_t)comp[p + 11] << 8);
-            if (comp[p] == 0x1f && comp[p + 1] == 0x8b && comp[p + 2] == 8 && (comp[p + 3] & 4) && p + 12 + xlen + 8 > (uint64_t)n_comp)
+            const uint32_t xlen = (uint32_t)scan[p + 10] | ((uint32_t)scan[p + 11] << 8);
+            if (scan[p] == 0x1f && scan[p + 1] == 0x8b && scan[p + 2] == 8 && (scan[p + 3] & 4) && p + 12 + xlen + 8 > (uint64_t)n_comp)
                 break;
+            (void)hipStreamSynchronize(ix->copy_stream); // (the page-locked buffer is free again)
             return fail(KMM_ERR_MALFORMED, "kmm_map_bgzf: no BGZF member at compressed byte %llu of the chunk (a gzip file that bgzip did "
                         "not write has no member sizes in its headers: inflate it on the host)", (unsigned long long)p);
         }
         if (p + ms > (uint64_t)n_comp)
             break; // an incomplete member
-        const uint32_t isize = kmm_gz::rd32(comp + p + ms - 4);
-        if ((uint64_t)isize > (uint64_t)ms * 1032ull + 64ull)
+        const uint32_t isize = kmm_gz::rd32(scan + p + ms - 4);
+        if ((uint64_t)isize > (uint64_t)ms * 1032ull + 64ull) {
+            (void)hipStreamSynchronize(ix->copy_stream);
             return fail(KMM_ERR_MALFORMED, "kmm_map_bgzf: member at compressed byte %llu claims %u inflated bytes for %u compressed ones",
                         (unsigned long long)p, isize, ms);
+        }
         if (o_off.back() - (unsigned long long)carry + isize > out_cap && m_off.size() > 1) {
             last_chunk = false; // (the call stops at its own size limit: the caller continues with the same flags)
             break;
@@ -2629,60 +2683,33 @@ int kmm_map_bgzf(kmm_index_t *ix, const uint8_t *comp, int64_t n_comp, int forma
     const int64_t n_used = (int64_t)p, n_total = (int64_t)o_off.back();
     if (consumed_comp)
         *consumed_comp = n_used;
-    if (last_chunk && n_used != n_comp)
+    if (last_chunk && n_used != n_comp) {
+        (void)hipStreamSynchronize(ix->copy_stream);
         return fail(KMM_ERR_MALFORMED, "kmm_map_bgzf: the file ends inside a BGZF member (%lld bytes behind the last whole member)",
                     (long long)(n_comp - n_used));
-    if (n_members == 0 && !(last_chunk && carry > 0))
+    }
+    if (n_members == 0 && !(last_chunk && carry > 0)) {
+        HIPCHK(hipStreamSynchronize(ix->copy_stream)); // (the page-locked buffer is free again)
         return KMM_OK;
-    const int cur = ix->bgzf_cur;
-    ix->bgzf_cur ^= 1;
-    if (!ix->bgzf_done[cur])
-        HIPCHK(hipEventCreateWithFlags(&ix->bgzf_done[cur], hipEventDisableTiming));
-    if (ix->bgzf_used[cur])
-        HIPCHK(hipStreamWaitEvent(ix->copy_stream, ix->bgzf_done[cur], 0)); // the kernels that last read these buffers are done
-    KMMCHK(ensure(ix->bgzf_comp[cur], (size_t)n_used + 64));
+    }
+    const double ms_scan = ms_since(t_0) - ms_stage;
     KMMCHK(ensure(ix->bgzf_raw[cur], (size_t)n_total + 4096));
     KMMCHK(ensure(ix->bgzf_meta[cur], (size_t)(n_members + 1) * 16 + 64));
     KMMCHK(ensure(ix->bgzf_err, 64));
+    if (!ix->bgzf_crc.p) { // the CRC32 tables (slicing by 8), once per handle
+        std::vector<uint32_t> t(8 * 256);
+        for (int kk = 0; kk < 8; ++kk)
+            for (uint32_t bb = 0; bb < 256u; ++bb)
+                t[(size_t)kk * 256 + bb] = kmm_gz::crc_table_entry(kk, bb);
+        KMMCHK(ensure(ix->bgzf_crc, t.size() * 4));
+        HIPCHK(hipMemcpy(ix->bgzf_crc.p, t.data(), t.size() * 4, hipMemcpyHostToDevice));
+    }
     const uint32_t grid_threads = ((n_members < 65536u ? n_members : 65536u) + 63u) / 64u * 64u;
     if (n_members)
-        KMMCHK(ensure(ix->bgzf_tabs, (size_t)grid_threads * kmm_gz::TAB_WORDS * 4));
-    uint8_t *d_comp = (uint8_t *)ix->bgzf_comp[cur].p, *d_raw = (uint8_t *)ix->bgzf_raw[cur].p;
+        KMMCHK(ensure(ix->bgzf_tabs, (size_t)grid_threads * kmm_gz::SCRATCH_BYTES));
+    uint8_t *d_raw = (uint8_t *)ix->bgzf_raw[cur].p;
     unsigned long long *d_moff = (unsigned long long *)ix->bgzf_meta[cur].p, *d_ooff = d_moff + (n_members + 1);
     if (n_members) {
-        // compressed bytes -> HBM.  From a file mapping (pageable memory) the runtime's own staging is slow: the packing threads
-        // copy 8 MiB pieces into the page-locked buffer, each piece leaves as soon as it is there
-        bool staged = false;
-        if (ensure_pack_pool(ix) && ensure_pinned(ix->pack_pinned, ix->pack_pinned_bytes, (size_t)n_used + 64)) {
-            constexpr size_t PIECE = (size_t)8 << 20;
-            const size_t n_pieces = ((size_t)n_used + PIECE - 1) / PIECE;
-            std::vector<std::atomic<uint8_t>> done(n_pieces);
-            for (auto &f : done)
-                f.store(0, std::memory_order_relaxed);
-            std::atomic<size_t> next{0};
-            uint8_t *pin = ix->pack_pinned;
-            ix->pack_pool->start([&](int) {
-                for (;;) {
-                    const size_t c = next.fetch_add(1);
-                    if (c >= n_pieces)
-                        return;
-                    const size_t b0 = c * PIECE, len = (size_t)n_used - b0 < PIECE ? (size_t)n_used - b0 : PIECE;
-                    memcpy(pin + b0, comp + b0, len);
-                    done[c].store(1, std::memory_order_release);
-                }
-            });
-            int rc = KMM_OK;
-            for (size_t c = 0; c < n_pieces && rc == KMM_OK; ++c) {
-                while (!done[c].load(std::memory_order_acquire))
-                    std::this_thread::sleep_for(std::chrono::microseconds(30));
-                const size_t b0 = c * PIECE, len = (size_t)n_used - b0 < PIECE ? (size_t)n_used - b0 : PIECE;
-                if (hipMemcpyAsync(d_comp + b0, pin + b0, len, hipMemcpyHostToDevice, ix->copy_stream) != hipSuccess)
-                    rc = fail(KMM_ERR_HIP, "hipMemcpyAsync of compressed bytes: %s", hipGetErrorString(hipGetLastError()));
-            }
-            ix->pack_pool->wait();
-            KMMCHK(rc);
-            staged = true;
-        }
         if (!staged)
             HIPCHK(hipMemcpyAsync(d_comp, comp, (size_t)n_used, hipMemcpyHostToDevice, ix->copy_stream));
         HIPCHK(hipMemcpyAsync(d_moff, m_off.data(), (size_t)(n_members + 1) * 8, hipMemcpyHostToDevice, ix->copy_stream));
@@ -2695,7 +2722,7 @@ int kmm_map_bgzf(kmm_index_t *ix, const uint8_t *comp, int64_t n_comp, int forma
         HIPCHK(hipMemcpyAsync(d_raw, ix->bgzf_carry.p, (size_t)carry, hipMemcpyDeviceToDevice, ix->stream));
     if (n_members) {
         hipLaunchKernelGGL(kmm_gz::k_inflate_bgzf, dim3(grid_threads / 64u), dim3(64), 0, ix->stream, d_comp, d_moff, d_ooff, d_raw, n_members,
-                           (uint32_t *)ix->bgzf_tabs.p, (unsigned int *)ix->bgzf_err.p);
+                           (uint8_t *)ix->bgzf_tabs.p, (const uint32_t *)ix->bgzf_crc.p, (unsigned int *)ix->bgzf_err.p);
         HIPCHK(hipGetLastError());
     }
     unsigned int err[4] = {0, 0, 0, 0};
@@ -2704,6 +2731,7 @@ int kmm_map_bgzf(kmm_index_t *ix, const uint8_t *comp, int64_t n_comp, int forma
     if (last_chunk && n_total > 0)
         HIPCHK(hipMemcpyAsync(&last_byte, d_raw + n_total - 1, 1, hipMemcpyDeviceToHost, ix->stream));
     HIPCHK(hipStreamSynchronize(ix->stream)); // (CRC32 / ISIZE of every member are checked before a byte is mapped)
+    const double ms_inflate = ms_since(t_0) - ms_scan - ms_stage;
     ix->bgzf_calls++;
     ix->bgzf_members += n_members;
     if (err[0]) {
@@ -2724,6 +2752,10 @@ int kmm_map_bgzf(kmm_index_t *ix, const uint8_t *comp, int64_t n_comp, int forma
         KMMCHK(kmm_map_records(ix, d_raw, n_raw, fmt, k, max_freq, also_revcomp, lut, &used, &recs));
     if (n_records)
         *n_records = recs;
+    if (verbose)
+        fprintf(stderr, "libkmm: kmm_map_bgzf: %u members, %lld -> %lld bytes: member scan %.2f ms, buffers + staging + copy %.2f ms, "
+                "copy tail + inflate kernel %.2f ms, records %.2f ms\n", n_members, (long long)n_used, (long long)n_total, ms_scan, ms_stage,
+                ms_inflate, ms_since(t_0) - ms_scan - ms_stage - ms_inflate);
     const int64_t tail = n_raw - used;
     if (last_chunk && tail > 0) {
         ix->bgzf_carry_len = 0;
