@@ -237,6 +237,8 @@ int kmm_host_free(void *p);
  * page-locked allocation costs ~50 ms per GB: a caller that knows its batch size calls this from another thread while
  * the index is created (kmer_mapper map does), and the first map call finds the buffers ready.  Optional. */
 int kmm_host_reserve(int64_t raw_batch_bytes);
+/* The same for ONE page-locked buffer of `bytes` bytes: what kmm_map_bgzf stages a window of compressed bytes in. */
+int kmm_host_reserve_buffer(int64_t bytes);
 
 /*
  * kmm_extract_kmers — replaces get_kmer_hashes_from_chunk_sequence (util.py:71-75) as an

@@ -41,6 +41,7 @@ SIGNATURES = {
     "kmm_host_alloc": (_c.c_int, [_c.c_size_t, _P]),
     "kmm_host_free": (_c.c_int, [_P]),
     "kmm_host_reserve": (_c.c_int, [_c.c_int64]),
+    "kmm_host_reserve_buffer": (_c.c_int, [_c.c_int64]),
     "kmm_index_create": (_c.c_int, [_P, _P, _c.c_uint64, _P, _P, _P, _c.c_int64, _c.c_int64,
                                     _c.c_int, _P]),
     "kmm_index_destroy": (None, [_P]),

@@ -138,7 +138,7 @@ def map_gpu_raw(index, path, chunk_size, fmt, k, map_reverse_complements=False,
             if n_threads > 1 and not str(path).endswith(".gz"):
                 _lib.check(_lib.lib().kmm_host_reserve(min(size // max(world_size, 1) + (1 << 20), 2 << 30)))
             elif world_size == 1 and _is_bgzf(path):      # the compressed window's page-locked staging (kmm_map_bgzf)
-                _lib.check(_lib.lib().kmm_host_reserve(4 * (min(size, _BGZF_WINDOW) + (1 << 20))))
+                _lib.check(_lib.lib().kmm_host_reserve_buffer(min(size, _BGZF_WINDOW + (1 << 16)) + 4096))
             prepared["counts"] = _lib.pinned_array(max_node_id + 1, np.uint32)
         except Exception as exc:                         # noqa: BLE001 - an optimisation: the map calls allocate what is missing
             logging.debug("host memory was not prepared ahead: %s", exc)
@@ -203,6 +203,7 @@ def map_gpu_raw(index, path, chunk_size, fmt, k, map_reverse_complements=False,
         chunker.close()
         if helper.ident is not None:
             helper.join()
+        logging.info("Waited %.0f ms for the page-locked buffers", (time.perf_counter() - t_start) * 1e3)
         return _map_bgzf_file(dev, path, kfmt, k, max_index_lookup_frequency, map_reverse_complements, before_fetch, t_start,
                               counts_out=prepared.get("counts"))
     try:
@@ -280,6 +281,7 @@ def _map_bgzf_file(dev, path, kfmt, k, max_freq, revcomp, before_fetch, t_start,
                 # milliseconds) whatever its size
                 n_calls = max(1, -(-size // _BGZF_WINDOW))
                 pos, window = 0, int(comp_batch) if comp_batch else size // n_calls + (1 << 16)
+                t_calls = time.perf_counter()
                 while pos < size:
                     end = min(pos + window, size)
                     used, n_rec = dev.map_bgzf(whole[pos:end], fmt=kfmt, k=k, max_index_lookup_frequency=max_freq,
@@ -304,7 +306,10 @@ def _map_bgzf_file(dev, path, kfmt, k, max_freq, revcomp, before_fetch, t_start,
         n_radix, n_direct = dev.get_param("radix_batches"), dev.get_param("direct_batches")
         if before_fetch is not None:
             before_fetch(dev)
+        t_fetch = time.perf_counter()
         node_counts = dev.get_node_counts(out=counts_out)
+        logging.info("%.0f ms in kmm_map_bgzf, %.0f ms more until the node counts were on the host",
+                     (t_fetch - t_calls) * 1e3, (time.perf_counter() - t_fetch) * 1e3)
     finally:
         dt = time.perf_counter() - t_start
         dev.close()

@@ -967,6 +967,22 @@ int kmm_host_reserve(int64_t raw_batch_bytes)
     return KMM_OK;
 }
 
+int kmm_host_reserve_buffer(int64_t bytes)
+{
+    if (bytes < 0)
+        return fail(KMM_ERR_INVALID_ARG, "bytes negative");
+    if (bytes == 0)
+        return KMM_OK;
+    uint8_t *p = nullptr;
+    const size_t take = ((size_t)bytes + 4095) & ~(size_t)4095;
+    if (hipHostMalloc(reinterpret_cast<void **>(&p), take, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(KMM_ERR_NOMEM, "hipHostMalloc(%zu bytes) failed", take);
+    }
+    g_shelf.give(p, take);
+    return KMM_OK;
+}
+
 int kmm_host_free(void *p)
 {
     if (p)
@@ -1921,9 +1937,16 @@ static int map_reads_host_packed(kmm_index_t *ix, const uint8_t *bases, const in
     const size_t code_bytes = ((total + 3) / 4 + 256 + 63) & ~(size_t)63;
     if (!ensure_pack_pool(ix) || !ensure_pinned(ix->pack_pinned, ix->pack_pinned_bytes, code_bytes))
         return KMM_OK; // (no threads / no page-locked memory to be had: the ordinary route)
+    static const bool verbose = getenv("KMM_VERBOSE") != nullptr;
+    const auto t_0 = std::chrono::steady_clock::now();
+    auto ms_since = [](std::chrono::steady_clock::time_point a) {
+        return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count();
+    };
     Stage &s = next_stage(ix);
     KMMCHK(stage_acquire(ix, s));
     KMMCHK(ensure(s.kmers, code_bytes));
+    const double ms_stage = ms_since(t_0);
+    const auto t_1 = std::chrono::steady_clock::now();
     constexpr size_t CHUNK = (size_t)4 << 20;      // bases per packing task (1 MiB packed)
     constexpr size_t GROUP = 8;                    // tasks per copy (8 MiB packed)
     kmm_hostpack::FlatJob job;
@@ -1932,6 +1955,7 @@ static int map_reads_host_packed(kmm_index_t *ix, const uint8_t *bases, const in
     const size_t packed_total = (total + 3) / 4;
     memset(ix->pack_pinned + packed_total, 0, code_bytes - packed_total); // (the halo words pass 1 loads behind the last read)
     int rc = KMM_OK;
+    double ms_in_copy_calls = 0;
     for (size_t c0 = 0; c0 < job.n_chunks && rc == KMM_OK; c0 += GROUP) {
         const size_t c1 = c0 + GROUP < job.n_chunks ? c0 + GROUP : job.n_chunks;
         for (size_t c = c0; c < c1; ++c)
@@ -1939,10 +1963,17 @@ static int map_reads_host_packed(kmm_index_t *ix, const uint8_t *bases, const in
         if (job.bad.load())
             break;
         const size_t b0 = c0 * CHUNK / 4, b1 = c1 == job.n_chunks ? code_bytes : c1 * CHUNK / 4;
+        const auto t_c = std::chrono::steady_clock::now();
         if (hipMemcpyAsync((uint8_t *)s.kmers.p + b0, ix->pack_pinned + b0, b1 - b0, hipMemcpyHostToDevice, ix->copy_stream) != hipSuccess)
             rc = fail(KMM_ERR_HIP, "hipMemcpyAsync of packed reads: %s", hipGetErrorString(hipGetLastError()));
+        if (verbose)
+            ms_in_copy_calls += ms_since(t_c);
     }
     ix->pack_pool->wait();
+    if (verbose)
+        fprintf(stderr, "libkmm: host flat packer: %zu bases, waited %.2f ms for the stage, pack + copies issued %.2f ms (%.1f GB/s; %.2f ms of it "
+                "inside the %zu hipMemcpyAsync calls), %d threads\n", total, ms_stage, ms_since(t_1), (double)total / 1e6 / ms_since(t_1),
+                ms_in_copy_calls, (job.n_chunks + GROUP - 1) / GROUP, ix->host_pack_threads);
     if (rc != KMM_OK || job.bad.load()) {
         // nothing was launched on the handle's stream; the copies issued so far only touched this stage's own buffer
         HIPCHK(hipEventRecord(ix->copied, ix->copy_stream));
@@ -2722,7 +2753,8 @@ int kmm_map_bgzf(kmm_index_t *ix, const uint8_t *comp, int64_t n_comp, int forma
         HIPCHK(hipMemcpyAsync(d_raw, ix->bgzf_carry.p, (size_t)carry, hipMemcpyDeviceToDevice, ix->stream));
     if (n_members) {
         hipLaunchKernelGGL(kmm_gz::k_inflate_bgzf, dim3(grid_threads / 64u), dim3(64), 0, ix->stream, d_comp, d_moff, d_ooff, d_raw, n_members,
-                           (uint8_t *)ix->bgzf_tabs.p, (const uint32_t *)ix->bgzf_crc.p, (unsigned int *)ix->bgzf_err.p);
+                           (uint8_t *)ix->bgzf_tabs.p, (const uint32_t *)ix->bgzf_crc.p, (unsigned int *)ix->bgzf_err.p,
+                           (unsigned long long *)nullptr);
         HIPCHK(hipGetLastError());
     }
     unsigned int err[4] = {0, 0, 0, 0};

@@ -10,15 +10,14 @@
 // straight into the device-side record parser (kmm_records.hpp).
 //
 // How.  One THREAD per member — not a wavefront: a deflate stream is a serial chain (the position of every symbol depends
-// on the one before), lanes cannot share one; but a batch holds tens of thousands of members (3 GB of FASTQ = 47 000),
-// so every lane of every wavefront gets a stream of its own and the chip hides each lane's memory latency behind the
-// other lanes' — the same latency-bound-per-lane, throughput-by-parallelism regime as the direct probe kernel.  A lane
-// keeps its two Huffman tables (literal/length: 10-bit primary + subtables; distance: 8-bit primary + subtables) in a
-// 12 KB scratch area of its own in HBM (L2 / MALL resident while in use), reads its input through a 64-bit bit buffer
-// refilled by 4-byte loads that are requested one refill ahead, writes literals as they come and copies matches in
-// 8-byte pieces where the distance allows.  Stored, fixed and dynamic blocks (RFC 1951); every access is bounds-checked
-// against the member's ISIZE / compressed size, so a damaged member ends in an error code, never in a stray access; the
-// CRC32 of the output is checked on the device too (slicing-by-8, the tables in LDS).
+// on the one before), lanes cannot share one; but a batch holds tens of thousands of members (3 GB of FASTQ = 50 000),
+// so every lane of every wavefront gets a stream of its own.  A lane's time is memory round trips, not arithmetic, and the
+// design follows from that (inflate_stream below): the primary Huffman tables in LDS, lane-interleaved; block headers, symbol
+// decoding and match copies as separate phases that the 64 lanes of a wavefront pass through together; the input through a
+// 16-byte register FIFO; matches copied up to eight at a time with one request per source and at most two per destination.
+// Stored, fixed and dynamic blocks (RFC 1951); every access is bounds-checked against the member's ISIZE / compressed size,
+// so a damaged member ends in an error code, never in a stray access; the CRC32 of the output is checked on the device too
+// (slicing-by-8, the tables in HBM / L2).
 // The decoder is restated from RFC 1951 / RFC 1952 and the BGZF section of the SAM specification; no code taken.
 #pragma once
 
@@ -34,14 +33,33 @@
 namespace kmm_gz {
 
 // Decoding tables: 16-bit entries.  The PRIMARY tables — indexed by the next LIT_PB / DIST_PB bits of the stream — live in
-// LDS on the GPU (576 entries = 1152 bytes per lane, 72 KB per wavefront: two wavefronts per CU), codes longer than that go
-// through a link to a SECONDARY table in the lane's scratch area in HBM (rare: the frequent symbols have the short codes).
+// LDS on the GPU (256 + 32 entries + 32 words of construction state = 640 bytes per lane, 40 KB per wavefront: FOUR
+// wavefronts per CU), codes longer than that go through a link to a SECONDARY table in the lane's scratch area in HBM.
 //   direct entry   bits 0..3 code length (subtables: length beyond the primary bits; 0 = no code), bits 4..12 symbol
 //   link           bit 15, bits 4..14 offset of the subtable in the secondary table, bits 0..3 its index bits
-constexpr int LIT_PB = 9, DIST_PB = 6;
-constexpr int PRIM_LIT = 1 << LIT_PB, PRIM_DIST = 1 << DIST_PB, PRIM_WORDS = PRIM_LIT + PRIM_DIST; // uint16 per lane (LDS)
+// On the GPU entry x of lane i is word x * 64 + i of the wavefront's LDS area (PS = 64): whatever the 64 lanes' indexes are,
+// they fall into 32 different banks (two lanes share a 32-bit word).  With one contiguous table per lane every lane's table
+// started in the same bank, and lanes looking up the same frequent symbol — FASTQ has few — queued up behind each other.
+// Table width against residency, measured (profiles/r05/gz_phase_table_widths.txt; 49 939 members = 3.26 GB of FASTQ):
+// 9 / 6 bits (76 KB, two wavefronts per CU) 65.6 ms, 8 / 6 bits (three) 67.6 ms, 8 / 5 bits (four) 45.9 ms — a lane waits on
+// memory most of its time, and what hides that is another wavefront on the CU, not a rarer subtable lookup.
+#ifndef KMM_GZ_LIT_PB
+#define KMM_GZ_LIT_PB 8
+#endif
+#ifndef KMM_GZ_DIST_PB
+#define KMM_GZ_DIST_PB 5
+#endif
+constexpr int LIT_PB = KMM_GZ_LIT_PB, DIST_PB = KMM_GZ_DIST_PB;
+constexpr int PRIM_LIT = 1 << LIT_PB, PRIM_DIST = 1 << DIST_PB, PRIM_TMP = 32;
+constexpr int PRIM_WORDS = PRIM_LIT + PRIM_DIST + PRIM_TMP;                                          // uint16 per lane (LDS)
 constexpr int SEC_LIT = 1024, SEC_DIST = 1024, SEC_WORDS = SEC_LIT + SEC_DIST;                     // uint16 per lane (HBM)
 constexpr uint32_t LINK = 0x8000u;
+#if defined(__HIP_DEVICE_COMPILE__)
+constexpr int PS = 64; // stride between a lane's consecutive primary entries
+#else
+constexpr int PS = 1;
+#endif
+constexpr int LENS_WORDS = 20; // 320 code lengths, 4 bits each
 
 enum Err {
     OK = 0,
@@ -75,80 +93,97 @@ KMM_HD inline uint32_t rev_bits(uint32_t v, int n)
 KMM_HD inline uint32_t rd16(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8); }
 KMM_HD inline uint32_t rd32(const uint8_t *p) { return rd16(p) | (rd16(p + 2) << 16); }
 
-// Decoding tables of a canonical Huffman code (RFC 1951 3.2.2) from its code lengths: prim[0 .. 2^pb), subtables in
-// sec[0 .. sec_cap).  Two sweeps over the symbols, no temporary arrays: the primary entries of the prefixes that need a
-// subtable first hold the longest code length under them, then the link.  Returns OK or E_TABLE.  allow_incomplete: a
-// distance code may consist of one code.
-KMM_HD inline int build_table(const uint8_t *lens, int n, int pb, uint16_t *prim, uint16_t *sec, int sec_cap, bool allow_incomplete)
+// code length i of a block header (4 bits each, 16 per word)
+KMM_HD inline uint32_t lens_get(const uint64_t *w, int i) { return (uint32_t)(w[i >> 4] >> (4 * (i & 15))) & 15u; }
+
+// Decoding tables of a canonical Huffman code (RFC 1951 3.2.2) from its code lengths lens[at .. at + n) (4 bits each):
+// prim[0 .. 2^pb) (stride PS), subtables in sec[0 .. sec_cap).  tmp: 32 words (stride PS) — symbols per length and the next
+// code of every length: the two arrays the sweeps index by a code length live in LDS, not in the lane's private memory,
+// where every step of such a chain is a round trip to HBM / L2.  Two sweeps over the symbols: the primary entries of the
+// prefixes that need a subtable first hold the longest code length under them, then the link.  Returns OK or E_TABLE.
+// allow_incomplete: a distance code may consist of one code.
+KMM_HD inline int build_table(const uint64_t *lens, int at, int n, int pb, uint16_t *prim, uint16_t *tmp, uint16_t *sec, int sec_cap,
+                              bool allow_incomplete)
 {
-    int count[16];
+    uint16_t *count = tmp, *nx = tmp + 16 * PS;
     for (int i = 0; i < 16; ++i)
-        count[i] = 0;
-    for (int i = 0; i < n; ++i)
-        count[lens[i] & 15]++;
+        count[i * PS] = 0;
+    {
+        uint64_t w = 0;
+        for (int i = 0; i < n; ++i) {
+            const int j = at + i;
+            if (i == 0 || (j & 15) == 0)
+                w = lens[j >> 4] >> (4 * (j & 15));
+            count[(int)(w & 15u) * PS]++;
+            w >>= 4;
+        }
+    }
     if (count[0] == n)
         return E_TABLE;
     int left = 1; // Kraft: code space still free
-    for (int l = 1; l <= 15; ++l) {
-        left = (left << 1) - count[l];
-        if (left < 0)
-            return E_TABLE;
+    bool any_long = false;
+    {
+        uint32_t code = 0, prev = 0;
+        for (int l = 1; l <= 15; ++l) {
+            const uint32_t c = count[l * PS];
+            left = (left << 1) - (int)c;
+            if (left < 0)
+                return E_TABLE;
+            code = (code + prev) << 1;
+            nx[l * PS] = (uint16_t)code;
+            prev = c;
+            any_long = any_long || (l > pb && c);
+        }
     }
     if (left > 0 && !allow_incomplete)
         return E_TABLE;
-    uint32_t first[16];
-    {
-        uint32_t code = 0;
-        first[0] = 0;
-        for (int l = 1; l <= 15; ++l) {
-            code = (code + (l > 1 ? (uint32_t)count[l - 1] : 0u)) << 1;
-            first[l] = code;
-        }
-    }
     const uint32_t psize = 1u << pb, pmask = psize - 1u;
     for (uint32_t i = 0; i < psize; ++i)
-        prim[i] = 0;
-    uint32_t nx[16];
-    bool any_long = false;
-    for (int l = 0; l < 16; ++l)
-        nx[l] = first[l];
-    for (int s = 0; s < n; ++s) { // sweep 1: longest code under every primary index
-        const int l = lens[s] & 15;
-        if (!l)
-            continue;
-        const uint32_t r = rev_bits(nx[l]++, l);
-        if (l > pb) {
-            any_long = true;
-            if ((uint32_t)l > prim[r & pmask])
-                prim[r & pmask] = (uint16_t)l;
-        }
-    }
+        prim[i * PS] = 0;
     if (any_long) {
+        uint64_t w = 0;
+        for (int s = 0; s < n; ++s) { // sweep 1: longest code under every primary index
+            const int j = at + s;
+            if (s == 0 || (j & 15) == 0)
+                w = lens[j >> 4] >> (4 * (j & 15));
+            const int l = (int)(w & 15u);
+            w >>= 4;
+            if (!l)
+                continue;
+            const uint32_t r = rev_bits(nx[l * PS]++, l);
+            if (l > pb && (uint32_t)l > prim[(r & pmask) * PS])
+                prim[(r & pmask) * PS] = (uint16_t)l;
+        }
         uint32_t total = 0;
         for (uint32_t i = 0; i < psize; ++i)
-            if (prim[i]) {
-                const uint32_t sb = (uint32_t)prim[i] - (uint32_t)pb;
+            if (prim[i * PS]) {
+                const uint32_t sb = (uint32_t)prim[i * PS] - (uint32_t)pb;
                 if (!sec || total + (1u << sb) > (uint32_t)sec_cap || total >= 2048u)
                     return E_TABLE;
-                prim[i] = (uint16_t)(LINK | (total << 4) | sb);
+                prim[i * PS] = (uint16_t)(LINK | (total << 4) | sb);
                 total += 1u << sb;
             }
         for (uint32_t i = 0; i < total; ++i)
             sec[i] = 0;
+        for (int l = 1; l <= 15; ++l) // back to every length's first code
+            nx[l * PS] = (uint16_t)(nx[l * PS] - count[l * PS]);
     }
-    for (int l = 0; l < 16; ++l)
-        nx[l] = first[l];
+    uint64_t w = 0;
     for (int s = 0; s < n; ++s) { // sweep 2: the entries
-        const int l = lens[s] & 15;
+        const int j = at + s;
+        if (s == 0 || (j & 15) == 0)
+            w = lens[j >> 4] >> (4 * (j & 15));
+        const int l = (int)(w & 15u);
+        w >>= 4;
         if (!l)
             continue;
-        const uint32_t r = rev_bits(nx[l]++, l);
+        const uint32_t r = rev_bits(nx[l * PS]++, l);
         if (l <= pb) {
             const uint16_t e = (uint16_t)(((uint32_t)s << 4) | (uint32_t)l);
             for (uint32_t i = r; i < psize; i += 1u << l)
-                prim[i] = e;
+                prim[i * PS] = e;
         } else {
-            const uint32_t link = prim[r & pmask], off = (link >> 4) & 0x7FFu, sb = link & 15u;
+            const uint32_t link = prim[(r & pmask) * PS], off = (link >> 4) & 0x7FFu, sb = link & 15u;
             const uint16_t e = (uint16_t)(((uint32_t)s << 4) | (uint32_t)(l - pb));
             for (uint32_t i = r >> pb; i < (1u << sb); i += 1u << (l - pb))
                 sec[off + i] = e;
@@ -234,21 +269,38 @@ KMM_HD inline uint32_t bits_consumed_bytes(const Bits &b)
     return b.pos - 16u - 4u * (uint32_t)b.fw - ((uint32_t)b.cnt >> 3);
 }
 
-// n <= 16 bytes of the 16 in (lo, hi) -> q
+// the first n (1 .. 16) of the 16 bytes in (lo, hi) -> q, exactly: at most two stores, the second one overlapping the first
+// (a byte loop is up to seven store instructions per match, and on the GPU what a wavefront of 64 scattered lanes pays for
+// is the NUMBER of requests, not their size)
 KMM_HD inline void store_upto16(uint8_t *q, uint64_t lo, uint64_t hi, uint32_t n)
 {
     if (n >= 8u) {
         memcpy(q, &lo, 8);
-        if (n == 16u) {
-            memcpy(q + 8, &hi, 8);
-        } else {
-            for (uint32_t j = 8; j < n; ++j)
-                q[j] = (uint8_t)(hi >> (8u * (j - 8u)));
+        if (n > 8u) {
+            const uint32_t s = 8u * (n - 8u); // 8 .. 64
+            const uint64_t tail = s == 64u ? hi : (lo >> s) | (hi << (64u - s));
+            memcpy(q + n - 8u, &tail, 8);
         }
-    } else {
-        for (uint32_t j = 0; j < n; ++j)
-            q[j] = (uint8_t)(lo >> (8u * j));
+    } else if (n >= 4u) {
+        const uint32_t a = (uint32_t)lo, t = (uint32_t)(lo >> (8u * (n - 4u)));
+        memcpy(q, &a, 4);
+        memcpy(q + n - 4u, &t, 4);
+    } else if (n >= 2u) {
+        const uint16_t a = (uint16_t)lo, t = (uint16_t)(lo >> (8u * (n - 2u)));
+        memcpy(q, &a, 2);
+        memcpy(q + n - 2u, &t, 2);
+    } else if (n == 1u) {
+        q[0] = (uint8_t)lo;
     }
+}
+
+// 16 bytes at p (any alignment) in one request
+KMM_HD inline void load16u(const uint8_t *p, uint64_t &lo, uint64_t &hi)
+{
+    struct Pair { uint64_t a, b; } v;
+    memcpy(&v, p, 16);
+    lo = v.a;
+    hi = v.b;
 }
 
 // One deflate stream in[0, n_in) -> out[0, n_out) exactly (the caller's buffer has 16 readable bytes of slack behind
@@ -269,14 +321,20 @@ KMM_HD inline void store_upto16(uint8_t *q, uint64_t lo, uint64_t hi, uint32_t n
 //            pattern shorter than 16) takes a step of its own.
 // A block header (code lengths, table construction: ~0.1 ms of serial work per lane, the first one of all 64 lanes at once)
 // and the rare code longer than the primary tables' index (a subtable in HBM) are the other costs.
-// History (profiles/r05/bgzf_e2e_*.txt, bgzf_v*_kernel_stats.csv; 3.26 GB of FASTQ in 47 000 members, kernel time for 23 000
-// members = 1.5 GB): v1, a plain symbol loop, the match copy inside it, all tables in HBM — 2-3 dependent trips per
-// symbol: ~75 ms; v2, the same as a one-access-per-turn state machine: 74 ms (as many trips, just tidier); v3, primary
-// tables in LDS and up to six literals per turn, one trip per match: 48 ms; v4, this one.
+// History (profiles/r05/bgzf_e2e_*.txt, bgzf_v*_kernel_stats.csv, gz_phase_*.txt; 3.26 GB of FASTQ in 50 000 members): v1, a
+// plain symbol loop, the match copy inside it, all tables in HBM: ~75 ms per 23 000 members; v2, the same as a
+// one-access-per-turn state machine: 74 ms; v3, primary tables in LDS, up to six literals per turn: 48 ms; v4 / v5, decode and
+// copy phases: 34 ms per wavefront whatever the batch, 84 ms for the whole file; v6 (phase timers, tools/gz_phase.py, said:
+// decoding 14 ms, copies 17 ms, CRC 2 ms, headers 0.4 ms per lane): headers as a phase of their own, lane-interleaved tables,
+// the length / distance bases as arithmetic, at most two stores per match, one request per source and per two list entries,
+// eight matches per step (5.2 on average in FASTQ), 8 / 5-bit tables for four wavefronts per CU: 46 ms for the whole file =
+// 71 GB/s of FASTQ out.  What is left is the memory system's request rate: ~28 000 requests per member in the copy phase alone.
 constexpr int DECODE_RUN = 1024;    // symbols per phase A
 constexpr int LIST_CAP = 512;       // matches per phase A (8 bytes each)
+constexpr int GROUP = 8;            // matches per step of phase B
+constexpr int LIST_ALLOC = LIST_CAP + GROUP; // (a step's entry loads may reach GROUP entries behind the last one)
 enum State { S_HDR = 0, S_SYM, S_DONE };
-constexpr int SCRATCH_BYTES = LIST_CAP * 8 + SEC_WORDS * 2; // per lane, in HBM: the match list, then the subtables
+constexpr int SCRATCH_BYTES = LIST_ALLOC * 8 + SEC_WORDS * 2; // per lane, in HBM: the match list, then the subtables
 
 // the bytes of one match: len bytes from `dist` behind q (q = out + position); every load before the first dependent store
 KMM_HD inline void copy_match(uint8_t *q, uint32_t len, uint32_t dist)
@@ -288,13 +346,10 @@ KMM_HD inline void copy_match(uint8_t *q, uint32_t len, uint32_t dist)
         const bool indep = dist >= len;
         while (len) {
             uint64_t a0, a1, b0 = 0, b1 = 0;
-            memcpy(&a0, s, 8);
-            memcpy(&a1, s + 8, 8);
+            load16u(s, a0, a1);
             const bool two = indep && len > 16u;
-            if (two) {
-                memcpy(&b0, s + 16, 8);
-                memcpy(&b1, s + 24, 8);
-            }
+            if (two)
+                load16u(s + 16, b0, b1);
             uint32_t n = len < 16u ? len : 16u;
             store_upto16(q, a0, a1, n);
             q += n;
@@ -312,8 +367,7 @@ KMM_HD inline void copy_match(uint8_t *q, uint32_t len, uint32_t dist)
     }
     // distance 1 .. 15 < len: the last `dist` bytes repeat; the pattern is built once, pc = the largest multiple of dist within 16
     uint64_t d0, d1, p0 = 0, p1 = 0;
-    memcpy(&d0, s, 8);
-    memcpy(&d1, s + 8, 8);
+    load16u(s, d0, d1);
     uint32_t k2 = 0;
     for (uint32_t j = 0; j < 16u; ++j) {
         const uint64_t byte = k2 < 8u ? (d0 >> (8u * k2)) & 0xFFull : (d1 >> (8u * (k2 - 8u))) & 0xFFull;
@@ -333,122 +387,183 @@ KMM_HD inline void copy_match(uint8_t *q, uint32_t len, uint32_t dist)
     }
 }
 
-KMM_HD inline int inflate_stream(const uint8_t *in, uint32_t n_in, uint8_t *out, uint32_t n_out, uint16_t *prim, uint16_t *sec,
-                                 uint64_t *list)
+// Phase timers (tools/gz_phase.hip builds with -DKMM_GZ_TIMERS): 100 MHz ticks a lane spends in [0] block headers,
+// [1] symbol decoding, [2] the match copies, [3] the CRC; [4] block headers seen, [5] rounds of the outer loop, [6] steps of
+// the copy phase, [7] matches.
+#if defined(KMM_GZ_TIMERS)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define KMM_GZ_NOW() wall_clock64()
+#else
+#define KMM_GZ_NOW() 0ull
+#endif
+#define KMM_GZ_T(slot)                                                                                                \
+    do {                                                                                                              \
+        if (tm) {                                                                                                     \
+            const unsigned long long now_ = KMM_GZ_NOW();                                                             \
+            tm[slot] += now_ - t_last;                                                                                \
+            t_last = now_;                                                                                            \
+        }                                                                                                             \
+    } while (0)
+#define KMM_GZ_COUNT(slot, v) do { if (tm) tm[slot] += (v); } while (0)
+#define KMM_GZ_T0 unsigned long long t_last = tm ? KMM_GZ_NOW() : 0ull
+#else
+#define KMM_GZ_T(slot) do { } while (0)
+#define KMM_GZ_COUNT(slot, v) do { } while (0)
+#define KMM_GZ_T0 do { } while (0)
+#endif
+
+// length symbol 257 + s -> (base, extra bits); distance symbol d -> (base, extra bits): RFC 1951 3.2.5's two tables as
+// arithmetic — a table indexed by a lane's own symbol is a gather from memory, a round trip per match
+KMM_HD inline uint32_t len_extra_bits(uint32_t s) { return (s < 8u || s == 28u) ? 0u : (s - 4u) >> 2; }
+KMM_HD inline uint32_t len_base_of(uint32_t s) { return s < 8u ? 3u + s : s == 28u ? 258u : 3u + ((4u + (s & 3u)) << ((s - 4u) >> 2)); }
+KMM_HD inline uint32_t dist_extra_bits(uint32_t d) { return d < 4u ? 0u : (d >> 1) - 1u; }
+KMM_HD inline uint32_t dist_base_of(uint32_t d) { return d < 4u ? 1u + d : 1u + ((2u + (d & 1u)) << ((d >> 1) - 1u)); }
+
+KMM_HD inline void lens_put(uint64_t *w, int i, uint32_t v)
 {
-    // RFC 1951 3.2.5: length codes 257..285, distance codes 0..29
-    const uint16_t len_base[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
-    const uint8_t len_extra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
-    const uint16_t dist_base[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
-    const uint8_t dist_extra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
-    const uint8_t cl_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
-    uint16_t *lit = prim, *dst = prim + PRIM_LIT, *lit2 = sec, *dst2 = sec ? sec + SEC_LIT : nullptr;
+    if ((i & 15) == 0)
+        w[i >> 4] = (uint64_t)v;
+    else
+        w[i >> 4] |= (uint64_t)v << (4 * (i & 15));
+}
+
+// One block header at the bit reader's position (RFC 1951 3.2.3-3.2.7).  A stored block is copied right here.  Returns OK or
+// an Err; *stored = the block was a stored one (no tables made), *final = BFINAL.
+KMM_HD inline int block_header(Bits &b, uint32_t n_in, uint8_t *out, uint32_t n_out, uint32_t &o, uint16_t *prim, uint16_t *sec,
+                               uint32_t *final, bool *stored)
+{
+    uint16_t *lit = prim, *dst = prim + PRIM_LIT * PS, *tmp = prim + (PRIM_LIT + PRIM_DIST) * PS;
+    uint16_t *lit2 = sec, *dst2 = sec ? sec + SEC_LIT : nullptr;
+    bits_refill(b);
+    *final = bits_take(b, 1);
+    const uint32_t type = bits_take(b, 2);
+    *stored = type == 0u;
+    if (type == 3u)
+        return E_BTYPE;
+    if (type == 0u) { // stored: to the next byte boundary, LEN, NLEN, LEN bytes
+        bits_take(b, b.cnt & 7);
+        bits_refill(b);
+        const uint32_t slen = bits_take(b, 16);
+        bits_refill(b);
+        const uint32_t nlen = bits_take(b, 16);
+        if ((slen ^ nlen) != 0xFFFFu)
+            return E_STORED;
+        const uint32_t at = bits_consumed_bytes(b); // (on a byte boundary: the bytes follow in the input as they are)
+        if (at + slen > n_in)
+            return E_STORED;
+        if (o + slen > n_out)
+            return E_OUTPUT;
+        for (uint32_t j = 0; j < slen; ++j)
+            out[o + j] = b.in[at + j];
+        o += slen;
+        bits_start(b, at + slen);
+        return bits_consumed_bytes(b) > n_in ? E_INPUT : OK;
+    }
+    uint64_t lens[LENS_WORDS];
+    int hlit = 288, hdist = 30;
+    if (type == 1u) { // fixed code (RFC 1951 3.2.6): 144 x 8, 112 x 9, 24 x 7, 8 x 8 bits; 30 distance codes of 5
+        for (int i = 0; i < 9; ++i) lens[i] = 0x8888888888888888ull;
+        for (int i = 9; i < 16; ++i) lens[i] = 0x9999999999999999ull;
+        lens[16] = 0x7777777777777777ull;
+        lens[17] = 0x8888888877777777ull;
+        lens[18] = 0x5555555555555555ull;
+        lens[19] = 0x0055555555555555ull;
+    } else {
+        hlit = (int)bits_take(b, 5) + 257;
+        hdist = (int)bits_take(b, 5) + 1;
+        const int hclen = (int)bits_take(b, 4) + 4;
+        if (hlit > 286 || hdist > 30)
+            return E_CODELEN;
+        // the code-length code's lengths arrive in the order 16 17 18 0 8 7 9 6 10 5 11 4 12 3 13 2 14 1 15 (5 bits each below)
+        const uint64_t order_lo = 16ull | 17ull << 5 | 18ull << 10 | 0ull << 15 | 8ull << 20 | 7ull << 25 | 9ull << 30 | 6ull << 35 |
+                                  10ull << 40 | 5ull << 45 | 11ull << 50 | 4ull << 55;
+        const uint64_t order_hi = 12ull | 3ull << 5 | 13ull << 10 | 2ull << 15 | 14ull << 20 | 1ull << 25 | 15ull << 30;
+        uint64_t cl[2] = {0, 0}; // 19 lengths of 3 bits, stored 4 bits each
+        for (int i = 0; i < hclen; ++i) {
+            bits_refill(b);
+            const uint32_t sym = (uint32_t)((i < 12 ? order_lo >> (5 * i) : order_hi >> (5 * (i - 12))) & 31u);
+            const uint64_t v = (uint64_t)bits_take(b, 3) << (4 * (sym & 15u));
+            if (sym < 16u)
+                cl[0] |= v;
+            else
+                cl[1] |= v;
+        }
+        // the code-length code (codes of at most 7 bits): a 7-bit table in the literal table's place (rebuilt below)
+        if (build_table(cl, 0, 19, 7, lit, tmp, nullptr, 0, false) != OK)
+            return E_CODELEN;
+        int i = 0;
+        uint32_t prev = 0;
+        while (i < hlit + hdist) {
+            bits_refill(b);
+            const uint32_t ce = lit[((uint32_t)b.buf & 127u) * PS];
+            const int cl_len = (int)(ce & 15u);
+            if (!cl_len)
+                return E_CODELEN;
+            bits_take(b, cl_len);
+            const uint32_t sym = ce >> 4;
+            if (sym < 16u) {
+                lens_put(lens, i++, sym);
+                prev = sym;
+            } else {
+                int rep;
+                uint32_t v = 0;
+                if (sym == 16u) {
+                    if (i == 0)
+                        return E_CODELEN;
+                    v = prev;
+                    rep = 3 + (int)bits_take(b, 2);
+                } else if (sym == 17u) {
+                    rep = 3 + (int)bits_take(b, 3);
+                } else {
+                    rep = 11 + (int)bits_take(b, 7);
+                }
+                if (i + rep > hlit + hdist)
+                    return E_CODELEN;
+                for (int j = 0; j < rep; ++j)
+                    lens_put(lens, i++, v);
+                prev = v;
+            }
+        }
+        if (lens_get(lens, 256) == 0)
+            return E_TABLE; // no end-of-block code
+    }
+    if (build_table(lens, 0, hlit, LIT_PB, lit, tmp, lit2, SEC_LIT, false) != OK ||
+        build_table(lens, hlit, hdist, DIST_PB, dst, tmp, dst2, SEC_DIST, true) != OK)
+        return E_TABLE;
+    return OK;
+}
+
+KMM_HD inline int inflate_stream(const uint8_t *in, uint32_t n_in, uint8_t *out, uint32_t n_out, uint16_t *prim, uint16_t *sec,
+                                 uint64_t *list, unsigned long long *tm = nullptr)
+{
+    (void)tm;
+    const uint16_t *lit = prim, *dst = prim + PRIM_LIT * PS;
+    const uint16_t *lit2 = sec, *dst2 = sec ? sec + SEC_LIT : nullptr;
     Bits b;
     b.in = in;
     b.n = n_in;
     bits_start(b, 0);
     uint32_t o = 0, final = 0;
     int state = S_HDR;
+    KMM_GZ_T0;
     while (state != S_DONE) {
-        // ---- phase A: decode; literals are stored, matches written down
+        KMM_GZ_COUNT(5, 1);
+        // ---- block header: a phase of its own — the lanes of a wavefront that stand at a header work through it TOGETHER
+        // here (inside the symbol loop each lane's header, thousands of instructions, was executed while the other 63 waited)
+        if (state == S_HDR) {
+            bool stored;
+            const int rc = block_header(b, n_in, out, n_out, o, prim, sec, &final, &stored);
+            if (rc != OK)
+                return rc;
+            state = stored ? (final ? S_DONE : S_HDR) : S_SYM;
+            KMM_GZ_COUNT(4, 1);
+        }
+        KMM_GZ_T(0);
+        // ---- phase A: decode until the block ends; literals are stored, matches written down
         uint32_t n_list = 0;
-        for (int t = 0; t < DECODE_RUN && state != S_DONE && n_list < (uint32_t)LIST_CAP; ++t) {
-            if (state == S_HDR) {
-                bits_refill(b);
-                if ((((uint32_t)b.buf >> 1) & 3u) == 0u && n_list)
-                    break; // (a stored block's bytes are copied right here: the matches written down so far go first)
-                final = bits_take(b, 1);
-                const uint32_t type = bits_take(b, 2);
-                if (type == 3u)
-                    return E_BTYPE;
-                if (type == 0u) { // stored: to the next byte boundary, LEN, NLEN, LEN bytes
-                    bits_take(b, b.cnt & 7);
-                    bits_refill(b);
-                    const uint32_t slen = bits_take(b, 16);
-                    bits_refill(b);
-                    const uint32_t nlen = bits_take(b, 16);
-                    if ((slen ^ nlen) != 0xFFFFu)
-                        return E_STORED;
-                    const uint32_t at = bits_consumed_bytes(b); // (on a byte boundary: the bytes follow in the input as they are)
-                    if (at + slen > n_in)
-                        return E_STORED;
-                    if (o + slen > n_out)
-                        return E_OUTPUT;
-                    for (uint32_t j = 0; j < slen; ++j)
-                        out[o + j] = in[at + j];
-                    o += slen;
-                    bits_start(b, at + slen);
-                    if (bits_consumed_bytes(b) > n_in)
-                        return E_INPUT;
-                    state = final ? S_DONE : S_HDR;
-                    continue;
-                }
-                uint8_t lens[320];
-                int hlit = 288, hdist = 30;
-                if (type == 1u) { // fixed code (RFC 1951 3.2.6)
-                    for (int i = 0; i < 144; ++i) lens[i] = 8;
-                    for (int i = 144; i < 256; ++i) lens[i] = 9;
-                    for (int i = 256; i < 280; ++i) lens[i] = 7;
-                    for (int i = 280; i < 288; ++i) lens[i] = 8;
-                    for (int i = 0; i < 30; ++i) lens[288 + i] = 5;
-                } else {
-                    hlit = (int)bits_take(b, 5) + 257;
-                    hdist = (int)bits_take(b, 5) + 1;
-                    const int hclen = (int)bits_take(b, 4) + 4;
-                    if (hlit > 286 || hdist > 30)
-                        return E_CODELEN;
-                    uint8_t cl[19];
-                    for (int i = 0; i < 19; ++i)
-                        cl[i] = 0;
-                    for (int i = 0; i < hclen; ++i) {
-                        bits_refill(b);
-                        cl[cl_order[i]] = (uint8_t)bits_take(b, 3);
-                    }
-                    // the code-length code (codes of at most 7 bits): a 7-bit table in the literal table's place (rebuilt below)
-                    if (build_table(cl, 19, 7, lit, nullptr, 0, false) != OK)
-                        return E_CODELEN;
-                    int i = 0;
-                    while (i < hlit + hdist) {
-                        bits_refill(b);
-                        const uint32_t ce = lit[(uint32_t)b.buf & 127u];
-                        const int cl_len = (int)(ce & 15u);
-                        if (!cl_len)
-                            return E_CODELEN;
-                        bits_take(b, cl_len);
-                        const uint32_t sym = ce >> 4;
-                        if (sym < 16u) {
-                            lens[i++] = (uint8_t)sym;
-                        } else {
-                            int rep;
-                            uint8_t v = 0;
-                            if (sym == 16u) {
-                                if (i == 0)
-                                    return E_CODELEN;
-                                v = lens[i - 1];
-                                rep = 3 + (int)bits_take(b, 2);
-                            } else if (sym == 17u) {
-                                rep = 3 + (int)bits_take(b, 3);
-                            } else {
-                                rep = 11 + (int)bits_take(b, 7);
-                            }
-                            if (i + rep > hlit + hdist)
-                                return E_CODELEN;
-                            for (int j = 0; j < rep; ++j)
-                                lens[i++] = v;
-                        }
-                    }
-                    if (lens[256] == 0)
-                        return E_TABLE; // no end-of-block code
-                }
-                if (build_table(lens, hlit, LIT_PB, lit, lit2, SEC_LIT, false) != OK ||
-                    build_table(lens + hlit, hdist, DIST_PB, dst, dst2, SEC_DIST, true) != OK)
-                    return E_TABLE;
-                state = S_SYM;
-                continue;
-            }
-            // one symbol
+        for (int t = 0; t < DECODE_RUN && state == S_SYM && n_list < (uint32_t)LIST_CAP; ++t) {
             bits_refill(b);
-            uint32_t e = lit[(uint32_t)b.buf & (uint32_t)(PRIM_LIT - 1)];
+            uint32_t e = lit[((uint32_t)b.buf & (uint32_t)(PRIM_LIT - 1)) * PS];
             if (e & LINK) { // a code longer than the primary index: its subtable (HBM)
                 e = lit2[((e >> 4) & 0x7FFu) + (((uint32_t)b.buf >> LIT_PB) & ((1u << (e & 15u)) - 1u))];
                 if (!(e & 15u))
@@ -474,9 +589,9 @@ KMM_HD inline int inflate_stream(const uint8_t *in, uint32_t n_in, uint8_t *out,
             }
             if (sym > 285u)
                 return E_SYMBOL;
-            const uint32_t len = (uint32_t)len_base[sym - 257u] + bits_take(b, len_extra[sym - 257u]);
+            const uint32_t len = len_base_of(sym - 257u) + bits_take(b, (int)len_extra_bits(sym - 257u));
             bits_refill(b);
-            uint32_t d = dst[(uint32_t)b.buf & (uint32_t)(PRIM_DIST - 1)];
+            uint32_t d = dst[((uint32_t)b.buf & (uint32_t)(PRIM_DIST - 1)) * PS];
             if (d & LINK) {
                 d = dst2[((d >> 4) & 0x7FFu) + (((uint32_t)b.buf >> DIST_PB) & ((1u << (d & 15u)) - 1u))];
                 if (!(d & 15u))
@@ -490,10 +605,7 @@ KMM_HD inline int inflate_stream(const uint8_t *in, uint32_t n_in, uint8_t *out,
             const uint32_t dsym = d >> 4;
             if (dsym > 29u)
                 return E_SYMBOL;
-            const int de = dist_extra[dsym];
-            uint32_t dist = dist_base[dsym];
-            if (de)
-                dist += bits_take(b, de); // (a refill leaves >= 33 bits: 15 + 13 fit)
+            const uint32_t dist = dist_base_of(dsym) + bits_take(b, (int)dist_extra_bits(dsym)); // (a refill leaves >= 33 bits: 15 + 13 fit)
             if (dist > o)
                 return E_DISTANCE;
             if (o + len > n_out)
@@ -501,47 +613,59 @@ KMM_HD inline int inflate_stream(const uint8_t *in, uint32_t n_in, uint8_t *out,
             list[n_list++] = (uint64_t)o | ((uint64_t)len << 32) | ((uint64_t)dist << 41);
             o += len;
         }
-        // ---- phase B: the matches, in order; up to four per step when none of them can depend on another.  The list lies in
-        // HBM: the four entries a step looks at were requested during the step before (entries beyond the end read as an
-        // entry that always goes by itself), so a step costs ONE round trip — its sources'.
+        KMM_GZ_T(1);
+        // ---- phase B: the matches, in order; up to GROUP per step when none of them can depend on another.  The list lies in
+        // HBM: the entries a step looks at were requested during the step before (two per request; entries beyond the end
+        // read as an entry that always goes by itself), so a step costs ONE round trip — its sources'.
         uint32_t i = 0;
-        uint64_t ent[4];
-        for (int x = 0; x < 4; ++x)
-            ent[x] = (uint32_t)x < n_list ? list[x] : ~0ull;
+        uint64_t ent[GROUP];
+        for (int x = 0; x < GROUP; x += 2) {
+            load16u(reinterpret_cast<const uint8_t *>(list + x), ent[x], ent[x + 1]);
+            ent[x] = (uint32_t)x < n_list ? ent[x] : ~0ull;
+            ent[x + 1] = (uint32_t)x + 1u < n_list ? ent[x + 1] : ~0ull;
+        }
         while (i < n_list) {
             const uint32_t o0 = (uint32_t)ent[0], l0 = (uint32_t)(ent[0] >> 32) & 0x1FFu, d0 = (uint32_t)(ent[0] >> 41);
             uint32_t g = 1;
             const bool simple = l0 <= 16u && d0 >= l0;
             if (simple) {
-                for (; g < 4u; ++g) { // (an entry behind the end has length 511: it ends the group)
+                for (; g < (uint32_t)GROUP; ++g) { // (an entry behind the end has length 511: it ends the group)
                     const uint32_t og = (uint32_t)ent[g], lg = (uint32_t)(ent[g] >> 32) & 0x1FFu, dg = (uint32_t)(ent[g] >> 41);
                     if (lg > 16u || dg < lg || og - dg + lg > o0)
                         break;
                 }
             }
             // the next step's entries, and this step's sources: all loads leave before the first is used
-            uint64_t nxt[4];
-            for (int x = 0; x < 4; ++x)
-                nxt[x] = i + g + (uint32_t)x < n_list ? list[i + g + (uint32_t)x] : ~0ull;
-            if (simple) {
-                uint64_t lo[4], hi[4];
-                for (uint32_t x = 0; x < 4u; ++x) {
-                    lo[x] = hi[x] = 0;
-                    if (x < g) {
-                        const uint8_t *src = out + (uint32_t)ent[x] - (uint32_t)(ent[x] >> 41);
-                        memcpy(&lo[x], src, 8);
-                        memcpy(&hi[x], src + 8, 8);
-                    }
+            uint64_t nxt[GROUP];
+            for (int x = 0; x < GROUP; x += 2) {
+                const uint32_t at = i + g + (uint32_t)x;
+                if (at < n_list) {
+                    load16u(reinterpret_cast<const uint8_t *>(list + at), nxt[x], nxt[x + 1]);
+                    nxt[x + 1] = at + 1u < n_list ? nxt[x + 1] : ~0ull;
+                } else {
+                    nxt[x] = nxt[x + 1] = ~0ull;
                 }
-                for (uint32_t x = 0; x < g; ++x)
-                    store_upto16(out + (uint32_t)ent[x], lo[x], hi[x], (uint32_t)(ent[x] >> 32) & 0x1FFu);
+            }
+            if (simple) {
+                uint64_t lo[GROUP], hi[GROUP];
+                for (uint32_t x = 0; x < (uint32_t)GROUP; ++x) {
+                    lo[x] = hi[x] = 0;
+                    if (x < g)
+                        load16u(out + (uint32_t)ent[x] - (uint32_t)(ent[x] >> 41), lo[x], hi[x]);
+                }
+                for (uint32_t x = 0; x < (uint32_t)GROUP; ++x)
+                    if (x < g)
+                        store_upto16(out + (uint32_t)ent[x], lo[x], hi[x], (uint32_t)(ent[x] >> 32) & 0x1FFu);
             } else { // long, or repeating a pattern: by itself
                 copy_match(out + o0, l0, d0);
             }
-            for (int x = 0; x < 4; ++x)
+            for (int x = 0; x < GROUP; ++x)
                 ent[x] = nxt[x];
             i += g;
+            KMM_GZ_COUNT(6, 1);
+            KMM_GZ_COUNT(7, g);
         }
+        KMM_GZ_T(2);
     }
     if (bits_consumed_bytes(b) > n_in)
         return E_INPUT;
@@ -590,12 +714,21 @@ KMM_HD inline uint32_t crc32_sliced(const uint32_t *T, const uint8_t *p, uint32_
 {
     uint32_t c = 0xFFFFFFFFu;
     uint32_t i = 0;
-    for (; i + 8u <= n; i += 8u) {
-        uint64_t w;
-        memcpy(&w, p + i, 8);
+    auto step8 = [&](uint64_t w) {
         const uint32_t lo = (uint32_t)w ^ c, hi = (uint32_t)(w >> 32);
         c = T[7 * 256 + (lo & 0xFFu)] ^ T[6 * 256 + ((lo >> 8) & 0xFFu)] ^ T[5 * 256 + ((lo >> 16) & 0xFFu)] ^ T[4 * 256 + (lo >> 24)] ^
             T[3 * 256 + (hi & 0xFFu)] ^ T[2 * 256 + ((hi >> 8) & 0xFFu)] ^ T[1 * 256 + ((hi >> 16) & 0xFFu)] ^ T[0 * 256 + (hi >> 24)];
+    };
+    for (; i + 16u <= n; i += 16u) { // (one request per 16 bytes of the output)
+        uint64_t w0, w1;
+        load16u(p + i, w0, w1);
+        step8(w0);
+        step8(w1);
+    }
+    for (; i + 8u <= n; i += 8u) {
+        uint64_t w;
+        memcpy(&w, p + i, 8);
+        step8(w);
     }
     for (; i < n; ++i)
         c = (c >> 8) ^ T[(c ^ p[i]) & 0xFFu];
@@ -605,7 +738,7 @@ KMM_HD inline uint32_t crc32_sliced(const uint32_t *T, const uint8_t *p, uint32_
 // One BGZF member at m (its total size msize from the header) -> out[0, n_out), n_out = the trailer's ISIZE as the caller
 // planned it.  crcT: the sliced CRC tables.
 KMM_HD inline int inflate_bgzf_member(const uint8_t *m, uint32_t msize, uint8_t *out, uint32_t n_out, uint16_t *prim, uint16_t *sec,
-                                      uint64_t *list, const uint32_t *crcT)
+                                      uint64_t *list, const uint32_t *crcT, unsigned long long *tm = nullptr)
 {
     if (bgzf_member_size(m, msize) != msize)
         return E_HEADER;
@@ -614,10 +747,13 @@ KMM_HD inline int inflate_bgzf_member(const uint8_t *m, uint32_t msize, uint8_t 
     const uint32_t plen = msize - 12u - xlen - 8u;
     if (rd32(m + msize - 4) != n_out)
         return E_HEADER;
-    const int rc = inflate_stream(payload, plen, out, n_out, prim, sec, list);
+    const int rc = inflate_stream(payload, plen, out, n_out, prim, sec, list, tm);
     if (rc != OK)
         return rc;
-    return crc32_sliced(crcT, out, n_out) == rd32(m + msize - 8) ? OK : E_CRC;
+    KMM_GZ_T0;
+    const bool same = crc32_sliced(crcT, out, n_out) == rd32(m + msize - 8);
+    KMM_GZ_T(3);
+    return same ? OK : E_CRC;
 }
 
 #if defined(__HIPCC__)
@@ -627,16 +763,17 @@ KMM_HD inline int inflate_bgzf_member(const uint8_t *m, uint32_t msize, uint8_t 
 __global__ void __launch_bounds__(64) k_inflate_bgzf(const uint8_t *__restrict__ comp, const unsigned long long *__restrict__ m_off,
                                                      const unsigned long long *__restrict__ o_off, uint8_t *__restrict__ out,
                                                      uint32_t n_members, uint8_t *__restrict__ tabs, const uint32_t *__restrict__ crcT,
-                                                     unsigned int *__restrict__ err)
+                                                     unsigned int *__restrict__ err, unsigned long long *__restrict__ timers)
 {
-    __shared__ uint16_t s_prim[64 * PRIM_WORDS]; // 72 KB: two wavefronts per CU
+    __shared__ uint16_t s_prim[64 * PRIM_WORDS]; // 40 KB: four wavefronts per CU
     const uint32_t slot = blockIdx.x * 64u + threadIdx.x, stride = gridDim.x * 64u;
-    uint16_t *prim = s_prim + threadIdx.x * PRIM_WORDS;
+    uint16_t *prim = s_prim + threadIdx.x;       // entry x of this lane: prim[x * PS]
+    unsigned long long *tm = timers ? timers + (size_t)slot * 8 : nullptr;
     uint64_t *list = reinterpret_cast<uint64_t *>(tabs + (size_t)slot * SCRATCH_BYTES);
     uint16_t *sec = reinterpret_cast<uint16_t *>(list + LIST_CAP);
     for (uint32_t m = slot; m < n_members; m += stride) {
         const unsigned long long a = m_off[m], b = m_off[m + 1], oa = o_off[m], ob = o_off[m + 1];
-        const int rc = inflate_bgzf_member(comp + a, (uint32_t)(b - a), out + oa, (uint32_t)(ob - oa), prim, sec, list, crcT);
+        const int rc = inflate_bgzf_member(comp + a, (uint32_t)(b - a), out + oa, (uint32_t)(ob - oa), prim, sec, list, crcT, tm);
         if (rc != OK) {
             atomicAdd(&err[0], 1u);
             if (atomicMin(&err[1], m) > m)

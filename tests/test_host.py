@@ -443,10 +443,10 @@ def test_gpu_inflater_decodes_like_zlib_on_the_cpu(tmp_path):
                    'static const uint32_t *crcT() { if (g_crc.empty()) { g_crc.resize(2048); for (int k = 0; k < 8; ++k) for (uint32_t b = 0; b < 256; ++b) '
                    'g_crc[k * 256 + b] = kmm_gz::crc_table_entry(k, b); } return g_crc.data(); }\n'
                    'extern "C" int gz_stream(const uint8_t *in, uint32_t n_in, uint8_t *out, uint32_t n_out) {\n'
-                   '    std::vector<uint16_t> prim(kmm_gz::PRIM_WORDS), sec(kmm_gz::SEC_WORDS); std::vector<uint64_t> list(kmm_gz::LIST_CAP);\n'
+                   '    std::vector<uint16_t> prim(kmm_gz::PRIM_WORDS), sec(kmm_gz::SEC_WORDS); std::vector<uint64_t> list(kmm_gz::LIST_ALLOC);\n'
                    '    return kmm_gz::inflate_stream(in, n_in, out, n_out, prim.data(), sec.data(), list.data()); }\n'
                    'extern "C" int gz_member(const uint8_t *m, uint32_t msize, uint8_t *out, uint32_t n_out) {\n'
-                   '    std::vector<uint16_t> prim(kmm_gz::PRIM_WORDS), sec(kmm_gz::SEC_WORDS); std::vector<uint64_t> list(kmm_gz::LIST_CAP);\n'
+                   '    std::vector<uint16_t> prim(kmm_gz::PRIM_WORDS), sec(kmm_gz::SEC_WORDS); std::vector<uint64_t> list(kmm_gz::LIST_ALLOC);\n'
                    '    return kmm_gz::inflate_bgzf_member(m, msize, out, n_out, prim.data(), sec.data(), list.data(), crcT()); }\n'
                    'extern "C" uint32_t gz_member_size(const uint8_t *p, uint64_t n) { return kmm_gz::bgzf_member_size(p, n); }\n'
                    'extern "C" uint32_t gz_crc(const uint8_t *p, uint32_t n) { return kmm_gz::crc32_sliced(crcT(), p, n); }\n')
