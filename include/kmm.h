@@ -325,8 +325,10 @@ int kmm_get_kmer_counts(kmm_index_t *idx, uint32_t *out);
  *   "fine_bits"        experiments: log2 fine partitions per coarse partition of the radix path
  *   "radix_sub_batch_kmers" k-mer slots per sub-batch of the radix path: a larger map call is cut into equal sub-batches,
  *                      each a full run of the passes (the index slices are streamed once per sub-batch); default and
- *                      maximum 2^32 - 2 * 8192 (a coarse partition's k-mers are numbered with 32 bits); halved by the
- *                      library when the batch buffers of that size do not fit the free HBM
+ *                      maximum 2^32 - 2 * 8192 (a coarse partition's k-mers are numbered with 32 bits).  When the batch
+ *                      buffers of that size do not fit the free HBM a call takes one sub-batch more, and again (down to
+ *                      2^28 slots); the size it ran with is "radix_sub_batch_kmers_effective" (read-only), kept for the
+ *                      handle's next 15 calls, after which the caller's value is tried again
  *   "host_pack_threads" the host cores' share of the read bytes — the reference's `-t` (command_line_interface.py:168).  > 0: reads
  *                      that arrive in HOST memory (kmm_map_reads_uniform; kmm_map_reads with host offsets; kmm_map_records
  *                      with FASTQ / two-line FASTA bytes — a file mapping or an inflater's output, pinned or not; default
@@ -349,8 +351,9 @@ int kmm_get_kmer_counts(kmm_index_t *idx, uint32_t *out);
  *   "debug_records_copy_stream" / "debug_records_skip" / "debug_rx_*"  test hooks of tools/records_overlap_bisect.py (run
  *                      the compaction kernels of kmm_map_records on the copy stream, next to the radix passes; skip one
  *                      of them; directory sums of pass 1) and of the tests ("debug_rx_buffer_limit": a pass-1 buffer
- *                      beyond that many bytes counts as out of memory, which halves "radix_sub_batch_kmers";
- *                      "debug_skew_p2_counter": trips the conservation check): not for callers, no effect at 0
+ *                      beyond that many bytes counts as out of memory: the call takes more sub-batches;
+ *                      "debug_skew_p2_counter": trips the conservation check; "debug_bgzf_ring_slot_kb": slot size of
+ *                      kmm_map_bgzf's staging ring): not for callers, no effect at 0
  * Read-only (kmm_get_param): "radix_available", "radix_unavailable_reason" (0 available, 1 modulo >= 2^31, 2 slices too
  *   dense for LDS, 3 out of memory, 4 the index's buckets overlap), "n_partitions", "n_coarse_partitions",
  *   "n_fine_per_coarse", "radix_p2_kmers" / "radix_p3_kmers" / "radix_p2_dropped" (the conservation counters every

@@ -127,8 +127,9 @@ def map_gpu_raw(index, path, chunk_size, fmt, k, map_reverse_complements=False,
     (kmm_map_records): the host only reads (and for .gz inflates) raw bytes."""
     t_index = time.perf_counter()
     max_node_id = index.max_node_id() if hasattr(index, "max_node_id") else int(np.max(index._nodes))
-    # page-locked memory is slow to make (~50 ms per GB): the staging buffers of the host packer and the count vector's
-    # landing place are made by a helper thread WHILE the index is uploaded and repacked, not inside the map phase
+    # page-locked memory is slow to make (~50 ms per GB): the staging buffers of the host packer are made by a helper thread
+    # WHILE the index is uploaded and repacked, not inside the map phase.  (The count vector needs none: kmm_get_node_counts
+    # brings a large vector to ordinary memory through the handle's page-locked ring at the link's rate.)
     import threading
     prepared = {}
 
@@ -137,14 +138,13 @@ def map_gpu_raw(index, path, chunk_size, fmt, k, map_reverse_complements=False,
             size = os.stat(path).st_size
             if n_threads > 1 and not str(path).endswith(".gz"):
                 _lib.check(_lib.lib().kmm_host_reserve(min(size // max(world_size, 1) + (1 << 20), 2 << 30)))
-            elif world_size == 1 and _is_bgzf(path):      # the compressed window's page-locked staging (kmm_map_bgzf)
-                _lib.check(_lib.lib().kmm_host_reserve_buffer(min(size, _BGZF_WINDOW + (1 << 16)) + 4096))
-            prepared["counts"] = _lib.pinned_array(max_node_id + 1, np.uint32)
         except Exception as exc:                         # noqa: BLE001 - an optimisation: the map calls allocate what is missing
             logging.debug("host memory was not prepared ahead: %s", exc)
 
     helper = threading.Thread(target=prepare_host_memory, daemon=True)
-    if _lib.device_count() > 0:
+    # (.gz input needs 128 MB of it, made in 7 ms by the first call that wants it; behind a helper thread the same allocation
+    # came back 100 ms after the index upload it was meant to hide behind: profiles/r05/bgzf_e2e_v6_*.txt)
+    if _lib.device_count() > 0 and n_threads > 1 and not str(path).endswith(".gz"):
         helper.start()
     dev = DeviceIndex.from_index(index, max_node_id, device=device)
     logging.info("Index resident in HBM after %.3f sec (max_node_id scan + upload + repack)", time.perf_counter() - t_index)
@@ -188,22 +188,23 @@ def map_gpu_raw(index, path, chunk_size, fmt, k, map_reverse_complements=False,
     # plain FASTQ / two-line FASTA with host packing: the chunks are views of the file mapping (no copy, nothing pinned)
     use_mmap = (seekable and fmt in ("fastq", "fasta") and dev.get_param("host_pack_threads") > 0
                 and not os.environ.get("KMM_CLI_NO_MMAP"))
-    chunker = (MmapChunker if use_mmap else PrefetchingRawChunker if use_prefetch else RawChunker)(path, batch_bytes, byte_range,
-                                                                                                   pinned=True)
+    # BGZF (.gz written by bgzip / htslib: independent members of <= 64 KiB): the compressed bytes go to the GPU as they lie
+    # in the file mapping, one GPU thread inflates one member, the records are parsed there too (kmm_map_bgzf) — the host's
+    # inflater (10.8 GB/s of FASTQ on 16 cores) is out of the way.  One process only: ranks that share a .gz keep the host reader.
+    # (Decided BEFORE a chunker is made: the prefetching one starts a reader thread and page-locks two batch buffers — making
+    # and freeing those cost this route 100 ms of its map phase until it was noticed.)
+    gpu_inflate = (not seekable and world_size == 1 and fmt in ("fastq", "fasta") and not os.environ.get("KMM_CLI_NO_GPU_INFLATE")
+                   and _is_bgzf(path))
+    chunker = None if gpu_inflate else (MmapChunker if use_mmap else PrefetchingRawChunker if use_prefetch
+                                        else RawChunker)(path, batch_bytes, byte_range, pinned=True)
     owns = (lambda i: True) if (world_size == 1 or seekable) else (lambda i: chunk_owner(i, world_size) == rank)
     # FASTQ and two-line FASTA are parsed as they are; FASTA with wrapped sequence lines is unwrapped on the GPU first
     kfmt = {"fastq": _lib.FORMAT_FASTQ, "fasta": _lib.FORMAT_FASTA2, "fasta_ml": _lib.FORMAT_FASTA}[fmt]
     t_start = time.perf_counter()
     n_reads = n_bytes = 0
-    # BGZF (.gz written by bgzip / htslib: independent members of <= 64 KiB): the compressed bytes go to the GPU as they lie
-    # in the file mapping, one GPU thread inflates one member, the records are parsed there too (kmm_map_bgzf) — the host's
-    # inflater (10.8 GB/s of FASTQ on 16 cores) is out of the way.  One process only: ranks that share a .gz keep the host reader.
-    if (not seekable and world_size == 1 and fmt in ("fastq", "fasta") and not os.environ.get("KMM_CLI_NO_GPU_INFLATE")
-            and _is_bgzf(path)):
-        chunker.close()
+    if gpu_inflate:
         if helper.ident is not None:
             helper.join()
-        logging.info("Waited %.0f ms for the page-locked buffers", (time.perf_counter() - t_start) * 1e3)
         return _map_bgzf_file(dev, path, kfmt, k, max_index_lookup_frequency, map_reverse_complements, before_fetch, t_start,
                               counts_out=prepared.get("counts"))
     try:

@@ -182,6 +182,8 @@ struct PinnedShelf {
     }
 };
 static PinnedShelf g_shelf;
+constexpr size_t RING_SLOT = (size_t)16 << 20;
+constexpr int RING_SLOTS = 8;
 
 
 struct TimedEvent {
@@ -193,6 +195,8 @@ struct kmm_index {
     int device = 0;
     hipStream_t stream = nullptr;      // kernels
     hipStream_t copy_stream = nullptr; // host -> HBM staging, overlaps the previous kernel
+    hipStream_t copy_stream2 = nullptr; // every second slot of the staging ring (a second copy engine)
+    hipEvent_t copied2 = nullptr;
     hipEvent_t copied = nullptr;
     uint4 *buckets = nullptr;
     uint4 *entries = nullptr;
@@ -233,14 +237,18 @@ struct kmm_index {
     int rx_grid_per_cu = 2;   // persistent workgroups of passes 2 and 3 per CU (1: leave room for another stream's kernels)
     int64_t rx_min_units = 0; // auto: batches of at least this many positions / k-mers take the radix path
     int64_t rx_sub_cap = ((int64_t)1 << 32) - 2 * RX_B; // k-mer slots per sub-batch of the radix path ("radix_sub_batch_kmers")
+    int64_t rx_sub_cap_eff = 0;  // > 0: the smaller size an out-of-memory call settled on, tried first by the next calls
+    int rx_sub_cap_eff_age = 0;  // calls since then (at 16 the caller's cap is tried again)
+    int64_t rx_sub_cap_last = 0; // the size the last radix call ran with ("radix_sub_batch_kmers_effective")
     const uint32_t *dbg_T1 = nullptr, *dbg_item_base = nullptr; // the latest sub-batch's tables (debug_rx_* parameters)
     const uint16_t *dbg_start1 = nullptr;
     uint32_t dbg_F1 = 0, dbg_NB = 0;
     int host_pack_threads = 0;     // "host_pack_threads": reads / raw records in host memory are packed to 2 bits per base by that
                                    // many host threads before they cross PCIe (default: min(16, the process's CPU budget))
     std::unique_ptr<kmm_hostpack::Workers> pack_pool; // the packing threads, asleep between calls
-    uint8_t *pack_pinned = nullptr; // page-locked home of the packed batch (kmm_hostpack.hpp)
+    uint8_t *pack_pinned = nullptr; // page-locked home of a packed records batch (kmm_hostpack.hpp)
     size_t pack_pinned_bytes = 0;
+    uint8_t *ring[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; // the page-locked staging ring (ensure_ring)
     uint8_t *pack_bits_pinned = nullptr; // ... and of the read-start bitset of packed raw records
     size_t pack_bits_pinned_bytes = 0;
     int64_t host_packed_calls = 0, host_packed_record_calls = 0;
@@ -250,10 +258,12 @@ struct kmm_index {
     // for the next call.
     DevBuf bgzf_comp[2], bgzf_raw[2], bgzf_meta[2], bgzf_tabs, bgzf_err, bgzf_carry, bgzf_crc;
     hipEvent_t bgzf_done[2] = {nullptr, nullptr};
+    hipEvent_t bgzf_slot_ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; // copies out of the staging ring
     bool bgzf_used[2] = {false, false};
     int bgzf_cur = 0;
     int64_t bgzf_carry_len = 0;
     int64_t bgzf_calls = 0, bgzf_members = 0;
+    int dbg_bgzf_slot_kb = 0;     // test hook ("debug_bgzf_ring_slot_kb"): slot size of kmm_map_bgzf's staging ring (a power of two, >= 4)
     int64_t dbg_rx_buf_limit = 0; // test hook ("debug_rx_buffer_limit"): a pass-1 buffer beyond this many bytes counts as out of memory
     int dbg_rec_copy_stream = 0; // experiments (tools/records_overlap_bisect.py): compaction kernels on the copy stream again,
     int dbg_rec_skip = 0;        // and which of them to leave out (1 count2, 2 scans, 4 scatter, 8 uniform, 16 the large memsets)
@@ -610,11 +620,22 @@ int launch_rx(kmm_index *ix, const ReadsView &rv, const uint64_t *kmers_in, int6
     // case (one k-mer repeated) ALL of a sub-batch's k-mers fall into one coarse partition, hence fewer than 2^32 k-mer
     // slots per sub-batch (r03: 2^31; the 1 B-k-mer index streamed its 14 GB of slices twice per 28 M-read batch).  Every
     // other offset is 64-bit or relative (to a table's first block, to a work item's first item).  Without the HBM for
-    // the buffers of that size the cap is halved (and stays halved for the handle).
+    // the buffers of that size the call takes one sub-batch more, and again, down to 2^28 slots per sub-batch; the handle
+    // remembers the size that fitted ("radix_sub_batch_kmers_effective") for its next 15 calls and then tries the caller's
+    // cap again — an allocation that failed because something else held the memory for a moment does not shrink the handle's
+    // sub-batches for good (round 4 halved "radix_sub_batch_kmers" itself: four failing rounds for a 2^29-slot batch, for ever).
     // Sub-batches of equal size: no small last one.
     int64_t n_sub = 1, max_src = 0;
+    static const bool verbose = getenv("KMM_VERBOSE") != nullptr;
+    const auto t_0 = std::chrono::steady_clock::now();
+    auto ms_since = [](std::chrono::steady_clock::time_point a) {
+        return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count();
+    };
+    if (ix->rx_sub_cap_eff > 0 && ++ix->rx_sub_cap_eff_age >= 16)
+        ix->rx_sub_cap_eff = 0;
+    int64_t cap = ix->rx_sub_cap_eff > 0 && ix->rx_sub_cap_eff < ix->rx_sub_cap ? ix->rx_sub_cap_eff : ix->rx_sub_cap;
     for (;;) {
-        const int64_t cap_src = (ix->rx_sub_cap / RX_B) / X;
+        const int64_t cap_src = (cap / RX_B) / X > 0 ? (cap / RX_B) / X : 1;
         n_sub = (n_src_total + cap_src - 1) / cap_src;
         max_src = n_sub ? (n_src_total + n_sub - 1) / n_sub : cap_src;
         const size_t NBm = (size_t)max_src * X, chunks_m = (NBm + RX_CH - 1) / RX_CH, items_m = NBm + F1 + 1;
@@ -629,13 +650,21 @@ int launch_rx(kmm_index *ix, const ReadsView &rv, const uint64_t *kmers_in, int6
             rc = ensure(ix->rx_buf2, items_m * RX_B * 8);
         if (rc == KMM_OK)
             break;
-        if (rc != KMM_ERR_NOMEM || ix->rx_sub_cap <= ((int64_t)1 << 28) || n_src_total <= 1)
+        if (rc != KMM_ERR_NOMEM || cap <= ((int64_t)1 << 28) || n_src_total <= 1)
             return rc;
         (void)hipGetLastError();
         release(ix->rx_buf1);
         release(ix->rx_buf2);
-        ix->rx_sub_cap /= 2;
+        // the next size that really is smaller: one sub-batch more than this attempt had
+        const int64_t next_src = (n_src_total + n_sub) / (n_sub + 1);
+        cap = next_src * RX_B * X;
+        if (cap < ((int64_t)1 << 28))
+            cap = (int64_t)1 << 28;
+        ix->rx_sub_cap_eff = cap;
+        ix->rx_sub_cap_eff_age = 0;
     }
+    ix->rx_sub_cap_last = cap;
+    const double ms_buffers = ms_since(t_0);
     for (int64_t s0 = 0; s0 < n_src_total; s0 += max_src) {
         const uint32_t n_src = (uint32_t)(n_src_total - s0 < max_src ? n_src_total - s0 : max_src);
         const uint32_t NB = n_src * X;
@@ -758,6 +787,10 @@ int launch_rx(kmm_index *ix, const ReadsView &rv, const uint64_t *kmers_in, int6
         ix->rx_unchecked = true;
     }
     ix->n_radix_batches++;
+    if (verbose && ms_since(t_0) > 20.0)
+        fprintf(stderr, "libkmm: radix passes of %lld positions: %.2f ms for the batch buffers (%zu + %zu + %zu bytes), %.2f ms to issue %lld "
+                "sub-batch(es)\n", (long long)units, ms_buffers, ix->rx_meta.cap, ix->rx_buf1.cap, ix->rx_buf2.cap, ms_since(t_0) - ms_buffers,
+                (long long)n_sub);
     return KMM_OK;
 }
 
@@ -1022,6 +1055,8 @@ void kmm_index_destroy(kmm_index_t *ix)
         (void)hipStreamSynchronize(ix->stream);
     if (ix->copy_stream)
         (void)hipStreamSynchronize(ix->copy_stream);
+    if (ix->copy_stream2)
+        (void)hipStreamSynchronize(ix->copy_stream2);
     for (Stage &s : ix->stage) {
         release(s.bases);
         release(s.offsets);
@@ -1043,6 +1078,9 @@ void kmm_index_destroy(kmm_index_t *ix)
         release(ix->bgzf_meta[i]);
         if (ix->bgzf_done[i])
             (void)hipEventDestroy(ix->bgzf_done[i]);
+        for (int j = i * 4; j < i * 4 + 4; ++j)
+            if (ix->bgzf_slot_ev[j])
+                (void)hipEventDestroy(ix->bgzf_slot_ev[j]);
     }
     release(ix->bgzf_tabs);
     release(ix->bgzf_crc);
@@ -1050,6 +1088,10 @@ void kmm_index_destroy(kmm_index_t *ix)
     release(ix->bgzf_carry);
     ix->pack_pool.reset();
     g_shelf.give(ix->pack_pinned, ix->pack_pinned_bytes);
+    for (uint8_t *&slot : ix->ring) {
+        g_shelf.give(slot, RING_SLOT);
+        slot = nullptr;
+    }
     g_shelf.give(ix->pack_bits_pinned, ix->pack_bits_pinned_bytes);
     for (hipEvent_t e : ix->comm_events)
         (void)hipEventDestroy(e);
@@ -1092,6 +1134,10 @@ void kmm_index_destroy(kmm_index_t *ix)
         (void)g_rccl.CommDestroy(ix->comm);
     if (ix->copy_stream)
         (void)hipStreamDestroy(ix->copy_stream);
+    if (ix->copy_stream2)
+        (void)hipStreamDestroy(ix->copy_stream2);
+    if (ix->copied2)
+        (void)hipEventDestroy(ix->copied2);
     if (ix->stream)
         (void)hipStreamDestroy(ix->stream);
     delete ix;
@@ -1340,6 +1386,8 @@ static int index_create_impl(kmm_index *ix, const int32_t *h2i, const int32_t *n
     ix->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     HIPCHK(hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&ix->copy_stream, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&ix->copy_stream2, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&ix->copied2, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&ix->copied, hipEventDisableTiming));
     for (Stage &s : ix->stage)
         HIPCHK(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
@@ -1575,14 +1623,101 @@ int kmm_synchronize(kmm_index_t *ix)
     return drain(ix);
 }
 
+static bool ensure_pack_pool(kmm_index_t *ix);
+static bool ensure_pinned(uint8_t *&p, size_t &have, size_t want);
+
+// The staging ring: RING_SLOTS page-locked buffers of RING_SLOT bytes, each an allocation of its own.  Host threads fill a
+// slot, a copy engine empties it (or the other way round), and a slot is touched by one side at a time.  Why a ring and not
+// one buffer the size of the batch: (a) 128 MB are made in 7 ms, 750 MB in 40; (b) host threads that write a buffer while a
+// copy engine reads THE SAME buffer lose a third of their rate (16 threads pack 295 GB/s into page-locked memory, 210 while
+// the buffer they are filling is being copied, 264 while another part of the same allocation is, 285 while another
+// allocation is: profiles/r05/host_membw_dma.txt).
+static bool ensure_ring(kmm_index_t *ix)
+{
+    for (int i = 0; i < RING_SLOTS; ++i) {
+        if (ix->ring[i])
+            continue;
+        size_t got = 0;
+        uint8_t *p = g_shelf.take(RING_SLOT, &got);
+        if (p && got != RING_SLOT) { // (a larger buffer someone reserved: not for a slot)
+            g_shelf.give(p, got);
+            p = nullptr;
+        }
+        if (!p && hipHostMalloc(reinterpret_cast<void **>(&p), RING_SLOT, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        ix->ring[i] = p;
+    }
+    for (int i = 0; i < RING_SLOTS; ++i)
+        if (!ix->bgzf_slot_ev[i] && hipEventCreateWithFlags(&ix->bgzf_slot_ev[i], hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+    return true;
+}
+
+// HBM -> PAGEABLE host memory (a fresh numpy array: what get_node_counts hands to the reference's caller).  The runtime's own
+// path for pageable memory moves ~10 GB/s and a page-locked landing buffer costs ~50 ms per GB to make — either way tens of
+// milliseconds for configs[2]'s 400 MB vector, as long as the whole map phase of a 3 GB FASTQ.  So: through the handle's
+// page-locked ring (8 slots of 16 MiB, the one kmm_map_bgzf stages through), the packing threads copying a slot out —
+// and taking the destination's first-touch page faults — while the next slots are in flight: PCIe rate.
+static int fetch_to_pageable(kmm_index_t *ix, uint8_t *dst, const uint8_t *src, size_t bytes, bool *done)
+{
+    *done = false;
+    constexpr size_t SLOT = RING_SLOT;
+    constexpr int SLOTS = RING_SLOTS;
+    if (bytes < 4 * SLOT || !ensure_pack_pool(ix) || !ensure_ring(ix))
+        return KMM_OK;
+    const size_t n_slots = (bytes + SLOT - 1) / SLOT;
+    auto issue = [&](size_t c) -> int {
+        const size_t b0 = c * SLOT, len = bytes - b0 < SLOT ? bytes - b0 : SLOT;
+        HIPCHK(hipMemcpyAsync(ix->ring[c % SLOTS], src + b0, len, hipMemcpyDeviceToHost, ix->copy_stream));
+        HIPCHK(hipEventRecord(ix->bgzf_slot_ev[c % SLOTS], ix->copy_stream));
+        return KMM_OK;
+    };
+    for (size_t c = 0; c < n_slots && c < (size_t)SLOTS; ++c)
+        KMMCHK(issue(c));
+    const int T = ix->pack_pool->size();
+    for (size_t c = 0; c < n_slots; ++c) {
+        HIPCHK(hipEventSynchronize(ix->bgzf_slot_ev[c % SLOTS]));
+        const size_t b0 = c * SLOT, len = bytes - b0 < SLOT ? bytes - b0 : SLOT;
+        const uint8_t *from = ix->ring[c % SLOTS];
+        const size_t per = ((len + (size_t)T - 1) / (size_t)T + 63) & ~(size_t)63;
+        ix->pack_pool->start([=](int w) {
+            const size_t a = (size_t)w * per;
+            if (a < len)
+                memcpy(dst + b0 + a, from + a, len - a < per ? len - a : per);
+        });
+        ix->pack_pool->wait();
+        if (c + SLOTS < n_slots)
+            KMMCHK(issue(c + SLOTS));
+    }
+    *done = true;
+    return KMM_OK;
+}
+
 int kmm_get_node_counts(kmm_index_t *ix, uint32_t *out)
 {
     if (!ix || !out)
         return fail(KMM_ERR_INVALID_ARG, "NULL argument");
     HIPCHK(hipSetDevice(ix->device));
     KMMCHK(drain(ix));
-    HIPCHK(hipMemcpy(out, ix->counts, sizeof(uint32_t) * (size_t)(ix->max_node_id + 1),
-                     is_device_ptr(out) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost));
+    const size_t bytes = sizeof(uint32_t) * (size_t)(ix->max_node_id + 1);
+    hipPointerAttribute_t a;
+    memset(&a, 0, sizeof a);
+    const bool known = hipPointerGetAttributes(&a, out) == hipSuccess;
+    if (!known)
+        (void)hipGetLastError(); // (ordinary host memory the runtime has never seen)
+    const bool on_device = known && (a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged);
+    const bool page_locked = known && a.type == hipMemoryTypeHost;
+    if (!on_device && !page_locked) {
+        bool done = false;
+        KMMCHK(fetch_to_pageable(ix, reinterpret_cast<uint8_t *>(out), reinterpret_cast<const uint8_t *>(ix->counts), bytes, &done));
+        if (done)
+            return KMM_OK;
+    }
+    HIPCHK(hipMemcpy(out, ix->counts, bytes, on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost));
     return KMM_OK;
 }
 
@@ -1934,8 +2069,8 @@ static int map_reads_host_packed(kmm_index_t *ix, const uint8_t *bases, const in
 {
     *done = false;
     const size_t total = (size_t)total_bases;
-    const size_t code_bytes = ((total + 3) / 4 + 256 + 63) & ~(size_t)63;
-    if (!ensure_pack_pool(ix) || !ensure_pinned(ix->pack_pinned, ix->pack_pinned_bytes, code_bytes))
+    const size_t packed_total = (total + 3) / 4, code_bytes = (packed_total + 256 + 63) & ~(size_t)63;
+    if (!ensure_pack_pool(ix) || !ensure_ring(ix))
         return KMM_OK; // (no threads / no page-locked memory to be had: the ordinary route)
     static const bool verbose = getenv("KMM_VERBOSE") != nullptr;
     const auto t_0 = std::chrono::steady_clock::now();
@@ -1947,40 +2082,119 @@ static int map_reads_host_packed(kmm_index_t *ix, const uint8_t *bases, const in
     KMMCHK(ensure(s.kmers, code_bytes));
     const double ms_stage = ms_since(t_0);
     const auto t_1 = std::chrono::steady_clock::now();
-    constexpr size_t CHUNK = (size_t)4 << 20;      // bases per packing task (1 MiB packed)
-    constexpr size_t GROUP = 8;                    // tasks per copy (8 MiB packed)
-    kmm_hostpack::FlatJob job;
-    job.prepare(bases, total, ix->pack_pinned, CHUNK);
-    ix->pack_pool->start([&job](int) { job.run(); });
-    const size_t packed_total = (total + 3) / 4;
-    memset(ix->pack_pinned + packed_total, 0, code_bytes - packed_total); // (the halo words pass 1 loads behind the last read)
+    // Tasks of 4 Mi bases (1 MiB packed) handed out in order; 16 of them fill a slot of the staging ring, a full slot leaves
+    // for HBM (copy stream: under the previous call's kernels and under the packing of the next slots) and is written again
+    // when its copy has landed.
+    constexpr size_t CHUNK = (size_t)4 << 20, PER_SLOT = RING_SLOT / (CHUNK / 4);
+    constexpr int SLOTS = RING_SLOTS;
+    const size_t n_chunks = (total + CHUNK - 1) / CHUNK, n_slots = (n_chunks + PER_SLOT - 1) / PER_SLOT;
+    std::vector<std::atomic<uint32_t>> filled(n_slots);
+    for (auto &f : filled)
+        f.store(0, std::memory_order_relaxed);
+    std::atomic<size_t> next{0}, slots_free{(size_t)SLOTS};
+    std::atomic<bool> stop{false}, bad{false};
+    uint8_t *const *ring = ix->ring;
+    ix->pack_pool->start([&](int) {
+        for (;;) {
+            const size_t c = next.fetch_add(1);
+            if (c >= n_chunks)
+                return;
+            const size_t piece = c / PER_SLOT;
+            int spins = 0;
+            while (piece >= slots_free.load(std::memory_order_acquire) && !stop.load(std::memory_order_relaxed)) {
+                if (++spins < 4000) {
+#if defined(__x86_64__)
+                    __builtin_ia32_pause();
+#endif
+                } else {
+                    std::this_thread::sleep_for(std::chrono::microseconds(50));
+                }
+            }
+            if (stop.load(std::memory_order_relaxed))
+                return;
+            const size_t b0 = c * CHUNK, len = total - b0 < CHUNK ? total - b0 : CHUNK;
+            if (!bad.load(std::memory_order_relaxed) && !kmm_hostpack::pack2(bases + b0, len, ring[piece % SLOTS] + (c % PER_SLOT) * (CHUNK / 4)))
+                bad.store(true);
+            filled[piece].fetch_add(1, std::memory_order_release);
+        }
+    });
     int rc = KMM_OK;
+    size_t landed = 0; // slot-sized pieces whose copy to HBM is known to have finished
     double ms_in_copy_calls = 0;
-    for (size_t c0 = 0; c0 < job.n_chunks && rc == KMM_OK; c0 += GROUP) {
-        const size_t c1 = c0 + GROUP < job.n_chunks ? c0 + GROUP : job.n_chunks;
-        for (size_t c = c0; c < c1; ++c)
-            job.wait_chunk(c);
-        if (job.bad.load())
+    static const bool two_streams = getenv("KMM_H2D_TWO_STREAMS") && atoi(getenv("KMM_H2D_TWO_STREAMS")) != 0; // (experiment)
+    if (two_streams) { // the second stream starts where the first one stands (behind the stage's last reader)
+        HIPCHK(hipEventRecord(ix->copied2, ix->copy_stream));
+        HIPCHK(hipStreamWaitEvent(ix->copy_stream2, ix->copied2, 0));
+    }
+    for (size_t c = 0; c < n_slots && rc == KMM_OK && !bad.load(); ++c) {
+        const size_t first = c * PER_SLOT, want = n_chunks - first < PER_SLOT ? n_chunks - first : PER_SLOT;
+        int idle = 0;
+        while (filled[c].load(std::memory_order_acquire) < (uint32_t)want) {
+            bool did = false;
+            while (landed + SLOTS < n_slots && landed < c) { // slots whose copies have landed go back to the threads
+                if (hipEventQuery(ix->bgzf_slot_ev[landed % SLOTS]) != hipSuccess) {
+                    (void)hipGetLastError(); // ("not ready" is no error to keep)
+                    break;
+                }
+                ++landed;
+                slots_free.store(landed + SLOTS, std::memory_order_release);
+                did = true;
+            }
+            if (!did) {
+                if (++idle < 2000) {
+#if defined(__x86_64__)
+                    __builtin_ia32_pause();
+#endif
+                } else {
+                    std::this_thread::sleep_for(std::chrono::microseconds(20));
+                }
+            }
+        }
+        if (bad.load())
             break;
-        const size_t b0 = c0 * CHUNK / 4, b1 = c1 == job.n_chunks ? code_bytes : c1 * CHUNK / 4;
+        const size_t b0 = c * RING_SLOT, len = packed_total - b0 < RING_SLOT ? packed_total - b0 : RING_SLOT;
         const auto t_c = std::chrono::steady_clock::now();
-        if (hipMemcpyAsync((uint8_t *)s.kmers.p + b0, ix->pack_pinned + b0, b1 - b0, hipMemcpyHostToDevice, ix->copy_stream) != hipSuccess)
-            rc = fail(KMM_ERR_HIP, "hipMemcpyAsync of packed reads: %s", hipGetErrorString(hipGetLastError()));
+#ifdef KMM_EXPERIMENT_PACK_WITHOUT_COPIES // (tools/ab_build.sh only: how fast do the threads pack when nothing is copied? results are garbage)
+        (void)b0; (void)len;
+        if (hipEventRecord(ix->bgzf_slot_ev[c % SLOTS], ix->copy_stream) != hipSuccess)
+            rc = fail(KMM_ERR_HIP, "hipEventRecord: %s", hipGetErrorString(hipGetLastError()));
+#else
+        hipStream_t cs = two_streams && (c & 1) ? ix->copy_stream2 : ix->copy_stream;
+        if (hipMemcpyAsync((uint8_t *)s.kmers.p + b0, ring[c % SLOTS], len, hipMemcpyHostToDevice, cs) != hipSuccess ||
+            hipEventRecord(ix->bgzf_slot_ev[c % SLOTS], cs) != hipSuccess)
+            rc = fail(KMM_ERR_HIP, "copy of packed reads: %s", hipGetErrorString(hipGetLastError()));
+#endif
         if (verbose)
             ms_in_copy_calls += ms_since(t_c);
+        while (rc == KMM_OK && landed + SLOTS < n_slots && landed + SLOTS <= c + 1) { // the ring is full: the oldest copy is waited for
+            if (hipEventSynchronize(ix->bgzf_slot_ev[landed % SLOTS]) != hipSuccess) {
+                rc = fail(KMM_ERR_HIP, "hipEventSynchronize: %s", hipGetErrorString(hipGetLastError()));
+                break;
+            }
+            ++landed;
+            slots_free.store(landed + SLOTS, std::memory_order_release);
+        }
     }
+    if (rc != KMM_OK || bad.load())
+        stop.store(true);
     ix->pack_pool->wait();
+    if (two_streams) { // the first stream stands for both from here on
+        HIPCHK(hipEventRecord(ix->copied2, ix->copy_stream2));
+        HIPCHK(hipStreamWaitEvent(ix->copy_stream, ix->copied2, 0));
+    }
     if (verbose)
         fprintf(stderr, "libkmm: host flat packer: %zu bases, waited %.2f ms for the stage, pack + copies issued %.2f ms (%.1f GB/s; %.2f ms of it "
-                "inside the %zu hipMemcpyAsync calls), %d threads\n", total, ms_stage, ms_since(t_1), (double)total / 1e6 / ms_since(t_1),
-                ms_in_copy_calls, (job.n_chunks + GROUP - 1) / GROUP, ix->host_pack_threads);
-    if (rc != KMM_OK || job.bad.load()) {
+                "inside the %zu copy calls), %d threads\n", total, ms_stage, ms_since(t_1), (double)total / 1e6 / ms_since(t_1),
+                ms_in_copy_calls, n_slots, ix->host_pack_threads);
+    if (rc != KMM_OK || bad.load()) {
         // nothing was launched on the handle's stream; the copies issued so far only touched this stage's own buffer
         HIPCHK(hipEventRecord(ix->copied, ix->copy_stream));
         HIPCHK(hipEventSynchronize(ix->copied));
         ix->cur ^= 1; // (hand the stage back: the ordinary route takes it again)
         return rc;
     }
+    // (the halo words pass 1 loads behind the last read)
+    HIPCHK(hipMemsetAsync((uint8_t *)s.kmers.p + packed_total, 0, code_bytes - packed_total, ix->copy_stream));
     ix->map_calls++;
     ix->host_packed_calls++;
     const uint32_t *start_bits = nullptr;
@@ -2328,8 +2542,14 @@ static int map_records_piece_radix(kmm_index_t *ix, Stage &s, const uint8_t *d_r
 static int map_records_radix_call(kmm_index_t *ix, const uint8_t *raw, int64_t n_bytes, int format, int k, int max_freq,
                                   int also_revcomp, const uint8_t *lut, int64_t *consumed, int64_t *n_records)
 {
+    static const bool verbose = getenv("KMM_VERBOSE") != nullptr;
+    const auto t_0 = std::chrono::steady_clock::now();
+    auto ms_since = [](std::chrono::steady_clock::time_point a) {
+        return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count();
+    };
     Stage &s = next_stage(ix);
     KMMCHK(stage_acquire(ix, s));
+    const double ms_acquire = ms_since(t_0);
     ix->map_calls++;
     bool staged = false;
     const uint8_t *d_lut = nullptr;
@@ -2372,9 +2592,14 @@ static int map_records_radix_call(kmm_index_t *ix, const uint8_t *raw, int64_t n
         *consumed = off;
     if (n_records)
         *n_records = recs;
+    const double ms_compact = ms_since(t_0) - ms_acquire;
     if (flat > 0 && !ix->dbg_rec_skip && !ix->dbg_rec_copy_stream)
         KMMCHK(rec_launch_flat(ix, (const uint32_t *)s.kmers.p, flat, recs, (const uint32_t *)s.start_bits.p, (int64_t)n_words,
                                L > 0 ? L : 0, k, max_freq, also_revcomp));
+    if (verbose)
+        fprintf(stderr, "libkmm: records on the radix path: %lld bytes %s: waited %.2f ms for the stage, census + compaction issued %.2f ms, "
+                "passes issued %.2f ms\n", (long long)n_bytes, on_device ? "in HBM" : "in host memory", ms_acquire, ms_compact,
+                ms_since(t_0) - ms_acquire - ms_compact);
     return stage_release(ix, s, false);
 }
 
@@ -2631,9 +2856,12 @@ int kmm_map_bgzf(kmm_index_t *ix, const uint8_t *comp, int64_t n_comp, int forma
     auto ms_since = [](std::chrono::steady_clock::time_point a) {
         return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count();
     };
-    // The compressed bytes go to a page-locked buffer first (from a file mapping — pageable memory — the runtime's own staging
-    // is slow): the packing threads copy 8 MiB pieces, each piece leaves for HBM as soon as it is there; the member chain is
-    // then read from that copy (the mapping's page faults are spread over the threads instead of all landing on the scan).
+    // The compressed bytes go through a RING of page-locked memory (8 slots of 16 MiB; from a file mapping — pageable memory —
+    // the runtime's own staging is slow, and a page-locked buffer the size of the window costs ~50 ms per GB to make, more
+    // than the whole call): the packing threads copy 1 MiB pieces into the slots, a slot leaves for HBM as soon as it is full
+    // and is refilled when its copy has landed.  The member chain is read from the caller's bytes BEHIND the threads — what
+    // they have copied is mapped into the process, so the walk (two cache lines per member) pays no page fault — and at the
+    // same time: the calling thread has nothing else to do while the threads copy.
     const int cur = ix->bgzf_cur;
     ix->bgzf_cur ^= 1;
     if (!ix->bgzf_done[cur])
@@ -2642,40 +2870,6 @@ int kmm_map_bgzf(kmm_index_t *ix, const uint8_t *comp, int64_t n_comp, int forma
         HIPCHK(hipStreamWaitEvent(ix->copy_stream, ix->bgzf_done[cur], 0)); // the kernels that last read these buffers are done
     KMMCHK(ensure(ix->bgzf_comp[cur], (size_t)n_comp + 64));
     uint8_t *d_comp = (uint8_t *)ix->bgzf_comp[cur].p;
-    const uint8_t *scan = comp;
-    bool staged = false;
-    if (n_comp > 0 && ensure_pack_pool(ix) && ensure_pinned(ix->pack_pinned, ix->pack_pinned_bytes, (size_t)n_comp + 64)) {
-        constexpr size_t PIECE = (size_t)8 << 20;
-        const size_t n_pieces = ((size_t)n_comp + PIECE - 1) / PIECE;
-        std::vector<std::atomic<uint8_t>> done(n_pieces);
-        for (auto &f : done)
-            f.store(0, std::memory_order_relaxed);
-        std::atomic<size_t> next{0};
-        uint8_t *pin = ix->pack_pinned;
-        ix->pack_pool->start([&](int) {
-            for (;;) {
-                const size_t c = next.fetch_add(1);
-                if (c >= n_pieces)
-                    return;
-                const size_t b0 = c * PIECE, len = (size_t)n_comp - b0 < PIECE ? (size_t)n_comp - b0 : PIECE;
-                memcpy(pin + b0, comp + b0, len);
-                done[c].store(1, std::memory_order_release);
-            }
-        });
-        int rc = KMM_OK;
-        for (size_t c = 0; c < n_pieces && rc == KMM_OK; ++c) {
-            while (!done[c].load(std::memory_order_acquire))
-                std::this_thread::sleep_for(std::chrono::microseconds(30));
-            const size_t b0 = c * PIECE, len = (size_t)n_comp - b0 < PIECE ? (size_t)n_comp - b0 : PIECE;
-            if (hipMemcpyAsync(d_comp + b0, pin + b0, len, hipMemcpyHostToDevice, ix->copy_stream) != hipSuccess)
-                rc = fail(KMM_ERR_HIP, "hipMemcpyAsync of compressed bytes: %s", hipGetErrorString(hipGetLastError()));
-        }
-        ix->pack_pool->wait();
-        KMMCHK(rc);
-        staged = true;
-        scan = pin;
-    }
-    const double ms_stage = ms_since(t_0);
     // the member chain: whole members only, at most 3.5 GiB of inflated bytes per call (the caller comes back with the rest)
     std::vector<unsigned long long> m_off, o_off;
     m_off.push_back(0);
@@ -2683,32 +2877,143 @@ int kmm_map_bgzf(kmm_index_t *ix, const uint8_t *comp, int64_t n_comp, int forma
     o_off.push_back((unsigned long long)carry);
     const unsigned long long out_cap = (7ull << 29) - (unsigned long long)carry; // 3.5 GiB per call
     uint64_t p = 0;
-    while (p + 18 <= (uint64_t)n_comp) {
-        const uint32_t ms = kmm_gz::bgzf_member_size(scan + p, (uint64_t)n_comp - p);
-        if (!ms) {
-            // (a header that needs more bytes than are left is an incomplete member: the caller brings it again)
-            const uint32_t xlen = (uint32_t)scan[p + 10] | ((uint32_t)scan[p + 11] << 8);
-            if (scan[p] == 0x1f && scan[p + 1] == 0x8b && scan[p + 2] == 8 && (scan[p + 3] & 4) && p + 12 + xlen + 8 > (uint64_t)n_comp)
-                break;
-            (void)hipStreamSynchronize(ix->copy_stream); // (the page-locked buffer is free again)
+    bool chain_end = false;
+    int chain_err = 0; // 1: no member at p, 2: implausible ISIZE
+    uint32_t bad_isize = 0, bad_ms = 0;
+    // walks the chain through comp[0, limit); all = the limit is the end of the chunk
+    auto scan_upto = [&](uint64_t limit, bool all) {
+        while (!chain_end && p + 18 <= limit) {
+            const uint32_t ms = kmm_gz::bgzf_member_size(comp + p, limit - p);
+            if (!ms) {
+                // (a header that needs more bytes than are in reach: wait for them, or — at the end of the chunk — an
+                // incomplete member that the caller brings again)
+                const uint32_t xlen = (uint32_t)comp[p + 10] | ((uint32_t)comp[p + 11] << 8);
+                if (comp[p] == 0x1f && comp[p + 1] == 0x8b && comp[p + 2] == 8 && (comp[p + 3] & 4) && p + 12 + xlen + 8 > limit) {
+                    chain_end = all;
+                    return;
+                }
+                chain_err = 1;
+                chain_end = true;
+                return;
+            }
+            if (p + ms > limit) {
+                chain_end = all; // (an incomplete member at the end of the chunk)
+                return;
+            }
+            const uint32_t isize = kmm_gz::rd32(comp + p + ms - 4);
+            if ((uint64_t)isize > (uint64_t)ms * 1032ull + 64ull) {
+                chain_err = 2;
+                bad_isize = isize;
+                bad_ms = ms;
+                chain_end = true;
+                return;
+            }
+            if (o_off.back() - (unsigned long long)carry + isize > out_cap && m_off.size() > 1) {
+                last_chunk = false; // (the call stops at its own size limit: the caller continues with the same flags)
+                chain_end = true;
+                return;
+            }
+            p += ms;
+            m_off.push_back(p);
+            o_off.push_back(o_off.back() + isize);
+        }
+        if (all)
+            chain_end = true;
+    };
+    bool staged = false;
+    double ms_scan_inside = 0;
+    // ("debug_bgzf_ring_slot_kb": tests wrap the ring many times with a small input)
+    const size_t SLOT = ix->dbg_bgzf_slot_kb > 0 && ((size_t)ix->dbg_bgzf_slot_kb << 10) < RING_SLOT ? (size_t)ix->dbg_bgzf_slot_kb << 10 : RING_SLOT;
+    const size_t SUB = SLOT < ((size_t)1 << 20) ? SLOT : (size_t)1 << 20;
+    constexpr int SLOTS = RING_SLOTS;
+    if (n_comp > 0 && ensure_pack_pool(ix) && ensure_ring(ix)) {
+        const size_t n_slots = ((size_t)n_comp + SLOT - 1) / SLOT, n_sub = ((size_t)n_comp + SUB - 1) / SUB;
+        std::vector<std::atomic<uint32_t>> filled(n_slots); // 1 MiB pieces copied, per slot-sized piece
+        for (auto &f : filled)
+            f.store(0, std::memory_order_relaxed);
+        std::atomic<size_t> next{0}, slots_free{(size_t)SLOTS}; // slot-sized pieces [0, slots_free) may be written
+        std::atomic<bool> stop{false};
+        uint8_t *const *ring = ix->ring;
+        ix->pack_pool->start([&](int) {
+            for (;;) {
+                const size_t c = next.fetch_add(1);
+                if (c >= n_sub)
+                    return;
+                const size_t piece = c / (SLOT / SUB);
+                int spins = 0;
+                while (piece >= slots_free.load(std::memory_order_acquire) && !stop.load(std::memory_order_relaxed)) {
+                    if (++spins < 2000) {
+#if defined(__x86_64__)
+                        __builtin_ia32_pause();
+#endif
+                    } else
+                        std::this_thread::sleep_for(std::chrono::microseconds(50));
+                }
+                if (stop.load(std::memory_order_relaxed))
+                    return;
+                const size_t b0 = c * SUB, len = (size_t)n_comp - b0 < SUB ? (size_t)n_comp - b0 : SUB;
+                memcpy(ring[piece % SLOTS] + (b0 - piece * SLOT), comp + b0, len);
+                filled[piece].fetch_add(1, std::memory_order_release);
+            }
+        });
+        int rc = KMM_OK;
+        size_t landed = 0; // slot-sized pieces whose copy to HBM is known to have finished
+        for (size_t c = 0; c < n_slots && rc == KMM_OK; ++c) {
+            const size_t b0 = c * SLOT, len = (size_t)n_comp - b0 < SLOT ? (size_t)n_comp - b0 : SLOT;
+            const uint32_t want = (uint32_t)((len + SUB - 1) / SUB);
+            while (filled[c].load(std::memory_order_acquire) < want) {
+                // meanwhile: slots whose copies have landed are handed back, the chain is walked through what is there
+                bool did = false;
+                while (landed + SLOTS < n_slots && landed < c) {
+                    if (hipEventQuery(ix->bgzf_slot_ev[landed % SLOTS]) != hipSuccess) {
+                        (void)hipGetLastError(); // ("not ready" is no error to keep)
+                        break;
+                    }
+                    ++landed;
+                    slots_free.store(landed + SLOTS, std::memory_order_release);
+                    did = true;
+                }
+                if (!chain_end && !chain_err && c > 0) {
+                    const auto t_s = std::chrono::steady_clock::now();
+                    const uint64_t before = p;
+                    scan_upto((uint64_t)b0, false);
+                    ms_scan_inside += ms_since(t_s);
+                    did = did || p != before;
+                }
+                if (!did)
+                    std::this_thread::sleep_for(std::chrono::microseconds(20));
+            }
+            if (hipMemcpyAsync(d_comp + b0, ring[c % SLOTS], len, hipMemcpyHostToDevice, ix->copy_stream) != hipSuccess ||
+                hipEventRecord(ix->bgzf_slot_ev[c % SLOTS], ix->copy_stream) != hipSuccess)
+                rc = fail(KMM_ERR_HIP, "copy of compressed bytes: %s", hipGetErrorString(hipGetLastError()));
+            // a slot is written again only when its copy has landed: the oldest one is waited for when the ring is full
+            while (rc == KMM_OK && landed + SLOTS < n_slots && landed + SLOTS <= c + 1) {
+                if (hipEventSynchronize(ix->bgzf_slot_ev[landed % SLOTS]) != hipSuccess) {
+                    rc = fail(KMM_ERR_HIP, "hipEventSynchronize: %s", hipGetErrorString(hipGetLastError()));
+                    break;
+                }
+                ++landed;
+                slots_free.store(landed + SLOTS, std::memory_order_release);
+            }
+        }
+        if (rc != KMM_OK)
+            stop.store(true);
+        ix->pack_pool->wait();
+        if (rc != KMM_OK) {
+            (void)hipStreamSynchronize(ix->copy_stream);
+            return rc;
+        }
+        staged = true;
+    }
+    const double ms_stage = ms_since(t_0) - ms_scan_inside;
+    scan_upto((uint64_t)n_comp, true);
+    if (chain_err) {
+        (void)hipStreamSynchronize(ix->copy_stream); // (the page-locked ring is free again)
+        if (chain_err == 1)
             return fail(KMM_ERR_MALFORMED, "kmm_map_bgzf: no BGZF member at compressed byte %llu of the chunk (a gzip file that bgzip did "
                         "not write has no member sizes in its headers: inflate it on the host)", (unsigned long long)p);
-        }
-        if (p + ms > (uint64_t)n_comp)
-            break; // an incomplete member
-        const uint32_t isize = kmm_gz::rd32(scan + p + ms - 4);
-        if ((uint64_t)isize > (uint64_t)ms * 1032ull + 64ull) {
-            (void)hipStreamSynchronize(ix->copy_stream);
-            return fail(KMM_ERR_MALFORMED, "kmm_map_bgzf: member at compressed byte %llu claims %u inflated bytes for %u compressed ones",
-                        (unsigned long long)p, isize, ms);
-        }
-        if (o_off.back() - (unsigned long long)carry + isize > out_cap && m_off.size() > 1) {
-            last_chunk = false; // (the call stops at its own size limit: the caller continues with the same flags)
-            break;
-        }
-        p += ms;
-        m_off.push_back(p);
-        o_off.push_back(o_off.back() + isize);
+        return fail(KMM_ERR_MALFORMED, "kmm_map_bgzf: member at compressed byte %llu claims %u inflated bytes for %u compressed ones",
+                    (unsigned long long)p, bad_isize, bad_ms);
     }
     const uint32_t n_members = (uint32_t)(m_off.size() - 1);
     const int64_t n_used = (int64_t)p, n_total = (int64_t)o_off.back();
@@ -3219,6 +3524,7 @@ int kmm_set_param(kmm_index_t *ix, const char *name, int64_t value)
         if (value < 4 * RX_B || value > ((int64_t)1 << 32) - 2 * RX_B)
             return fail(KMM_ERR_INVALID_ARG, "radix_sub_batch_kmers outside [%d, 2^32 - %d]", 4 * RX_B, 2 * RX_B);
         ix->rx_sub_cap = value;
+        ix->rx_sub_cap_eff = 0;
     } else if (!strcmp(name, "comm_overlap_slices")) {
         // kmm_comm_reduce_counts: node ranges whose flush runs under the previous range's reduce (1: flush, then one reduce)
         if (value < 1 || value > 64)
@@ -3273,8 +3579,12 @@ int kmm_set_param(kmm_index_t *ix, const char *name, int64_t value)
         if (value < 0 || value > 65536)
             return fail(KMM_ERR_INVALID_ARG, "host_pack_slice_kb outside [0, 65536]");
         ix->host_pack_slice_kb = value;
+    } else if (!strcmp(name, "debug_bgzf_ring_slot_kb")) {
+        if (value != 0 && (value < 4 || value > (1 << 20) || (value & (value - 1))))
+            return fail(KMM_ERR_INVALID_ARG, "debug_bgzf_ring_slot_kb: 0 or a power of two in [4, 2^20]");
+        ix->dbg_bgzf_slot_kb = (int)value;
     } else if (!strcmp(name, "debug_rx_buffer_limit")) {
-        // test hook of the out-of-memory route of launch_rx (the sub-batch cap is halved until the buffers fit)
+        // test hook of the out-of-memory route of launch_rx (the call takes more sub-batches until the buffers fit)
         ix->dbg_rx_buf_limit = value;
     } else if (!strcmp(name, "debug_records_skip")) {
         ix->dbg_rec_skip = (int)value;
@@ -3321,6 +3631,8 @@ int kmm_get_param(kmm_index_t *ix, const char *name, int64_t *value)
         *value = kmm_hostpack::cpu_budget();
     else if (!strcmp(name, "radix_sub_batch_kmers"))
         *value = ix->rx_sub_cap;
+    else if (!strcmp(name, "radix_sub_batch_kmers_effective"))
+        *value = ix->rx_sub_cap_last;
     else if (!strcmp(name, "comm_overlap_slices"))
         *value = ix->comm_slices;
     else if (!strcmp(name, "comm_sliced_reduces")) // kmm_comm_reduce_counts calls that issued one reduce per node range

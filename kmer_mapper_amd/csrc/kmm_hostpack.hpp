@@ -191,7 +191,11 @@ KMM_AVX512_TARGET inline bool pack2_avx512(const uint8_t *src, size_t n, uint8_t
     const __m512i t0 = _mm512_load_si512(tab128().t), t1 = _mm512_load_si512(tab128().t + 64);
     __m512i flags = _mm512_setzero_si512();
     size_t i = 0;
-    if ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0) {
+    static const bool streaming = [] {
+        const char *env = getenv("KMM_HOSTPACK_STREAMING_STORES"); // (experiments: 0 = ordinary stores)
+        return env ? atoi(env) != 0 : true;
+    }();
+    if (streaming && (reinterpret_cast<uintptr_t>(dst) & 15u) == 0) {
         // streaming stores: the packed codes are read next by the GPU's copy engine, not by this core, and a line that is
         // written whole need not be fetched first (16 threads pack at the host's DRAM rate: every byte not moved counts)
         for (; i + 64 <= n; i += 64) {

@@ -485,6 +485,11 @@ void ahead_main_parallel(kmm_io *h)
     std::vector<uint32_t> crcs((size_t)T), lowest((size_t)T);
     size_t p = 0;
     bool any_member = false, stopped = false;
+    // A file of many SMALL plain-gzip members (cat of small .gz files): a wave planned over the rest of the FILE puts T - 1
+    // speculative chunks into the members behind this one, all thrown away when chunk 0 reaches BFINAL — T-fold work.
+    // So once a member has ended inside the first chunk of its first wave, the next member's first wave is that one chunk
+    // alone, decoded in order; a member that does not end in it goes on in parallel waves as before.
+    int small_run = 0;
     while (p < n && err.empty() && !stopped) {
         if (any_member) { // behind a member: zero padding is skipped, another member must start with the magic
             while (p < n && d[p] == 0)
@@ -509,6 +514,7 @@ void ahead_main_parallel(kmm_io *h)
         size_t hist = 0; // real bytes at the end of windows[0]
         bool final = false;
         int barren = 0;  // waves in a row whose byte ranges held no dynamic block start (stored blocks: incompressible data)
+        int waves = 0;
         while (!final && err.empty() && !stopped) {
             const size_t cur_byte = (size_t)(cur_bit >> 3), left = n - cur_byte;
             size_t csize = left / (size_t)(2 * T);
@@ -519,7 +525,10 @@ void ahead_main_parallel(kmm_io *h)
             if (barren >= 2) { // no starting points to be found: one chunk per wave, decoded in order, no search
                 csize *= (size_t)n_ch;
                 n_ch = 1;
+            } else if (waves == 0 && small_run > 0) { // the members before this one were small: see above
+                n_ch = 1;
             }
+            ++waves;
             const uint64_t wave_end_bit = (uint64_t)std::min(n, cur_byte + (size_t)n_ch * csize) * 8;
             // phase A: where the chunks start
             const bool dbg = getenv("KMM_IO_DEBUG") != nullptr;
@@ -592,6 +601,8 @@ void ahead_main_parallel(kmm_io *h)
             if (!err.empty())
                 break;
             barren = (n_ch > 1 && ok.size() == 1) ? barren + 1 : (n_ch > 1 ? 0 : barren);
+            if (waves == 1) // did the member end inside the first chunk's byte range?
+                small_run = (cur->final_seen && (cur->end_bit >> 3) <= (uint64_t)(cur_byte + csize)) ? small_run + 1 : 0;
             // the windows in order (32 KiB each), then every accepted chunk in parallel
             const double t_c = now();
             for (size_t q = 0; q < ok.size(); ++q) {

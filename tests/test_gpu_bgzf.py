@@ -92,6 +92,14 @@ def test_bgzf_members_inflated_on_the_gpu_give_the_oracles_counts(kmm, syn, orac
                 assert np.array_equal(dev.get_node_counts(), expect), (path, step)
                 assert dev.get_param("bgzf_carry_bytes") == 0
         assert dev.get_param("bgzf_members") > 0
+        # the page-locked staging ring wrapped hundreds of times (8 slots of 4 KiB / 64 KiB instead of 16 MiB): same counts
+        comp = _bgzf(raw, level=level, strategy=strategy)
+        for slot_kb in (4, 64):
+            dev.set_param("debug_bgzf_ring_slot_kb", slot_kb)
+            dev.reset()
+            assert _feed(dev, comp, _lib.FORMAT_FASTQ, 31, 1 << 30) == len(reads)
+            assert np.array_equal(dev.get_node_counts(), expect), slot_kb
+        dev.set_param("debug_bgzf_ring_slot_kb", 0)
 
 
 def test_bgzf_two_line_fasta_and_a_last_line_without_newline(kmm, syn, oracle):

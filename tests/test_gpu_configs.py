@@ -221,7 +221,7 @@ def test_configs4_index_on_one_gpu(kmm, oracle):
 
 def test_sub_batch_cap_is_halved_when_the_buffers_do_not_fit(kmm, oracle):
     """The out-of-memory route of the radix path's buffer sizing: when the buffers of a sub-batch at the current cap
-    cannot be allocated the cap is halved (and stays halved for the handle) until the call is cut finely enough — here
+    cannot be allocated the call takes one sub-batch more until it is cut finely enough (the caller's parameter stays) — here
     forced with a test hook that treats a pass-1 buffer beyond 1.6 GB as out of memory: a 2.5 M-read call (3.0e8 k-mer
     slots, 2.4 GB at one sub-batch) ends up as two sub-batches at a cap of 2^28.  Same counts as the direct path and,
     on a sample, as the oracle (mapper.pyx:53-69); below the floor of 2^28 slots the call fails with MemoryError."""
@@ -248,7 +248,8 @@ def test_sub_batch_cap_is_halved_when_the_buffers_do_not_fit(kmm, oracle):
             dev.set_timing(True)
             dev.map_reads_uniform(reads, R, L, k)
             assert np.array_equal(dev.get_node_counts(), direct), packed
-            assert dev.get_param("radix_sub_batch_kmers") == (2 ** 32 - 2 * 8192) // 16      # four halvings: just under 2^28
+            assert dev.get_param("radix_sub_batch_kmers") == 2 ** 32 - 2 * 8192                # the caller's value stays
+            assert dev.get_param("radix_sub_batch_kmers_effective") == 2 ** 28                 # one sub-batch more (the floor)
             assert dev.get_timing()["k_rx_p1"][1] == 2, "two sub-batches"
             dev.set_timing(False)
             assert dev.get_param("radix_p2_kmers") == R * (L - k + 1)

@@ -312,3 +312,25 @@ def test_cli_maps_a_plain_fastq_from_its_file_mapping(kmm, syn, oracle, tmp_path
             line = [r.getMessage() for r in caplog.records if "path_taken" in r.getMessage()][0]
             packed = int(line.split(";")[1].split()[0])
             assert (packed > 0) == (t > 1), (name, t, line)
+
+
+def test_a_large_count_vector_reaches_pageable_memory_through_the_page_locked_ring(kmm, syn, oracle):
+    """kmm_get_node_counts into an ordinary numpy array (what the reference's caller gets, mapper.py): vectors of 64 MiB and
+    more cross PCIe through the handle's page-locked ring, the packing threads copying the slots out.  Same vector as into
+    page-locked memory, as without threads (the runtime's own copy), and as the oracle's — for sizes that end inside a slot,
+    at a slot boundary and one element behind it."""
+    index, genome = syn.make_index(30000, seed=921)
+    real_mx = index.max_node_id()
+    bases, offs = syn.make_ragged_reads(genome, 4000, 31, 200, seed=922)
+    expect_small, _ = oracle.map_reads(index, real_mx, bases, offs, 31, n_threads=4)
+    slot = (16 << 20) // 4
+    for mx in (5 * slot + 12345, 6 * slot - 1, 6 * slot):
+        assert mx > real_mx
+        with kmm.DeviceIndex.from_index(index, mx) as dev:
+            dev.map_reads(bases, offs, 31)
+            got = dev.get_node_counts()
+            assert got.shape == (mx + 1,)
+            assert np.array_equal(got[:real_mx + 1], expect_small) and not got[real_mx + 1:].any()
+            assert np.array_equal(dev.get_node_counts(pinned=True), got)
+            dev.set_param("host_pack_threads", 0)
+            assert np.array_equal(dev.get_node_counts(), got)

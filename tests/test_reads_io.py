@@ -585,6 +585,10 @@ def test_one_gzip_member_is_inflated_on_many_threads(tmp_path, monkeypatch, chun
     files["stored"] = (co.compress(data[:1_000_000]) + co.flush(), data[:1_000_000])
     half = len(data) // 2
     files["members"] = (gzip.compress(data[:half], 6) + b"\0" * 37 + gzip.compress(data[half:], 2) + b"\0" * 5, data)
+    # many SMALL members with a large one among them (cat of small .gz files): the small ones are decoded one chunk at a
+    # time, in order (no speculative chunks into the members behind them), the large one in parallel waves again
+    cuts = [0] + sorted(int(x) for x in rng.integers(1, 600_000, size=40)) + [600_000, 2_400_000, 2_450_000, 2_500_000]
+    files["small_members"] = (b"".join(gzip.compress(data[a:b], 6) for a, b in zip(cuts[:-1], cuts[1:])), data[:2_500_000])
     named = bytearray(gzip.compress(data[:2_000_000], 6))
     named[3] |= 8                                                   # FNAME: a zero-terminated name behind the fixed header
     files["with_name"] = (bytes(named[:10]) + b"reads.fq\0" + bytes(named[10:]), data[:2_000_000])

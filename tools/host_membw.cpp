@@ -9,6 +9,7 @@
 #endif
 
 #include <chrono>
+#include <thread>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -135,12 +136,49 @@ int main(int argc, char **argv)
         if (!huge) {
             uint8_t *psrc = nullptr, *pdst = nullptr;
             if (hipHostMalloc(reinterpret_cast<void **>(&psrc), n, hipHostMallocDefault) == hipSuccess &&
-                hipHostMalloc(reinterpret_cast<void **>(&pdst), n / 4 + 4096, hipHostMallocDefault) == hipSuccess) {
+                hipHostMalloc(reinterpret_cast<void **>(&pdst), 2 * (n / 4) + 4096, hipHostMallocDefault) == hipSuccess) {
                 memcpy(psrc, src, n);
-                memset(pdst, 0, n / 4 + 4096);
+                memset(pdst, 0, 2 * (n / 4) + 4096);
                 flat(src, pdst, "FlatJob -> page-locked");
                 flat(psrc, dst, "FlatJob, page-locked ->");
                 flat(psrc, pdst, "FlatJob, page-locked both");
+                // the same while a copy engine reads page-locked memory at PCIe rate: another buffer, then the destination itself
+                uint8_t *other = nullptr, *dev = nullptr;
+                hipStream_t st;
+                hipEvent_t ev;
+                (void)hipEventCreateWithFlags(&ev, hipEventBlockingSync);
+                const size_t other_bytes = n / 4; // as large as the destination, walked through like it
+                if (hipHostMalloc(reinterpret_cast<void **>(&other), other_bytes, hipHostMallocDefault) == hipSuccess &&
+                    hipMalloc(reinterpret_cast<void **>(&dev), (size_t)256 << 20) == hipSuccess && hipStreamCreate(&st) == hipSuccess) {
+                    memset(other, 1, other_bytes);
+                    for (int which = 0; which < 3; ++which) {
+                        std::atomic<bool> stop{false};
+                        std::atomic<uint64_t> copied{0};
+                        const auto t0 = Clock::now();
+                        std::thread dma([&] {
+                            size_t at = 0;
+                            while (!stop.load()) {
+                                for (int q = 0; q < 8; ++q) {
+                                    const size_t walk = at % ((n / 4) - ((size_t)8 << 20));
+                                    const uint8_t *from = which == 0 ? other + walk : which == 1 ? pdst + walk : pdst + n / 4 + walk;
+                                    (void)hipMemcpyAsync(dev + ((size_t)q << 23), from, (size_t)8 << 20, hipMemcpyHostToDevice, st);
+                                    at += (size_t)8 << 20;
+                                }
+                                (void)hipEventRecord(ev, st); // (a blocking wait: the waiting thread sleeps, it does not spin)
+                                (void)hipEventSynchronize(ev);
+                                copied += (uint64_t)64 << 20;
+                            }
+                        });
+                        flat(psrc, pdst, which == 0 ? "... while another buffer is copied" : which == 1 ? "... while the destination is copied"
+                                                                                     : "... the same allocation's other half");
+                        stop = true;
+                        dma.join();
+                        printf("    (the copy engine moved %.1f GB/s meanwhile)\n",
+                               (double)copied.load() / std::chrono::duration<double>(Clock::now() - t0).count() / 1e9);
+                    }
+                }
+                (void)hipHostFree(other);
+                (void)hipFree(dev);
             }
             (void)hipHostFree(psrc);
             (void)hipHostFree(pdst);
