@@ -93,7 +93,10 @@ void kmm_index_destroy(kmm_index_t *idx);
 int kmm_reset_counts(kmm_index_t *idx);
 int kmm_bind_counts(kmm_index_t *idx, uint32_t *device_counts);
 int kmm_counts_device_ptr(kmm_index_t *idx, uint32_t **out);
-/* Copies the max_node_id+1 counts to host memory `out` after draining the stream. */
+/* Copies the max_node_id+1 counts to `out` after draining the stream.  out: host memory of any kind (or device memory).  Into
+ * ORDINARY (pageable) memory a vector of 64 MiB and more travels through the handle's page-locked staging ring, the
+ * "host_pack_threads" threads copying the slots out: the link's rate without a page-locked destination (which costs ~50 ms
+ * per GB to make — as much as a whole map phase; configs[2]'s 400 MB vector: ~10 ms instead of 30-40). */
 int kmm_get_node_counts(kmm_index_t *idx, uint32_t *out);
 int kmm_synchronize(kmm_index_t *idx);
 
@@ -193,7 +196,9 @@ int kmm_map_records(kmm_index_t *idx, const uint8_t *raw, int64_t n_bytes, int f
  * Readme.md:11; the igzip reader of util.py:78-101) without a host-side inflater — the compressed bytes cross PCIe (about a
  * quarter of the raw ones), one GPU thread inflates one member (thousands per chunk; stored, fixed and dynamic blocks;
  * every member's ISIZE and CRC32 checked on the device), and the raw records go to the device-side parser as in
- * kmm_map_records.  comp: n_comp compressed bytes in HOST memory (a file mapping will do) that start at a member boundary;
+ * kmm_map_records.  The bytes reach HBM through the handle's page-locked staging ring (eight slots of 16 MiB, filled by the
+ * "host_pack_threads" threads, emptied by a copy engine); the member chain is walked in the caller's bytes meanwhile.
+ * comp: n_comp compressed bytes in HOST memory (a file mapping will do) that start at a member boundary;
  * the call uses the whole members inside (at most 3.5 GiB of inflated bytes) and returns in *consumed_comp how many
  * compressed bytes that was — the caller continues there.  Records do not end where members end: the handle keeps the
  * inflated bytes behind the call's last complete record and puts them in front of the next call's (a STREAM per handle:
@@ -237,7 +242,7 @@ int kmm_host_free(void *p);
  * page-locked allocation costs ~50 ms per GB: a caller that knows its batch size calls this from another thread while
  * the index is created (kmer_mapper map does), and the first map call finds the buffers ready.  Optional. */
 int kmm_host_reserve(int64_t raw_batch_bytes);
-/* The same for ONE page-locked buffer of `bytes` bytes: what kmm_map_bgzf stages a window of compressed bytes in. */
+/* The same for ONE page-locked buffer of `bytes` bytes, for callers that know what the next handle will ask for. */
 int kmm_host_reserve_buffer(int64_t bytes);
 
 /*

@@ -183,7 +183,10 @@ struct PinnedShelf {
 };
 static PinnedShelf g_shelf;
 constexpr size_t RING_SLOT = (size_t)16 << 20;
-constexpr int RING_SLOTS = 8;
+#ifndef KMM_RING_SLOTS
+#define KMM_RING_SLOTS 8 // (A/B builds: a ring the size of a batch never makes the packing threads wait)
+#endif
+constexpr int RING_SLOTS = KMM_RING_SLOTS;
 
 
 struct TimedEvent {
@@ -195,8 +198,6 @@ struct kmm_index {
     int device = 0;
     hipStream_t stream = nullptr;      // kernels
     hipStream_t copy_stream = nullptr; // host -> HBM staging, overlaps the previous kernel
-    hipStream_t copy_stream2 = nullptr; // every second slot of the staging ring (a second copy engine)
-    hipEvent_t copied2 = nullptr;
     hipEvent_t copied = nullptr;
     uint4 *buckets = nullptr;
     uint4 *entries = nullptr;
@@ -248,7 +249,7 @@ struct kmm_index {
     std::unique_ptr<kmm_hostpack::Workers> pack_pool; // the packing threads, asleep between calls
     uint8_t *pack_pinned = nullptr; // page-locked home of a packed records batch (kmm_hostpack.hpp)
     size_t pack_pinned_bytes = 0;
-    uint8_t *ring[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; // the page-locked staging ring (ensure_ring)
+    uint8_t *ring[RING_SLOTS] = {}; // the page-locked staging ring (ensure_ring)
     uint8_t *pack_bits_pinned = nullptr; // ... and of the read-start bitset of packed raw records
     size_t pack_bits_pinned_bytes = 0;
     int64_t host_packed_calls = 0, host_packed_record_calls = 0;
@@ -258,7 +259,7 @@ struct kmm_index {
     // for the next call.
     DevBuf bgzf_comp[2], bgzf_raw[2], bgzf_meta[2], bgzf_tabs, bgzf_err, bgzf_carry, bgzf_crc;
     hipEvent_t bgzf_done[2] = {nullptr, nullptr};
-    hipEvent_t bgzf_slot_ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; // copies out of the staging ring
+    hipEvent_t bgzf_slot_ev[RING_SLOTS] = {}; // copies out of / into the slots of the staging ring
     bool bgzf_used[2] = {false, false};
     int bgzf_cur = 0;
     int64_t bgzf_carry_len = 0;
@@ -1055,8 +1056,6 @@ void kmm_index_destroy(kmm_index_t *ix)
         (void)hipStreamSynchronize(ix->stream);
     if (ix->copy_stream)
         (void)hipStreamSynchronize(ix->copy_stream);
-    if (ix->copy_stream2)
-        (void)hipStreamSynchronize(ix->copy_stream2);
     for (Stage &s : ix->stage) {
         release(s.bases);
         release(s.offsets);
@@ -1078,9 +1077,11 @@ void kmm_index_destroy(kmm_index_t *ix)
         release(ix->bgzf_meta[i]);
         if (ix->bgzf_done[i])
             (void)hipEventDestroy(ix->bgzf_done[i]);
-        for (int j = i * 4; j < i * 4 + 4; ++j)
-            if (ix->bgzf_slot_ev[j])
-                (void)hipEventDestroy(ix->bgzf_slot_ev[j]);
+    }
+    for (hipEvent_t &ev : ix->bgzf_slot_ev) {
+        if (ev)
+            (void)hipEventDestroy(ev);
+        ev = nullptr;
     }
     release(ix->bgzf_tabs);
     release(ix->bgzf_crc);
@@ -1134,10 +1135,6 @@ void kmm_index_destroy(kmm_index_t *ix)
         (void)g_rccl.CommDestroy(ix->comm);
     if (ix->copy_stream)
         (void)hipStreamDestroy(ix->copy_stream);
-    if (ix->copy_stream2)
-        (void)hipStreamDestroy(ix->copy_stream2);
-    if (ix->copied2)
-        (void)hipEventDestroy(ix->copied2);
     if (ix->stream)
         (void)hipStreamDestroy(ix->stream);
     delete ix;
@@ -1386,8 +1383,6 @@ static int index_create_impl(kmm_index *ix, const int32_t *h2i, const int32_t *n
     ix->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     HIPCHK(hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&ix->copy_stream, hipStreamNonBlocking));
-    HIPCHK(hipStreamCreateWithFlags(&ix->copy_stream2, hipStreamNonBlocking));
-    HIPCHK(hipEventCreateWithFlags(&ix->copied2, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&ix->copied, hipEventDisableTiming));
     for (Stage &s : ix->stage)
         HIPCHK(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
@@ -1628,10 +1623,11 @@ static bool ensure_pinned(uint8_t *&p, size_t &have, size_t want);
 
 // The staging ring: RING_SLOTS page-locked buffers of RING_SLOT bytes, each an allocation of its own.  Host threads fill a
 // slot, a copy engine empties it (or the other way round), and a slot is touched by one side at a time.  Why a ring and not
-// one buffer the size of the batch: (a) 128 MB are made in 7 ms, 750 MB in 40; (b) host threads that write a buffer while a
-// copy engine reads THE SAME buffer lose a third of their rate (16 threads pack 295 GB/s into page-locked memory, 210 while
-// the buffer they are filling is being copied, 264 while another part of the same allocation is, 285 while another
-// allocation is: profiles/r05/host_membw_dma.txt).
+// one buffer the size of the batch: 128 MB are made in 7 ms, a 750 MB batch buffer in 40 — as long as the map phase of a
+// whole file.  (It does not make the threads faster: 16 threads pack 300 GB/s into page-locked memory with no copy in
+// flight and 200 GB/s with one, whether the copies read the buffer being filled, slots of a ring of 8 or of a ring of 64
+// that never makes anyone wait — profiles/r05/pack_without_copies.txt, host_membw_dma.txt; at 200 GB/s the packing of a
+// batch takes as long as its 2-bit stream needs to cross PCIe, which is what bounds the leg.)
 static bool ensure_ring(kmm_index_t *ix)
 {
     for (int i = 0; i < RING_SLOTS; ++i) {
@@ -2121,11 +2117,7 @@ static int map_reads_host_packed(kmm_index_t *ix, const uint8_t *bases, const in
     int rc = KMM_OK;
     size_t landed = 0; // slot-sized pieces whose copy to HBM is known to have finished
     double ms_in_copy_calls = 0;
-    static const bool two_streams = getenv("KMM_H2D_TWO_STREAMS") && atoi(getenv("KMM_H2D_TWO_STREAMS")) != 0; // (experiment)
-    if (two_streams) { // the second stream starts where the first one stands (behind the stage's last reader)
-        HIPCHK(hipEventRecord(ix->copied2, ix->copy_stream));
-        HIPCHK(hipStreamWaitEvent(ix->copy_stream2, ix->copied2, 0));
-    }
+    // (every second slot on a second copy stream: 141 against 146 G k-mers/s, profiles/r05/h2d_two_copy_streams.txt — one stream)
     for (size_t c = 0; c < n_slots && rc == KMM_OK && !bad.load(); ++c) {
         const size_t first = c * PER_SLOT, want = n_chunks - first < PER_SLOT ? n_chunks - first : PER_SLOT;
         int idle = 0;
@@ -2159,7 +2151,7 @@ static int map_reads_host_packed(kmm_index_t *ix, const uint8_t *bases, const in
         if (hipEventRecord(ix->bgzf_slot_ev[c % SLOTS], ix->copy_stream) != hipSuccess)
             rc = fail(KMM_ERR_HIP, "hipEventRecord: %s", hipGetErrorString(hipGetLastError()));
 #else
-        hipStream_t cs = two_streams && (c & 1) ? ix->copy_stream2 : ix->copy_stream;
+        hipStream_t cs = ix->copy_stream;
         if (hipMemcpyAsync((uint8_t *)s.kmers.p + b0, ring[c % SLOTS], len, hipMemcpyHostToDevice, cs) != hipSuccess ||
             hipEventRecord(ix->bgzf_slot_ev[c % SLOTS], cs) != hipSuccess)
             rc = fail(KMM_ERR_HIP, "copy of packed reads: %s", hipGetErrorString(hipGetLastError()));
@@ -2178,10 +2170,6 @@ static int map_reads_host_packed(kmm_index_t *ix, const uint8_t *bases, const in
     if (rc != KMM_OK || bad.load())
         stop.store(true);
     ix->pack_pool->wait();
-    if (two_streams) { // the first stream stands for both from here on
-        HIPCHK(hipEventRecord(ix->copied2, ix->copy_stream2));
-        HIPCHK(hipStreamWaitEvent(ix->copy_stream, ix->copied2, 0));
-    }
     if (verbose)
         fprintf(stderr, "libkmm: host flat packer: %zu bases, waited %.2f ms for the stage, pack + copies issued %.2f ms (%.1f GB/s; %.2f ms of it "
                 "inside the %zu copy calls), %d threads\n", total, ms_stage, ms_since(t_1), (double)total / 1e6 / ms_since(t_1),
