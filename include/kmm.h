@@ -357,8 +357,8 @@ int kmm_get_kmer_counts(kmm_index_t *idx, uint32_t *out);
  *                      the compaction kernels of kmm_map_records on the copy stream, next to the radix passes; skip one
  *                      of them; directory sums of pass 1) and of the tests ("debug_rx_buffer_limit": a pass-1 buffer
  *                      beyond that many bytes counts as out of memory: the call takes more sub-batches;
- *                      "debug_skew_p2_counter": trips the conservation check; "debug_bgzf_ring_slot_kb": slot size of
- *                      kmm_map_bgzf's staging ring): not for callers, no effect at 0
+ *                      "debug_skew_p2_counter": trips the conservation check; "debug_ring_slot_kb": slot size of the
+ *                      page-locked staging ring): not for callers, no effect at 0
  * Read-only (kmm_get_param): "radix_available", "radix_unavailable_reason" (0 available, 1 modulo >= 2^31, 2 slices too
  *   dense for LDS, 3 out of memory, 4 the index's buckets overlap), "n_partitions", "n_coarse_partitions",
  *   "n_fine_per_coarse", "radix_p2_kmers" / "radix_p3_kmers" / "radix_p2_dropped" (the conservation counters every

@@ -2081,7 +2081,9 @@ static int map_reads_host_packed(kmm_index_t *ix, const uint8_t *bases, const in
     // Tasks of 4 Mi bases (1 MiB packed) handed out in order; 16 of them fill a slot of the staging ring, a full slot leaves
     // for HBM (copy stream: under the previous call's kernels and under the packing of the next slots) and is written again
     // when its copy has landed.
-    constexpr size_t CHUNK = (size_t)4 << 20, PER_SLOT = RING_SLOT / (CHUNK / 4);
+    // ("debug_ring_slot_kb": tests wrap the ring many times with a small batch)
+    const size_t SLOT_BYTES = ix->dbg_bgzf_slot_kb > 0 && ((size_t)ix->dbg_bgzf_slot_kb << 10) < RING_SLOT ? (size_t)ix->dbg_bgzf_slot_kb << 10 : RING_SLOT;
+    const size_t CHUNK = 4 * (SLOT_BYTES < ((size_t)1 << 20) ? SLOT_BYTES : (size_t)1 << 20), PER_SLOT = SLOT_BYTES / (CHUNK / 4);
     constexpr int SLOTS = RING_SLOTS;
     const size_t n_chunks = (total + CHUNK - 1) / CHUNK, n_slots = (n_chunks + PER_SLOT - 1) / PER_SLOT;
     std::vector<std::atomic<uint32_t>> filled(n_slots);
@@ -2144,7 +2146,7 @@ static int map_reads_host_packed(kmm_index_t *ix, const uint8_t *bases, const in
         }
         if (bad.load())
             break;
-        const size_t b0 = c * RING_SLOT, len = packed_total - b0 < RING_SLOT ? packed_total - b0 : RING_SLOT;
+        const size_t b0 = c * SLOT_BYTES, len = packed_total - b0 < SLOT_BYTES ? packed_total - b0 : SLOT_BYTES;
         const auto t_c = std::chrono::steady_clock::now();
 #ifdef KMM_EXPERIMENT_PACK_WITHOUT_COPIES // (tools/ab_build.sh only: how fast do the threads pack when nothing is copied? results are garbage)
         (void)b0; (void)len;
@@ -3567,9 +3569,9 @@ int kmm_set_param(kmm_index_t *ix, const char *name, int64_t value)
         if (value < 0 || value > 65536)
             return fail(KMM_ERR_INVALID_ARG, "host_pack_slice_kb outside [0, 65536]");
         ix->host_pack_slice_kb = value;
-    } else if (!strcmp(name, "debug_bgzf_ring_slot_kb")) {
+    } else if (!strcmp(name, "debug_bgzf_ring_slot_kb") || !strcmp(name, "debug_ring_slot_kb")) {
         if (value != 0 && (value < 4 || value > (1 << 20) || (value & (value - 1))))
-            return fail(KMM_ERR_INVALID_ARG, "debug_bgzf_ring_slot_kb: 0 or a power of two in [4, 2^20]");
+            return fail(KMM_ERR_INVALID_ARG, "debug_ring_slot_kb: 0 or a power of two in [4, 2^20]");
         ix->dbg_bgzf_slot_kb = (int)value;
     } else if (!strcmp(name, "debug_rx_buffer_limit")) {
         // test hook of the out-of-memory route of launch_rx (the call takes more sub-batches until the buffers fit)

@@ -586,6 +586,25 @@ def test_reads_packed_on_the_host_before_they_cross_pcie(kmm, syn, oracle):
                 assert np.array_equal(dev.get_node_counts(), 2 * expect), (R, L, k, rc)
                 n_packed += 2
                 assert dev.get_param("host_packed_calls") == n_packed
+        # the page-locked staging ring wrapped many times (8 slots of 4 KiB / 64 KiB instead of 16 MiB): same counts
+        R, L, k = 30_001, 151, 31
+        bases, offs = syn.make_reads(genome, R, L, seed=972 + L)
+        expect, _ = oracle.map_reads(index, mx, bases, offs, k, n_threads=4)
+        for slot_kb in (4, 64):
+            dev.set_param("debug_ring_slot_kb", slot_kb)
+            dev.reset()
+            dev.map_reads_uniform(bases, R, L, k)
+            assert np.array_equal(dev.get_node_counts(), expect), slot_kb
+            n_packed += 1
+            assert dev.get_param("host_packed_calls") == n_packed
+        broken = bases.copy()
+        broken[len(broken) // 2 + 3] = ord("!")                               # refused in the middle of a wrapped ring
+        dev.reset()
+        dev.map_reads_uniform(broken, R, L, k)
+        with pytest.raises(ValueError, match="offset %d" % (len(broken) // 2 + 3)):
+            dev.get_node_counts()
+        dev.set_param("debug_ring_slot_kb", 0)
+        dev.reset()
         # ragged reads (kmm_map_reads with host offsets): the same packed bases + the read-start bitset
         rbases, roffs = syn.make_ragged_reads(genome, 60_000, 0, 260, seed=975)
         for k in (31, 9):
