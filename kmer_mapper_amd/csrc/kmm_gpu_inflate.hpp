@@ -263,6 +263,37 @@ KMM_HD inline uint32_t bits_take(Bits &b, int k) // k <= 16 bits, after a refill
     return v;
 }
 
+// The symbol loop's refill: 32 bits more from the open block — never a memory access.  The loop runs only while buffer and
+// open block together hold a whole symbol (48 bits), so there is a word to take whenever fewer than 33 bits are buffered
+// and more are needed.
+KMM_HD inline void bits_refill_local(Bits &b)
+{
+    if (b.cnt <= 32 && b.fw > 0) {
+        const uint32_t x = (uint32_t)b.flo;
+        b.flo = (b.flo >> 32) | (b.fhi << 32);
+        b.fhi >>= 32;
+        --b.fw;
+        b.buf |= (uint64_t)x << b.cnt;
+        b.cnt += 32;
+    }
+}
+
+// The open block no longer holds a symbol (fewer than 48 bits with the buffer: at most one word is left, it moves into
+// the buffer): the block requested one block-time ago takes its place and the one behind it is requested.  THE ONE place
+// where the symbol phase waits for input — and what it waits for has been in flight for a whole block's symbols.
+KMM_HD inline void bits_next_block(Bits &b)
+{
+    if (b.fw > 0) {
+        b.buf |= (uint64_t)(uint32_t)b.flo << b.cnt;
+        b.cnt += 32;
+    }
+    b.flo = b.nlo;
+    b.fhi = b.nhi;
+    b.fw = 4;
+    load16(b.in, b.n, b.pos, b.nlo, b.nhi);
+    b.pos += 16u;
+}
+
 // bytes of the input the decoder has really used (the buffer, the open block and the block behind it hold bytes it has not)
 KMM_HD inline uint32_t bits_consumed_bytes(const Bits &b)
 {
@@ -331,7 +362,10 @@ KMM_HD inline void load16u(const uint8_t *p, uint64_t &lo, uint64_t &hi)
 // 71 GB/s of FASTQ out.  What is left is the memory system's request rate: ~28 000 requests per member in the copy phase alone.
 constexpr int DECODE_RUN = 1024;    // symbols per phase A
 constexpr int LIST_CAP = 512;       // matches per phase A (8 bytes each)
-constexpr int GROUP = 8;            // matches per step of phase B
+#ifndef KMM_GZ_GROUP
+#define KMM_GZ_GROUP 8
+#endif
+constexpr int GROUP = KMM_GZ_GROUP; // matches per step of phase B (even)
 constexpr int LIST_ALLOC = LIST_CAP + GROUP; // (a step's entry loads may reach GROUP entries behind the last one)
 enum State { S_HDR = 0, S_SYM, S_DONE };
 constexpr int SCRATCH_BYTES = LIST_ALLOC * 8 + SEC_WORDS * 2; // per lane, in HBM: the match list, then the subtables
@@ -560,9 +594,19 @@ KMM_HD inline int inflate_stream(const uint8_t *in, uint32_t n_in, uint8_t *out,
         }
         KMM_GZ_T(0);
         // ---- phase A: decode until the block ends; literals are stored, matches written down
+        // The input: the symbol loop proper (inner) runs on the bits at hand — buffer + open 16-byte block, both registers —
+        // and never touches memory for input; when they no longer hold a whole symbol the outer loop opens the next block.
+        // (Before, the refill sat inside the symbol and the compiler waited for every block load on the spot — its registers
+        // are copied into loop-carried ones at the branch's end.  Moving it out changed nothing measurable, 15.0 against
+        // 15.2 ms per lane, nor did leaving out this phase's stores altogether, 13.0: the symbol phase is bound by its chain of
+        // dependent instructions at one wavefront per SIMD — ~1 900 clocks per symbol — not by memory;
+        // profiles/r05/gz_phase_v7_*.txt.)
         uint32_t n_list = 0;
-        for (int t = 0; t < DECODE_RUN && state == S_SYM && n_list < (uint32_t)LIST_CAP; ++t) {
-            bits_refill(b);
+        int t = 0;
+        for (;;) {
+        while (t < DECODE_RUN && state == S_SYM && n_list < (uint32_t)LIST_CAP && b.cnt + 32 * b.fw >= 48) {
+            ++t;
+            bits_refill_local(b);
             uint32_t e = lit[((uint32_t)b.buf & (uint32_t)(PRIM_LIT - 1)) * PS];
             if (e & LINK) { // a code longer than the primary index: its subtable (HBM)
                 e = lit2[((e >> 4) & 0x7FFu) + (((uint32_t)b.buf >> LIT_PB) & ((1u << (e & 15u)) - 1u))];
@@ -578,7 +622,10 @@ KMM_HD inline int inflate_stream(const uint8_t *in, uint32_t n_in, uint8_t *out,
             if (sym < 256u) {
                 if (o >= n_out)
                     return E_OUTPUT;
-                out[o++] = (uint8_t)sym;
+#ifndef KMM_GZ_EXPERIMENT_NO_DECODE_STORES // (tools/gz_phase.py: what do the decode phase's stores cost? output is garbage)
+                out[o] = (uint8_t)sym;
+#endif
+                ++o;
                 continue;
             }
             if (sym == 256u) {
@@ -590,7 +637,7 @@ KMM_HD inline int inflate_stream(const uint8_t *in, uint32_t n_in, uint8_t *out,
             if (sym > 285u)
                 return E_SYMBOL;
             const uint32_t len = len_base_of(sym - 257u) + bits_take(b, (int)len_extra_bits(sym - 257u));
-            bits_refill(b);
+            bits_refill_local(b);
             uint32_t d = dst[((uint32_t)b.buf & (uint32_t)(PRIM_DIST - 1)) * PS];
             if (d & LINK) {
                 d = dst2[((d >> 4) & 0x7FFu) + (((uint32_t)b.buf >> DIST_PB) & ((1u << (d & 15u)) - 1u))];
@@ -610,8 +657,15 @@ KMM_HD inline int inflate_stream(const uint8_t *in, uint32_t n_in, uint8_t *out,
                 return E_DISTANCE;
             if (o + len > n_out)
                 return E_OUTPUT;
-            list[n_list++] = (uint64_t)o | ((uint64_t)len << 32) | ((uint64_t)dist << 41);
+#ifndef KMM_GZ_EXPERIMENT_NO_DECODE_STORES
+            list[n_list] = (uint64_t)o | ((uint64_t)len << 32) | ((uint64_t)dist << 41);
+#endif
+            ++n_list;
             o += len;
+        }
+        if (!(t < DECODE_RUN && state == S_SYM && n_list < (uint32_t)LIST_CAP))
+            break;
+        bits_next_block(b);
         }
         KMM_GZ_T(1);
         // ---- phase B: the matches, in order; up to GROUP per step when none of them can depend on another.  The list lies in
