@@ -347,6 +347,12 @@ int kmm_get_kmer_counts(kmm_index_t *idx, uint32_t *out);
  *                      0; environment KMM_HOST_PACK_THREADS overrides it at index creation.
  *                      "host_packed_calls" / "host_packed_record_calls" (read-only) count the calls that took the route;
  *                      "host_pack_slice_kb": raw bytes per slice the records packer hands its threads (0 = default, 1024)
+ *   "bgzf_head_skip" / "bgzf_tail_stop"  a RANK'S SHARE of a BGZF file (several processes on one file, kmm_map_bgzf): the next
+ *                      call with KMM_FORMAT_NEW_STREAM passes over that many inflated bytes of its first member (they end a
+ *                      record of the rank before), the next call with KMM_FORMAT_LAST_CHUNK takes only that many inflated
+ *                      bytes of its last member (the rest starts the next rank's first record); each is used once
+ *                      (tail: -1 = all, the default).  The boundaries are the caller's business
+ *                      (kmer_mapper_amd/bgzf_ranges.py: record-structure resynchronisation on the members around a boundary)
  *   "comm_overlap_slices" kmm_comm_reduce_counts: node ranges whose flush (per-entry hits -> node counts) runs under the
  *                      previous range's RCCL reduce on a second stream (default 8; 1 = flush, then one reduce).  A
  *                      parameter of the JOB: every rank must use the same value — it alone (with the vector's length)

@@ -190,11 +190,11 @@ def map_gpu_raw(index, path, chunk_size, fmt, k, map_reverse_complements=False,
                 and not os.environ.get("KMM_CLI_NO_MMAP"))
     # BGZF (.gz written by bgzip / htslib: independent members of <= 64 KiB): the compressed bytes go to the GPU as they lie
     # in the file mapping, one GPU thread inflates one member, the records are parsed there too (kmm_map_bgzf) — the host's
-    # inflater (10.8 GB/s of FASTQ on 16 cores) is out of the way.  One process only: ranks that share a .gz keep the host reader.
+    # inflater (10.8 GB/s of FASTQ on 16 cores) is out of the way.  Several ranks: each takes the members that start in its share
+    # of the compressed bytes, resynchronised to the records at both ends (bgzf_ranges.py).
     # (Decided BEFORE a chunker is made: the prefetching one starts a reader thread and page-locks two batch buffers — making
     # and freeing those cost this route 100 ms of its map phase until it was noticed.)
-    gpu_inflate = (not seekable and world_size == 1 and fmt in ("fastq", "fasta") and not os.environ.get("KMM_CLI_NO_GPU_INFLATE")
-                   and _is_bgzf(path))
+    gpu_inflate = (not seekable and fmt in ("fastq", "fasta") and not os.environ.get("KMM_CLI_NO_GPU_INFLATE") and _is_bgzf(path))
     chunker = None if gpu_inflate else (MmapChunker if use_mmap else PrefetchingRawChunker if use_prefetch
                                         else RawChunker)(path, batch_bytes, byte_range, pinned=True)
     owns = (lambda i: True) if (world_size == 1 or seekable) else (lambda i: chunk_owner(i, world_size) == rank)
@@ -206,7 +206,7 @@ def map_gpu_raw(index, path, chunk_size, fmt, k, map_reverse_complements=False,
         if helper.ident is not None:
             helper.join()
         return _map_bgzf_file(dev, path, kfmt, k, max_index_lookup_frequency, map_reverse_complements, before_fetch, t_start,
-                              counts_out=prepared.get("counts"))
+                              counts_out=prepared.get("counts"), rank=rank, world_size=world_size, fmt=fmt)
     try:
         i = 0
         while True:
@@ -265,28 +265,43 @@ def _is_bgzf(path):
 _BGZF_WINDOW = 1100 << 20      # compressed bytes per kmm_map_bgzf call (~3.5 GiB inflated at FASTQ's usual 3.3 : 1)
 
 
-def _map_bgzf_file(dev, path, kfmt, k, max_freq, revcomp, before_fetch, t_start, comp_batch=None, counts_out=None):
+def _map_bgzf_file(dev, path, kfmt, k, max_freq, revcomp, before_fetch, t_start, comp_batch=None, counts_out=None, rank=0,
+                   world_size=1, fmt="fastq"):
     """`kmer_mapper map -f reads.fq.gz` for BGZF files: compressed chunks of the file mapping -> kmm_map_bgzf (members inflated
-    and records parsed on the GPU; the handle carries the bytes behind a chunk's last complete record to the next chunk)."""
+    and records parsed on the GPU; the handle carries the bytes behind a chunk's last complete record to the next chunk).
+    Several ranks: each maps its member range (bgzf_ranges.rank_member_range), the first member's head and the last member's
+    tail trimmed to the record boundaries the ranks agree on."""
     import mmap
-    n_reads = 0
+    n_reads = lo = size = 0
     try:
         with open(path, "rb") as f:
-            size = os.fstat(f.fileno()).st_size
+            file_size = os.fstat(f.fileno()).st_size
             mm = mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ)
             try:
+                lo, size, head_skip, tail_stop = 0, file_size, 0, None
+                if world_size > 1:
+                    from . import bgzf_ranges
+                    offs = bgzf_ranges.member_chain(mm)
+                    m0, s0, m1, s1 = bgzf_ranges.rank_member_range(mm, offs, fmt, rank, world_size)
+                    lo, size = int(offs[m0]), int(offs[m1 + 1 if s1 > 0 else m1])
+                    head_skip, tail_stop = s0, (s1 if s1 > 0 else None)
+                    logging.info("Rank %d of %d maps BGZF members [%d, %d) of %d: compressed bytes [%d, %d), %d inflated bytes of "
+                                 "the first member skipped, %s of the last one taken", rank, world_size, m0, m1 + (1 if s1 > 0 else 0),
+                                 len(offs) - 1, lo, size, s0, "all" if tail_stop is None else "%d bytes" % s1)
                 if hasattr(mm, "madvise") and hasattr(mmap, "MADV_SEQUENTIAL"):
                     mm.madvise(mmap.MADV_SEQUENTIAL)
                 whole = np.frombuffer(mm, dtype=np.uint8)
                 # equal windows, none small: one GPU thread inflates one member, a call's time is one member's (~tens of
                 # milliseconds) whatever its size
-                n_calls = max(1, -(-size // _BGZF_WINDOW))
-                pos, window = 0, int(comp_batch) if comp_batch else size // n_calls + (1 << 16)
+                n_calls = max(1, -(-(size - lo) // _BGZF_WINDOW))
+                pos, window = lo, int(comp_batch) if comp_batch else (size - lo) // n_calls + (1 << 16)
                 t_calls = time.perf_counter()
                 while pos < size:
                     end = min(pos + window, size)
                     used, n_rec = dev.map_bgzf(whole[pos:end], fmt=kfmt, k=k, max_index_lookup_frequency=max_freq,
-                                               also_revcomp=revcomp, first=pos == 0, last=end == size)
+                                               also_revcomp=revcomp, first=pos == lo, last=end == size,
+                                               head_skip=head_skip if pos == lo else 0,
+                                               tail_stop=tail_stop if end == size else None)
                     if used == 0 and end < size:
                         window *= 2                      # (a member larger than the window: cannot happen with BGZF's 64 KiB)
                         continue
@@ -316,7 +331,7 @@ def _map_bgzf_file(dev, path, kfmt, k, max_freq, revcomp, before_fetch, t_start,
         dev.close()
     logging.info("Time spent only on hashing and counting hashes: %.5f" % dt)
     logging.info("Mapped %d reads from %d compressed bytes (%.1f MB/s compressed; %d BGZF members inflated on the GPU): %d k-mer "
-                 "lookups (%.1f M/s), %d index hits" % (n_reads, size, size / max(dt, 1e-9) / 1e6, n_members, n_lookups,
+                 "lookups (%.1f M/s), %d index hits" % (n_reads, size - lo, (size - lo) / max(dt, 1e-9) / 1e6, n_members, n_lookups,
                                                           n_lookups / max(dt, 1e-9) / 1e6, n_hits))
     logging.info("path_taken: %s (%d batches on the radix path, %d on the direct path; 0 batches packed to 2 bits per base by "
                  "the host threads)" % ("radix" if n_radix and not n_direct else "direct" if n_direct and not n_radix else "mixed",

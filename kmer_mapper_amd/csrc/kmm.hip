@@ -263,6 +263,8 @@ struct kmm_index {
     bool bgzf_used[2] = {false, false};
     int bgzf_cur = 0;
     int64_t bgzf_carry_len = 0;
+    int64_t bgzf_head_skip = 0;  // "bgzf_head_skip": inflated bytes of the next NEW_STREAM call's first member that belong to someone else
+    int64_t bgzf_tail_stop = -1; // "bgzf_tail_stop": >= 0: of the next LAST_CHUNK call's last member only this many inflated bytes are taken
     int64_t bgzf_calls = 0, bgzf_members = 0;
     int dbg_bgzf_slot_kb = 0;     // test hook ("debug_bgzf_ring_slot_kb"): slot size of kmm_map_bgzf's staging ring (a power of two, >= 4)
     int64_t dbg_rx_buf_limit = 0; // test hook ("debug_rx_buffer_limit"): a pass-1 buffer beyond this many bytes counts as out of memory
@@ -3052,11 +3054,33 @@ int kmm_map_bgzf(kmm_index_t *ix, const uint8_t *comp, int64_t n_comp, int forma
                            (unsigned long long *)nullptr);
         HIPCHK(hipGetLastError());
     }
+    // A RANK'S SHARE of a file (kmer_mapper map with several ranks, bgzf_ranges.py): its first member starts inside a record
+    // that belongs to the rank before it — "bgzf_head_skip" bytes of the stream's first member are passed over — and its last
+    // member holds the start of the next rank's first record — only "bgzf_tail_stop" bytes of the last member are taken.
+    int64_t head = 0, n_raw = n_total;
+    if (new_stream) {
+        head = ix->bgzf_head_skip;
+        ix->bgzf_head_skip = 0;
+    }
+    if (last_chunk && ix->bgzf_tail_stop >= 0) {
+        if (n_members == 0 || (unsigned long long)ix->bgzf_tail_stop > o_off[n_members] - o_off[n_members - 1]) {
+            (void)hipStreamSynchronize(ix->stream);
+            return fail(KMM_ERR_INVALID_ARG, "kmm_map_bgzf: bgzf_tail_stop %lld lies beyond the last member's %llu bytes",
+                        (long long)ix->bgzf_tail_stop, n_members ? o_off[n_members] - o_off[n_members - 1] : 0ull);
+        }
+        n_raw = (int64_t)o_off[n_members - 1] + ix->bgzf_tail_stop;
+        ix->bgzf_tail_stop = -1;
+    }
+    if (head > n_raw) {
+        (void)hipStreamSynchronize(ix->stream);
+        return fail(KMM_ERR_INVALID_ARG, "kmm_map_bgzf: bgzf_head_skip %lld lies beyond the %lld bytes of the call", (long long)head,
+                    (long long)n_raw);
+    }
     unsigned int err[4] = {0, 0, 0, 0};
     uint8_t last_byte = 10;
     HIPCHK(hipMemcpyAsync(err, ix->bgzf_err.p, sizeof err, hipMemcpyDeviceToHost, ix->stream));
-    if (last_chunk && n_total > 0)
-        HIPCHK(hipMemcpyAsync(&last_byte, d_raw + n_total - 1, 1, hipMemcpyDeviceToHost, ix->stream));
+    if (last_chunk && n_raw > head)
+        HIPCHK(hipMemcpyAsync(&last_byte, d_raw + n_raw - 1, 1, hipMemcpyDeviceToHost, ix->stream));
     HIPCHK(hipStreamSynchronize(ix->stream)); // (CRC32 / ISIZE of every member are checked before a byte is mapped)
     const double ms_inflate = ms_since(t_0) - ms_scan - ms_stage;
     ix->bgzf_calls++;
@@ -3069,14 +3093,14 @@ int kmm_map_bgzf(kmm_index_t *ix, const uint8_t *comp, int64_t n_comp, int forma
         return fail(KMM_ERR_MALFORMED, "kmm_map_bgzf: %u corrupt BGZF member(s); the first starts at compressed byte %llu of the chunk: %s",
                     err[0], err[1] < n_members ? m_off[err[1]] : 0ull, err[2] < 12 ? why[err[2]] : "?");
     }
-    int64_t n_raw = n_total;
-    if (last_chunk && n_raw > 0 && last_byte != 10) { // a last line without its newline gets one (as the file readers do)
+    if (last_chunk && n_raw > head && last_byte != 10) { // a last line without its newline gets one (as the file readers do)
         HIPCHK(hipMemsetAsync(d_raw + n_raw, 10, 1, ix->stream));
         ++n_raw;
     }
     int64_t used = 0, recs = 0;
-    if (n_raw > 0)
-        KMMCHK(kmm_map_records(ix, d_raw, n_raw, fmt, k, max_freq, also_revcomp, lut, &used, &recs));
+    if (n_raw > head)
+        KMMCHK(kmm_map_records(ix, d_raw + head, n_raw - head, fmt, k, max_freq, also_revcomp, lut, &used, &recs));
+    used += head;
     if (n_records)
         *n_records = recs;
     if (verbose)
@@ -3569,6 +3593,12 @@ int kmm_set_param(kmm_index_t *ix, const char *name, int64_t value)
         if (value < 0 || value > 65536)
             return fail(KMM_ERR_INVALID_ARG, "host_pack_slice_kb outside [0, 65536]");
         ix->host_pack_slice_kb = value;
+    } else if (!strcmp(name, "bgzf_head_skip")) {
+        if (value < 0)
+            return fail(KMM_ERR_INVALID_ARG, "bgzf_head_skip negative");
+        ix->bgzf_head_skip = value;
+    } else if (!strcmp(name, "bgzf_tail_stop")) {
+        ix->bgzf_tail_stop = value < 0 ? -1 : value;
     } else if (!strcmp(name, "debug_bgzf_ring_slot_kb") || !strcmp(name, "debug_ring_slot_kb")) {
         if (value != 0 && (value < 4 || value > (1 << 20) || (value & (value - 1))))
             return fail(KMM_ERR_INVALID_ARG, "debug_ring_slot_kb: 0 or a power of two in [4, 2^20]");

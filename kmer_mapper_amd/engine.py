@@ -207,11 +207,17 @@ class DeviceIndex:
         return consumed.value, n_rec.value
 
     def map_bgzf(self, comp, n_bytes=None, fmt=_lib.FORMAT_FASTQ, k=31, max_index_lookup_frequency=1000, also_revcomp=False,
-                 lut=None, first=False, last=False):
+                 lut=None, first=False, last=False, head_skip=0, tail_stop=None):
         """Map a chunk of a BGZF-compressed FASTQ (fmt=4) / two-line FASTA (fmt=2) file, inflated on the GPU (kmm_map_bgzf).
         `comp` starts at a member boundary; returns (compressed bytes used, records mapped): continue at comp[used:].  The
         handle carries the inflated bytes behind the last complete record to the next call; first / last mark the file's
-        first / last chunk."""
+        first / last chunk.  A rank's share of a file (bgzf_ranges.rank_member_range): head_skip = inflated bytes of the
+        FIRST chunk's first member that belong to the rank before; tail_stop = how many inflated bytes of the LAST chunk's
+        last member are this rank's (None: all)."""
+        if head_skip:
+            self.set_param("bgzf_head_skip", int(head_skip))
+        if tail_stop is not None:
+            self.set_param("bgzf_tail_stop", int(tail_stop))
         b = _Arg(comp, np.uint8, "comp")
         t = _Arg(lut, np.uint8, "lut")
         n = b.n if n_bytes is None else int(n_bytes)

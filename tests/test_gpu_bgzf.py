@@ -102,6 +102,47 @@ def test_bgzf_members_inflated_on_the_gpu_give_the_oracles_counts(kmm, syn, orac
         dev.set_param("debug_bgzf_ring_slot_kb", 0)
 
 
+@pytest.mark.parametrize("fmt", ["fastq", "fasta"])
+def test_ranks_map_their_member_ranges(kmm, syn, oracle, fmt):
+    """Several ranks on one BGZF file (kmer_mapper map under torchrun; emulated here on one handle): rank r maps the
+    members of bgzf_ranges.rank_member_range with the head of its first member skipped ("bgzf_head_skip") and only the
+    head of the member behind its range taken ("bgzf_tail_stop").  Summed over the ranks: the oracle's counts and every
+    record once — for members of 64 KiB and of 3 000 bytes (ranges that start and end inside records), 1 to 9 ranks, a
+    rank with nothing to do among them."""
+    from kmer_mapper_amd import _lib, bgzf_ranges
+    index, genome = syn.make_index(20000, seed=731)
+    mx = index.max_node_id()
+    bases, offs = syn.make_ragged_reads(genome, 6000, 31, 240, seed=732)
+    reads = [bases[offs[i]:offs[i + 1]].tobytes() for i in range(len(offs) - 1)]
+    expect, _ = oracle.map_reads(index, mx, bases, offs, 31, n_threads=4)
+    rng = np.random.default_rng(733)
+    raw = _fastq(reads, rng) if fmt == "fastq" else b"".join(b">r%d\n" % i + r + b"\n" for i, r in enumerate(reads))
+    kfmt = _lib.FORMAT_FASTQ if fmt == "fastq" else _lib.FORMAT_FASTA2
+    with kmm.DeviceIndex.from_index(index, mx) as dev:
+        for block, worlds in ((0xFF00, (2, 5, 40)), (3000, (1, 3, 9))):
+            comp = _bgzf(raw, block)
+            m_offs = bgzf_ranges.member_chain(comp)
+            buf = np.frombuffer(comp, dtype=np.uint8)
+            for world in worlds:
+                dev.reset()
+                total = 0
+                for r in range(world):
+                    m0, s0, m1, s1 = bgzf_ranges.rank_member_range(comp, m_offs, fmt, r, world)
+                    lo, hi = int(m_offs[m0]), int(m_offs[m1 + 1 if s1 > 0 else m1])
+                    if lo == hi:
+                        continue
+                    used, n_rec = dev.map_bgzf(buf[lo:hi], fmt=kfmt, k=31, first=True, last=True, head_skip=s0,
+                                               tail_stop=s1 if s1 > 0 else None)
+                    assert used == hi - lo
+                    total += n_rec
+                assert total == len(reads), (block, world)
+                assert np.array_equal(dev.get_node_counts(), expect), (block, world)
+        with pytest.raises(ValueError):                     # a tail beyond the last member's bytes
+            dev.map_bgzf(buf, fmt=kfmt, k=31, first=True, last=True, tail_stop=10 ** 6)
+        dev.set_param("bgzf_tail_stop", -1)
+        dev.reset()
+
+
 def test_bgzf_two_line_fasta_and_a_last_line_without_newline(kmm, syn, oracle):
     from kmer_mapper_amd import _lib
     index, genome = syn.make_index(8000, seed=711)

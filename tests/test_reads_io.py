@@ -708,3 +708,49 @@ def test_parallel_inflate_of_damaged_streams_raises_or_matches_zlib(tmp_path, mo
             n_ok += 1
     assert n_raised > 40                                          # (nearly every damage is caught; a flipped bit in a
     #                                                               name-less header field may pass in both readers)
+
+
+def test_bgzf_member_ranges_partition_the_records_exactly():
+    """bgzf_ranges.rank_member_range: the ranks of a job take the BGZF members that start in their share of the compressed
+    bytes, resynchronised to the record structure — a member starts wherever the compressor's buffer ended.  For FASTQ
+    (quality lines that start with '@' among them) and two-line FASTA, members of 64 KiB, 5 000 and 777 bytes, 1 to 40 ranks:
+    the ranges, as positions in the inflated file, follow each other without gap or overlap from 0 to the end, every
+    non-empty one starts at a record start and holds whole records."""
+    import struct
+    import zlib
+    from kmer_mapper_amd import bgzf_ranges as br
+    rng = np.random.default_rng(5)
+
+    def member(chunk):
+        c = zlib.compressobj(6, zlib.DEFLATED, -15)
+        payload = c.compress(chunk) + c.flush()
+        return (b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", 18 + len(payload) + 8 - 1) + payload +
+                struct.pack("<II", zlib.crc32(chunk) & 0xFFFFFFFF, len(chunk)))
+
+    eof = bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
+    reads = [bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=int(rng.integers(20, 300)))) for _ in range(3000)]
+    fastq = b"".join(b"@r%d\n" % i + r + b"\n+\n" + bytes(rng.choice(np.frombuffer(b"@@FF:,#I", dtype=np.uint8), size=len(r))) + b"\n"
+                     for i, r in enumerate(reads))
+    fasta = b"".join(b">r%d\n" % i + r + b"\n" for i, r in enumerate(reads))
+    for raw, fmt, period, first in ((fastq, "fastq", 4, b"@"), (fasta, "fasta", 2, b">")):
+        for block in (0xFF00, 5000, 777):
+            comp = b"".join(member(raw[p:p + block]) for p in range(0, len(raw), block)) + eof
+            offs = br.member_chain(comp)
+            assert offs[0] == 0 and offs[-1] == len(comp)
+            sizes = [len(br.inflate_member(comp, int(offs[i]), int(offs[i + 1]))) for i in range(len(offs) - 1)]
+            assert sum(sizes) == len(raw)
+            cum = np.concatenate([[0], np.cumsum(sizes)])
+            for world in (1, 2, 3, 7, 40):
+                spans = []
+                for r in range(world):
+                    m0, s0, m1, s1 = br.rank_member_range(comp, offs, fmt, r, world)
+                    assert 0 <= s0 < max(sizes[m0] if m0 < len(sizes) else 1, 1) and 0 <= s1
+                    spans.append((int(cum[m0]) + s0, int(cum[m1]) + s1))
+                assert spans[0][0] == 0 and spans[-1][1] == len(raw), (fmt, block, world)
+                assert all(a[1] == b[0] for a, b in zip(spans[:-1], spans[1:])), (fmt, block, world)
+                for a, b in spans:
+                    if a < b:
+                        assert raw[a:a + 1] == first and (a == 0 or raw[a - 1:a] == b"\n")
+                        assert raw[a:b].count(b"\n") % period == 0
+    with pytest.raises(ValueError):
+        br.member_chain(comp[:-40] + b"garbage that is no member header, forty bytes")

@@ -22,17 +22,30 @@ def main():
     index, genome = syn.make_index(20000, seed=5)
     bases, offs = syn.make_ragged_reads(genome, 30000, 20, 220, seed=6)
     idx_path, fq, fa = os.path.join(d, "index.npz"), os.path.join(d, "reads.fq"), os.path.join(d, "reads.fa")
+    bgz_fq, bgz_fa = os.path.join(d, "reads_bgzf.fq.gz"), os.path.join(d, "reads_bgzf.fa.gz")
     if rank == 0:
         index.to_file(idx_path)
         reads_io.write_fastq(fq, ReadBatch(bases, offs))
         reads_io.write_fastq(fq + ".gz", ReadBatch(bases, offs), gz=True)
         reads_io.write_fasta(fa + ".gz", ReadBatch(bases, offs), gz=True)   # two-line FASTA through the GPU parser
+        # BGZF (what bgzip writes): members inflated on the GPU, every rank its own member range (bgzf_ranges.py); small
+        # members here, so that every rank's range starts and ends inside records
+        from tools.bgzf_e2e import _member, _EOF
+        for src, dst in ((fq, bgz_fq), (None, bgz_fa)):
+            if src is None:
+                reads_io.write_fasta(fa, ReadBatch(bases, offs))
+                src = fa
+            raw = open(src, "rb").read()
+            with open(dst, "wb") as g:
+                for p in range(0, len(raw), 23456):
+                    g.write(_member(raw[p:p + 23456]))
+                g.write(_EOF)
     import torch.distributed as dist
     dist.init_process_group(os.environ.get("KMM_DIST_BACKEND", "gloo"))
     dist.barrier()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     ok = True
-    for path in (fq, fq + ".gz", fa + ".gz"):
+    for path in (fq, fq + ".gz", fa + ".gz", bgz_fq, bgz_fa):
         out = os.path.join(d, "out_" + os.path.basename(path).replace(".", "_"))
         run_argument_parser(["map", "-i", idx_path, "-f", path, "-o", out, "-c", "300000"])
         dist.barrier()
