@@ -281,13 +281,12 @@ def _map_bgzf_file(dev, path, kfmt, k, max_freq, revcomp, before_fetch, t_start,
                 lo, size, head_skip, tail_stop = 0, file_size, 0, None
                 if world_size > 1:
                     from . import bgzf_ranges
-                    offs = bgzf_ranges.member_chain(mm)
-                    m0, s0, m1, s1 = bgzf_ranges.rank_member_range(mm, offs, fmt, rank, world_size)
-                    lo, size = int(offs[m0]), int(offs[m1 + 1 if s1 > 0 else m1])
+                    lo, s0, hi, s1 = bgzf_ranges.rank_member_range(mm, fmt, rank, world_size)
+                    size = bgzf_ranges.member_end(mm, hi) if s1 > 0 else hi
                     head_skip, tail_stop = s0, (s1 if s1 > 0 else None)
-                    logging.info("Rank %d of %d maps BGZF members [%d, %d) of %d: compressed bytes [%d, %d), %d inflated bytes of "
-                                 "the first member skipped, %s of the last one taken", rank, world_size, m0, m1 + (1 if s1 > 0 else 0),
-                                 len(offs) - 1, lo, size, s0, "all" if tail_stop is None else "%d bytes" % s1)
+                    logging.info("Rank %d of %d maps the BGZF members in compressed bytes [%d, %d) of %d: %d inflated bytes of the "
+                                 "first member skipped, %s of the last one taken", rank, world_size, lo, size, file_size, s0,
+                                 "all" if tail_stop is None else "%d bytes" % s1)
                 if hasattr(mm, "madvise") and hasattr(mmap, "MADV_SEQUENTIAL"):
                     mm.madvise(mmap.MADV_SEQUENTIAL)
                 whole = np.frombuffer(mm, dtype=np.uint8)

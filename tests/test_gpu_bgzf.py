@@ -121,14 +121,13 @@ def test_ranks_map_their_member_ranges(kmm, syn, oracle, fmt):
     with kmm.DeviceIndex.from_index(index, mx) as dev:
         for block, worlds in ((0xFF00, (2, 5, 40)), (3000, (1, 3, 9))):
             comp = _bgzf(raw, block)
-            m_offs = bgzf_ranges.member_chain(comp)
             buf = np.frombuffer(comp, dtype=np.uint8)
             for world in worlds:
                 dev.reset()
                 total = 0
                 for r in range(world):
-                    m0, s0, m1, s1 = bgzf_ranges.rank_member_range(comp, m_offs, fmt, r, world)
-                    lo, hi = int(m_offs[m0]), int(m_offs[m1 + 1 if s1 > 0 else m1])
+                    lo, s0, hi, s1 = bgzf_ranges.rank_member_range(comp, fmt, r, world)
+                    hi = bgzf_ranges.member_end(comp, hi) if s1 > 0 else hi
                     if lo == hi:
                         continue
                     used, n_rec = dev.map_bgzf(buf[lo:hi], fmt=kfmt, k=31, first=True, last=True, head_skip=s0,

@@ -721,8 +721,8 @@ def test_bgzf_member_ranges_partition_the_records_exactly():
     from kmer_mapper_amd import bgzf_ranges as br
     rng = np.random.default_rng(5)
 
-    def member(chunk):
-        c = zlib.compressobj(6, zlib.DEFLATED, -15)
+    def member(chunk, level=6):
+        c = zlib.compressobj(level, zlib.DEFLATED, -15)
         payload = c.compress(chunk) + c.flush()
         return (b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", 18 + len(payload) + 8 - 1) + payload +
                 struct.pack("<II", zlib.crc32(chunk) & 0xFFFFFFFF, len(chunk)))
@@ -742,8 +742,10 @@ def test_bgzf_member_ranges_partition_the_records_exactly():
             cum = np.concatenate([[0], np.cumsum(sizes)])
             for world in (1, 2, 3, 7, 40):
                 spans = []
+                where = {int(o): i for i, o in enumerate(offs)}                   # member index by compressed offset
                 for r in range(world):
-                    m0, s0, m1, s1 = br.rank_member_range(comp, offs, fmt, r, world)
+                    lo, s0, hi, s1 = br.rank_member_range(comp, fmt, r, world)
+                    m0, m1 = where[lo], where[hi]
                     assert 0 <= s0 < max(sizes[m0] if m0 < len(sizes) else 1, 1) and 0 <= s1
                     spans.append((int(cum[m0]) + s0, int(cum[m1]) + s1))
                 assert spans[0][0] == 0 and spans[-1][1] == len(raw), (fmt, block, world)
@@ -754,3 +756,13 @@ def test_bgzf_member_ranges_partition_the_records_exactly():
                         assert raw[a:b].count(b"\n") % period == 0
     with pytest.raises(ValueError):
         br.member_chain(comp[:-40] + b"garbage that is no member header, forty bytes")
+    # a boundary is found from its byte position alone: bytes that look like a header inside a member's payload are passed over
+    # (stored blocks: the payload holds the decoys verbatim — a bare magic number, and a complete header whose BSIZE leads nowhere)
+    decoy = b"\x1f\x8b\x08\x04" + bytes(60) + b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00\x63\x00" + bytes(120)
+    noisy = b"".join(member(decoy * 3 + raw[p:p + 5000], level=0) for p in range(0, 200_000, 5000)) + eof
+    assert noisy.count(b"\x1f\x8b\x08\x04") > 3 * (len(noisy) // 6000)
+    n_offs = br.member_chain(noisy)
+    for t in range(1, len(noisy), 997):
+        m, prev = br.member_at_or_after(noisy, t)
+        k2 = int(np.searchsorted(n_offs, t, side="left"))
+        assert m == n_offs[k2] and (prev is None or prev == n_offs[k2 - 1])
