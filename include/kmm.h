@@ -211,6 +211,12 @@ int kmm_map_records(kmm_index_t *idx, const uint8_t *raw, int64_t n_bytes, int f
  * `bgzip`) is refused the same way — inflate it on the host (libkmm_io).  *n_records: reads mapped by this call.
  */
 #define KMM_FORMAT_NEW_STREAM 0x400
+/* Optional, before a kmm_map_bgzf call whose chunk is followed in the caller's memory by more of the file (a file mapping):
+ * comp_next = comp + n_comp of that call, n_next = how many more bytes the NEXT call will bring (the next call then passes
+ * comp + *consumed_comp, n_comp - *consumed_comp + n_next).  The library stages and walks those bytes while this chunk's
+ * members are being inflated — a chunk's 20 ms over PCIe then no longer stand in front of its 46 ms of kernel.  A hint that
+ * the next call does not keep to costs nothing but the copy.  "bgzf_prestaged_calls" (read-only) counts the hints used. */
+int kmm_map_bgzf_hint_next(kmm_index_t *idx, const uint8_t *comp_next, int64_t n_next);
 int kmm_map_bgzf(kmm_index_t *idx, const uint8_t *comp, int64_t n_comp, int format, int k, int max_index_lookup_frequency,
                  int also_revcomp, const uint8_t *lut, int64_t *consumed_comp, int64_t *n_records);
 

@@ -62,6 +62,7 @@ SIGNATURES = {
                                          _c.c_int, _P]),
     "kmm_map_records": (_c.c_int, [_P, _P, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _P, _P, _P]),
     "kmm_map_bgzf": (_c.c_int, [_P, _P, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _P, _P, _P]),
+    "kmm_map_bgzf_hint_next": (_c.c_int, [_P, _P, _c.c_int64]),
     "kmm_map_packed": (_c.c_int, [_P, _P, _c.c_int64, _c.c_int64, _c.c_int64, _P, _c.c_int, _c.c_int, _c.c_int]),
     "kmm_extract_kmers": (_c.c_int, [_c.c_int, _P, _P, _c.c_int64, _c.c_int, _P, _P, _c.c_int64]),
     "kmm_build_index": (_c.c_int, [_c.c_int, _P, _P, _c.c_int64, _c.c_uint64, _P, _P, _P, _P, _P]),

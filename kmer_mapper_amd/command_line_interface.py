@@ -295,21 +295,21 @@ def _map_bgzf_file(dev, path, kfmt, k, max_freq, revcomp, before_fetch, t_start,
                 n_calls = max(1, -(-(size - lo) // _BGZF_WINDOW))
                 pos, window = lo, int(comp_batch) if comp_batch else (size - lo) // n_calls + (1 << 16)
                 t_calls = time.perf_counter()
-                while pos < size:
-                    end = min(pos + window, size)
+                end = min(lo + window, size)             # windows END at fixed places; a window starts where the one before
+                while pos < size:                        # it ran out of whole members (at most 64 KiB in front of that end)
+                    nxt = min(end + window, size)
                     used, n_rec = dev.map_bgzf(whole[pos:end], fmt=kfmt, k=k, max_index_lookup_frequency=max_freq,
                                                also_revcomp=revcomp, first=pos == lo, last=end == size,
                                                head_skip=head_skip if pos == lo else 0,
-                                               tail_stop=tail_stop if end == size else None)
-                    if used == 0 and end < size:
-                        window *= 2                      # (a member larger than the window: cannot happen with BGZF's 64 KiB)
-                        continue
-                    if used == 0:
+                                               tail_stop=tail_stop if end == size else None,
+                                               next_chunk=whole[end:nxt] if nxt > end else None)
+                    if used == 0 and end == size:
                         raise ValueError("trailing bytes of %s are no complete BGZF member" % path)
                     pos += used
                     n_reads += n_rec
-                    if end == size and pos < size:       # the last window held more than one call takes: go on
+                    if pos < end and end == size:        # the last window held more than one call takes: go on
                         continue
+                    end = nxt
                 del whole
             finally:
                 try:

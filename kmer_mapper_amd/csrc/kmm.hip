@@ -194,6 +194,17 @@ struct TimedEvent {
     int kernel_id;
 };
 
+// What kmm_map_bgzf knows about a chunk of compressed bytes once they are on their way to HBM: the member chain.
+struct BgzfStaged {
+    std::vector<unsigned long long> m_off, o_rel; // member starts in the chunk; inflated offsets from the chunk's first member (o_rel[0] = 0)
+    uint64_t p = 0;                               // bytes of whole members
+    int chain_err = 0;                            // 1: no member at p, 2: implausible ISIZE
+    uint32_t bad_isize = 0, bad_ms = 0;
+    bool hit_cap = false;                         // the chain was cut at the size limit of a call
+    bool staged = false;                          // the bytes went through the page-locked ring (else: not copied at all yet)
+    double ms_scan_inside = 0;
+};
+
 struct kmm_index {
     int device = 0;
     hipStream_t stream = nullptr;      // kernels
@@ -263,6 +274,12 @@ struct kmm_index {
     bool bgzf_used[2] = {false, false};
     int bgzf_cur = 0;
     int64_t bgzf_carry_len = 0;
+    BgzfStaged bgzf_pre;         // the NEXT chunk, staged and walked under this chunk's inflate kernel (kmm_map_bgzf_hint_next)
+    bool bgzf_pre_valid = false;
+    const uint8_t *bgzf_pre_from = nullptr, *bgzf_hint_ptr = nullptr;
+    int64_t bgzf_pre_n = 0, bgzf_hint_n = 0;
+    int bgzf_pre_buf = 0;
+    int64_t bgzf_prestaged_calls = 0;
     int64_t bgzf_head_skip = 0;  // "bgzf_head_skip": inflated bytes of the next NEW_STREAM call's first member that belong to someone else
     int64_t bgzf_tail_stop = -1; // "bgzf_tail_stop": >= 0: of the next LAST_CHUNK call's last member only this many inflated bytes are taken
     int64_t bgzf_calls = 0, bgzf_members = 0;
@@ -2821,6 +2838,168 @@ int kmm_map_packed(kmm_index_t *ix, const uint32_t *codes, int64_t n_bases, int6
     return stage_release(ix, s, staged);
 }
 
+
+// Stages comp[pre, n_comp) to d_comp + pre through the page-locked ring (comp[0, pre) is there already: a member's head left
+// over from the chunk before) and walks the member chain of comp[0, n_comp) behind the copying threads.  cap: inflated bytes
+// the chain may hold.  all: n_comp is where the chunk ends (an incomplete last member ends the chain).
+static int bgzf_stage_and_scan(kmm_index_t *ix, const uint8_t *comp, int64_t pre, int64_t n_comp, uint8_t *d_comp, unsigned long long out_cap,
+                               BgzfStaged &st)
+{
+    auto ms_since = [](std::chrono::steady_clock::time_point a) {
+        return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count();
+    };
+    std::vector<unsigned long long> &m_off = st.m_off, &o_off = st.o_rel;
+    m_off.assign(1, 0ull);
+    o_off.assign(1, 0ull);
+    const int64_t carry = 0; // (offsets relative to the chunk: the caller adds what it carries over)
+    uint64_t &p = st.p;
+    p = 0;
+    bool chain_end = false, last_chunk = false;
+    int &chain_err = st.chain_err;
+    uint32_t &bad_isize = st.bad_isize, &bad_ms = st.bad_ms;
+    chain_err = 0;
+    // walks the chain through comp[0, limit); all = the limit is the end of the chunk
+    auto scan_upto = [&](uint64_t limit, bool all) {
+        while (!chain_end && p + 18 <= limit) {
+            const uint32_t ms = kmm_gz::bgzf_member_size(comp + p, limit - p);
+            if (!ms) {
+                // (a header that needs more bytes than are in reach: wait for them, or — at the end of the chunk — an
+                // incomplete member that the caller brings again)
+                const uint32_t xlen = (uint32_t)comp[p + 10] | ((uint32_t)comp[p + 11] << 8);
+                if (comp[p] == 0x1f && comp[p + 1] == 0x8b && comp[p + 2] == 8 && (comp[p + 3] & 4) && p + 12 + xlen + 8 > limit) {
+                    chain_end = all;
+                    return;
+                }
+                chain_err = 1;
+                chain_end = true;
+                return;
+            }
+            if (p + ms > limit) {
+                chain_end = all; // (an incomplete member at the end of the chunk)
+                return;
+            }
+            const uint32_t isize = kmm_gz::rd32(comp + p + ms - 4);
+            if ((uint64_t)isize > (uint64_t)ms * 1032ull + 64ull) {
+                chain_err = 2;
+                bad_isize = isize;
+                bad_ms = ms;
+                chain_end = true;
+                return;
+            }
+            if (o_off.back() - (unsigned long long)carry + isize > out_cap && m_off.size() > 1) {
+                st.hit_cap = true; // (the call stops at its own size limit: the caller continues with the same flags)
+                chain_end = true;
+                return;
+            }
+            p += ms;
+            m_off.push_back(p);
+            o_off.push_back(o_off.back() + isize);
+        }
+        if (all)
+            chain_end = true;
+    };
+    (void)last_chunk;
+    bool &staged = st.staged;
+    double &ms_scan_inside = st.ms_scan_inside;
+    staged = false;
+    ms_scan_inside = 0;
+    // ("debug_bgzf_ring_slot_kb": tests wrap the ring many times with a small input)
+    const size_t SLOT = ix->dbg_bgzf_slot_kb > 0 && ((size_t)ix->dbg_bgzf_slot_kb << 10) < RING_SLOT ? (size_t)ix->dbg_bgzf_slot_kb << 10 : RING_SLOT;
+    const size_t SUB = SLOT < ((size_t)1 << 20) ? SLOT : (size_t)1 << 20;
+    constexpr int SLOTS = RING_SLOTS;
+    if (n_comp > pre && ensure_pack_pool(ix) && ensure_ring(ix)) {
+        const size_t n_stage = (size_t)(n_comp - pre); // bytes to copy: [pre, n_comp)
+        const size_t n_slots = (n_stage + SLOT - 1) / SLOT, n_sub = (n_stage + SUB - 1) / SUB;
+        std::vector<std::atomic<uint32_t>> filled(n_slots); // 1 MiB pieces copied, per slot-sized piece
+        for (auto &f : filled)
+            f.store(0, std::memory_order_relaxed);
+        std::atomic<size_t> next{0}, slots_free{(size_t)SLOTS}; // slot-sized pieces [0, slots_free) may be written
+        std::atomic<bool> stop{false};
+        uint8_t *const *ring = ix->ring;
+        ix->pack_pool->start([&](int) {
+            for (;;) {
+                const size_t c = next.fetch_add(1);
+                if (c >= n_sub)
+                    return;
+                const size_t piece = c / (SLOT / SUB);
+                int spins = 0;
+                while (piece >= slots_free.load(std::memory_order_acquire) && !stop.load(std::memory_order_relaxed)) {
+                    if (++spins < 2000) {
+#if defined(__x86_64__)
+                        __builtin_ia32_pause();
+#endif
+                    } else
+                        std::this_thread::sleep_for(std::chrono::microseconds(50));
+                }
+                if (stop.load(std::memory_order_relaxed))
+                    return;
+                const size_t b0 = c * SUB, len = n_stage - b0 < SUB ? n_stage - b0 : SUB;
+                memcpy(ring[piece % SLOTS] + (b0 - piece * SLOT), comp + pre + b0, len);
+                filled[piece].fetch_add(1, std::memory_order_release);
+            }
+        });
+        int rc = KMM_OK;
+        size_t landed = 0; // slot-sized pieces whose copy to HBM is known to have finished
+        for (size_t c = 0; c < n_slots && rc == KMM_OK; ++c) {
+            const size_t b0 = c * SLOT, len = n_stage - b0 < SLOT ? n_stage - b0 : SLOT;
+            const uint32_t want = (uint32_t)((len + SUB - 1) / SUB);
+            while (filled[c].load(std::memory_order_acquire) < want) {
+                // meanwhile: slots whose copies have landed are handed back, the chain is walked through what is there
+                bool did = false;
+                while (landed + SLOTS < n_slots && landed < c) {
+                    if (hipEventQuery(ix->bgzf_slot_ev[landed % SLOTS]) != hipSuccess) {
+                        (void)hipGetLastError(); // ("not ready" is no error to keep)
+                        break;
+                    }
+                    ++landed;
+                    slots_free.store(landed + SLOTS, std::memory_order_release);
+                    did = true;
+                }
+                if (!chain_end && !chain_err && c > 0) {
+                    const auto t_s = std::chrono::steady_clock::now();
+                    const uint64_t before = p;
+                    scan_upto((uint64_t)pre + (uint64_t)b0, false);
+                    ms_scan_inside += ms_since(t_s);
+                    did = did || p != before;
+                }
+                if (!did)
+                    std::this_thread::sleep_for(std::chrono::microseconds(20));
+            }
+            if (hipMemcpyAsync(d_comp + pre + b0, ring[c % SLOTS], len, hipMemcpyHostToDevice, ix->copy_stream) != hipSuccess ||
+                hipEventRecord(ix->bgzf_slot_ev[c % SLOTS], ix->copy_stream) != hipSuccess)
+                rc = fail(KMM_ERR_HIP, "copy of compressed bytes: %s", hipGetErrorString(hipGetLastError()));
+            // a slot is written again only when its copy has landed: the oldest one is waited for when the ring is full
+            while (rc == KMM_OK && landed + SLOTS < n_slots && landed + SLOTS <= c + 1) {
+                if (hipEventSynchronize(ix->bgzf_slot_ev[landed % SLOTS]) != hipSuccess) {
+                    rc = fail(KMM_ERR_HIP, "hipEventSynchronize: %s", hipGetErrorString(hipGetLastError()));
+                    break;
+                }
+                ++landed;
+                slots_free.store(landed + SLOTS, std::memory_order_release);
+            }
+        }
+        if (rc != KMM_OK)
+            stop.store(true);
+        ix->pack_pool->wait();
+        if (rc != KMM_OK) {
+            (void)hipStreamSynchronize(ix->copy_stream);
+            return rc;
+        }
+        staged = true;
+    }
+    scan_upto((uint64_t)n_comp, true);
+    return KMM_OK;
+}
+
+int kmm_map_bgzf_hint_next(kmm_index_t *ix, const uint8_t *comp_next, int64_t n_next)
+{
+    if (!ix)
+        return fail(KMM_ERR_INVALID_ARG, "idx is NULL");
+    ix->bgzf_hint_ptr = n_next > 0 ? comp_next : nullptr;
+    ix->bgzf_hint_n = n_next > 0 ? n_next : 0;
+    return KMM_OK;
+}
+
 int kmm_map_bgzf(kmm_index_t *ix, const uint8_t *comp, int64_t n_comp, int format, int k, int max_freq, int also_revcomp,
                  const uint8_t *lut, int64_t *consumed_comp, int64_t *n_records)
 {
@@ -2858,155 +3037,40 @@ int kmm_map_bgzf(kmm_index_t *ix, const uint8_t *comp, int64_t n_comp, int forma
     ix->bgzf_cur ^= 1;
     if (!ix->bgzf_done[cur])
         HIPCHK(hipEventCreateWithFlags(&ix->bgzf_done[cur], hipEventDisableTiming));
-    if (ix->bgzf_used[cur])
-        HIPCHK(hipStreamWaitEvent(ix->copy_stream, ix->bgzf_done[cur], 0)); // the kernels that last read these buffers are done
-    KMMCHK(ensure(ix->bgzf_comp[cur], (size_t)n_comp + 64));
-    uint8_t *d_comp = (uint8_t *)ix->bgzf_comp[cur].p;
-    // the member chain: whole members only, at most 3.5 GiB of inflated bytes per call (the caller comes back with the rest)
-    std::vector<unsigned long long> m_off, o_off;
-    m_off.push_back(0);
     const int64_t carry = ix->bgzf_carry_len;
-    o_off.push_back((unsigned long long)carry);
-    const unsigned long long out_cap = (7ull << 29) - (unsigned long long)carry; // 3.5 GiB per call
-    uint64_t p = 0;
-    bool chain_end = false;
-    int chain_err = 0; // 1: no member at p, 2: implausible ISIZE
-    uint32_t bad_isize = 0, bad_ms = 0;
-    // walks the chain through comp[0, limit); all = the limit is the end of the chunk
-    auto scan_upto = [&](uint64_t limit, bool all) {
-        while (!chain_end && p + 18 <= limit) {
-            const uint32_t ms = kmm_gz::bgzf_member_size(comp + p, limit - p);
-            if (!ms) {
-                // (a header that needs more bytes than are in reach: wait for them, or — at the end of the chunk — an
-                // incomplete member that the caller brings again)
-                const uint32_t xlen = (uint32_t)comp[p + 10] | ((uint32_t)comp[p + 11] << 8);
-                if (comp[p] == 0x1f && comp[p + 1] == 0x8b && comp[p + 2] == 8 && (comp[p + 3] & 4) && p + 12 + xlen + 8 > limit) {
-                    chain_end = all;
-                    return;
-                }
-                chain_err = 1;
-                chain_end = true;
-                return;
-            }
-            if (p + ms > limit) {
-                chain_end = all; // (an incomplete member at the end of the chunk)
-                return;
-            }
-            const uint32_t isize = kmm_gz::rd32(comp + p + ms - 4);
-            if ((uint64_t)isize > (uint64_t)ms * 1032ull + 64ull) {
-                chain_err = 2;
-                bad_isize = isize;
-                bad_ms = ms;
-                chain_end = true;
-                return;
-            }
-            if (o_off.back() - (unsigned long long)carry + isize > out_cap && m_off.size() > 1) {
-                last_chunk = false; // (the call stops at its own size limit: the caller continues with the same flags)
-                chain_end = true;
-                return;
-            }
-            p += ms;
-            m_off.push_back(p);
-            o_off.push_back(o_off.back() + isize);
-        }
-        if (all)
-            chain_end = true;
-    };
-    bool staged = false;
-    double ms_scan_inside = 0;
-    // ("debug_bgzf_ring_slot_kb": tests wrap the ring many times with a small input)
-    const size_t SLOT = ix->dbg_bgzf_slot_kb > 0 && ((size_t)ix->dbg_bgzf_slot_kb << 10) < RING_SLOT ? (size_t)ix->dbg_bgzf_slot_kb << 10 : RING_SLOT;
-    const size_t SUB = SLOT < ((size_t)1 << 20) ? SLOT : (size_t)1 << 20;
-    constexpr int SLOTS = RING_SLOTS;
-    if (n_comp > 0 && ensure_pack_pool(ix) && ensure_ring(ix)) {
-        const size_t n_slots = ((size_t)n_comp + SLOT - 1) / SLOT, n_sub = ((size_t)n_comp + SUB - 1) / SUB;
-        std::vector<std::atomic<uint32_t>> filled(n_slots); // 1 MiB pieces copied, per slot-sized piece
-        for (auto &f : filled)
-            f.store(0, std::memory_order_relaxed);
-        std::atomic<size_t> next{0}, slots_free{(size_t)SLOTS}; // slot-sized pieces [0, slots_free) may be written
-        std::atomic<bool> stop{false};
-        uint8_t *const *ring = ix->ring;
-        ix->pack_pool->start([&](int) {
-            for (;;) {
-                const size_t c = next.fetch_add(1);
-                if (c >= n_sub)
-                    return;
-                const size_t piece = c / (SLOT / SUB);
-                int spins = 0;
-                while (piece >= slots_free.load(std::memory_order_acquire) && !stop.load(std::memory_order_relaxed)) {
-                    if (++spins < 2000) {
-#if defined(__x86_64__)
-                        __builtin_ia32_pause();
-#endif
-                    } else
-                        std::this_thread::sleep_for(std::chrono::microseconds(50));
-                }
-                if (stop.load(std::memory_order_relaxed))
-                    return;
-                const size_t b0 = c * SUB, len = (size_t)n_comp - b0 < SUB ? (size_t)n_comp - b0 : SUB;
-                memcpy(ring[piece % SLOTS] + (b0 - piece * SLOT), comp + b0, len);
-                filled[piece].fetch_add(1, std::memory_order_release);
-            }
-        });
-        int rc = KMM_OK;
-        size_t landed = 0; // slot-sized pieces whose copy to HBM is known to have finished
-        for (size_t c = 0; c < n_slots && rc == KMM_OK; ++c) {
-            const size_t b0 = c * SLOT, len = (size_t)n_comp - b0 < SLOT ? (size_t)n_comp - b0 : SLOT;
-            const uint32_t want = (uint32_t)((len + SUB - 1) / SUB);
-            while (filled[c].load(std::memory_order_acquire) < want) {
-                // meanwhile: slots whose copies have landed are handed back, the chain is walked through what is there
-                bool did = false;
-                while (landed + SLOTS < n_slots && landed < c) {
-                    if (hipEventQuery(ix->bgzf_slot_ev[landed % SLOTS]) != hipSuccess) {
-                        (void)hipGetLastError(); // ("not ready" is no error to keep)
-                        break;
-                    }
-                    ++landed;
-                    slots_free.store(landed + SLOTS, std::memory_order_release);
-                    did = true;
-                }
-                if (!chain_end && !chain_err && c > 0) {
-                    const auto t_s = std::chrono::steady_clock::now();
-                    const uint64_t before = p;
-                    scan_upto((uint64_t)b0, false);
-                    ms_scan_inside += ms_since(t_s);
-                    did = did || p != before;
-                }
-                if (!did)
-                    std::this_thread::sleep_for(std::chrono::microseconds(20));
-            }
-            if (hipMemcpyAsync(d_comp + b0, ring[c % SLOTS], len, hipMemcpyHostToDevice, ix->copy_stream) != hipSuccess ||
-                hipEventRecord(ix->bgzf_slot_ev[c % SLOTS], ix->copy_stream) != hipSuccess)
-                rc = fail(KMM_ERR_HIP, "copy of compressed bytes: %s", hipGetErrorString(hipGetLastError()));
-            // a slot is written again only when its copy has landed: the oldest one is waited for when the ring is full
-            while (rc == KMM_OK && landed + SLOTS < n_slots && landed + SLOTS <= c + 1) {
-                if (hipEventSynchronize(ix->bgzf_slot_ev[landed % SLOTS]) != hipSuccess) {
-                    rc = fail(KMM_ERR_HIP, "hipEventSynchronize: %s", hipGetErrorString(hipGetLastError()));
-                    break;
-                }
-                ++landed;
-                slots_free.store(landed + SLOTS, std::memory_order_release);
-            }
-        }
-        if (rc != KMM_OK)
-            stop.store(true);
-        ix->pack_pool->wait();
-        if (rc != KMM_OK) {
-            (void)hipStreamSynchronize(ix->copy_stream);
-            return rc;
-        }
-        staged = true;
+    constexpr unsigned long long CALL_CAP = 7ull << 29, PRE_CARRY = 256ull << 20; // 3.5 GiB per call; what a prestaged chain leaves for a carry
+    BgzfStaged st;
+    bool from_pre = false;
+    if (ix->bgzf_pre_valid && ix->bgzf_pre_from == comp && ix->bgzf_pre_n == n_comp && ix->bgzf_pre_buf == cur &&
+        (unsigned long long)carry <= PRE_CARRY) {
+        st = std::move(ix->bgzf_pre); // staged and walked while the chunk before this one was being inflated
+        st.ms_scan_inside = 0;
+        from_pre = true;
     }
-    const double ms_stage = ms_since(t_0) - ms_scan_inside;
-    scan_upto((uint64_t)n_comp, true);
-    if (chain_err) {
+    ix->bgzf_pre_valid = false;
+    if (!from_pre) {
+        if (ix->bgzf_used[cur])
+            HIPCHK(hipStreamWaitEvent(ix->copy_stream, ix->bgzf_done[cur], 0)); // the kernels that last read these buffers are done
+        KMMCHK(ensure(ix->bgzf_comp[cur], (size_t)n_comp + 64));
+        KMMCHK(bgzf_stage_and_scan(ix, comp, 0, n_comp, (uint8_t *)ix->bgzf_comp[cur].p, CALL_CAP - (unsigned long long)carry, st));
+    }
+    uint8_t *d_comp = (uint8_t *)ix->bgzf_comp[cur].p;
+    const bool staged = st.staged;
+    if (st.hit_cap)
+        last_chunk = false; // (the call stops at its own size limit: the caller continues with the same flags)
+    const double ms_stage = ms_since(t_0) - st.ms_scan_inside;
+    const uint64_t p = st.p;
+    if (st.chain_err) {
         (void)hipStreamSynchronize(ix->copy_stream); // (the page-locked ring is free again)
-        if (chain_err == 1)
+        if (st.chain_err == 1)
             return fail(KMM_ERR_MALFORMED, "kmm_map_bgzf: no BGZF member at compressed byte %llu of the chunk (a gzip file that bgzip did "
                         "not write has no member sizes in its headers: inflate it on the host)", (unsigned long long)p);
         return fail(KMM_ERR_MALFORMED, "kmm_map_bgzf: member at compressed byte %llu claims %u inflated bytes for %u compressed ones",
-                    (unsigned long long)p, bad_isize, bad_ms);
+                    (unsigned long long)p, st.bad_isize, st.bad_ms);
     }
+    std::vector<unsigned long long> &m_off = st.m_off, &o_off = st.o_rel;
+    for (unsigned long long &o : o_off) // (the inflated bytes carried over from the call before lie in front)
+        o += (unsigned long long)carry;
     const uint32_t n_members = (uint32_t)(m_off.size() - 1);
     const int64_t n_used = (int64_t)p, n_total = (int64_t)o_off.back();
     if (consumed_comp)
@@ -3054,6 +3118,33 @@ int kmm_map_bgzf(kmm_index_t *ix, const uint8_t *comp, int64_t n_comp, int forma
                            (unsigned long long *)nullptr);
         HIPCHK(hipGetLastError());
     }
+    // The chunk BEHIND this one (kmm_map_bgzf_hint_next: the caller's bytes go on where this chunk ends) is staged and walked NOW,
+    // under this chunk's inflate kernel: its 20 ms over PCIe would otherwise stand in front of its own 46 ms of kernel.  The next
+    // call starts where this call's whole members end — the head of a member that this chunk cut off is copied in front.
+    if (ix->bgzf_hint_ptr && ix->bgzf_hint_ptr == comp + n_comp && ix->bgzf_hint_n > 0 && n_members > 0 && n_used <= n_comp) {
+        const int nxt = cur ^ 1;
+        const int64_t head_len = n_comp - n_used, total = head_len + ix->bgzf_hint_n;
+        bool ok = hipStreamSynchronize(ix->copy_stream) == hipSuccess; // (this chunk's copies have landed: the ring is free)
+        if (ok && ix->bgzf_used[nxt])
+            ok = hipStreamWaitEvent(ix->copy_stream, ix->bgzf_done[nxt], 0) == hipSuccess;
+        if (ok && ix->bgzf_comp[nxt].cap < (size_t)total + 64) // (growing it frees it first: a device-wide wait, once)
+            ok = ensure(ix->bgzf_comp[nxt], (size_t)total + 64) == KMM_OK;
+        if (ok && head_len > 0)
+            ok = hipMemcpyAsync(ix->bgzf_comp[nxt].p, d_comp + n_used, (size_t)head_len, hipMemcpyDeviceToDevice, ix->copy_stream) == hipSuccess;
+        if (ok && bgzf_stage_and_scan(ix, comp + n_used, head_len, total, (uint8_t *)ix->bgzf_comp[nxt].p, CALL_CAP - PRE_CARRY, ix->bgzf_pre) == KMM_OK &&
+            ix->bgzf_pre.staged && !ix->bgzf_pre.chain_err) {
+            ix->bgzf_pre_valid = true;
+            ix->bgzf_pre_from = comp + n_used;
+            ix->bgzf_pre_n = total;
+            ix->bgzf_pre_buf = nxt;
+            ix->bgzf_prestaged_calls++;
+        } else {
+            (void)hipGetLastError();
+        }
+        (void)hipStreamSynchronize(ix->copy_stream); // (between calls the ring is free: its last slots have landed, ~2 ms)
+    }
+    ix->bgzf_hint_ptr = nullptr;
+    ix->bgzf_hint_n = 0;
     // A RANK'S SHARE of a file (kmer_mapper map with several ranks, bgzf_ranges.py): its first member starts inside a record
     // that belongs to the rank before it — "bgzf_head_skip" bytes of the stream's first member are passed over — and its last
     // member holds the start of the next rank's first record — only "bgzf_tail_stop" bytes of the last member are taken.
@@ -3104,8 +3195,9 @@ int kmm_map_bgzf(kmm_index_t *ix, const uint8_t *comp, int64_t n_comp, int forma
     if (n_records)
         *n_records = recs;
     if (verbose)
-        fprintf(stderr, "libkmm: kmm_map_bgzf: %u members, %lld -> %lld bytes: member scan %.2f ms, buffers + staging + copy %.2f ms, "
-                "copy tail + inflate kernel %.2f ms, records %.2f ms\n", n_members, (long long)n_used, (long long)n_total, ms_scan, ms_stage,
+        fprintf(stderr, "libkmm: kmm_map_bgzf: %u members, %lld -> %lld bytes: member scan %.2f ms, buffers + staging + copy %.2f ms%s, "
+                "copy tail + inflate kernel%s %.2f ms, records %.2f ms\n", n_members, (long long)n_used, (long long)n_total, ms_scan, ms_stage,
+                from_pre ? " (staged and walked under the call before)" : "", ix->bgzf_pre_valid ? " + the next chunk's staging" : "",
                 ms_inflate, ms_since(t_0) - ms_scan - ms_stage - ms_inflate);
     const int64_t tail = n_raw - used;
     if (last_chunk && tail > 0) {
@@ -3643,6 +3735,8 @@ int kmm_get_param(kmm_index_t *ix, const char *name, int64_t *value)
         *value = ix->host_packed_calls;
     else if (!strcmp(name, "host_packed_record_calls")) // kmm_map_records calls whose sequence lines were packed on the host
         *value = ix->host_packed_record_calls;
+    else if (!strcmp(name, "bgzf_prestaged_calls")) // kmm_map_bgzf calls that staged the chunk behind them under their own kernel
+        *value = ix->bgzf_prestaged_calls;
     else if (!strcmp(name, "bgzf_members")) // BGZF members inflated on the GPU by kmm_map_bgzf
         *value = ix->bgzf_members;
     else if (!strcmp(name, "bgzf_carry_bytes")) // inflated bytes behind the last complete record, waiting for the next call

@@ -207,13 +207,18 @@ class DeviceIndex:
         return consumed.value, n_rec.value
 
     def map_bgzf(self, comp, n_bytes=None, fmt=_lib.FORMAT_FASTQ, k=31, max_index_lookup_frequency=1000, also_revcomp=False,
-                 lut=None, first=False, last=False, head_skip=0, tail_stop=None):
+                 lut=None, first=False, last=False, head_skip=0, tail_stop=None, next_chunk=None):
         """Map a chunk of a BGZF-compressed FASTQ (fmt=4) / two-line FASTA (fmt=2) file, inflated on the GPU (kmm_map_bgzf).
         `comp` starts at a member boundary; returns (compressed bytes used, records mapped): continue at comp[used:].  The
         handle carries the inflated bytes behind the last complete record to the next call; first / last mark the file's
         first / last chunk.  A rank's share of a file (bgzf_ranges.rank_member_range): head_skip = inflated bytes of the
         FIRST chunk's first member that belong to the rank before; tail_stop = how many inflated bytes of the LAST chunk's
-        last member are this rank's (None: all)."""
+        last member are this rank's (None: all).  next_chunk: see below."""
+        if next_chunk is not None and len(next_chunk):
+            # the bytes that follow `comp` in the caller's memory (a view of the same file mapping): staged under this chunk's
+            # inflate kernel (kmm_map_bgzf_hint_next); the next call passes comp[used:] + next_chunk as one view
+            nx = _Arg(next_chunk, np.uint8, "next_chunk")
+            _lib.check(_lib.lib().kmm_map_bgzf_hint_next(self._h, nx.ptr, nx.n))
         if head_skip:
             self.set_param("bgzf_head_skip", int(head_skip))
         if tail_stop is not None:

@@ -68,6 +68,25 @@ def _feed(dev, comp, fmt, k, step):
     return total
 
 
+def _feed_hinted(dev, comp, fmt, k, step):
+    """The CLI's loop (command_line_interface._map_bgzf_file): windows that END at fixed places, each call told which bytes
+    follow (kmm_map_bgzf_hint_next: staged under the call's own inflate kernel)."""
+    buf = np.frombuffer(comp, dtype=np.uint8)
+    size, pos, total = len(comp), 0, 0
+    end = min(step, size)
+    while pos < size:
+        nxt = min(end + step, size)
+        used, n_rec = dev.map_bgzf(buf[pos:end], fmt=fmt, k=k, first=pos == 0, last=end == size,
+                                   next_chunk=buf[end:nxt] if nxt > end else None)
+        assert used > 0 or end < size
+        pos += used
+        total += n_rec
+        if pos < end and end == size:
+            continue
+        end = nxt
+    return total
+
+
 @pytest.mark.parametrize("level,strategy", [(6, zlib.Z_DEFAULT_STRATEGY), (1, zlib.Z_DEFAULT_STRATEGY), (9, zlib.Z_FILTERED),
                                             (0, zlib.Z_DEFAULT_STRATEGY), (6, zlib.Z_FIXED), (6, zlib.Z_HUFFMAN_ONLY)])
 def test_bgzf_members_inflated_on_the_gpu_give_the_oracles_counts(kmm, syn, oracle, level, strategy):
@@ -100,6 +119,30 @@ def test_bgzf_members_inflated_on_the_gpu_give_the_oracles_counts(kmm, syn, orac
             assert _feed(dev, comp, _lib.FORMAT_FASTQ, 31, 1 << 30) == len(reads)
             assert np.array_equal(dev.get_node_counts(), expect), slot_kb
         dev.set_param("debug_bgzf_ring_slot_kb", 0)
+        # windows announced one call ahead: the next window is staged and its member chain walked under this window's kernel
+        for comp2, step in ((comp, 150_001), (_bgzf(raw, 20000, level, strategy, rng=rng), 64 * 1024 + 5), (comp, 1 << 30)):
+            for slot_kb in (0, 16):
+                dev.set_param("debug_bgzf_ring_slot_kb", slot_kb)
+                dev.reset()
+                before = dev.get_param("bgzf_prestaged_calls")
+                assert _feed_hinted(dev, comp2, _lib.FORMAT_FASTQ, 31, step) == len(reads)
+                assert np.array_equal(dev.get_node_counts(), expect), (step, slot_kb)
+                assert dev.get_param("bgzf_carry_bytes") == 0
+                assert (dev.get_param("bgzf_prestaged_calls") > before) == (step < len(comp2)), step
+        dev.set_param("debug_bgzf_ring_slot_kb", 0)
+        # a hint the next call does not keep to is dropped: an ordinary call follows
+        buf = np.frombuffer(comp, dtype=np.uint8)
+        dev.reset()
+        used, n1 = dev.map_bgzf(buf[:200_000], fmt=_lib.FORMAT_FASTQ, k=31, first=True, last=False, next_chunk=buf[200_000:300_000])
+        assert 0 < used <= 200_000
+        assert n1 + _feed_rest(dev, buf[used:], _lib.FORMAT_FASTQ, 31) == len(reads)
+        assert np.array_equal(dev.get_node_counts(), expect)
+
+
+def _feed_rest(dev, buf, fmt, k):
+    used, n_rec = dev.map_bgzf(buf, fmt=fmt, k=k, first=False, last=True)
+    assert used == len(buf)
+    return n_rec
 
 
 @pytest.mark.parametrize("fmt", ["fastq", "fasta"])

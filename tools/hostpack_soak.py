@@ -33,6 +33,8 @@ def main():
             nt = int(rng.integers(1, 17))
             view = bases[first * L:(first + n) * L]
             dev.set_param("host_pack_threads", nt)
+            slot_kb = int(rng.choice([0, 0, 16, 64, 1024, 4096]))   # the staging ring's slots (0: 16 MiB), wrapped up to hundreds of times
+            dev.set_param("debug_ring_slot_kb", slot_kb)
             dev.reset()
             ref.reset()
             before = dev.get_param("host_packed_calls")
@@ -47,7 +49,7 @@ def main():
             got, want = dev.get_node_counts(), ref.get_node_counts()
             ok = np.array_equal(got, want) and dev.get_param("host_packed_calls") == before + 1
             fails += 0 if ok else 1
-            print("round %d: %d reads from %d, %d threads, %s: %s" % (r, n, first, nt, "ragged" if r % 3 == 2 else "uniform",
+            print("round %d: %d reads from %d, %d threads, ring slots of %d KiB, %s: %s" % (r, n, first, nt, slot_kb or 16384, "ragged" if r % 3 == 2 else "uniform",
                                                                       "same as the direct kernel" if ok else "DIFFERENT"), flush=True)
     print("failures: %d of %d (%.1f s)" % (fails, rounds, time.perf_counter() - t0))
     sys.exit(1 if fails else 0)
