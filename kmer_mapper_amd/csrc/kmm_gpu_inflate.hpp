@@ -370,57 +370,6 @@ constexpr int LIST_ALLOC = LIST_CAP + GROUP; // (a step's entry loads may reach 
 enum State { S_HDR = 0, S_SYM, S_DONE };
 constexpr int SCRATCH_BYTES = LIST_ALLOC * 8 + SEC_WORDS * 2; // per lane, in HBM: the match list, then the subtables
 
-// the bytes of one match: len bytes from `dist` behind q (q = out + position); every load before the first dependent store
-KMM_HD inline void copy_match(uint8_t *q, uint32_t len, uint32_t dist)
-{
-    const uint8_t *s = q - dist;
-    if (dist >= len || dist >= 16u) {
-        // 16-byte pieces; with dist >= len none of them reads what this match writes: two pieces per trip; with
-        // 16 <= dist < len a piece may read the piece before it: one piece per trip (program order does the rest)
-        const bool indep = dist >= len;
-        while (len) {
-            uint64_t a0, a1, b0 = 0, b1 = 0;
-            load16u(s, a0, a1);
-            const bool two = indep && len > 16u;
-            if (two)
-                load16u(s + 16, b0, b1);
-            uint32_t n = len < 16u ? len : 16u;
-            store_upto16(q, a0, a1, n);
-            q += n;
-            s += n;
-            len -= n;
-            if (two) {
-                n = len < 16u ? len : 16u;
-                store_upto16(q, b0, b1, n);
-                q += n;
-                s += n;
-                len -= n;
-            }
-        }
-        return;
-    }
-    // distance 1 .. 15 < len: the last `dist` bytes repeat; the pattern is built once, pc = the largest multiple of dist within 16
-    uint64_t d0, d1, p0 = 0, p1 = 0;
-    load16u(s, d0, d1);
-    uint32_t k2 = 0;
-    for (uint32_t j = 0; j < 16u; ++j) {
-        const uint64_t byte = k2 < 8u ? (d0 >> (8u * k2)) & 0xFFull : (d1 >> (8u * (k2 - 8u))) & 0xFFull;
-        if (j < 8u)
-            p0 |= byte << (8u * j);
-        else
-            p1 |= byte << (8u * (j - 8u));
-        if (++k2 == dist)
-            k2 = 0;
-    }
-    const uint32_t pc = 16u / dist * dist;
-    while (len) {
-        const uint32_t n = len < pc ? len : pc;
-        store_upto16(q, p0, p1, n);
-        q += n;
-        len -= n;
-    }
-}
-
 // Phase timers (tools/gz_phase.hip builds with -DKMM_GZ_TIMERS): 100 MHz ticks a lane spends in [0] block headers,
 // [1] symbol decoding, [2] the match copies, [3] the CRC; [4] block headers seen, [5] rounds of the outer loop, [6] steps of
 // the copy phase, [7] matches.
@@ -602,75 +551,75 @@ KMM_HD inline int inflate_stream(const uint8_t *in, uint32_t n_in, uint8_t *out,
         // dependent instructions at one wavefront per SIMD — ~1 900 clocks per symbol — not by memory;
         // profiles/r05/gz_phase_v7_*.txt.)
         uint32_t n_list = 0;
-        int t = 0;
+        int t = 0, bad = 0;
         for (;;) {
+        // ONE way out of the loop — its condition.  A symbol that cannot be (no code, a distance before the start, more
+        // output than ISIZE) sets `bad` and the lane decodes on, harmlessly (every access below is in bounds whatever the
+        // bits say), until the round ends and the error is returned: with a `return` at every check the compiler wove
+        // thirteen exits into the loop, and the 64 lanes paid for the exec-mask and register bookkeeping of all of them on
+        // every symbol (~330 instructions per symbol, most of them that).
         while (t < DECODE_RUN && state == S_SYM && n_list < (uint32_t)LIST_CAP && b.cnt + 32 * b.fw >= 48) {
             ++t;
             bits_refill_local(b);
             uint32_t e = lit[((uint32_t)b.buf & (uint32_t)(PRIM_LIT - 1)) * PS];
             if (e & LINK) { // a code longer than the primary index: its subtable (HBM)
                 e = lit2[((e >> 4) & 0x7FFu) + (((uint32_t)b.buf >> LIT_PB) & ((1u << (e & 15u)) - 1u))];
-                if (!(e & 15u))
-                    return E_SYMBOL;
                 bits_take(b, LIT_PB);
             }
-            const int l = (int)(e & 15u);
-            if (!l)
-                return E_SYMBOL;
-            bits_take(b, l);
-            const uint32_t sym = e >> 4;
+            const uint32_t l = e & 15u, sym = e >> 4;
+            bad = bad ? bad : (l ? 0 : (int)E_SYMBOL);
+            bits_take(b, (int)l);
             if (sym < 256u) {
-                if (o >= n_out)
-                    return E_OUTPUT;
+                if (o < n_out) {
 #ifndef KMM_GZ_EXPERIMENT_NO_DECODE_STORES // (tools/gz_phase.py: what do the decode phase's stores cost? output is garbage)
-                out[o] = (uint8_t)sym;
+                    out[o] = (uint8_t)sym;
 #endif
-                ++o;
-                continue;
-            }
-            if (sym == 256u) {
-                if (bits_consumed_bytes(b) > n_in)
-                    return E_INPUT;
+                    ++o;
+                } else {
+                    bad = bad ? bad : (int)E_OUTPUT;
+                }
+            } else if (sym == 256u) {
+                bad = bad ? bad : (bits_consumed_bytes(b) > n_in ? (int)E_INPUT : 0);
                 state = final ? S_DONE : S_HDR;
-                continue;
-            }
-            if (sym > 285u)
-                return E_SYMBOL;
-            const uint32_t len = len_base_of(sym - 257u) + bits_take(b, (int)len_extra_bits(sym - 257u));
-            bits_refill_local(b);
-            uint32_t d = dst[((uint32_t)b.buf & (uint32_t)(PRIM_DIST - 1)) * PS];
-            if (d & LINK) {
-                d = dst2[((d >> 4) & 0x7FFu) + (((uint32_t)b.buf >> DIST_PB) & ((1u << (d & 15u)) - 1u))];
-                if (!(d & 15u))
-                    return E_SYMBOL;
-                bits_take(b, DIST_PB);
-            }
-            const int dl = (int)(d & 15u);
-            if (!dl)
-                return E_SYMBOL;
-            bits_take(b, dl);
-            const uint32_t dsym = d >> 4;
-            if (dsym > 29u)
-                return E_SYMBOL;
-            const uint32_t dist = dist_base_of(dsym) + bits_take(b, (int)dist_extra_bits(dsym)); // (a refill leaves >= 33 bits: 15 + 13 fit)
-            if (dist > o)
-                return E_DISTANCE;
-            if (o + len > n_out)
-                return E_OUTPUT;
+            } else {
+                const uint32_t ls = sym <= 285u ? sym - 257u : 0u;
+                const uint32_t len = len_base_of(ls) + bits_take(b, (int)len_extra_bits(ls));
+                bits_refill_local(b);
+                uint32_t d = dst[((uint32_t)b.buf & (uint32_t)(PRIM_DIST - 1)) * PS];
+                if (d & LINK) {
+                    d = dst2[((d >> 4) & 0x7FFu) + (((uint32_t)b.buf >> DIST_PB) & ((1u << (d & 15u)) - 1u))];
+                    bits_take(b, DIST_PB);
+                }
+                const uint32_t dl = d & 15u, dcode = d >> 4, dsym = dcode <= 29u ? dcode : 0u;
+                bits_take(b, (int)dl);
+                const uint32_t dist = dist_base_of(dsym) + bits_take(b, (int)dist_extra_bits(dsym)); // (a refill leaves >= 33 bits: 15 + 13 fit)
+                const int why = sym > 285u || !dl || dcode > 29u ? (int)E_SYMBOL : dist > o ? (int)E_DISTANCE : o + len > n_out ? (int)E_OUTPUT : 0;
+                if (!why) {
 #ifndef KMM_GZ_EXPERIMENT_NO_DECODE_STORES
-            list[n_list] = (uint64_t)o | ((uint64_t)len << 32) | ((uint64_t)dist << 41);
+                    list[n_list] = (uint64_t)o | ((uint64_t)len << 32) | ((uint64_t)dist << 41);
 #endif
-            ++n_list;
-            o += len;
+                    ++n_list;
+                    o += len;
+                } else {
+                    bad = bad ? bad : why;
+                }
+            }
         }
         if (!(t < DECODE_RUN && state == S_SYM && n_list < (uint32_t)LIST_CAP))
             break;
         bits_next_block(b);
         }
+        if (bad)
+            return bad;
         KMM_GZ_T(1);
         // ---- phase B: the matches, in order; up to GROUP per step when none of them can depend on another.  The list lies in
         // HBM: the entries a step looks at were requested during the step before (two per request; entries beyond the end
-        // read as an entry that always goes by itself), so a step costs ONE round trip — its sources'.
+        // read as an entry that ends a group), so a step costs ONE round trip — its sources'.
+        // ONE kind of work: a piece of at most 16 bytes whose source ends in front of its destination.  A match that is longer,
+        // or repeats a pattern shorter than itself (distance < length: runs), gives up such a piece from its head and stays at
+        // the front of the list with the rest — a pattern's distance doubles with every piece (d, 2d, 4d .. bytes, then 16
+        // at a time: all the same bytes).  Until v8 those matches went through a loop of their own; with 64 lanes some lane
+        // was in it at nearly every step and the other 63 waited.
         uint32_t i = 0;
         uint64_t ent[GROUP];
         for (int x = 0; x < GROUP; x += 2) {
@@ -680,19 +629,22 @@ KMM_HD inline int inflate_stream(const uint8_t *in, uint32_t n_in, uint8_t *out,
         }
         while (i < n_list) {
             const uint32_t o0 = (uint32_t)ent[0], l0 = (uint32_t)(ent[0] >> 32) & 0x1FFu, d0 = (uint32_t)(ent[0] >> 41);
+            const bool pattern = d0 < l0 && d0 < 16u;
+            const uint32_t pl = pattern ? d0 : (l0 < 16u ? l0 : 16u); // the piece the head entry gives up now (pl <= d0)
+            const bool whole = pl == l0;
             uint32_t g = 1;
-            const bool simple = l0 <= 16u && d0 >= l0;
-            if (simple) {
+            if (whole) {
                 for (; g < (uint32_t)GROUP; ++g) { // (an entry behind the end has length 511: it ends the group)
                     const uint32_t og = (uint32_t)ent[g], lg = (uint32_t)(ent[g] >> 32) & 0x1FFu, dg = (uint32_t)(ent[g] >> 41);
                     if (lg > 16u || dg < lg || og - dg + lg > o0)
                         break;
                 }
             }
+            const uint32_t adv = whole ? g : 0u;
             // the next step's entries, and this step's sources: all loads leave before the first is used
             uint64_t nxt[GROUP];
             for (int x = 0; x < GROUP; x += 2) {
-                const uint32_t at = i + g + (uint32_t)x;
+                const uint32_t at = i + adv + (uint32_t)x;
                 if (at < n_list) {
                     load16u(reinterpret_cast<const uint8_t *>(list + at), nxt[x], nxt[x + 1]);
                     nxt[x + 1] = at + 1u < n_list ? nxt[x + 1] : ~0ull;
@@ -700,24 +652,23 @@ KMM_HD inline int inflate_stream(const uint8_t *in, uint32_t n_in, uint8_t *out,
                     nxt[x] = nxt[x + 1] = ~0ull;
                 }
             }
-            if (simple) {
-                uint64_t lo[GROUP], hi[GROUP];
-                for (uint32_t x = 0; x < (uint32_t)GROUP; ++x) {
-                    lo[x] = hi[x] = 0;
-                    if (x < g)
-                        load16u(out + (uint32_t)ent[x] - (uint32_t)(ent[x] >> 41), lo[x], hi[x]);
-                }
-                for (uint32_t x = 0; x < (uint32_t)GROUP; ++x)
-                    if (x < g)
-                        store_upto16(out + (uint32_t)ent[x], lo[x], hi[x], (uint32_t)(ent[x] >> 32) & 0x1FFu);
-            } else { // long, or repeating a pattern: by itself
-                copy_match(out + o0, l0, d0);
+            if (!whole) // the rest of the head entry stays in front
+                nxt[0] = (uint64_t)(o0 + pl) | ((uint64_t)(l0 - pl) << 32) | ((uint64_t)(pattern ? 2u * d0 : d0) << 41);
+            uint64_t lo[GROUP], hi[GROUP];
+            for (uint32_t x = 0; x < (uint32_t)GROUP; ++x) {
+                lo[x] = hi[x] = 0;
+                if (x < g)
+                    load16u(out + (uint32_t)ent[x] - (uint32_t)(ent[x] >> 41), lo[x], hi[x]);
             }
+            store_upto16(out + o0, lo[0], hi[0], pl);
+            for (uint32_t x = 1; x < (uint32_t)GROUP; ++x)
+                if (x < g)
+                    store_upto16(out + (uint32_t)ent[x], lo[x], hi[x], (uint32_t)(ent[x] >> 32) & 0x1FFu);
             for (int x = 0; x < GROUP; ++x)
                 ent[x] = nxt[x];
-            i += g;
+            i += adv;
             KMM_GZ_COUNT(6, 1);
-            KMM_GZ_COUNT(7, g);
+            KMM_GZ_COUNT(7, adv);
         }
         KMM_GZ_T(2);
     }

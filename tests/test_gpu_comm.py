@@ -99,7 +99,8 @@ def test_flush_of_node_ranges_under_the_reduce_of_the_previous_range(oracle):
 @pytest.mark.parametrize("n_ranks", [2, 3])
 def test_multi_rank_cli_flow_with_the_hip_engine(n_ranks, tmp_path):
     """The N > 1 flow end to end with the HIP engine on every rank (they share the box's one GPU, the sum of the count
-    vectors runs over gloo): byte-range sharding of a FASTQ, chunk round-robin of its .gz copy and of a two-line FASTA .gz, one reduce, rank 0
+    vectors runs over gloo): byte-range sharding of a FASTQ, chunk round-robin of its .gz copy and of a two-line FASTA .gz, member
+    ranges of BGZF copies of both (inflated on the GPU, every rank its own range), one reduce, rank 0
     compares with the oracle (tools/cli_two_rank_rehearsal.py).  Replaces the reference's process pool + additive
     reduce (kmer_mapper/command_line_interface.py:109-130)."""
     import os
@@ -113,7 +114,8 @@ def test_multi_rank_cli_flow_with_the_hip_engine(n_ranks, tmp_path):
     r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=300)
     out = r.stdout + r.stderr
     assert r.returncode == 0, out[-2000:]
-    assert out.count("BIT-EXACT") == 3 and "MISMATCH" not in out, out[-2000:]   # .fq, .fq.gz, .fa.gz
+    # .fq (byte ranges), .fq.gz and .fa.gz (plain gzip: chunk i to rank i mod N), BGZF .fq.gz and .fa.gz (member ranges, GPU inflate)
+    assert out.count("BIT-EXACT") == 5 and "MISMATCH" not in out, out[-2000:]
 
 
 def _bench_line(args, n_ranks=1, port=29655):
