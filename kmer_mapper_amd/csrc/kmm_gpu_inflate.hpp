@@ -358,12 +358,15 @@ KMM_HD inline void load16u(const uint8_t *p, uint64_t &lo, uint64_t &hi)
 // copy phases: 34 ms per wavefront whatever the batch, 84 ms for the whole file; v6 (phase timers, tools/gz_phase.py, said:
 // decoding 14 ms, copies 17 ms, CRC 2 ms, headers 0.4 ms per lane): headers as a phase of their own, lane-interleaved tables,
 // the length / distance bases as arithmetic, at most two stores per match, one request per source and per two list entries,
-// eight matches per step (5.2 on average in FASTQ), 8 / 5-bit tables for four wavefronts per CU: 46 ms for the whole file =
-// 71 GB/s of FASTQ out.  What is left is the memory system's request rate: ~28 000 requests per member in the copy phase alone.
+// 8 / 5-bit tables for four wavefronts per CU: 46 ms for the whole file; v7: what bounds the phases then — not their stores,
+// not the input's latency, not the table widths: chains of dependent instructions at one wavefront per SIMD; v8 therefore
+// shortens the chains: ONE exit from the symbol loop (errors deferred to the round's end: 330 -> 230 instructions per
+// symbol, 15.0 -> 11.9 ms per lane) and ONE kind of work in the copy phase (every match as pieces of at most 16 bytes from
+// the head of the list: 11.8 -> 9.0 ms): 37 ms for the whole file = 87 GB/s of FASTQ out.
 constexpr int DECODE_RUN = 1024;    // symbols per phase A
 constexpr int LIST_CAP = 512;       // matches per phase A (8 bytes each)
 #ifndef KMM_GZ_GROUP
-#define KMM_GZ_GROUP 8
+#define KMM_GZ_GROUP 6
 #endif
 constexpr int GROUP = KMM_GZ_GROUP; // matches per step of phase B (even)
 constexpr int LIST_ALLOC = LIST_CAP + GROUP; // (a step's entry loads may reach GROUP entries behind the last one)
