@@ -334,3 +334,30 @@ def test_a_large_count_vector_reaches_pageable_memory_through_the_page_locked_ri
             assert np.array_equal(dev.get_node_counts(pinned=True), got)
             dev.set_param("host_pack_threads", 0)
             assert np.array_equal(dev.get_node_counts(), got)
+
+
+def test_page_locked_buffers_reserved_ahead_are_found_by_the_next_handle(kmm, syn, oracle):
+    """kmm_host_reserve / kmm_host_reserve_buffer: page-locked staging memory made ahead of the first map call (the CLI does it
+    from a helper thread while the index is uploaded) is put on the process-wide shelf and taken by the handle that asks
+    next; the results do not depend on where the buffers came from, bad sizes are refused."""
+    from kmer_mapper_amd import _lib
+    L = _lib.lib()
+    _lib.check(L.kmm_host_reserve(64 << 20))
+    _lib.check(L.kmm_host_reserve_buffer(16 << 20))          # (one slot of the staging ring)
+    _lib.check(L.kmm_host_reserve_buffer(0))
+    with pytest.raises(ValueError):
+        _lib.check(L.kmm_host_reserve_buffer(-1))
+    with pytest.raises(ValueError):
+        _lib.check(L.kmm_host_reserve(-5))
+    index, genome = syn.make_index(30000, seed=941)
+    mx = index.max_node_id()
+    bases, offs = syn.make_ragged_reads(genome, 30000, 40, 200, seed=942)
+    expect, _ = oracle.map_reads(index, mx, bases, offs, 31, n_threads=4)
+    raw = _fastq(_reads(bases, offs))
+    with kmm.DeviceIndex.from_index(index, mx) as dev:
+        dev.set_param("path", 2)
+        dev.set_param("host_pack_threads", 4)
+        used, n_rec = dev.map_records(raw, raw.shape[0], _lib.FORMAT_FASTQ, 31)
+        assert used == raw.shape[0] and n_rec == len(offs) - 1
+        assert np.array_equal(dev.get_node_counts(), expect)
+        assert dev.get_param("host_packed_record_calls") == 1
