@@ -47,7 +47,17 @@ def make_fastq(path, bases, n_reads, L, seed=9):
     rec[:, W - 1] = 10
     rec[:, W:W + L] = bases.reshape(n_reads, L)
     rec[:, W + L:W + L + 3] = np.frombuffer(b"\n+\n", dtype=np.uint8)
-    q = rng.choice(np.frombuffer(b"FFFFFFFF:,#", dtype=np.uint8), size=(n_reads, L))
+    # quality strings: by default a skewed 4-letter alphabet (what binned NovaSeq qualities look like); KMM_E2E_QUAL=full41
+    # draws from all 41 Phred+33 values with a distribution that falls off from 'I' (older instruments: longer Huffman codes,
+    # more literals), KMM_E2E_QUAL=runs makes long runs of one value
+    mode = os.environ.get("KMM_E2E_QUAL", "")
+    if mode == "full41":
+        p41 = 0.85 ** np.arange(41)
+        q = (73 - rng.choice(41, size=(n_reads, L), p=p41 / p41.sum())).astype(np.uint8)
+    elif mode == "runs":
+        q = np.repeat(rng.choice(np.frombuffer(b"FFFFFF:,", dtype=np.uint8), size=(n_reads, L // 10)), 10, axis=1)
+    else:
+        q = rng.choice(np.frombuffer(b"FFFFFFFF:,#", dtype=np.uint8), size=(n_reads, L))
     rec[:, W + L + 3:W + L + 3 + L] = q
     rec[:, -1] = 10
     rec.tofile(path)
