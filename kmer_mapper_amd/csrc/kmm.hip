@@ -43,6 +43,22 @@ int fail(int code, const char *fmt, ...)
     return code;
 }
 
+// Nothing C++ throws may cross the C ABI (std::vector / std::function allocate; a thread may fail to start): the entry points
+// that run host-side machinery go through this.
+template <typename F>
+static int guarded(const char *what, F body)
+{
+    try {
+        return body();
+    } catch (const std::bad_alloc &) {
+        return fail(KMM_ERR_NOMEM, "%s: out of host memory", what);
+    } catch (const std::exception &e) {
+        return fail(KMM_ERR_INTERNAL, "%s: %s", what, e.what());
+    } catch (...) {
+        return fail(KMM_ERR_INTERNAL, "%s: unexpected exception", what);
+    }
+}
+
 #define HIPCHK(expr)                                                                               \
     do {                                                                                           \
         hipError_t e_ = (expr);                                                                    \
@@ -1728,7 +1744,9 @@ int kmm_get_node_counts(kmm_index_t *ix, uint32_t *out)
     const bool page_locked = known && a.type == hipMemoryTypeHost;
     if (!on_device && !page_locked) {
         bool done = false;
-        KMMCHK(fetch_to_pageable(ix, reinterpret_cast<uint8_t *>(out), reinterpret_cast<const uint8_t *>(ix->counts), bytes, &done));
+        KMMCHK(guarded("kmm_get_node_counts", [&] {
+            return fetch_to_pageable(ix, reinterpret_cast<uint8_t *>(out), reinterpret_cast<const uint8_t *>(ix->counts), bytes, &done);
+        }));
         if (done)
             return KMM_OK;
     }
@@ -2409,7 +2427,7 @@ int kmm_map_reads(kmm_index_t *ix, const uint8_t *bases, const int64_t *read_off
         return KMM_OK;
     if (!read_offsets)
         return fail(KMM_ERR_INVALID_ARG, "read_offsets is NULL");
-    return map_reads_common(ix, bases, read_offsets, n_reads, 0, k, max_freq, also_revcomp, lut);
+    return guarded("kmm_map_reads", [&] { return map_reads_common(ix, bases, read_offsets, n_reads, 0, k, max_freq, also_revcomp, lut); });
 }
 
 int kmm_map_reads_uniform(kmm_index_t *ix, const uint8_t *bases, int64_t n_reads, int64_t read_len,
@@ -2422,7 +2440,7 @@ int kmm_map_reads_uniform(kmm_index_t *ix, const uint8_t *bases, int64_t n_reads
         return fail(KMM_ERR_INVALID_ARG, "n_reads / read_len negative");
     if (n_reads == 0 || read_len == 0)
         return KMM_OK;
-    return map_reads_common(ix, bases, nullptr, n_reads, read_len, k, max_freq, also_revcomp, lut);
+    return guarded("kmm_map_reads_uniform", [&] { return map_reads_common(ix, bases, nullptr, n_reads, read_len, k, max_freq, also_revcomp, lut); });
 }
 
 // Raw records on the radix path: should a piece of n_bytes raw bytes take it?  (Same rule as for flat reads, on the
@@ -2738,9 +2756,18 @@ static int map_multiline_piece(kmm_index_t *ix, const uint8_t *raw, int64_t n_by
     return rc != KMM_OK ? rc : rel;
 }
 
+static int map_records_entry(kmm_index_t *ix, const uint8_t *raw, int64_t n_bytes, int format, int k, int max_freq, int also_revcomp,
+                             const uint8_t *lut, int64_t *consumed, int64_t *n_records);
+
 int kmm_map_records(kmm_index_t *ix, const uint8_t *raw, int64_t n_bytes, int format, int k,
                     int max_freq, int also_revcomp, const uint8_t *lut, int64_t *consumed,
                     int64_t *n_records)
+{
+    return guarded("kmm_map_records", [&] { return map_records_entry(ix, raw, n_bytes, format, k, max_freq, also_revcomp, lut, consumed, n_records); });
+}
+
+static int map_records_entry(kmm_index_t *ix, const uint8_t *raw, int64_t n_bytes, int format, int k, int max_freq, int also_revcomp,
+                             const uint8_t *lut, int64_t *consumed, int64_t *n_records)
 {
     if (!ix)
         return fail(KMM_ERR_INVALID_ARG, "idx is NULL");
@@ -3000,8 +3027,17 @@ int kmm_map_bgzf_hint_next(kmm_index_t *ix, const uint8_t *comp_next, int64_t n_
     return KMM_OK;
 }
 
+static int map_bgzf_entry(kmm_index_t *ix, const uint8_t *comp, int64_t n_comp, int format, int k, int max_freq, int also_revcomp,
+                          const uint8_t *lut, int64_t *consumed_comp, int64_t *n_records);
+
 int kmm_map_bgzf(kmm_index_t *ix, const uint8_t *comp, int64_t n_comp, int format, int k, int max_freq, int also_revcomp,
                  const uint8_t *lut, int64_t *consumed_comp, int64_t *n_records)
+{
+    return guarded("kmm_map_bgzf", [&] { return map_bgzf_entry(ix, comp, n_comp, format, k, max_freq, also_revcomp, lut, consumed_comp, n_records); });
+}
+
+static int map_bgzf_entry(kmm_index_t *ix, const uint8_t *comp, int64_t n_comp, int format, int k, int max_freq, int also_revcomp,
+                          const uint8_t *lut, int64_t *consumed_comp, int64_t *n_records)
 {
     if (!ix)
         return fail(KMM_ERR_INVALID_ARG, "idx is NULL");

@@ -130,6 +130,13 @@ def test_bgzf_members_inflated_on_the_gpu_give_the_oracles_counts(kmm, syn, orac
                 assert dev.get_param("bgzf_carry_bytes") == 0
                 assert (dev.get_param("bgzf_prestaged_calls") > before) == (step < len(comp2)), step
         dev.set_param("debug_bgzf_ring_slot_kb", 0)
+        # two BGZF files one behind the other (cat a.fq.gz b.fq.gz: an empty end-of-file member in the middle)
+        cut = raw.index(b"\n@read3000 ") + 1
+        cat = _bgzf(raw[:cut], level=level, strategy=strategy) + _bgzf(raw[cut:], 30000, level, strategy)
+        for step in (1 << 30, 99_991):
+            dev.reset()
+            assert _feed(dev, cat, _lib.FORMAT_FASTQ, 31, step) == len(reads)
+            assert np.array_equal(dev.get_node_counts(), expect), step
         # a hint the next call does not keep to is dropped: an ordinary call follows
         buf = np.frombuffer(comp, dtype=np.uint8)
         dev.reset()
