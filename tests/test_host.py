@@ -2,6 +2,7 @@
 symbol include/kmm.h declares (no compute calls — there is no GPU in this tier)."""
 import os
 import re
+import subprocess
 
 import numpy as np
 import pytest
@@ -519,3 +520,45 @@ def test_gpu_inflater_decodes_like_zlib_on_the_cpu(tmp_path):
                 ref = None
             assert ref is not None and ref[:len(data)] == out[:len(data)].tobytes(), "accepted a stream zlib refuses"
     assert sum(v for k2, v in outcomes.items() if k2 != 0) > 1000
+
+
+def test_gpu_inflater_touches_no_byte_outside_its_buffers_under_the_sanitizers(tmp_path):
+    """The decoder the GPU runs one lane per member (csrc/kmm_gpu_inflate.hpp), built for the CPU with AddressSanitizer and
+    UBSan (tests/gz_fuzz_main.cpp; GPU sanitizers are not to be had): 500 rounds x (an intact stream + five damaged versions
+    — a bit flipped, truncated, eight bytes overwritten, a byte inserted, the second half zeroed — with the right or a wrong
+    claimed size) in exact-size heap buffers.  After a symbol that cannot be, a lane decodes ON until its round ends (one exit
+    from the symbol loop): every access must stay inside the buffers whatever the bits say.  Intact streams come out right,
+    nothing crashes, nothing is reported."""
+    exe = str(tmp_path / "gz_fuzz")
+    src = os.path.join(ROOT, "tests", "gz_fuzz_main.cpp")
+    cmd = ["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+           "-I" + os.path.join(ROOT, "kmer_mapper_amd", "csrc"), src, "-o", exe, "-lz"]
+    build = subprocess.run(cmd, capture_output=True, text=True)
+    if build.returncode != 0 and ("asan" in build.stderr or "ubsan" in build.stderr or "sanitize" in build.stderr):
+        pytest.skip("no sanitizer runtime on this box: " + build.stderr[-200:])
+    assert build.returncode == 0, build.stderr[-2000:]
+    run = subprocess.run([exe, "500"], capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0, (run.stdout + run.stderr)[-3000:]
+    assert "500 rounds" in run.stdout and "ERROR" not in run.stderr and "runtime error" not in run.stderr, (run.stdout + run.stderr)[-3000:]
+
+
+@pytest.mark.parametrize("sanitizer", ["thread", "address,undefined"])
+def test_host_records_packer_under_the_sanitizers(tmp_path, sanitizer):
+    """csrc/kmm_hostpack.hpp RecordsJob with ThreadSanitizer, then with AddressSanitizer + UBSan (tests/hostpack_tsan_main.cpp):
+    raw FASTQ of random and of one read length, LF and CRLF, with and without an unfinished last record, slices of 1-32 KiB
+    (hundreds of hand-overs along the chained prefix, shared boundary words OR-ed in atomically), buffers full of garbage at the
+    start: one thread and six threads give the same stream, bitset and counts; no race, no stray access."""
+    exe = str(tmp_path / "hostpack_san")
+    src = os.path.join(ROOT, "tests", "hostpack_tsan_main.cpp")
+    cmd = ["g++", "-O1", "-g", "-std=c++17", "-pthread", "-fsanitize=" + sanitizer, "-I" + os.path.join(ROOT, "kmer_mapper_amd", "csrc"),
+           src, "-o", exe]
+    build = subprocess.run(cmd, capture_output=True, text=True)
+    if build.returncode != 0 and ("san" in build.stderr and "cannot find" in build.stderr):
+        pytest.skip("no sanitizer runtime on this box: " + build.stderr[-200:])
+    assert build.returncode == 0, build.stderr[-2000:]
+    run = subprocess.run([exe, "40"], capture_output=True, text=True, timeout=600)
+    out = run.stdout + run.stderr
+    if "ThreadSanitizer" in out and "unexpected memory mapping" in out:
+        pytest.skip("ThreadSanitizer cannot run in this address-space layout")
+    assert run.returncode == 0 and "40 rounds" in run.stdout, out[-3000:]
+    assert "WARNING: ThreadSanitizer" not in out and "ERROR: AddressSanitizer" not in out and "runtime error" not in out, out[-3000:]
