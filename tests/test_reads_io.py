@@ -766,3 +766,25 @@ def test_bgzf_member_ranges_partition_the_records_exactly():
         m, prev = br.member_at_or_after(noisy, t)
         k2 = int(np.searchsorted(n_offs, t, side="left"))
         assert m == n_offs[k2] and (prev is None or prev == n_offs[k2 - 1])
+
+
+def test_native_readers_under_thread_sanitizer(tmp_path):
+    """libkmm_io's readers (csrc/kmm_io.cpp + kmm_inflate.hpp) built with ThreadSanitizer (tests/kmm_io_tsan_main.cpp): one
+    plain gzip member inflated on four threads from block boundaries found by search, many small members one behind the other
+    (one chunk at a time), a BGZF file (members in parallel), read back in odd-sized pieces: the bytes that went in, no data
+    race between the read-ahead thread, the pool and the reader."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "io_tsan")
+    cmd = ["g++", "-O1", "-g", "-std=c++17", "-pthread", "-fsanitize=thread", "-I" + os.path.join(root, "include"),
+           "-I" + os.path.join(root, "kmer_mapper_amd", "csrc"), os.path.join(root, "tests", "kmm_io_tsan_main.cpp"), "-o", exe, "-lz", "-ldl"]
+    build = subprocess.run(cmd, capture_output=True, text=True)
+    if build.returncode != 0 and "tsan" in build.stderr and "cannot find" in build.stderr:
+        pytest.skip("no ThreadSanitizer runtime on this box")
+    assert build.returncode == 0, build.stderr[-2000:]
+    run = subprocess.run([exe], capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
+    out = run.stdout + run.stderr
+    if "unexpected memory mapping" in out:
+        pytest.skip("ThreadSanitizer cannot run in this address-space layout")
+    assert run.returncode == 0 and out.count(", same") == 3, out[-3000:]
+    assert "WARNING: ThreadSanitizer" not in out, out[-3000:]
