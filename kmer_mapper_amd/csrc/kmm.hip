@@ -284,7 +284,7 @@ struct kmm_index {
     // kmm_map_bgzf: BGZF members inflated on the GPU (kmm_gpu_inflate.hpp).  Two sets of buffers in turn (the copy of call
     // i + 1 runs under the kernels of call i); the uncompressed bytes behind a call's last complete record wait in `carry`
     // for the next call.
-    DevBuf bgzf_comp[2], bgzf_raw[2], bgzf_meta[2], bgzf_tabs, bgzf_err, bgzf_carry, bgzf_crc;
+    DevBuf bgzf_comp[2], bgzf_raw[2], bgzf_meta[2], bgzf_tabs, bgzf_err, bgzf_carry, bgzf_crc, bgzf_status;
     hipEvent_t bgzf_done[2] = {nullptr, nullptr};
     hipEvent_t bgzf_slot_ev[RING_SLOTS] = {}; // copies out of / into the slots of the staging ring
     bool bgzf_used[2] = {false, false};
@@ -1118,6 +1118,7 @@ void kmm_index_destroy(kmm_index_t *ix)
             (void)hipEventDestroy(ev);
         ev = nullptr;
     }
+    release(ix->bgzf_status);
     release(ix->bgzf_tabs);
     release(ix->bgzf_crc);
     release(ix->bgzf_err);
@@ -3133,8 +3134,10 @@ static int map_bgzf_entry(kmm_index_t *ix, const uint8_t *comp, int64_t n_comp, 
         HIPCHK(hipMemcpy(ix->bgzf_crc.p, t.data(), t.size() * 4, hipMemcpyHostToDevice));
     }
     const uint32_t grid_threads = ((n_members < 65536u ? n_members : 65536u) + 63u) / 64u * 64u;
-    if (n_members)
+    if (n_members) {
         KMMCHK(ensure(ix->bgzf_tabs, (size_t)grid_threads * kmm_gz::SCRATCH_BYTES));
+        KMMCHK(ensure(ix->bgzf_status, (size_t)n_members + 64));
+    }
     uint8_t *d_raw = (uint8_t *)ix->bgzf_raw[cur].p;
     unsigned long long *d_moff = (unsigned long long *)ix->bgzf_meta[cur].p, *d_ooff = d_moff + (n_members + 1);
     if (n_members) {
@@ -3149,9 +3152,15 @@ static int map_bgzf_entry(kmm_index_t *ix, const uint8_t *comp, int64_t n_comp, 
     if (carry > 0)
         HIPCHK(hipMemcpyAsync(d_raw, ix->bgzf_carry.p, (size_t)carry, hipMemcpyDeviceToDevice, ix->stream));
     if (n_members) {
+        // members refused by the inflater are marked; the CRC32s are checked by a kernel of its own behind it (there nothing holds
+        // the occupancy down: 2-3 ms of the inflater's 24 per wavefront become a fraction of a millisecond)
+        HIPCHK(hipMemsetAsync(ix->bgzf_status.p, 0, n_members, ix->stream));
         hipLaunchKernelGGL(kmm_gz::k_inflate_bgzf, dim3(grid_threads / 64u), dim3(64), 0, ix->stream, d_comp, d_moff, d_ooff, d_raw, n_members,
-                           (uint8_t *)ix->bgzf_tabs.p, (const uint32_t *)ix->bgzf_crc.p, (unsigned int *)ix->bgzf_err.p,
-                           (unsigned long long *)nullptr);
+                           (uint8_t *)ix->bgzf_tabs.p, (const uint32_t *)nullptr, (unsigned int *)ix->bgzf_err.p,
+                           (unsigned long long *)nullptr, (uint8_t *)ix->bgzf_status.p);
+        hipLaunchKernelGGL(kmm_gz::k_crc_bgzf, dim3((n_members + 255u) / 256u), dim3(256), 0, ix->stream, d_comp, d_moff, d_ooff,
+                           (const uint8_t *)d_raw, n_members, (const uint32_t *)ix->bgzf_crc.p, (unsigned int *)ix->bgzf_err.p,
+                           (const uint8_t *)ix->bgzf_status.p);
         HIPCHK(hipGetLastError());
     }
     // The chunk BEHIND this one (kmm_map_bgzf_hint_next: the caller's bytes go on where this chunk ends) is staged and walked NOW,

@@ -758,6 +758,8 @@ KMM_HD inline int inflate_bgzf_member(const uint8_t *m, uint32_t msize, uint8_t 
     const int rc = inflate_stream(payload, plen, out, n_out, prim, sec, list, tm);
     if (rc != OK)
         return rc;
+    if (!crcT) // (the GPU checks the CRC in a kernel of its own, k_crc_bgzf)
+        return OK;
     KMM_GZ_T0;
     const bool same = crc32_sliced(crcT, out, n_out) == rd32(m + msize - 8);
     KMM_GZ_T(3);
@@ -771,7 +773,8 @@ KMM_HD inline int inflate_bgzf_member(const uint8_t *m, uint32_t msize, uint8_t 
 __global__ void __launch_bounds__(64) k_inflate_bgzf(const uint8_t *__restrict__ comp, const unsigned long long *__restrict__ m_off,
                                                      const unsigned long long *__restrict__ o_off, uint8_t *__restrict__ out,
                                                      uint32_t n_members, uint8_t *__restrict__ tabs, const uint32_t *__restrict__ crcT,
-                                                     unsigned int *__restrict__ err, unsigned long long *__restrict__ timers)
+                                                     unsigned int *__restrict__ err, unsigned long long *__restrict__ timers,
+                                                     uint8_t *__restrict__ status)
 {
     __shared__ uint16_t s_prim[64 * PRIM_WORDS]; // 40 KB: four wavefronts per CU
     const uint32_t slot = blockIdx.x * 64u + threadIdx.x, stride = gridDim.x * 64u;
@@ -783,10 +786,52 @@ __global__ void __launch_bounds__(64) k_inflate_bgzf(const uint8_t *__restrict__
         const unsigned long long a = m_off[m], b = m_off[m + 1], oa = o_off[m], ob = o_off[m + 1];
         const int rc = inflate_bgzf_member(comp + a, (uint32_t)(b - a), out + oa, (uint32_t)(ob - oa), prim, sec, list, crcT, tm);
         if (rc != OK) {
+            if (status)
+                status[m] = (uint8_t)rc;
             atomicAdd(&err[0], 1u);
             if (atomicMin(&err[1], m) > m)
                 err[2] = (unsigned int)rc; // (the code of the lowest member seen so far; a later, lower member overwrites it)
         }
+    }
+}
+
+// The CRC32 of every member's output against its trailer, a kernel of its own behind k_inflate_bgzf (crcT = nullptr there):
+// inside the inflater the check ran at that kernel's four wavefronts per CU — 4 096 dependent rounds of table look-ups per lane,
+// 2-3 ms of its 24 — here nothing holds the occupancy down and the slicing tables (8 KB) sit in LDS.  One thread per member;
+// status[m] != 0: the inflater has refused the member already.
+__global__ void __launch_bounds__(256) k_crc_bgzf(const uint8_t *__restrict__ comp, const unsigned long long *__restrict__ m_off,
+                                                  const unsigned long long *__restrict__ o_off, const uint8_t *__restrict__ out,
+                                                  uint32_t n_members, const uint32_t *__restrict__ crcT, unsigned int *__restrict__ err,
+                                                  const uint8_t *__restrict__ status)
+{
+    __shared__ uint32_t T[8 * 256];
+    for (uint32_t i = threadIdx.x; i < 8u * 256u; i += 256u)
+        T[i] = crcT[i];
+    __syncthreads();
+    const uint32_t m = blockIdx.x * 256u + threadIdx.x;
+    if (m >= n_members || (status && status[m]))
+        return;
+    const uint8_t *p = out + o_off[m];
+    const uint32_t n = (uint32_t)(o_off[m + 1] - o_off[m]);
+    uint32_t c = 0xFFFFFFFFu, i = 0;
+    for (; i + 16u <= n; i += 16u) {
+        uint64_t w0, w1;
+        load16u(p + i, w0, w1);
+        uint32_t lo = (uint32_t)w0 ^ c, hi = (uint32_t)(w0 >> 32);
+        c = T[7 * 256 + (lo & 0xFFu)] ^ T[6 * 256 + ((lo >> 8) & 0xFFu)] ^ T[5 * 256 + ((lo >> 16) & 0xFFu)] ^ T[4 * 256 + (lo >> 24)] ^
+            T[3 * 256 + (hi & 0xFFu)] ^ T[2 * 256 + ((hi >> 8) & 0xFFu)] ^ T[1 * 256 + ((hi >> 16) & 0xFFu)] ^ T[0 * 256 + (hi >> 24)];
+        lo = (uint32_t)w1 ^ c;
+        hi = (uint32_t)(w1 >> 32);
+        c = T[7 * 256 + (lo & 0xFFu)] ^ T[6 * 256 + ((lo >> 8) & 0xFFu)] ^ T[5 * 256 + ((lo >> 16) & 0xFFu)] ^ T[4 * 256 + (lo >> 24)] ^
+            T[3 * 256 + (hi & 0xFFu)] ^ T[2 * 256 + ((hi >> 8) & 0xFFu)] ^ T[1 * 256 + ((hi >> 16) & 0xFFu)] ^ T[0 * 256 + (hi >> 24)];
+    }
+    for (; i < n; ++i)
+        c = (c >> 8) ^ T[(c ^ p[i]) & 0xFFu];
+    const unsigned long long e = m_off[m + 1];
+    if (~c != rd32(comp + e - 8)) {
+        atomicAdd(&err[0], 1u);
+        if (atomicMin(&err[1], m) > m)
+            err[2] = (unsigned int)E_CRC;
     }
 }
 #endif

@@ -21,7 +21,7 @@ extern "C" int gz_phase(const uint8_t *comp, uint64_t n_comp, const unsigned lon
                         uint32_t n_members, uint64_t n_out, uint8_t *out_host, uint32_t grid_threads, int reps, double *kernel_ms,
                         unsigned long long *timers_out, unsigned int *err3)
 {
-    uint8_t *d_comp, *d_out, *d_tabs;
+    uint8_t *d_comp, *d_out, *d_tabs, *d_status;
     unsigned long long *d_m, *d_o, *d_t;
     uint32_t *d_crc;
     unsigned int *d_err;
@@ -33,6 +33,7 @@ extern "C" int gz_phase(const uint8_t *comp, uint64_t n_comp, const unsigned lon
     CK(hipMalloc(&d_t, (size_t)grid_threads * 64));
     CK(hipMalloc(&d_crc, 8 * 256 * 4));
     CK(hipMalloc(&d_err, 16));
+    CK(hipMalloc(&d_status, n_members + 64));
     std::vector<uint32_t> t(8 * 256);
     for (int k = 0; k < 8; ++k)
         for (uint32_t b = 0; b < 256; ++b)
@@ -50,9 +51,12 @@ extern "C" int gz_phase(const uint8_t *comp, uint64_t n_comp, const unsigned lon
         const unsigned int init[4] = {0u, 0xFFFFFFFFu, 0u, 0u};
         CK(hipMemcpy(d_err, init, 16, hipMemcpyHostToDevice));
         CK(hipMemset(d_t, 0, (size_t)grid_threads * 64));
+        CK(hipMemset(d_status, 0, n_members + 64));
         CK(hipEventRecord(e0, 0));
         hipLaunchKernelGGL(kmm_gz::k_inflate_bgzf, dim3(grid_threads / 64u), dim3(64), 0, 0, d_comp, d_m, d_o, d_out, n_members, d_tabs,
-                           d_crc, d_err, d_t);
+                           (const uint32_t *)nullptr, d_err, d_t, d_status);
+        hipLaunchKernelGGL(kmm_gz::k_crc_bgzf, dim3((n_members + 255u) / 256u), dim3(256), 0, 0, d_comp, d_m, d_o, (const uint8_t *)d_out,
+                           n_members, (const uint32_t *)d_crc, d_err, (const uint8_t *)d_status);
         CK(hipGetLastError());
         CK(hipEventRecord(e1, 0));
         CK(hipEventSynchronize(e1));
@@ -70,7 +74,7 @@ extern "C" int gz_phase(const uint8_t *comp, uint64_t n_comp, const unsigned lon
     err3[2] = err[2];
     if (out_host)
         CK(hipMemcpy(out_host, d_out, n_out, hipMemcpyDeviceToHost));
-    for (void *p : {(void *)d_comp, (void *)d_out, (void *)d_tabs, (void *)d_m, (void *)d_o, (void *)d_t, (void *)d_crc, (void *)d_err})
+    for (void *p : {(void *)d_comp, (void *)d_out, (void *)d_tabs, (void *)d_m, (void *)d_o, (void *)d_t, (void *)d_crc, (void *)d_err, (void *)d_status})
         (void)hipFree(p);
     return 0;
 }
