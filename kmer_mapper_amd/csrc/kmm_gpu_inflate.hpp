@@ -17,7 +17,7 @@
 // 16-byte register FIFO; matches copied up to eight at a time with one request per source and at most two per destination.
 // Stored, fixed and dynamic blocks (RFC 1951); every access is bounds-checked against the member's ISIZE / compressed size,
 // so a damaged member ends in an error code, never in a stray access; the CRC32 of the output is checked on the device too
-// (slicing-by-8, the tables in HBM / L2).
+// (k_crc_bgzf behind the inflater: slicing-by-8, the tables in LDS).
 // The decoder is restated from RFC 1951 / RFC 1952 and the BGZF section of the SAM specification; no code taken.
 #pragma once
 
