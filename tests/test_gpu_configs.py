@@ -4,6 +4,8 @@ full batch is checked through size-independent properties (every entry point and
 bit, linearity over splits, hit-rate window) and a 200 k-read sample is checked against the oracle on the
 probe flavour each size really selects (Bloom filter at 10 M, wide buckets at 100 M, radix path for the batch).
 Semantics matched: reference kmer_mapper/mapper.pyx:53-69."""
+import os
+
 import numpy as np
 import pytest
 
@@ -443,3 +445,71 @@ def test_cli_accumulates_chunks_into_radix_batches_and_records_beyond_2_pow_30(k
     assert np.array_equal(got, expect)
     log = caplog.text
     assert "are accumulated into GPU batches" in log and "path_taken: radix" in log, log[-600:]
+
+
+def test_a_gigabyte_of_bgzf_maps_like_the_raw_bytes_whatever_the_windows(kmm, oracle, tmp_path):
+    """Size-independent property at a configs-sized input (3 M reads = 1 GB of FASTQ, 10 M-k-mer index): the node counts do
+    not depend on the route the bytes take — BGZF members inflated on the GPU in ONE call, in windows announced ahead
+    (staged under the kernel of the window before), as three ranks' member ranges — or the raw FASTQ packed by the host
+    threads (kmm_map_records); every read is counted once; a 40 000-read prefix equals the oracle (mapper.pyx:53-69 on
+    util.py:71-75's k-mers)."""
+    import sys
+    from concurrent.futures import ThreadPoolExecutor
+    from kmer_mapper_amd import _lib, bgzf_ranges, synthetic as syn
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import bgzf_e2e
+    n_reads, L, k = 3_000_000, 150, 31
+    index, genome = syn.make_index(10_000_000, seed=61, gpu_builder=True)
+    mx = index.max_node_id()
+    bases, offs = syn.make_reads(genome, n_reads, L, seed=62)
+    fq = str(tmp_path / "reads.fq")
+    bgzf_e2e.make_fastq(fq, bases, n_reads, L)
+    raw = np.fromfile(fq, dtype=np.uint8)
+    os.remove(fq)
+    view = memoryview(raw)
+    with ThreadPoolExecutor(16) as pool:                                   # (zlib releases the GIL; no fork next to a live GPU)
+        comp = b"".join(pool.map(lambda p: bgzf_e2e._member(bytes(view[p:p + 0xFF00])), range(0, raw.shape[0], 0xFF00))) + bgzf_e2e._EOF
+    buf = np.frombuffer(comp, dtype=np.uint8)
+    with kmm.DeviceIndex.from_index(index, mx) as dev:
+        used, n_rec = dev.map_records(raw, raw.shape[0], _lib.FORMAT_FASTQ, k)
+        assert used == raw.shape[0] and n_rec == n_reads
+        want = dev.get_node_counts()
+        assert dev.get_param("host_packed_record_calls") >= 1
+        # one call
+        dev.reset()
+        used, n_rec = dev.map_bgzf(buf, fmt=_lib.FORMAT_FASTQ, k=k, first=True, last=True)
+        assert used == len(comp) and n_rec == n_reads
+        assert np.array_equal(dev.get_node_counts(), want)
+        # windows of 100 MB, each announced while the one before is inflated
+        dev.reset()
+        step, pos, total = 100 << 20, 0, 0
+        end = min(step, len(comp))
+        before = dev.get_param("bgzf_prestaged_calls")
+        while pos < len(comp):
+            nxt = min(end + step, len(comp))
+            used, n_rec = dev.map_bgzf(buf[pos:end], fmt=_lib.FORMAT_FASTQ, k=k, first=pos == 0, last=end == len(comp),
+                                       next_chunk=buf[end:nxt] if nxt > end else None)
+            pos += used
+            total += n_rec
+            if pos < end and end == len(comp):
+                continue
+            end = nxt
+        assert total == n_reads and np.array_equal(dev.get_node_counts(), want)
+        assert dev.get_param("bgzf_prestaged_calls") - before == (len(comp) - 1) // step
+        # three ranks' member ranges on one handle
+        dev.reset()
+        total = 0
+        for r in range(3):
+            lo, s0, hi, s1 = bgzf_ranges.rank_member_range(comp, "fastq", r, 3)
+            hi = bgzf_ranges.member_end(comp, hi) if s1 > 0 else hi
+            used, n_rec = dev.map_bgzf(buf[lo:hi], fmt=_lib.FORMAT_FASTQ, k=k, first=True, last=True, head_skip=s0,
+                                       tail_stop=s1 if s1 > 0 else None)
+            assert used == hi - lo
+            total += n_rec
+        assert total == n_reads and np.array_equal(dev.get_node_counts(), want)
+        # and the oracle on a prefix
+        n_s = 40_000
+        dev.reset()
+        dev.map_reads_uniform(bases[:n_s * L], n_s, L, k)
+        expect, _ = oracle.map_reads(index, mx, bases[:n_s * L], offs[:n_s + 1], k, n_threads=8)
+        assert np.array_equal(dev.get_node_counts(), expect)
