@@ -3126,10 +3126,12 @@ static int map_bgzf_entry(kmm_index_t *ix, const uint8_t *comp, int64_t n_comp, 
     KMMCHK(ensure(ix->bgzf_meta[cur], (size_t)(n_members + 1) * 16 + 64));
     KMMCHK(ensure(ix->bgzf_err, 64));
     if (!ix->bgzf_crc.p) { // the CRC32 tables (slicing by 8), once per handle
-        std::vector<uint32_t> t(8 * 256);
+        std::vector<uint32_t> t(kmm_gz::CRC_TABLE_WORDS);
         for (int kk = 0; kk < 8; ++kk)
             for (uint32_t bb = 0; bb < 256u; ++bb)
                 t[(size_t)kk * 256 + bb] = kmm_gz::crc_table_entry(kk, bb);
+        for (int kk = 0; kk < kmm_gz::CRC_SHIFT_WORDS; ++kk) // (x^(8 * 2^kk): a part's register moved forward by the bytes behind it)
+            t[8 * 256 + kk] = kmm_gz::crc_shift_table_entry(kk);
         KMMCHK(ensure(ix->bgzf_crc, t.size() * 4));
         HIPCHK(hipMemcpy(ix->bgzf_crc.p, t.data(), t.size() * 4, hipMemcpyHostToDevice));
     }
@@ -3158,7 +3160,7 @@ static int map_bgzf_entry(kmm_index_t *ix, const uint8_t *comp, int64_t n_comp, 
         hipLaunchKernelGGL(kmm_gz::k_inflate_bgzf, dim3(grid_threads / 64u), dim3(64), 0, ix->stream, d_comp, d_moff, d_ooff, d_raw, n_members,
                            (uint8_t *)ix->bgzf_tabs.p, (const uint32_t *)nullptr, (unsigned int *)ix->bgzf_err.p,
                            (unsigned long long *)nullptr, (uint8_t *)ix->bgzf_status.p);
-        hipLaunchKernelGGL(kmm_gz::k_crc_bgzf, dim3((n_members + 255u) / 256u), dim3(256), 0, ix->stream, d_comp, d_moff, d_ooff,
+        hipLaunchKernelGGL(kmm_gz::k_crc_bgzf, dim3((n_members + 63u) / 64u), dim3(256), 0, ix->stream, d_comp, d_moff, d_ooff,
                            (const uint8_t *)d_raw, n_members, (const uint32_t *)ix->bgzf_crc.p, (unsigned int *)ix->bgzf_err.p,
                            (const uint8_t *)ix->bgzf_status.p);
         HIPCHK(hipGetLastError());

@@ -17,7 +17,7 @@
 // 16-byte register FIFO; matches copied up to eight at a time with one request per source and at most two per destination.
 // Stored, fixed and dynamic blocks (RFC 1951); every access is bounds-checked against the member's ISIZE / compressed size,
 // so a damaged member ends in an error code, never in a stray access; the CRC32 of the output is checked on the device too
-// (k_crc_bgzf behind the inflater: slicing-by-8, the tables in LDS).
+// (k_crc_bgzf behind the inflater: slicing-by-8, the tables in LDS, four lanes per member whose registers are combined in GF(2)).
 // The decoder is restated from RFC 1951 / RFC 1952 and the BGZF section of the SAM specification; no code taken.
 #pragma once
 
@@ -717,10 +717,54 @@ KMM_HD inline uint32_t crc_table_entry(int k, uint32_t b)
     return c;
 }
 
-// crc over p[0, n) with the 8 x 256 tables T (flat: T[k * 256 + b])
-KMM_HD inline uint32_t crc32_sliced(const uint32_t *T, const uint8_t *p, uint32_t n)
+// The CRC of a member from the CRCs of its PARTS.  The CRC register is linear in the message: after part A the register holds
+// r_A; running on over part B gives r_A * x^(8 |B|) + r_B(from a zero register) in GF(2)[x] modulo the CRC's polynomial.  So the
+// parts are summed independently (the first from the register's initial 0xFFFFFFFF, the others from 0), each register is moved
+// forward by the bytes BEHIND its part with one multiplication, and the exclusive-or of the results is the register after the
+// whole message.  Polynomials in the CRC's reflected bit order: bit 31 is x^0.
+KMM_HD inline uint32_t gf2_mul(uint32_t a, uint32_t b)
 {
-    uint32_t c = 0xFFFFFFFFu;
+    uint32_t p = 0;
+    for (int i = 0; i < 32; ++i) {
+        p ^= b & (0u - ((a >> (31 - i)) & 1u));
+        b = (b >> 1) ^ (0xEDB88320u & (0u - (b & 1u)));
+    }
+    return p;
+}
+
+constexpr int CRC_SHIFT_WORDS = 32, CRC_TABLE_WORDS = 8 * 256 + CRC_SHIFT_WORDS;
+
+// X[k] = x^(8 * 2^k): the tables' tail (crcT[8 * 256 + k])
+KMM_HD inline uint32_t crc_shift_table_entry(int k)
+{
+    uint32_t v = 0x00800000u; // x^8
+    for (int i = 0; i < k; ++i)
+        v = gf2_mul(v, v);
+    return v;
+}
+
+// register r moved forward by n zero bytes
+KMM_HD inline uint32_t crc_shift(const uint32_t *X, uint32_t r, uint32_t n)
+{
+    for (int k = 0; n; ++k, n >>= 1)
+        if (n & 1u)
+            r = gf2_mul(X[k], r);
+    return r;
+}
+
+constexpr uint32_t CRC_PARTS = 4;
+
+// part j of n bytes: [a, b); the cuts at multiples of 16 bytes
+KMM_HD inline void crc_part_range(uint32_t n, uint32_t j, uint32_t &a, uint32_t &b)
+{
+    const uint32_t q = n / CRC_PARTS & ~15u;
+    a = j * q;
+    b = j + 1u < CRC_PARTS ? a + q : n;
+}
+
+// the register after p[0, n) from the start value c (slicing by 8; T as in crc32_sliced)
+KMM_HD inline uint32_t crc_register(const uint32_t *T, const uint8_t *p, uint32_t n, uint32_t c)
+{
     uint32_t i = 0;
     auto step8 = [&](uint64_t w) {
         const uint32_t lo = (uint32_t)w ^ c, hi = (uint32_t)(w >> 32);
@@ -733,14 +777,23 @@ KMM_HD inline uint32_t crc32_sliced(const uint32_t *T, const uint8_t *p, uint32_
         step8(w0);
         step8(w1);
     }
-    for (; i + 8u <= n; i += 8u) {
-        uint64_t w;
-        memcpy(&w, p + i, 8);
-        step8(w);
-    }
     for (; i < n; ++i)
         c = (c >> 8) ^ T[(c ^ p[i]) & 0xFFu];
-    return ~c;
+    return c;
+}
+
+// crc over p[0, n) with the 8 x 256 tables T (flat: T[k * 256 + b])
+KMM_HD inline uint32_t crc32_sliced(const uint32_t *T, const uint8_t *p, uint32_t n)
+{
+    return ~crc_register(T, p, n, 0xFFFFFFFFu);
+}
+
+// part j's share of the whole message's register (the exclusive-or over the parts, complemented, is the CRC)
+KMM_HD inline uint32_t crc_part_share(const uint32_t *T, const uint32_t *X, const uint8_t *p, uint32_t n, uint32_t j)
+{
+    uint32_t a, b;
+    crc_part_range(n, j, a, b);
+    return crc_shift(X, crc_register(T, p + a, b - a, j ? 0u : 0xFFFFFFFFu), n - b);
 }
 
 // One BGZF member at m (its total size msize from the header) -> out[0, n_out), n_out = the trailer's ISIZE as the caller
@@ -797,38 +850,28 @@ __global__ void __launch_bounds__(64) k_inflate_bgzf(const uint8_t *__restrict__
 
 // The CRC32 of every member's output against its trailer, a kernel of its own behind k_inflate_bgzf (crcT = nullptr there):
 // inside the inflater the check ran at that kernel's four wavefronts per CU — 4 096 dependent rounds of table look-ups per lane,
-// 2-3 ms of its 24 — here nothing holds the occupancy down and the slicing tables (8 KB) sit in LDS.  One thread per member;
+// 2-3 ms of its 24 — here nothing holds the occupancy down and the slicing tables (8 KB) sit in LDS.  CRC_PARTS neighbouring
+// threads per member: each sums its part of the bytes and moves its register forward by the bytes behind it (crc_part_share),
+// the exclusive-or over the four lanes is the member's register — a quarter of the dependent rounds per lane.
 // status[m] != 0: the inflater has refused the member already.
 __global__ void __launch_bounds__(256) k_crc_bgzf(const uint8_t *__restrict__ comp, const unsigned long long *__restrict__ m_off,
                                                   const unsigned long long *__restrict__ o_off, const uint8_t *__restrict__ out,
                                                   uint32_t n_members, const uint32_t *__restrict__ crcT, unsigned int *__restrict__ err,
                                                   const uint8_t *__restrict__ status)
 {
-    __shared__ uint32_t T[8 * 256];
-    for (uint32_t i = threadIdx.x; i < 8u * 256u; i += 256u)
+    static_assert(CRC_PARTS == 4, "the lanes of a member are combined by two butterfly steps");
+    __shared__ uint32_t T[CRC_TABLE_WORDS];
+    for (uint32_t i = threadIdx.x; i < (uint32_t)CRC_TABLE_WORDS; i += 256u)
         T[i] = crcT[i];
     __syncthreads();
-    const uint32_t m = blockIdx.x * 256u + threadIdx.x;
-    if (m >= n_members || (status && status[m]))
-        return;
-    const uint8_t *p = out + o_off[m];
-    const uint32_t n = (uint32_t)(o_off[m + 1] - o_off[m]);
-    uint32_t c = 0xFFFFFFFFu, i = 0;
-    for (; i + 16u <= n; i += 16u) {
-        uint64_t w0, w1;
-        load16u(p + i, w0, w1);
-        uint32_t lo = (uint32_t)w0 ^ c, hi = (uint32_t)(w0 >> 32);
-        c = T[7 * 256 + (lo & 0xFFu)] ^ T[6 * 256 + ((lo >> 8) & 0xFFu)] ^ T[5 * 256 + ((lo >> 16) & 0xFFu)] ^ T[4 * 256 + (lo >> 24)] ^
-            T[3 * 256 + (hi & 0xFFu)] ^ T[2 * 256 + ((hi >> 8) & 0xFFu)] ^ T[1 * 256 + ((hi >> 16) & 0xFFu)] ^ T[0 * 256 + (hi >> 24)];
-        lo = (uint32_t)w1 ^ c;
-        hi = (uint32_t)(w1 >> 32);
-        c = T[7 * 256 + (lo & 0xFFu)] ^ T[6 * 256 + ((lo >> 8) & 0xFFu)] ^ T[5 * 256 + ((lo >> 16) & 0xFFu)] ^ T[4 * 256 + (lo >> 24)] ^
-            T[3 * 256 + (hi & 0xFFu)] ^ T[2 * 256 + ((hi >> 8) & 0xFFu)] ^ T[1 * 256 + ((hi >> 16) & 0xFFu)] ^ T[0 * 256 + (hi >> 24)];
-    }
-    for (; i < n; ++i)
-        c = (c >> 8) ^ T[(c ^ p[i]) & 0xFFu];
-    const unsigned long long e = m_off[m + 1];
-    if (~c != rd32(comp + e - 8)) {
+    const uint32_t m = blockIdx.x * (256u / CRC_PARTS) + threadIdx.x / CRC_PARTS, j = threadIdx.x % CRC_PARTS;
+    const bool live = m < n_members && !(status && status[m]); // (the same for the four lanes of a member)
+    uint32_t c = 0;
+    if (live)
+        c = crc_part_share(T, T + 8 * 256, out + o_off[m], (uint32_t)(o_off[m + 1] - o_off[m]), j);
+    c ^= (uint32_t)__shfl_xor((int)c, 1);
+    c ^= (uint32_t)__shfl_xor((int)c, 2);
+    if (live && j == 0 && ~c != rd32(comp + m_off[m + 1] - 8)) {
         atomicAdd(&err[0], 1u);
         if (atomicMin(&err[1], m) > m)
             err[2] = (unsigned int)E_CRC;

@@ -33,6 +33,13 @@ int main(int argc, char **argv)
     const int rounds = argc > 1 ? atoi(argv[1]) : 400;
     std::mt19937_64 rng(12345);
     long ok = 0, refused = 0, wrong = 0;
+    // the CRC tables as the library makes them (kmm.hip): slicing tables + x^(8 * 2^k)
+    std::vector<uint32_t> crcT(kmm_gz::CRC_TABLE_WORDS);
+    for (int k = 0; k < 8; ++k)
+        for (uint32_t b = 0; b < 256u; ++b)
+            crcT[(size_t)k * 256 + b] = kmm_gz::crc_table_entry(k, b);
+    for (int k = 0; k < kmm_gz::CRC_SHIFT_WORDS; ++k)
+        crcT[8 * 256 + k] = kmm_gz::crc_shift_table_entry(k);
     for (int r = 0; r < rounds; ++r) {
         // FASTQ-like text, runs, noise: every block type and long / overlapping matches
         std::vector<uint8_t> data;
@@ -49,6 +56,19 @@ int main(int argc, char **argv)
             else
                 c = (uint8_t)("FFFFFFFFFFFFFFFF:"[rng() % 17]);
             data.push_back(c);
+        }
+        // the CRC the way k_crc_bgzf computes it: four parts, each moved forward by the bytes behind it, against zlib's
+        {
+            const size_t n_crc = r % 7 == 0 ? (size_t)(r % 67) : n; // (short messages too: empty parts)
+            std::vector<uint8_t> msg(data.begin(), data.begin() + (long)n_crc); // exact size: no byte read behind a part
+            uint32_t reg = 0;
+            for (uint32_t j = 0; j < kmm_gz::CRC_PARTS; ++j)
+                reg ^= kmm_gz::crc_part_share(crcT.data(), crcT.data() + 8 * 256, msg.data(), (uint32_t)n_crc, j);
+            const uint32_t want = (uint32_t)crc32(0L, msg.data(), (uInt)n_crc);
+            if (~reg != want || kmm_gz::crc32_sliced(crcT.data(), msg.data(), (uint32_t)n_crc) != want) {
+                fprintf(stderr, "round %d: CRC of %zu bytes by parts %08x, zlib %08x\n", r, n_crc, ~reg, want);
+                return 1;
+            }
         }
         const int levels[4] = {0, 1, 6, 9}, strategies[4] = {Z_DEFAULT_STRATEGY, Z_FIXED, Z_RLE, Z_HUFFMAN_ONLY};
         std::vector<uint8_t> comp = deflate_raw(data, levels[rng() % 4], strategies[rng() % 4]);
