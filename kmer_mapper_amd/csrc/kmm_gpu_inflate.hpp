@@ -52,7 +52,11 @@ namespace kmm_gz {
 constexpr int LIT_PB = KMM_GZ_LIT_PB, DIST_PB = KMM_GZ_DIST_PB;
 constexpr int PRIM_LIT = 1 << LIT_PB, PRIM_DIST = 1 << DIST_PB, PRIM_TMP = 32;
 constexpr int PRIM_WORDS = PRIM_LIT + PRIM_DIST + PRIM_TMP;                                          // uint16 per lane (LDS)
+#if defined(KMM_GZ_EXPERIMENT_SEC_IN_LDS) || defined(KMM_GZ_EXPERIMENT_PAD_LDS) // (tools/gz_phase.py: what do the subtables' trips cost?)
+constexpr int SEC_LIT = 512, SEC_DIST = 384, SEC_WORDS = SEC_LIT + SEC_DIST;
+#else
 constexpr int SEC_LIT = 1024, SEC_DIST = 1024, SEC_WORDS = SEC_LIT + SEC_DIST;                     // uint16 per lane (HBM)
+#endif
 constexpr uint32_t LINK = 0x8000u;
 #if defined(__HIP_DEVICE_COMPILE__)
 constexpr int PS = 64; // stride between a lane's consecutive primary entries
@@ -202,25 +206,43 @@ struct Bits {
     int cnt;             // valid bits in buf
     uint64_t flo, fhi;   // the rest of the open block, lowest word next
     int fw;              // 32-bit words left in it
-    uint64_t nlo, nhi;   // the block behind it (bytes [pos - 16, pos))
+    uint64_t nlo, nhi;   // the block behind it (bytes [pos - 16, pos)) as block_load returned it: block_fix when it is taken
 };
+
+// The 16-byte blocks of the input.  block_load: ONE request whatever pos is and never an access outside in[0, n) — at the end
+// of the input the 16 bytes that END there are loaded (a byte loop there was sixteen dependent round trips, and the 64 lanes of
+// a wavefront reach the ends of their members in different rounds).  block_fix turns what block_load returned into bytes
+// [pos, pos + 16) with zeros behind the end.  (n >= 16: inflate_stream pads a shorter input.)  Two functions because the fix USES the loaded registers: it belongs where the
+// block is taken (bits_advance), not where it is requested — the wavefront waits for a load at the first use of its registers.
+KMM_HD inline void block_load(const uint8_t *in, uint32_t n, uint32_t pos, uint64_t &lo, uint64_t &hi) // n >= 16
+{
+    const uint32_t p = pos + 16u <= n ? pos : n - 16u;
+    memcpy(&lo, in + p, 8); // (unaligned loads)
+    memcpy(&hi, in + p + 8, 8);
+}
+
+KMM_HD inline void block_fix(uint32_t n, uint32_t pos, uint64_t &lo, uint64_t &hi)
+{
+    if (pos + 16u > n) {
+        const uint32_t k = pos - (n - 16u); // bytes of the load that lie in front of pos (>= 1)
+        const uint32_t sh = 8u * (k & 7u);
+        if (k >= 16u) {
+            lo = 0;
+            hi = 0;
+        } else if (k >= 8u) {
+            lo = hi >> sh;
+            hi = 0;
+        } else {
+            lo = (lo >> sh) | (hi << (64u - sh)); // (0 < sh < 64 here)
+            hi >>= sh;
+        }
+    }
+}
 
 KMM_HD inline void load16(const uint8_t *in, uint32_t n, uint32_t pos, uint64_t &lo, uint64_t &hi)
 {
-    if (pos + 16u <= n) {
-        memcpy(&lo, in + pos, 8); // (unaligned loads)
-        memcpy(&hi, in + pos + 8, 8);
-        return;
-    }
-    lo = 0;
-    hi = 0;
-    for (uint32_t j = 0; j < 16u; ++j)
-        if (pos + j < n) {
-            if (j < 8u)
-                lo |= (uint64_t)in[pos + j] << (8u * j);
-            else
-                hi |= (uint64_t)in[pos + j] << (8u * (j - 8u));
-        }
+    block_load(in, n, pos, lo, hi);
+    block_fix(n, pos, lo, hi);
 }
 
 KMM_HD inline void bits_start(Bits &b, uint32_t at) // (re)start reading at byte `at`
@@ -232,7 +254,7 @@ KMM_HD inline void bits_start(Bits &b, uint32_t at) // (re)start reading at byte
     b.flo = hi;
     b.fhi = 0;
     b.fw = 2;
-    load16(b.in, b.n, at + 16u, b.nlo, b.nhi);
+    block_load(b.in, b.n, at + 16u, b.nlo, b.nhi); // (nlo / nhi: as loaded — fixed when the block is taken)
     b.pos = at + 32u;
 }
 
@@ -242,8 +264,9 @@ KMM_HD inline void bits_refill(Bits &b)
         if (b.fw == 0) {
             b.flo = b.nlo;
             b.fhi = b.nhi;
+            block_fix(b.n, b.pos - 16u, b.flo, b.fhi);
             b.fw = 4;
-            load16(b.in, b.n, b.pos, b.nlo, b.nhi);
+            block_load(b.in, b.n, b.pos, b.nlo, b.nhi);
             b.pos += 16u;
         }
         const uint32_t x = (uint32_t)b.flo;
@@ -279,9 +302,9 @@ KMM_HD inline void bits_refill_local(Bits &b)
 }
 
 // The open block no longer holds a symbol (fewer than 48 bits with the buffer: at most one word is left, it moves into
-// the buffer): the block requested one block-time ago takes its place and the one behind it is requested.  THE ONE place
-// where the symbol phase waits for input — and what it waits for has been in flight for a whole block's symbols.
-KMM_HD inline void bits_next_block(Bits &b)
+// the buffer): the block requested one block-time ago takes its place (bits_advance: registers only — where the end of the
+// input is fixed up) and the one behind it is requested (bits_prefetch).
+KMM_HD inline void bits_advance(Bits &b)
 {
     if (b.fw > 0) {
         b.buf |= (uint64_t)(uint32_t)b.flo << b.cnt;
@@ -289,9 +312,20 @@ KMM_HD inline void bits_next_block(Bits &b)
     }
     b.flo = b.nlo;
     b.fhi = b.nhi;
+    block_fix(b.n, b.pos - 16u, b.flo, b.fhi);
     b.fw = 4;
-    load16(b.in, b.n, b.pos, b.nlo, b.nhi);
     b.pos += 16u;
+}
+
+KMM_HD inline void bits_prefetch(Bits &b) // nlo / nhi = the block at pos - 16, as loaded
+{
+    block_load(b.in, b.n, b.pos - 16u, b.nlo, b.nhi);
+}
+
+KMM_HD inline void bits_next_block(Bits &b)
+{
+    bits_advance(b);
+    bits_prefetch(b);
 }
 
 // bytes of the input the decoder has really used (the buffer, the open block and the block behind it hold bytes it has not)
@@ -374,8 +408,9 @@ enum State { S_HDR = 0, S_SYM, S_DONE };
 constexpr int SCRATCH_BYTES = LIST_ALLOC * 8 + SEC_WORDS * 2; // per lane, in HBM: the match list, then the subtables
 
 // Phase timers (tools/gz_phase.hip builds with -DKMM_GZ_TIMERS): 100 MHz ticks a lane spends in [0] block headers,
-// [1] symbol decoding, [2] the match copies, [3] the CRC; [4] block headers seen, [5] rounds of the outer loop, [6] steps of
-// the copy phase, [7] matches.
+// [1] symbol decoding, [2] the match copies; [3] subtable lookups (literal / length code: low half, distance code: high half);
+// [4] block headers seen (low half), symbols (high half), [5] rounds of the outer loop, [6] steps of the copy
+// phase, [7] matches.
 #if defined(KMM_GZ_TIMERS)
 #if defined(__HIP_DEVICE_COMPILE__)
 #define KMM_GZ_NOW() wall_clock64()
@@ -528,6 +563,13 @@ KMM_HD inline int inflate_stream(const uint8_t *in, uint32_t n_in, uint8_t *out,
     Bits b;
     b.in = in;
     b.n = n_in;
+    if (n_in < 16u) { // (BGZF's end-of-file member: two bytes) the block loads want 16 bytes: a zero-padded copy at the far end
+        uint8_t *tiny = reinterpret_cast<uint8_t *>(list + LIST_CAP - 2); // of the match list, which so little input cannot fill
+        for (uint32_t j = 0; j < 16u; ++j)
+            tiny[j] = j < n_in ? in[j] : (uint8_t)0;
+        b.in = tiny;
+        b.n = 16u;
+    }
     bits_start(b, 0);
     uint32_t o = 0, final = 0;
     int state = S_HDR;
@@ -553,8 +595,17 @@ KMM_HD inline int inflate_stream(const uint8_t *in, uint32_t n_in, uint8_t *out,
         // 15.2 ms per lane, nor did leaving out this phase's stores altogether, 13.0: the symbol phase is bound by its chain of
         // dependent instructions at one wavefront per SIMD — ~1 900 clocks per symbol — not by memory;
         // profiles/r05/gz_phase_v7_*.txt.)
+        // What a symbol costs, measured with one wavefront per CU (tools/gz_phase.py, profiles/r05/gz_phase_v9_*.txt): 1.04 us,
+        // of which 0.35 us are the trips to the subtables in HBM — one literal / length code in fifty and one distance code in
+        // ten is longer than the primary index, but SOME lane of 64 has one in nearly every turn (with the subtables in LDS,
+        // which four wavefronts per CU leave no room for: 0.69 us) — and the rest the chain of ~200 dependent instructions.
+        // Tried and not kept: rounds of "up to three literals from LDS, then the one symbol that needs more, with one load for
+        // whichever subtable a lane needs" — 30 % slower: FASTQ's symbols are matches by three quarters, and a round's
+        // instructions outweigh the trip it saves; and one block request per lane and turn with no branch around it, so that
+        // no load is waited for where it is issued — 5 % slower (34.8 against 33.1 ms): sixty-four more requests per turn.
         uint32_t n_list = 0;
         int t = 0, bad = 0;
+        unsigned long long n_sub = 0; // (timers build: subtable lookups, literal / length low half, distance high half)
         for (;;) {
         // ONE way out of the loop — its condition.  A symbol that cannot be (no code, a distance before the start, more
         // output than ISIZE) sets `bad` and the lane decodes on, harmlessly (every access below is in bounds whatever the
@@ -568,6 +619,7 @@ KMM_HD inline int inflate_stream(const uint8_t *in, uint32_t n_in, uint8_t *out,
             if (e & LINK) { // a code longer than the primary index: its subtable (HBM)
                 e = lit2[((e >> 4) & 0x7FFu) + (((uint32_t)b.buf >> LIT_PB) & ((1u << (e & 15u)) - 1u))];
                 bits_take(b, LIT_PB);
+                n_sub += 1ull;
             }
             const uint32_t l = e & 15u, sym = e >> 4;
             bad = bad ? bad : (l ? 0 : (int)E_SYMBOL);
@@ -592,6 +644,7 @@ KMM_HD inline int inflate_stream(const uint8_t *in, uint32_t n_in, uint8_t *out,
                 if (d & LINK) {
                     d = dst2[((d >> 4) & 0x7FFu) + (((uint32_t)b.buf >> DIST_PB) & ((1u << (d & 15u)) - 1u))];
                     bits_take(b, DIST_PB);
+                    n_sub += 1ull << 32;
                 }
                 const uint32_t dl = d & 15u, dcode = d >> 4, dsym = dcode <= 29u ? dcode : 0u;
                 bits_take(b, (int)dl);
@@ -614,6 +667,9 @@ KMM_HD inline int inflate_stream(const uint8_t *in, uint32_t n_in, uint8_t *out,
         }
         if (bad)
             return bad;
+        KMM_GZ_COUNT(4, (unsigned long long)t << 32);
+        KMM_GZ_COUNT(3, n_sub);
+        (void)n_sub;
         KMM_GZ_T(1);
         // ---- phase B: the matches, in order; up to GROUP per step when none of them can depend on another.  The list lies in
         // HBM: the entries a step looks at were requested during the step before (two per request; entries beyond the end
@@ -835,6 +891,16 @@ __global__ void __launch_bounds__(64) k_inflate_bgzf(const uint8_t *__restrict__
     unsigned long long *tm = timers ? timers + (size_t)slot * 8 : nullptr;
     uint64_t *list = reinterpret_cast<uint64_t *>(tabs + (size_t)slot * SCRATCH_BYTES);
     uint16_t *sec = reinterpret_cast<uint16_t *>(list + LIST_CAP);
+#if defined(KMM_GZ_EXPERIMENT_SEC_IN_LDS) || defined(KMM_GZ_EXPERIMENT_PAD_LDS)
+    __shared__ uint16_t s_sec[64 * SEC_WORDS]; // 64 KB more: one wavefront per CU in both experiments
+#if defined(KMM_GZ_EXPERIMENT_SEC_IN_LDS)
+    sec = s_sec + threadIdx.x * SEC_WORDS;
+#else
+    s_sec[threadIdx.x] = 0;
+    if (n_members == 0xFFFFFFFFu)
+        err[3] = s_sec[threadIdx.x ^ 1];
+#endif
+#endif
     for (uint32_t m = slot; m < n_members; m += stride) {
         const unsigned long long a = m_off[m], b = m_off[m + 1], oa = o_off[m], ob = o_off[m + 1];
         const int rc = inflate_bgzf_member(comp + a, (uint32_t)(b - a), out + oa, (uint32_t)(ob - oa), prim, sec, list, crcT, tm);

@@ -31,13 +31,15 @@ extern "C" int gz_phase(const uint8_t *comp, uint64_t n_comp, const unsigned lon
     CK(hipMalloc(&d_m, (n_members + 1) * 8));
     CK(hipMalloc(&d_o, (n_members + 1) * 8));
     CK(hipMalloc(&d_t, (size_t)grid_threads * 64));
-    CK(hipMalloc(&d_crc, 8 * 256 * 4));
+    CK(hipMalloc(&d_crc, kmm_gz::CRC_TABLE_WORDS * 4));
     CK(hipMalloc(&d_err, 16));
     CK(hipMalloc(&d_status, n_members + 64));
-    std::vector<uint32_t> t(8 * 256);
+    std::vector<uint32_t> t(kmm_gz::CRC_TABLE_WORDS);
     for (int k = 0; k < 8; ++k)
         for (uint32_t b = 0; b < 256; ++b)
             t[(size_t)k * 256 + b] = kmm_gz::crc_table_entry(k, b);
+    for (int k = 0; k < kmm_gz::CRC_SHIFT_WORDS; ++k)
+        t[8 * 256 + k] = kmm_gz::crc_shift_table_entry(k);
     CK(hipMemcpy(d_crc, t.data(), t.size() * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(d_comp, comp, n_comp, hipMemcpyHostToDevice));
     CK(hipMemset(d_comp + n_comp, 0, 64));
@@ -55,7 +57,7 @@ extern "C" int gz_phase(const uint8_t *comp, uint64_t n_comp, const unsigned lon
         CK(hipEventRecord(e0, 0));
         hipLaunchKernelGGL(kmm_gz::k_inflate_bgzf, dim3(grid_threads / 64u), dim3(64), 0, 0, d_comp, d_m, d_o, d_out, n_members, d_tabs,
                            (const uint32_t *)nullptr, d_err, d_t, d_status);
-        hipLaunchKernelGGL(kmm_gz::k_crc_bgzf, dim3((n_members + 255u) / 256u), dim3(256), 0, 0, d_comp, d_m, d_o, (const uint8_t *)d_out,
+        hipLaunchKernelGGL(kmm_gz::k_crc_bgzf, dim3((n_members + 63u) / 64u), dim3(256), 0, 0, d_comp, d_m, d_o, (const uint8_t *)d_out,
                            n_members, (const uint32_t *)d_crc, d_err, (const uint8_t *)d_status);
         CK(hipGetLastError());
         CK(hipEventRecord(e1, 0));
