@@ -45,6 +45,24 @@ def member_chain(buf):
     return np.asarray(offs, dtype=np.int64)
 
 
+def inflation_ratio(buf, lo, hi, n_members=64):
+    """Inflated / compressed size over the first `n_members` members of buf[lo:hi] (their ISIZE trailers against their sizes):
+    what a caller needs to cut a file into calls of a given INFLATED size without walking its whole member chain.  1.0 if
+    there is no member at lo."""
+    p, comp, raw = lo, 0, 0
+    try:
+        for _ in range(n_members):
+            if p >= hi:
+                break
+            e = member_end(buf, p)
+            comp += e - p
+            raw += struct.unpack_from("<I", buf, e - 4)[0]
+            p = e
+    except ValueError:
+        pass
+    return raw / comp if comp and raw else 1.0
+
+
 def inflate_member(buf, lo, hi):
     """The inflated bytes of the member buf[lo:hi]."""
     xlen = struct.unpack_from("<H", buf, lo + 10)[0]

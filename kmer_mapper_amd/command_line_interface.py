@@ -262,7 +262,7 @@ def _is_bgzf(path):
     return len(h) == 18 and h[:4] == b"\x1f\x8b\x08\x04" and h[12:14] == b"BC" and h[14:16] == b"\x02\x00"
 
 
-_BGZF_WINDOW = 1100 << 20      # compressed bytes per kmm_map_bgzf call (~3.5 GiB inflated at FASTQ's usual 3.3 : 1)
+_BGZF_CALL_INFLATED = 3150 << 20   # inflated bytes per kmm_map_bgzf call: under what a call takes (3.5 GiB; 3.25 GiB for a window staged ahead)
 
 
 def _map_bgzf_file(dev, path, kfmt, k, max_freq, revcomp, before_fetch, t_start, comp_batch=None, counts_out=None, rank=0,
@@ -291,8 +291,12 @@ def _map_bgzf_file(dev, path, kfmt, k, max_freq, revcomp, before_fetch, t_start,
                     mm.madvise(mmap.MADV_SEQUENTIAL)
                 whole = np.frombuffer(mm, dtype=np.uint8)
                 # equal windows, none small: one GPU thread inflates one member, a call's time is one member's (~tens of
-                # milliseconds) whatever its size
-                n_calls = max(1, -(-(size - lo) // _BGZF_WINDOW))
+                # milliseconds) whatever its size — so as FEW calls as their inflated size allows: the compressed bytes of a
+                # call follow from the file's own ratio (its first members' ISIZE against their sizes; FASTQ with binned
+                # qualities 3.3, with forty quality values 2.1 — one call instead of two for 1.5 GB of it)
+                from . import bgzf_ranges as _br
+                per_call = int(_BGZF_CALL_INFLATED / max(1.0, _br.inflation_ratio(mm, lo, size)))
+                n_calls = max(1, -(-(size - lo) // per_call))
                 pos, window = lo, int(comp_batch) if comp_batch else (size - lo) // n_calls + (1 << 16)
                 t_calls = time.perf_counter()
                 end = min(lo + window, size)             # windows END at fixed places; a window starts where the one before

@@ -740,6 +740,10 @@ def test_bgzf_member_ranges_partition_the_records_exactly():
             sizes = [len(br.inflate_member(comp, int(offs[i]), int(offs[i + 1]))) for i in range(len(offs) - 1)]
             assert sum(sizes) == len(raw)
             cum = np.concatenate([[0], np.cumsum(sizes)])
+            # the ratio the CLI cuts its calls by: ISIZE against size over the first members (all of them / the first three)
+            assert abs(br.inflation_ratio(comp, 0, len(comp), n_members=10 ** 9) - len(raw) / len(comp)) < 1e-9
+            assert abs(br.inflation_ratio(comp, 0, len(comp), n_members=3) - sum(sizes[:3]) / int(offs[3])) < 1e-9
+            assert br.inflation_ratio(comp, 1, len(comp)) == 1.0 and br.inflation_ratio(comp, len(comp), len(comp)) == 1.0
             for world in (1, 2, 3, 7, 40):
                 spans = []
                 where = {int(o): i for i, o in enumerate(offs)}                   # member index by compressed offset

@@ -116,7 +116,9 @@ def main():
         c = map_bnp(ns)
         return c, time.perf_counter() - t
 
+    time.sleep(4) # (see below: the library loop's handle has just been closed)
     cli()
+    time.sleep(4)
     got, dt = cli()
     print("CLI, members inflated on the GPU: %.2f s end to end, %.1f GB/s of FASTQ, %.1f G k-mers/s" % (dt, size / dt / 1e9, n_reads * 120 / dt / 1e9), flush=True)
     os.environ["KMM_CLI_NO_GPU_INFLATE"] = "1"
