@@ -50,6 +50,55 @@ def log(*a):
         print(*a, file=sys.stderr, flush=True)
 
 
+class ClockSampler:
+    """The GPU's engine / memory / fabric clocks as the driver reports them (the starred level of
+    /sys/bus/pci/devices/<id>/pp_dpm_{sclk,mclk,fclk}), read every few milliseconds by a thread while the timed steps run:
+    a kernel that takes 5.96 ms on one box and 6.47 on another is to be read beside the clocks it ran at."""
+
+    def __init__(self, pci, period_s=0.004):
+        import threading
+        self.base = "/sys/bus/pci/devices/%s" % pci if pci else None
+        self.period = period_s
+        self.samples = {"sclk": [], "mclk": [], "fclk": []}
+        self._stop = threading.Event()
+        self._thread = threading.Thread(target=self._run, daemon=True)
+
+    def _read(self, name):
+        try:
+            with open("%s/pp_dpm_%s" % (self.base, name)) as f:
+                for line in f:
+                    if "*" in line:
+                        return int("".join(ch for ch in line.split(":")[1] if ch.isdigit()))
+        except (OSError, ValueError, IndexError):
+            pass
+        return None
+
+    def _run(self):
+        while not self._stop.is_set():
+            for name, got in self.samples.items():
+                v = self._read(name)
+                if v is not None:
+                    got.append(v)
+            self._stop.wait(self.period)
+
+    def start(self):
+        if self.base and os.path.exists(self.base + "/pp_dpm_sclk"):
+            self._thread.start()
+
+    def stop(self):
+        self._stop.set()
+        if self._thread.ident is not None:
+            self._thread.join()
+
+    def summary(self):
+        out = {}
+        for name, got in self.samples.items():
+            if got:
+                g = sorted(got)
+                out[name] = {"min": g[0], "median": g[len(g) // 2], "max": g[-1], "samples": len(g)}
+        return out or None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -327,11 +376,14 @@ def main():
     fence()
 
     dev.set_timing(True)
+    clocks = ClockSampler(numa.get("pci"))           # (the clocks beside every figure, box to box)
+    clocks.start()
     t0 = time.perf_counter()
     for i in range(len(sizes)):
         step(i)
     dev.synchronize()
     t_map = time.perf_counter()
+    clocks.stop()
     if world > 1:
         reduce_counts(counts)
     fence()
@@ -518,6 +570,7 @@ def main():
                                % (world, "kmm_comm_reduce_counts" if own_comm or world == 1 else
                                   "torch.distributed reduce, because kmm_comm_init_rank did not come up on every rank: " + comm_note),
                 "numa_binding": numa,
+                "gpu_clocks_MHz_during_timed_region": clocks.summary(),
                 "host_cores_of_this_rank": cpu_budget,
                 "kernel_ms_per_step": {n: round(t[0] / max(len(sizes), 1), 3) for n, t in timing.items() if t[1]},
             },

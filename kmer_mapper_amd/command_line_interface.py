@@ -146,6 +146,18 @@ def map_gpu_raw(index, path, chunk_size, fmt, k, map_reverse_complements=False,
     # came back 100 ms after the index upload it was meant to hide behind: profiles/r05/bgzf_e2e_v6_*.txt)
     if _lib.device_count() > 0 and n_threads > 1 and not str(path).endswith(".gz"):
         helper.start()
+    # A plain FASTQ / two-line FASTA is mapped into memory and handed to the packer threads as it lies in the page cache
+    # (MmapChunker).  The mapping is made HERE, before the index goes up, and helper threads populate its page tables
+    # meanwhile (MADV_POPULATE_READ): the 16 packer threads otherwise take a page fault per 64 KiB of a fresh mapping,
+    # all in one address space (profiles/r05/cli_populate_ab.txt).
+    seekable = not str(path).endswith(".gz")
+    byte_range = rank_byte_range(path, fmt, rank, world_size) if (world_size > 1 and seekable) else None
+    early = None
+    if (seekable and fmt in ("fastq", "fasta") and n_threads > 1 and _lib.device_count() > 0
+            and not os.environ.get("KMM_CLI_NO_MMAP")):
+        early = MmapChunker(path, int(chunk_size), byte_range, pinned=True)
+        if not os.environ.get("KMM_CLI_NO_POPULATE"):
+            early.populate(n_threads=max(1, min(4, host_threads(n_threads, world_size) // 2)))
     dev = DeviceIndex.from_index(index, max_node_id, device=device)
     logging.info("Index resident in HBM after %.3f sec (max_node_id scan + upload + repack)", time.perf_counter() - t_index)
     # -t: the host cores' share of the work (reference: command_line_interface.py:124-130,168) — reader / inflate threads
@@ -156,8 +168,6 @@ def map_gpu_raw(index, path, chunk_size, fmt, k, map_reverse_complements=False,
     from . import _io
     _io.set_default_threads(n_host)
     logging.info("%d host thread(s) read and pack the read bytes (-t %d, CPU budget %d)", n_host, n_threads, _io.cpu_budget())
-    seekable = not str(path).endswith(".gz")
-    byte_range = rank_byte_range(path, fmt, rank, world_size) if (world_size > 1 and seekable) else None
     if byte_range is not None:
         logging.info("Rank %d of %d maps bytes [%d, %d) of %s", rank, world_size, byte_range[0], byte_range[1], path)
     # GPU batches: the reference maps chunk by chunk (-c bytes, command_line_interface.py:109-111,169); here the chunks
@@ -195,8 +205,14 @@ def map_gpu_raw(index, path, chunk_size, fmt, k, map_reverse_complements=False,
     # (Decided BEFORE a chunker is made: the prefetching one starts a reader thread and page-locks two batch buffers — making
     # and freeing those cost this route 100 ms of its map phase until it was noticed.)
     gpu_inflate = (not seekable and fmt in ("fastq", "fasta") and not os.environ.get("KMM_CLI_NO_GPU_INFLATE") and _is_bgzf(path))
-    chunker = None if gpu_inflate else (MmapChunker if use_mmap else PrefetchingRawChunker if use_prefetch
-                                        else RawChunker)(path, batch_bytes, byte_range, pinned=True)
+    if early is not None and use_mmap and not gpu_inflate:
+        chunker = early
+        chunker.chunk_size = batch_bytes
+    else:
+        if early is not None:
+            early.close()
+        chunker = None if gpu_inflate else (MmapChunker if use_mmap else PrefetchingRawChunker if use_prefetch
+                                            else RawChunker)(path, batch_bytes, byte_range, pinned=True)
     owns = (lambda i: True) if (world_size == 1 or seekable) else (lambda i: chunk_owner(i, world_size) == rank)
     # FASTQ and two-line FASTA are parsed as they are; FASTA with wrapped sequence lines is unwrapped on the GPU first
     kfmt = {"fastq": _lib.FORMAT_FASTQ, "fasta": _lib.FORMAT_FASTA2, "fasta_ml": _lib.FORMAT_FASTA}[fmt]
@@ -229,6 +245,7 @@ def map_gpu_raw(index, path, chunk_size, fmt, k, map_reverse_complements=False,
             n_bytes += used
             chunker.consumed(used)
             i += 1
+        t_calls = time.perf_counter()
         n_lookups, n_hits = dev.get_stats()
         n_radix, n_direct = dev.get_param("radix_batches"), dev.get_param("direct_batches")
         n_host_packed = dev.get_param("host_packed_record_calls")
@@ -236,7 +253,14 @@ def map_gpu_raw(index, path, chunk_size, fmt, k, map_reverse_complements=False,
             before_fetch(dev)
         if helper.is_alive() or helper.ident is not None:
             helper.join()
+        t_fetch = time.perf_counter()
         node_counts = dev.get_node_counts(out=prepared.get("counts"))
+        # (the reference's timer stops before its get_node_counts, command_line_interface.py:78-79; ours runs on through
+        # the fetch, and says what the fetch was)
+        logging.info("%.1f ms in the map calls, %.1f ms until the GPU had finished them (= %.1f M k-mers/s up to where the "
+                     "reference stops its timer), %.1f ms more until the node counts were on the host",
+                     (t_calls - t_start) * 1e3, (t_fetch - t_calls) * 1e3, n_lookups / max(t_fetch - t_start, 1e-9) / 1e6,
+                     (time.perf_counter() - t_fetch) * 1e3)
     finally:
         dt = time.perf_counter() - t_start
         chunker.close()

@@ -63,13 +63,23 @@ def init_rccl_comm(dev, group=None):
     import torch.distributed as dist
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     on_gpu = dist.get_backend(group) == "nccl"
-    t = torch.zeros(128, dtype=torch.uint8)
+    # 128 bytes of id + one status byte: if rank 0 cannot make an id (RCCL not loadable, ...) it still takes part in the
+    # broadcast and EVERY rank raises — a rank 0 that left early would leave the others waiting in a collective nobody joins
+    t = torch.zeros(129, dtype=torch.uint8)
+    why = ""
     if rank == 0:
-        t = torch.frombuffer(bytearray(dev.comm_unique_id()), dtype=torch.uint8).clone()
+        try:
+            t[:128] = torch.frombuffer(bytearray(dev.comm_unique_id()), dtype=torch.uint8)
+            t[128] = 1
+        except Exception as exc:                                        # noqa: BLE001 - reported on every rank below
+            why = str(exc)
     if on_gpu:
         t = t.cuda(dev.device)
     dist.broadcast(t, src=0, group=group)
-    dev.comm_init(bytes(t.cpu().numpy().tobytes()), world, rank)
+    t = t.cpu()
+    if int(t[128]) != 1:
+        raise RuntimeError("rank 0 could not create an RCCL unique id" + (": " + why if why else ""))
+    dev.comm_init(bytes(t[:128].numpy().tobytes()), world, rank)
 
 
 def _parse_cpulist(text):

@@ -451,6 +451,51 @@ class MmapChunker:
         self.pos, self.hi = (0, size) if byte_range is None else (int(byte_range[0]), int(byte_range[1]))
         self.eof = False
         self._tail = None            # the file's last bytes + the newline its last line lacks
+        self._populators = []
+
+    def populate(self, n_threads=4, limit=16 << 30, piece=64 << 20):
+        """Map the range's pages AHEAD of the packer threads (madvise MADV_POPULATE_READ, Linux >= 5.14), from helper
+        threads, while the caller does something else (the CLI uploads the index meanwhile): the packer's threads then
+        read the mapping without taking a page fault per 64 KiB.  Pieces are handed out in file order, so the first
+        batch's pages come first.  Best effort: an older kernel refuses the advice and nothing changes."""
+        import ctypes
+        import threading
+        if self._mm is None or self.hi <= self.pos or self._populators:
+            return
+        try:
+            libc = ctypes.CDLL(None, use_errno=True)
+            madvise = libc.madvise
+        except (OSError, AttributeError):
+            return
+        madvise.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+        madvise.restype = ctypes.c_int
+        base = self._all.ctypes.data                       # page-aligned: the mapping starts at offset 0 of the file
+        lo = self.pos & ~4095
+        hi = min(self.hi, lo + int(limit))
+        pieces = [(a, min(a + piece, hi)) for a in range(lo, hi, piece)]
+        nxt = [0]
+        lock = threading.Lock()
+
+        def work():
+            while True:
+                with lock:
+                    j = nxt[0]
+                    nxt[0] += 1
+                if j >= len(pieces):
+                    return
+                a, b = pieces[j]
+                if madvise(base + a, b - a, 22) != 0:    # 22 = MADV_POPULATE_READ (ctypes releases the GIL for the call)
+                    return
+
+        for _ in range(max(1, min(int(n_threads), len(pieces)))):
+            t = threading.Thread(target=work, daemon=True)
+            t.start()
+            self._populators.append(t)
+
+    def wait_populated(self):
+        for t in self._populators:
+            t.join()
+        self._populators = []
 
     def next_chunk(self):
         if self._tail is not None:
@@ -474,6 +519,7 @@ class MmapChunker:
         self.pos += int(n)
 
     def close(self):
+        self.wait_populated()        # (no helper may touch the mapping once it goes)
         self._all = np.zeros(0, np.uint8)
         self._tail = None
         try:

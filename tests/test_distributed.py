@@ -80,3 +80,51 @@ def test_two_rank_gloo_reduce_is_bit_exact():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert sorted(res) == [(0, True), (1, True)]
+
+
+class _NoRccl:
+    """Stands for a DeviceIndex on a host where the RCCL library cannot be loaded: no id on rank 0, and nobody may reach
+    comm_init (a collective the other ranks would then wait in for ever)."""
+    device = 0
+
+    @staticmethod
+    def comm_unique_id():
+        raise RuntimeError("librccl.so could not be loaded")
+
+    def comm_init(self, unique_id, n_ranks, rank):  # pragma: no cover - reaching it is the failure
+        raise AssertionError("comm_init was reached without an id")
+
+
+def _worker_no_id(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from kmer_mapper_amd.distributed import init_rccl_comm
+        try:
+            init_rccl_comm(_NoRccl())
+            q.put((rank, "joined"))
+        except RuntimeError as exc:
+            q.put((rank, "refused: %s" % exc))
+        dist.barrier()                            # every rank is still in step with the others afterwards
+    finally:
+        dist.destroy_process_group()
+
+
+def test_every_rank_refuses_together_when_rank_0_has_no_unique_id():
+    """bench.py / map_bnp fall back to torch.distributed when the library's communicator does not come up; that decision
+    must be the same on every rank, or one rank sits in a broadcast the others never enter."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_no_id, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0].startswith("refused") and "librccl" in res[0]
+    assert res[1].startswith("refused")

@@ -792,3 +792,35 @@ def test_native_readers_under_thread_sanitizer(tmp_path):
         pytest.skip("ThreadSanitizer cannot run in this address-space layout")
     assert run.returncode == 0 and out.count(", same") == 3, out[-3000:]
     assert "WARNING: ThreadSanitizer" not in out, out[-3000:]
+
+
+def test_mmap_chunker_populated_ahead_hands_out_the_same_bytes(tmp_path):
+    """MmapChunker.populate(): helper threads map the file's pages ahead of the packer (the CLI starts them before the index
+    upload); the chunks are the same views, close() waits for the helpers, a second populate() is a no-op."""
+    p = str(tmp_path / "r.fq")
+    genome = syn.make_genome(4000, seed=5)
+    bases, offs = syn.make_reads(genome, 2000, 150, seed=6)
+    reads_io.write_fastq(p, ReadBatch(bases, offs))
+    raw = np.fromfile(p, dtype=np.uint8)
+    for byte_range in (None, (4097, raw.shape[0] - 10)):
+        c = reads_io.MmapChunker(p, 100_000, byte_range)
+        c.populate(n_threads=3, piece=1 << 16)
+        c.populate(n_threads=3)
+        got = []
+        while True:
+            v = c.next_chunk()
+            if v is None:
+                break
+            got.append(np.array(v))
+            c.consumed(v.shape[0])
+        c.wait_populated()
+        c.close()
+        lo, hi = (0, raw.shape[0]) if byte_range is None else byte_range
+        whole = np.concatenate(got)
+        assert np.array_equal(whole[:hi - lo], raw[lo:hi])
+    empty = str(tmp_path / "empty.fq")
+    open(empty, "wb").close()
+    c = reads_io.MmapChunker(empty, 1000)
+    c.populate()
+    assert c.next_chunk() is None
+    c.close()
