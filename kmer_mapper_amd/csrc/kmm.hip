@@ -1408,6 +1408,8 @@ static int rx_build(kmm_index *ix, const int32_t *h2i, const int32_t *nk, const 
     return KMM_OK;
 }
 
+static bool ensure_ring(kmm_index_t *ix);
+
 static int index_create_impl(kmm_index *ix, const int32_t *h2i, const int32_t *nk,
                              const uint64_t *kmers, const int32_t *nodes, const uint16_t *freqs)
 {
@@ -1490,6 +1492,13 @@ static int index_create_impl(kmm_index *ix, const int32_t *h2i, const int32_t *n
             ix->host_pack_threads = v < 0 ? 0 : (v > 256 ? 256 : v);
         }
     }
+
+    // The page-locked staging ring (8 x 16 MiB: 7-10 ms to make) is made HERE for an index whose count vector will leave
+    // through it (kmm_get_node_counts -> pageable memory; flat reads and BGZF windows come in through it): a one-shot
+    // `kmer_mapper map` otherwise makes it inside its first fetch — 18 ms instead of 8 for configs[2]'s 400 MB vector
+    // (profiles/r05/cli_populate_ab.txt).  Best effort: without it the first user makes it.
+    if (ix->host_pack_threads > 0 && (size_t)(ix->max_node_id + 1) * 4 >= ((size_t)64 << 20))
+        (void)ensure_ring(ix);
 
     // raw arrays -> HBM (temporary); validate, build the radix view, and the direct view now or on first use
     DevBuf d_h2i, d_nk, d_km, d_nd, d_fr, d_err;
