@@ -91,6 +91,8 @@ def map_gpu(index, chunks, k, hash_map_size=0, map_reverse_complements=False,
     before_fetch(dev): called with the open handle after the last chunk and before the counts are copied to the
     host (the multi-rank reduce runs there, on the device)."""
     max_node_id = index.max_node_id() if hasattr(index, "max_node_id") else int(np.max(index._nodes))
+    if early is not None and os.environ.get("KMM_CLI_POPULATE_LATE"):          # (A/B: the helpers start behind the scan)
+        early.populate(n_threads=max(1, min(4, host_threads(n_threads, world_size) // 2)))
     dev = DeviceIndex.from_index(index, max_node_id, device=device)
     dev.set_param("host_pack_threads", host_threads(n_threads, world_size) if n_threads > 1 else 0)
     t_start = time.perf_counter()
@@ -155,10 +157,12 @@ def map_gpu_raw(index, path, chunk_size, fmt, k, map_reverse_complements=False,
     if (seekable and fmt in ("fastq", "fasta") and n_threads > 1 and _lib.device_count() > 0
             and not os.environ.get("KMM_CLI_NO_MMAP")):
         early = MmapChunker(path, int(chunk_size), byte_range, pinned=True)
-        if not os.environ.get("KMM_CLI_NO_POPULATE"):
+        if not os.environ.get("KMM_CLI_NO_POPULATE") and not os.environ.get("KMM_CLI_POPULATE_LATE"):
             early.populate(n_threads=max(1, min(4, host_threads(n_threads, world_size) // 2)))
     # (the scan for the largest node id — 30 ms on one thread for 10^8 entries — runs with the helpers above already at work)
     max_node_id = index.max_node_id() if hasattr(index, "max_node_id") else int(np.max(index._nodes))
+    if early is not None and os.environ.get("KMM_CLI_POPULATE_LATE"):          # (A/B: the helpers start behind the scan)
+        early.populate(n_threads=max(1, min(4, host_threads(n_threads, world_size) // 2)))
     dev = DeviceIndex.from_index(index, max_node_id, device=device)
     logging.info("Index resident in HBM after %.3f sec (max_node_id scan + upload + repack)", time.perf_counter() - t_index)
     # -t: the host cores' share of the work (reference: command_line_interface.py:124-130,168) — reader / inflate threads
@@ -214,6 +218,20 @@ def map_gpu_raw(index, path, chunk_size, fmt, k, map_reverse_complements=False,
             early.close()
         chunker = None if gpu_inflate else (MmapChunker if use_mmap else PrefetchingRawChunker if use_prefetch
                                             else RawChunker)(path, batch_bytes, byte_range, pinned=True)
+    steered_from = None
+    if chunker is not None and chunker is early and not os.environ.get("KMM_CLI_NO_PACKER_STEERING"):
+        # the packer threads are made by the first map call and inherit this thread's CPUs: next to the file's pages
+        from .distributed import packer_cpus_near
+        try:
+            where = chunker.page_nodes()
+            near = packer_cpus_near(where)
+            if near is not None:
+                steered_from = os.sched_getaffinity(0)
+                os.sched_setaffinity(0, near[1])
+                logging.info("The read file's page-cache pages lie on NUMA node %d (%s): its packer threads run there (%d CPUs), "
+                             "the packed stream crosses to the GPU's node", near[0], where, len(near[1]))
+        except (OSError, AttributeError) as exc:
+            logging.debug("packer threads stay on the GPU's node: %s", exc)
     owns = (lambda i: True) if (world_size == 1 or seekable) else (lambda i: chunk_owner(i, world_size) == rank)
     # FASTQ and two-line FASTA are parsed as they are; FASTA with wrapped sequence lines is unwrapped on the GPU first
     kfmt = {"fastq": _lib.FORMAT_FASTQ, "fasta": _lib.FORMAT_FASTA2, "fasta_ml": _lib.FORMAT_FASTA}[fmt]
@@ -258,6 +276,10 @@ def map_gpu_raw(index, path, chunk_size, fmt, k, map_reverse_complements=False,
         node_counts = dev.get_node_counts(out=prepared.get("counts"))
         # (the reference's timer stops before its get_node_counts, command_line_interface.py:78-79; ours runs on through
         # the fetch, and says what the fetch was)
+        if getattr(chunker, "populate_t1", None) is not None:
+            logging.info("The file mapping's pages were populated in %.1f ms, done %.1f ms %s the first map call",
+                         (chunker.populate_t1 - chunker.populate_t0) * 1e3, abs(t_start - chunker.populate_t1) * 1e3,
+                         "before" if chunker.populate_t1 <= t_start else "AFTER")
         logging.info("%.1f ms in the map calls, %.1f ms until the GPU had finished them (= %.1f M k-mers/s up to where the "
                      "reference stops its timer), %.1f ms more until the node counts were on the host",
                      (t_calls - t_start) * 1e3, (t_fetch - t_calls) * 1e3, n_lookups / max(t_fetch - t_start, 1e-9) / 1e6,
@@ -266,6 +288,11 @@ def map_gpu_raw(index, path, chunk_size, fmt, k, map_reverse_complements=False,
         dt = time.perf_counter() - t_start
         chunker.close()
         dev.close()
+        if steered_from is not None:                     # (this thread goes back to the GPU's node)
+            try:
+                os.sched_setaffinity(0, steered_from)
+            except OSError:
+                pass
     logging.info("Time spent only on hashing and counting hashes: %.5f" % dt)
     logging.info("Mapped %d reads from %d bytes (%.1f MB/s, GPU record parser): %d k-mer lookups "
                  "(%.1f M/s), %d index hits" % (n_reads, n_bytes, n_bytes / max(dt, 1e-9) / 1e6, n_lookups,

@@ -125,14 +125,44 @@ def bind_to_gpu_numa_node(device, sysfs="/sys/bus/pci/devices"):
     if node < 0 or not cpus:
         info["why"] = "the platform reports no NUMA node for the device"
         return info
+    global _BOUND
     try:
-        allowed = os.sched_getaffinity(0) & cpus
+        before = os.sched_getaffinity(0)
+        allowed = before & cpus
         if not allowed:
             info["why"] = "none of the node's CPUs is in this process's affinity mask"
             return info
         os.sched_setaffinity(0, allowed)
         info["cpus"] = len(allowed)
         info["bound"] = True
+        if _BOUND is None or not (before <= _BOUND["before"]):     # (a second call sees the cut mask: keep the first one's)
+            _BOUND = {"before": set(before), "numa_node": node}
+        else:
+            _BOUND["numa_node"] = node
     except (AttributeError, OSError) as exc:
         info["why"] = "sched_setaffinity: %s" % exc
     return info
+
+
+_BOUND = None        # {"before": the affinity mask this process had before bind_to_gpu_numa_node cut it, "numa_node": the GPU's}
+
+
+def packer_cpus_near(page_nodes, sysfs="/sys/devices/system/node", min_share=0.75):
+    """Where should the threads that pack a memory-mapped read file run?  bind_to_gpu_numa_node keeps a rank on its GPU's
+    node; a file whose page-cache pages lie on the OTHER socket is then read across the socket link — 98 GB/s of FASTQ on 16
+    threads against 140-165 when the pages are local (profiles/r05/cli_page_cache_node.txt).  The packed stream is a quarter of
+    the bytes: better to read next to the pages and write across.  page_nodes: {node: sampled pages} (MmapChunker.page_nodes).
+    Returns (node, set of CPUs) when most pages lie on one node other than the GPU's and this process may run there, else
+    None."""
+    if not _BOUND or not page_nodes:
+        return None
+    total = sum(page_nodes.values())
+    node = max(page_nodes, key=page_nodes.get)
+    if node < 0 or node == _BOUND["numa_node"] or page_nodes[node] < min_share * total:
+        return None
+    try:
+        with open("%s/node%d/cpulist" % (sysfs, node)) as f:
+            cpus = _parse_cpulist(f.read()) & _BOUND["before"]
+    except (OSError, ValueError):
+        return None
+    return (node, cpus) if cpus else None

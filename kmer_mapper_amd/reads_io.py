@@ -476,21 +476,51 @@ class MmapChunker:
         nxt = [0]
         lock = threading.Lock()
 
+        import time
+        self.populate_t0 = time.perf_counter()
+        self.populate_t1 = None                              # when the last helper finished (perf_counter)
+
         def work():
-            while True:
-                with lock:
-                    j = nxt[0]
-                    nxt[0] += 1
-                if j >= len(pieces):
-                    return
-                a, b = pieces[j]
-                if madvise(base + a, b - a, 22) != 0:    # 22 = MADV_POPULATE_READ (ctypes releases the GIL for the call)
-                    return
+            try:
+                while True:
+                    with lock:
+                        j = nxt[0]
+                        nxt[0] += 1
+                    if j >= len(pieces):
+                        return
+                    a, b = pieces[j]
+                    if madvise(base + a, b - a, 22) != 0:    # 22 = MADV_POPULATE_READ (ctypes releases the GIL for the call)
+                        return
+            finally:
+                self.populate_t1 = time.perf_counter()
 
         for _ in range(max(1, min(int(n_threads), len(pieces)))):
             t = threading.Thread(target=work, daemon=True)
             t.start()
             self._populators.append(t)
+
+    def page_nodes(self, samples=48):
+        """{NUMA node: sampled pages} of the range's page-cache pages (get_mempolicy(MPOL_F_NODE | MPOL_F_ADDR), x86-64 syscall
+        239, on pages of the mapping): where the file lies decides where its packer threads should run
+        (distributed.packer_cpus_near).  {} when the platform does not say."""
+        import ctypes
+        import platform
+        if self._mm is None or self.hi <= self.pos or platform.machine() != "x86_64":
+            return {}
+        try:
+            libc = ctypes.CDLL(None, use_errno=True)
+        except OSError:
+            return {}
+        base = self._all.ctypes.data
+        lo, hi = self.pos & ~4095, self.hi
+        step = max(4096, ((hi - lo) // max(1, int(samples))) & ~4095)
+        out = {}
+        for off in range(lo, hi, step):
+            _ = int(self._all[off])                            # (mapped before it is asked about)
+            node = ctypes.c_int(-1)
+            if libc.syscall(239, ctypes.byref(node), None, ctypes.c_ulong(0), ctypes.c_void_p(base + off), ctypes.c_ulong(3)) == 0:
+                out[int(node.value)] = out.get(int(node.value), 0) + 1
+        return out
 
     def wait_populated(self):
         for t in self._populators:

@@ -824,3 +824,31 @@ def test_mmap_chunker_populated_ahead_hands_out_the_same_bytes(tmp_path):
     c.populate()
     assert c.next_chunk() is None
     c.close()
+
+
+def test_page_nodes_and_where_the_packer_threads_go(tmp_path, monkeypatch):
+    """MmapChunker.page_nodes samples the NUMA node of the file's page-cache pages; distributed.packer_cpus_near sends the
+    packer threads to that node when it is not the GPU's and holds most of the pages (fake sysfs: no second socket here)."""
+    from kmer_mapper_amd import distributed as D
+    p = str(tmp_path / "r.fq")
+    with open(p, "wb") as f:
+        f.write(b"@r\nACGTACGTACGTACGTACGTACGTACGTACGTACGT\n+\nIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIII\n" * 20000)
+    c = reads_io.MmapChunker(p, 1 << 16)
+    nodes = c.page_nodes(16)
+    c.close()
+    assert nodes == {} or (sum(nodes.values()) >= 16 and all(isinstance(k, int) for k in nodes))
+    sysfs = tmp_path / "node"
+    (sysfs / "node0").mkdir(parents=True)
+    (sysfs / "node1").mkdir()
+    (sysfs / "node0" / "cpulist").write_text("0-3\n")
+    (sysfs / "node1" / "cpulist").write_text("4-7,12\n")
+    monkeypatch.setattr(D, "_BOUND", None)
+    assert D.packer_cpus_near({1: 10}, sysfs=str(sysfs)) is None                  # (the rank was never bound: nothing to undo)
+    monkeypatch.setattr(D, "_BOUND", {"before": set(range(0, 12)), "numa_node": 0})
+    assert D.packer_cpus_near({1: 10}, sysfs=str(sysfs)) == (1, {4, 5, 6, 7})     # (CPU 12 was never this process's)
+    assert D.packer_cpus_near({0: 10}, sysfs=str(sysfs)) is None                  # the GPU's own node
+    assert D.packer_cpus_near({0: 4, 1: 6}, sysfs=str(sysfs)) is None             # no clear majority
+    assert D.packer_cpus_near({}, sysfs=str(sysfs)) is None
+    assert D.packer_cpus_near({2: 10}, sysfs=str(sysfs)) is None                  # a node sysfs does not know
+    monkeypatch.setattr(D, "_BOUND", {"before": {0, 1}, "numa_node": 0})
+    assert D.packer_cpus_near({1: 10}, sysfs=str(sysfs)) is None                  # none of that node's CPUs may be used

@@ -16,6 +16,22 @@ from kmer_mapper_amd.command_line_interface import map_bnp        # noqa: E402
 from tools.cli_e2e import write_fastq_fast                        # noqa: E402
 
 
+def _node_cpus(node):
+    from kmer_mapper_amd.distributed import _parse_cpulist
+    with open("/sys/devices/system/node/node%d/cpulist" % node) as f:
+        return _parse_cpulist(f.read())
+
+
+def page_nodes(path):
+    """On which NUMA nodes do the file's page-cache pages lie (sampled)?"""
+    from kmer_mapper_amd.reads_io import MmapChunker
+    c = MmapChunker(path, 1 << 20)
+    try:
+        return c.page_nodes(64)
+    finally:
+        c.close()
+
+
 def main():
     import logging
     logging.basicConfig(stream=sys.stdout, level=logging.INFO, format='%(asctime)s %(levelname)s: %(message)s')
@@ -27,8 +43,20 @@ def main():
     index, genome = syn.make_index(n_index, seed=1, gpu_builder=True)
     bases, offs = syn.make_reads(genome, n_reads, 150, seed=2)
     fq = os.path.join(out_dir, "reads.fq")
+    # KMM_E2E_WRITE_NODE=n: the file is WRITTEN by a process bound to node n's CPUs, so its page-cache pages lie there (first
+    # touch) — the controlled form of what otherwise depends on where the writer happened to run
+    write_node = os.environ.get("KMM_E2E_WRITE_NODE")
+    before = os.sched_getaffinity(0)
+    if write_node is not None:
+        os.sched_setaffinity(0, _node_cpus(int(write_node)) & before)
     write_fastq_fast(fq, bases, n_reads, 150)
+    if write_node is not None:
+        os.sched_setaffinity(0, before)
     size = os.path.getsize(fq)
+    try:
+        print("page-cache pages of the FASTQ by NUMA node (sampled): %s" % page_nodes(fq), flush=True)
+    except Exception as exc:                                  # noqa: BLE001 - a label for the measurement, nothing more
+        print("page-cache placement unknown: %s" % exc, flush=True)
     print("setup %.1f s: %d-entry index, %d reads, FASTQ of %.2f GB" % (time.time() - t0, len(index._kmers), n_reads, size / 1e9),
           flush=True)
 
