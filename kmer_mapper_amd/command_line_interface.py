@@ -91,8 +91,6 @@ def map_gpu(index, chunks, k, hash_map_size=0, map_reverse_complements=False,
     before_fetch(dev): called with the open handle after the last chunk and before the counts are copied to the
     host (the multi-rank reduce runs there, on the device)."""
     max_node_id = index.max_node_id() if hasattr(index, "max_node_id") else int(np.max(index._nodes))
-    if early is not None and os.environ.get("KMM_CLI_POPULATE_LATE"):          # (A/B: the helpers start behind the scan)
-        early.populate(n_threads=max(1, min(4, host_threads(n_threads, world_size) // 2)))
     dev = DeviceIndex.from_index(index, max_node_id, device=device)
     dev.set_param("host_pack_threads", host_threads(n_threads, world_size) if n_threads > 1 else 0)
     t_start = time.perf_counter()
@@ -157,12 +155,10 @@ def map_gpu_raw(index, path, chunk_size, fmt, k, map_reverse_complements=False,
     if (seekable and fmt in ("fastq", "fasta") and n_threads > 1 and _lib.device_count() > 0
             and not os.environ.get("KMM_CLI_NO_MMAP")):
         early = MmapChunker(path, int(chunk_size), byte_range, pinned=True)
-        if not os.environ.get("KMM_CLI_NO_POPULATE") and not os.environ.get("KMM_CLI_POPULATE_LATE"):
+        if not os.environ.get("KMM_CLI_NO_POPULATE"):
             early.populate(n_threads=max(1, min(4, host_threads(n_threads, world_size) // 2)))
     # (the scan for the largest node id — 30 ms on one thread for 10^8 entries — runs with the helpers above already at work)
     max_node_id = index.max_node_id() if hasattr(index, "max_node_id") else int(np.max(index._nodes))
-    if early is not None and os.environ.get("KMM_CLI_POPULATE_LATE"):          # (A/B: the helpers start behind the scan)
-        early.populate(n_threads=max(1, min(4, host_threads(n_threads, world_size) // 2)))
     dev = DeviceIndex.from_index(index, max_node_id, device=device)
     logging.info("Index resident in HBM after %.3f sec (max_node_id scan + upload + repack)", time.perf_counter() - t_index)
     # -t: the host cores' share of the work (reference: command_line_interface.py:124-130,168) — reader / inflate threads

@@ -314,6 +314,58 @@ def test_cli_maps_a_plain_fastq_from_its_file_mapping(kmm, syn, oracle, tmp_path
             assert (packed > 0) == (t > 1), (name, t, line)
 
 
+def test_cli_sends_its_packer_threads_to_the_node_of_the_files_pages(kmm, syn, oracle, tmp_path, monkeypatch, caplog):
+    """A read file whose page-cache pages lie on another NUMA node than the rank's GPU: the thread that makes the packer pool
+    takes that node's CPUs for the map phase (distributed.packer_cpus_near) and gets its own back afterwards.  No second socket
+    can be asked for here, so the rank is told it was bound to a node the file is NOT on and that the file's node holds half of
+    this process's CPUs: the steering runs for real (affinity cut, pool made inside it, affinity restored), the counts are the
+    oracle's, and KMM_CLI_NO_PACKER_STEERING leaves the threads where they are."""
+    import argparse
+    import logging
+    import os
+    from kmer_mapper_amd import distributed as D
+    from kmer_mapper_amd.command_line_interface import map_bnp
+    monkeypatch.setenv("KMM_RX_MIN_UNITS", "100000")
+    monkeypatch.setenv("KMM_NO_NUMA_BIND", "1")                # (the fake binding below is the only one)
+    index, genome = syn.make_index(8000, seed=71)
+    mx = index.max_node_id()
+    bases, offs = syn.make_ragged_reads(genome, 12000, 20, 200, seed=72)
+    expect, _ = oracle.map_reads(index, mx, bases, offs, 31, n_threads=4)
+    path = str(tmp_path / "r.fq")
+    open(path, "wb").write(_fastq(_reads(bases, offs)).tobytes())
+    mine = sorted(os.sched_getaffinity(0))
+    half = set(mine[:max(1, len(mine) // 2)])
+    sysfs = tmp_path / "node"
+    for node in range(8):                                      # whichever node the pages are on: it "owns" that half
+        (sysfs / ("node%d" % node)).mkdir(parents=True)
+        (sysfs / ("node%d" % node) / "cpulist").write_text(",".join(str(c) for c in sorted(half)) + "\n")
+    real = D.packer_cpus_near
+    seen = []
+
+    def near(page_nodes, **kw):
+        got = real(page_nodes, sysfs=str(sysfs))
+        seen.append((dict(page_nodes), got))
+        return got
+
+    monkeypatch.setattr(D, "packer_cpus_near", near)
+    monkeypatch.setattr(D, "_BOUND", {"before": set(mine), "numa_node": 99})
+    ns = argparse.Namespace(kmer_index=index, index_bundle=None, reads=path, kmer_size=31, n_threads=6, chunk_size=400_000,
+                            output_file=None, debug=None, max_hits_per_kmer=1000, gpu=True, gpu_hash_map_size=0,
+                            map_reverse_complements=False)
+    with caplog.at_level(logging.INFO):
+        caplog.clear()
+        got = map_bnp(ns)
+    assert np.array_equal(got, expect)
+    assert set(os.sched_getaffinity(0)) == set(mine)            # handed back
+    if seen and seen[0][0]:                                     # (the platform said where the pages are)
+        assert seen[0][1] is not None and seen[0][1][1] == half
+        assert any("its packer threads run there" in r.getMessage() for r in caplog.records)
+    monkeypatch.setenv("KMM_CLI_NO_PACKER_STEERING", "1")
+    n_before = len(seen)
+    assert np.array_equal(map_bnp(ns), expect)
+    assert len(seen) == n_before
+
+
 def test_a_large_count_vector_reaches_pageable_memory_through_the_page_locked_ring(kmm, syn, oracle):
     """kmm_get_node_counts into an ordinary numpy array (what the reference's caller gets, mapper.py): vectors of 64 MiB and
     more cross PCIe through the handle's page-locked ring, the packing threads copying the slots out.  Same vector as into
