@@ -53,6 +53,36 @@ def test_no_gpu_fails_loudly_not_silently():
         DeviceIndex.from_index(ix)
 
 
+@pytest.mark.parametrize("host_parser", [False, True])
+@pytest.mark.parametrize("name", ["r.fq", "r.fa", "r.fq.gz"])
+def test_cli_routes_reach_the_device_and_fail_there_without_a_gpu(tmp_path, name, host_parser):
+    """Every route of `kmer_mapper map --gpu` (raw records from the file mapping, a .gz through the reader library, the host
+    parser's chunks) runs its host-side preparation — chunker, helper threads, max_node_id — and then fails LOUDLY at the
+    device (no CPU fallback): the CPU tier walks the code in front of the first HIP call, so a slip there (an undefined
+    name on one route, say) does not wait for the GPU tier to be seen."""
+    if _lib.device_count() > 0:
+        pytest.skip("a GPU is present")
+    import argparse
+    import gzip
+    from kmer_mapper_amd.command_line_interface import map_bnp
+    index, genome = syn.make_index(300, seed=5)
+    bases, offs = syn.make_reads(genome, 50, 60, seed=6)
+    text = syn.ACGT_INV[bases] if hasattr(syn, "ACGT_INV") else bases
+    seqs = [bytes(np.asarray(text[offs[i]:offs[i + 1]], dtype=np.uint8)) for i in range(50)]
+    if name.endswith(".fa"):
+        data = b"".join(b">h%d\n" % i + q + b"\n" for i, q in enumerate(seqs))
+    else:
+        data = b"".join(b"@h%d\n" % i + q + b"\n+\n" + b"I" * len(q) + b"\n" for i, q in enumerate(seqs))
+    path = str(tmp_path / name)
+    with (gzip.open if name.endswith(".gz") else open)(path, "wb") as f:
+        f.write(data)
+    ns = argparse.Namespace(kmer_index=index, index_bundle=None, reads=path, kmer_size=31, n_threads=4, chunk_size=2000,
+                            output_file=None, debug=None, max_hits_per_kmer=1000, gpu=True, gpu_hash_map_size=0,
+                            map_reverse_complements=False, host_parser=host_parser)
+    with pytest.raises(_lib.KmmError, match="no HIP device|no CPU fallback"):
+        map_bnp(ns)
+
+
 def test_product_package_never_imports_the_oracle():
     pkg = os.path.join(ROOT, "kmer_mapper_amd")
     for dirpath, _, files in os.walk(pkg):
