@@ -192,6 +192,12 @@ def map_gpu_raw(index, path, chunk_size, fmt, k, map_reverse_complements=False,
             # equal batches, none below the threshold (a small last batch would take the direct path)
             batch_bytes = min(int(share / int(share // want)) + (1 << 20), 2 << 30) if seekable else want
             logging.info("Chunks of %d bytes are accumulated into GPU batches of %d bytes (radix path)", chunk_size, batch_bytes)
+        elif seekable and share > batch_bytes and share >= 2.5 * dev.get_param("radix_min_units"):
+            # a file (or a rank's share of one) between the radix path's break-even and the batch size above: ONE call.  Chunk
+            # by chunk it is 271 direct-path calls for 675 MB — 39-42 ms of map calls against 7.5 + 4.4 ms of GPU tail as one
+            # call packed by the host threads (profiles/r05/cli_mid_sized_file.txt)
+            batch_bytes = min(int(share) + (1 << 20), 2 << 30)
+            logging.info("Chunks of %d bytes are accumulated into ONE GPU batch of %d bytes (radix path)", chunk_size, batch_bytes)
     # .gz input: two pinned buffers and a reader thread — the next batch is inflated while the GPU works on this one
     # (BGZF 5.7 -> 6.5 GB/s end to end); plain files are read at memory speed and the second pinned buffer costs more
     # than the overlap returns (3 GB FASTQ: 0.30 s with one buffer, 0.37 s with two)
